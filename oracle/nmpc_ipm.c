@@ -1,0 +1,506 @@
+/*
+ * nmpc_ipm.c -- TEST INFRASTRUCTURE (see nmpc_oracle.h): CPU FP64 interior-point solver for the
+ * reference NLP (matlab_code/setup.m:36-66, mpc/normal/mpc_generator_normal.m:1-50):
+ *
+ *   min  sum_k f_k(z_k, p_k)
+ *   s.t. x_0 = xinit,  [x_{k+1}; w_{k+1}] = c(z_k, p_k)  (k = 0..N-2),
+ *        lb <= z_k <= ub,  A_k pos_k - b_k <= 1e-5.
+ *
+ * It stands in for the reference's closed ForcesPro binary (licence-locked: "parity unpinned" at
+ * the solver level, see nmpc_oracle.h).  Method: primal-dual interior point with Mehrotra
+ * predictor-corrector; the stage Hessian is the exact (constant) cost Hessian -- a Gauss-Newton
+ * Hessian of the Lagrangian, the reference uses per-stage BFGS instead -- and the
+ * Newton KKT system is solved by a block-structured Riccati recursion over the stage chain
+ * (state s = [w; x], 13, control u, 4).  The HIP product implements the same iteration, so the two
+ * can be compared iterate by iterate.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "nmpc_oracle.h"
+
+void orc_rk2(const double *x, const double *u, const double *fext, double *xn, double *Ax, double *Bx);
+void orc_cost_quadratic(const double *p, int stage_class, int model, double *hd, double *hc, double *q, double *cst);
+
+#define NS 13
+#define HU_OFF 1e-5 /* hu = 1e-5, mpc_generator_normal.m:14 */
+#define S_MIN 1e-2
+
+void orc_default_options(orc_options *o)
+{
+    o->maxit = 200;
+    o->tol_stat = 1e-4;
+    o->tol_eq = 1e-4;
+    o->tol_ineq = 1e-4;
+    o->tol_comp = 1e-4;
+    o->mu0 = 1.0;
+    o->ftb = 0.99;
+}
+
+typedef struct {
+    /* model linearisation */
+    double Ax[81], Bx[36], d[NS]; /* d = prev(z_{k}) - s_{k+1}, s-order [w;x]; stored on stage k   */
+    double hd[17], hc, q[17];      /* cost 1/2 z'Hz + q'z                                           */
+    /* factorisation */
+    double L[16], Kt[4 * NS], kt[4], P[NS * NS], p[NS], Pd[NS];
+    double phi[17];                /* rhs gradient of the current solve                             */
+    double PhiD[17], PhiPos[9];    /* barrier-augmented Hessian: diagonal + pos 3x3 block           */
+} stage_ws;
+
+static int stage_class_of(int k, int N) { return k == 0 ? ORC_STAGE_FIRST : (k == N - 1 ? ORC_STAGE_LAST : ORC_STAGE_MID); }
+
+/* Backward Riccati step for stage k given (Pn, pn) of stage k+1 (NULL on the last stage).
+ * full != 0: factorise (L, Kt, P, Pd) and the vector part; full == 0: vector part only (kt, p). */
+static int riccati_step(stage_ws *w, const double *Pn, const double *pn, int full)
+{
+    double Q[17 * 17], q[17];
+    const double *Ax = w->Ax, *Bx = w->Bx;
+    memcpy(q, w->phi, sizeof q);
+    if (pn) {
+        double h[NS];
+        if (full) {
+            for (int i = 0; i < NS; i++) {
+                double a = 0;
+                for (int j = 0; j < NS; j++) a += Pn[i * NS + j] * w->d[j];
+                w->Pd[i] = a;
+            }
+        }
+        for (int i = 0; i < NS; i++) h[i] = w->Pd[i] + pn[i];
+        for (int j = 0; j < 4; j++) {
+            double a = h[j];
+            for (int i = 0; i < 9; i++) a += Bx[i * 4 + j] * h[4 + i];
+            q[j] += a;
+        }
+        for (int j = 0; j < 9; j++) {
+            double a = 0;
+            for (int i = 0; i < 9; i++) a += Ax[i * 9 + j] * h[4 + i];
+            q[8 + j] += a;
+        }
+    }
+    if (full) {
+        memset(Q, 0, sizeof Q);
+        for (int i = 0; i < 17; i++) Q[i * 17 + i] = w->PhiD[i];
+        for (int i = 0; i < 4; i++) Q[i * 17 + 4 + i] = Q[(4 + i) * 17 + i] = w->hc;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) Q[(8 + i) * 17 + 8 + j] += w->PhiPos[i * 3 + j];
+        if (Pn) {
+            /* M = [I4 0 0; Bx 0 Ax] (rows [w;x] of stage k+1, cols [u w x] of stage k) */
+            double PxxA[81], PxxB[36], T[36]; /* T = Pwx + Bx'Pxx  (4x9) */
+            for (int i = 0; i < 9; i++) {
+                for (int j = 0; j < 9; j++) {
+                    double a = 0;
+                    for (int l = 0; l < 9; l++) a += Pn[(4 + i) * NS + 4 + l] * Ax[l * 9 + j];
+                    PxxA[i * 9 + j] = a;
+                }
+                for (int j = 0; j < 4; j++) {
+                    double a = 0;
+                    for (int l = 0; l < 9; l++) a += Pn[(4 + i) * NS + 4 + l] * Bx[l * 4 + j];
+                    PxxB[i * 4 + j] = a;
+                }
+            }
+            for (int i = 0; i < 4; i++)
+                for (int j = 0; j < 9; j++) T[i * 9 + j] = Pn[i * NS + 4 + j] + PxxB[j * 4 + i];
+            /* Quu += Pww + Pwx Bx + Bx' Pxw + Bx' Pxx Bx */
+            for (int i = 0; i < 4; i++)
+                for (int j = 0; j < 4; j++) {
+                    double a = Pn[i * NS + j];
+                    for (int l = 0; l < 9; l++) a += T[i * 9 + l] * Bx[l * 4 + j] + Bx[l * 4 + i] * Pn[(4 + l) * NS + j];
+                    Q[i * 17 + j] += a;
+                }
+            /* Qux += T Ax */
+            for (int i = 0; i < 4; i++)
+                for (int j = 0; j < 9; j++) {
+                    double a = 0;
+                    for (int l = 0; l < 9; l++) a += T[i * 9 + l] * Ax[l * 9 + j];
+                    Q[i * 17 + 8 + j] += a;
+                    Q[(8 + j) * 17 + i] += a;
+                }
+            /* Qxx += Ax' Pxx Ax */
+            for (int i = 0; i < 9; i++)
+                for (int j = 0; j < 9; j++) {
+                    double a = 0;
+                    for (int l = 0; l < 9; l++) a += Ax[l * 9 + i] * PxxA[l * 9 + j];
+                    Q[(8 + i) * 17 + 8 + j] += a;
+                }
+        }
+        /* Cholesky of Quu */
+        double *L = w->L;
+        memset(L, 0, 16 * sizeof(double));
+        for (int j = 0; j < 4; j++) {
+            double dsum = Q[j * 17 + j];
+            for (int l = 0; l < j; l++) dsum -= L[j * 4 + l] * L[j * 4 + l];
+            if (!(dsum > 0.0)) return -1;
+            const double dj = sqrt(dsum);
+            L[j * 4 + j] = dj;
+            for (int i = j + 1; i < 4; i++) {
+                double a = Q[i * 17 + j];
+                for (int l = 0; l < j; l++) a -= L[i * 4 + l] * L[j * 4 + l];
+                L[i * 4 + j] = a / dj;
+            }
+        }
+        /* Kt = L^-1 Qus (4 x 13) */
+        for (int c = 0; c < NS; c++)
+            for (int i = 0; i < 4; i++) {
+                double a = Q[i * 17 + 4 + c];
+                for (int l = 0; l < i; l++) a -= L[i * 4 + l] * w->Kt[l * NS + c];
+                w->Kt[i * NS + c] = a / L[i * 4 + i];
+            }
+        for (int i = 0; i < NS; i++)
+            for (int j = 0; j < NS; j++) {
+                double a = Q[(4 + i) * 17 + 4 + j];
+                for (int l = 0; l < 4; l++) a -= w->Kt[l * NS + i] * w->Kt[l * NS + j];
+                w->P[i * NS + j] = a;
+            }
+    }
+    for (int i = 0; i < 4; i++) {
+        double a = q[i];
+        for (int l = 0; l < i; l++) a -= w->L[i * 4 + l] * w->kt[l];
+        w->kt[i] = a / w->L[i * 4 + i];
+    }
+    for (int i = 0; i < NS; i++) {
+        double a = q[4 + i];
+        for (int l = 0; l < 4; l++) a -= w->Kt[l * NS + i] * w->kt[l];
+        w->p[i] = a;
+    }
+    return 0;
+}
+
+typedef struct {
+    int N, M, mc; /* mc = 34 + M constraint slots per stage */
+    stage_ws *st;
+    double *z, *y, *ynew, *dz;        /* [N*17], [N*13] (s-order), [N*13], [N*17] */
+    double *s, *lam, *ds, *dlam, *rin; /* [N*mc]: 0..16 lower, 17..33 upper, 34.. corridor */
+    double *corr;                       /* Mehrotra second-order term ds_aff*dlam_aff */
+    int *nf;
+} solver_ws;
+
+static const double *face_A(const double *params, int M, int k) { return params + (size_t)k * (ORC_NPRE + 4 * M) + ORC_NPRE; }
+static const double *face_b(const double *params, int M, int k) { return params + (size_t)k * (ORC_NPRE + 4 * M) + ORC_NPRE + 3 * M; }
+
+/* G dz for constraint slot i of stage k */
+static double gdz(const solver_ws *W, const double *params, int k, int i, const double *dzk)
+{
+    if (i < 17) return -dzk[i];
+    if (i < 34) return dzk[i - 17];
+    const double *a = face_A(params, W->M, k) + 3 * (i - 34);
+    return a[0] * dzk[8] + a[1] * dzk[9] + a[2] * dzk[10];
+}
+
+/* assemble phi = grad f + G'(Sigma r_in + (sigma mu - corr)/s) for all stages */
+static void build_phi(solver_ws *W, const double *params, double sigmamu, int use_corr)
+{
+    const int N = W->N, mc = W->mc;
+    for (int k = 0; k < N; k++) {
+        stage_ws *w = &W->st[k];
+        const double *zk = W->z + 17 * k;
+        double *phi = w->phi;
+        for (int i = 0; i < 17; i++) phi[i] = w->hd[i] * zk[i] + w->q[i];
+        for (int i = 0; i < 4; i++) {
+            phi[i] += w->hc * zk[4 + i];
+            phi[4 + i] += w->hc * zk[i];
+        }
+        const double *s = W->s + (size_t)k * mc, *l = W->lam + (size_t)k * mc, *r = W->rin + (size_t)k * mc;
+        const double *cr = W->corr + (size_t)k * mc;
+        for (int i = 0; i < 17; i++) {
+            const double tl = (l[i] * r[i] + sigmamu - (use_corr ? cr[i] : 0.0)) / s[i];
+            const double tu = (l[17 + i] * r[17 + i] + sigmamu - (use_corr ? cr[17 + i] : 0.0)) / s[17 + i];
+            phi[i] += tu - tl;
+        }
+        const double *A = face_A(params, W->M, k);
+        for (int j = 0; j < W->nf[k]; j++) {
+            const int i = 34 + j;
+            const double t = (l[i] * r[i] + sigmamu - (use_corr ? cr[i] : 0.0)) / s[i];
+            phi[8] += A[3 * j] * t;
+            phi[9] += A[3 * j + 1] * t;
+            phi[10] += A[3 * j + 2] * t;
+        }
+    }
+}
+
+/* backward (full or vector-only) + forward sweep; fills W->dz and W->ynew */
+static int kkt_solve(solver_ws *W, const double *xinit, int full)
+{
+    const int N = W->N;
+    for (int k = N - 1; k >= 0; k--) {
+        const double *Pn = (k < N - 1) ? W->st[k + 1].P : 0, *pn = (k < N - 1) ? W->st[k + 1].p : 0;
+        if (riccati_step(&W->st[k], Pn, pn, full)) return -1;
+    }
+    /* stage 0: dx_0 = xinit - x_0, dw_0 from Pww dw = -(Pwx dx + p_w) */
+    double ds[NS], dsn[NS];
+    {
+        const stage_ws *w = &W->st[0];
+        for (int i = 0; i < 9; i++) ds[4 + i] = xinit[i] - W->z[8 + i];
+        double Lw[16], rhs[4];
+        memset(Lw, 0, sizeof Lw);
+        for (int j = 0; j < 4; j++) {
+            double dsum = w->P[j * NS + j];
+            for (int l = 0; l < j; l++) dsum -= Lw[j * 4 + l] * Lw[j * 4 + l];
+            if (!(dsum > 0.0)) return -1;
+            Lw[j * 4 + j] = sqrt(dsum);
+            for (int i = j + 1; i < 4; i++) {
+                double a = w->P[i * NS + j];
+                for (int l = 0; l < j; l++) a -= Lw[i * 4 + l] * Lw[j * 4 + l];
+                Lw[i * 4 + j] = a / Lw[j * 4 + j];
+            }
+        }
+        for (int i = 0; i < 4; i++) {
+            double a = w->p[i];
+            for (int j = 0; j < 9; j++) a += w->P[i * NS + 4 + j] * ds[4 + j];
+            rhs[i] = -a;
+        }
+        for (int i = 0; i < 4; i++) {
+            double a = rhs[i];
+            for (int l = 0; l < i; l++) a -= Lw[i * 4 + l] * rhs[l];
+            rhs[i] = a / Lw[i * 4 + i];
+        }
+        for (int i = 3; i >= 0; i--) {
+            double a = rhs[i];
+            for (int l = i + 1; l < 4; l++) a -= Lw[l * 4 + i] * rhs[l];
+            rhs[i] = a / Lw[i * 4 + i];
+        }
+        for (int i = 0; i < 4; i++) ds[i] = rhs[i];
+    }
+    for (int k = 0; k < N; k++) {
+        const stage_ws *w = &W->st[k];
+        double *dzk = W->dz + 17 * k, *yn = W->ynew + NS * k;
+        for (int i = 0; i < NS; i++) {
+            double a = w->p[i];
+            for (int j = 0; j < NS; j++) a += w->P[i * NS + j] * ds[j];
+            yn[i] = a;
+        }
+        double t[4], du[4];
+        for (int i = 0; i < 4; i++) {
+            double a = w->kt[i];
+            for (int j = 0; j < NS; j++) a += w->Kt[i * NS + j] * ds[j];
+            t[i] = -a;
+        }
+        for (int i = 3; i >= 0; i--) {
+            double a = t[i];
+            for (int l = i + 1; l < 4; l++) a -= w->L[l * 4 + i] * du[l];
+            du[i] = a / w->L[i * 4 + i];
+        }
+        for (int i = 0; i < 4; i++) dzk[i] = du[i];
+        for (int i = 0; i < NS; i++) dzk[4 + i] = ds[i];
+        if (k < N - 1) {
+            for (int i = 0; i < 4; i++) dsn[i] = du[i] + w->d[i];
+            for (int i = 0; i < 9; i++) {
+                double a = w->d[4 + i];
+                for (int j = 0; j < 9; j++) a += w->Ax[i * 9 + j] * ds[4 + j];
+                for (int j = 0; j < 4; j++) a += w->Bx[i * 4 + j] * du[j];
+                dsn[4 + i] = a;
+            }
+            memcpy(ds, dsn, sizeof ds);
+        }
+    }
+    return 0;
+}
+
+/* ds, dlam from dz; returns max feasible step fractions (unscaled) through *ap, *ad */
+static void slack_steps(solver_ws *W, const double *params, double sigmamu, int use_corr, double *ap, double *ad)
+{
+    const int N = W->N, mc = W->mc;
+    double a_p = 1e300, a_d = 1e300;
+    for (int k = 0; k < N; k++) {
+        const double *dzk = W->dz + 17 * k;
+        const int cnt = 34 + W->nf[k];
+        for (int i = 0; i < cnt; i++) {
+            const size_t id = (size_t)k * mc + i;
+            const double dsi = -W->rin[id] - gdz(W, params, k, i, dzk);
+            const double rc = W->s[id] * W->lam[id] - sigmamu + (use_corr ? W->corr[id] : 0.0);
+            const double dli = (-rc - W->lam[id] * dsi) / W->s[id];
+            W->ds[id] = dsi;
+            W->dlam[id] = dli;
+            if (dsi < 0.0) { const double a = -W->s[id] / dsi; if (a < a_p) a_p = a; }
+            if (dli < 0.0) { const double a = -W->lam[id] / dli; if (a < a_d) a_d = a; }
+        }
+    }
+    *ap = a_p;
+    *ad = a_d;
+}
+
+int orc_solve(int N, int M, int model, const double *xinit, const double *z0,
+              const double *params, const int *nfaces, const orc_options *opt_in,
+              double *zout, orc_info *info)
+{
+    orc_options opt;
+    if (opt_in) opt = *opt_in; else orc_default_options(&opt);
+    const int np = ORC_NPRE + 4 * M, mc = 34 + M;
+    solver_ws W;
+    W.N = N; W.M = M; W.mc = mc;
+    W.st = (stage_ws *)calloc(N, sizeof(stage_ws));
+    double *buf = (double *)calloc((size_t)N * (17 * 2 + NS * 2 + 6 * mc), sizeof(double));
+    W.z = buf; W.dz = W.z + 17 * N; W.y = W.dz + 17 * N; W.ynew = W.y + NS * N;
+    W.s = W.ynew + NS * N; W.lam = W.s + (size_t)N * mc; W.ds = W.lam + (size_t)N * mc;
+    W.dlam = W.ds + (size_t)N * mc; W.rin = W.dlam + (size_t)N * mc; W.corr = W.rin + (size_t)N * mc;
+    W.nf = (int *)calloc(N, sizeof(int));
+    double lb[17], ub[17];
+    orc_bounds(lb, ub);
+    memcpy(W.z, z0, sizeof(double) * 17 * N);
+
+    int mtot = 0;
+    for (int k = 0; k < N; k++) {
+        const double *A = face_A(params, M, k), *b = face_b(params, M, k);
+        int nf;
+        if (nfaces) nf = nfaces[k];
+        else { /* padded rows are all-zero rows at the tail (forces_normal.cpp:127-135) */
+            nf = M;
+            while (nf > 0 && A[3 * (nf - 1)] == 0.0 && A[3 * (nf - 1) + 1] == 0.0 && A[3 * (nf - 1) + 2] == 0.0 && b[nf - 1] >= -HU_OFF) nf--;
+        }
+        W.nf[k] = nf;
+        mtot += 34 + nf;
+        orc_cost_quadratic(params + (size_t)k * np, stage_class_of(k, N), model, W.st[k].hd, &W.st[k].hc, W.st[k].q, 0);
+        const double *zk = W.z + 17 * k;
+        double *s = W.s + (size_t)k * mc, *l = W.lam + (size_t)k * mc;
+        for (int i = 0; i < 17; i++) {
+            s[i] = fmax(zk[i] - lb[i], S_MIN);
+            s[17 + i] = fmax(ub[i] - zk[i], S_MIN);
+        }
+        for (int j = 0; j < nf; j++) {
+            const double hj = A[3 * j] * zk[8] + A[3 * j + 1] * zk[9] + A[3 * j + 2] * zk[10] - b[j] - HU_OFF;
+            s[34 + j] = fmax(-hj, S_MIN);
+        }
+        for (int i = 0; i < 34 + nf; i++) l[i] = opt.mu0 / s[i];
+    }
+
+    int flag = ORC_MAXIT, it = 0;
+    orc_info inf;
+    memset(&inf, 0, sizeof inf);
+    for (it = 0;; it++) {
+        /* ---- evaluate model, residuals ---- */
+        double res_eq = 0, res_in = 0, rs = 0, rcomp = 0, gap = 0, pobj = 0;
+        for (int i = 0; i < 9; i++) res_eq = fmax(res_eq, fabs(xinit[i] - W.z[8 + i]));
+        for (int k = 0; k < N; k++) {
+            stage_ws *w = &W.st[k];
+            const double *zk = W.z + 17 * k, *pk = params + (size_t)k * np;
+            if (k < N - 1) {
+                double xn[9];
+                const double *zn = zk + 17;
+                orc_rk2(zk + 8, zk, pk + 3, xn, w->Ax, w->Bx);
+                for (int i = 0; i < 4; i++) w->d[i] = zk[i] - zn[4 + i];
+                for (int i = 0; i < 9; i++) w->d[4 + i] = xn[i] - zn[8 + i];
+                for (int i = 0; i < NS; i++) res_eq = fmax(res_eq, fabs(w->d[i]));
+            }
+            /* inequality residuals r = G z - g + s */
+            double *s = W.s + (size_t)k * mc, *l = W.lam + (size_t)k * mc, *r = W.rin + (size_t)k * mc;
+            for (int i = 0; i < 17; i++) {
+                r[i] = lb[i] - zk[i] + s[i];
+                r[17 + i] = zk[i] - ub[i] + s[17 + i];
+                res_in = fmax(res_in, fmax(lb[i] - zk[i], zk[i] - ub[i]));
+            }
+            const double *A = face_A(params, M, k), *b = face_b(params, M, k);
+            for (int j = 0; j < W.nf[k]; j++) {
+                const double hj = A[3 * j] * zk[8] + A[3 * j + 1] * zk[9] + A[3 * j + 2] * zk[10] - b[j] - HU_OFF;
+                r[34 + j] = hj + s[34 + j];
+                res_in = fmax(res_in, hj);
+            }
+            for (int i = 0; i < 34 + W.nf[k]; i++) {
+                res_in = fmax(res_in, fabs(r[i]));
+                rcomp = fmax(rcomp, s[i] * l[i]);
+                gap += s[i] * l[i];
+            }
+            /* stationarity: grad f + M' y_{k+1} - [0; y_k] + G' lam */
+            double g[17], fk;
+            for (int i = 0; i < 17; i++) g[i] = w->hd[i] * zk[i] + w->q[i];
+            for (int i = 0; i < 4; i++) { g[i] += w->hc * zk[4 + i]; g[4 + i] += w->hc * zk[i]; }
+            orc_stage_eval(zk, pk, M, stage_class_of(k, N), model, &fk, 0, 0, 0, 0, 0);
+            pobj += fk;
+            for (int i = 0; i < 17; i++) g[i] += l[17 + i] - l[i];
+            for (int j = 0; j < W.nf[k]; j++)
+                for (int c = 0; c < 3; c++) g[8 + c] += A[3 * j + c] * l[34 + j];
+            const double *yk = W.y + NS * k;
+            for (int i = 0; i < NS; i++) g[4 + i] -= yk[i];
+            if (k < N - 1) {
+                const double *yn = W.y + NS * (k + 1);
+                for (int j = 0; j < 4; j++) {
+                    double a = yn[j];
+                    for (int i = 0; i < 9; i++) a += w->Bx[i * 4 + j] * yn[4 + i];
+                    g[j] += a;
+                }
+                for (int j = 0; j < 9; j++) {
+                    double a = 0;
+                    for (int i = 0; i < 9; i++) a += w->Ax[i * 9 + j] * yn[4 + i];
+                    g[8 + j] += a;
+                }
+            }
+            for (int i = 0; i < 17; i++) rs = fmax(rs, fabs(g[i]));
+        }
+        const double mu = gap / mtot;
+        inf.it = it; inf.res_eq = res_eq; inf.res_ineq = res_in; inf.rsnorm = rs; inf.rcompnorm = rcomp;
+        inf.pobj = pobj; inf.mu = mu;
+        if (!(res_eq == res_eq) || !(rs == rs) || !(pobj == pobj)) { flag = ORC_BADFUNCEVAL; break; }
+        if (res_eq <= opt.tol_eq && res_in <= opt.tol_ineq && rs <= opt.tol_stat && rcomp <= opt.tol_comp) { flag = ORC_OPTIMAL; break; }
+        if (it >= opt.maxit) { flag = ORC_MAXIT; break; }
+
+        /* ---- barrier-augmented Hessian ---- */
+        for (int k = 0; k < N; k++) {
+            stage_ws *w = &W.st[k];
+            const double *s = W.s + (size_t)k * mc, *l = W.lam + (size_t)k * mc;
+            for (int i = 0; i < 17; i++) w->PhiD[i] = w->hd[i] + l[i] / s[i] + l[17 + i] / s[17 + i];
+            memset(w->PhiPos, 0, sizeof w->PhiPos);
+            const double *A = face_A(params, M, k);
+            for (int j = 0; j < W.nf[k]; j++) {
+                const double sg = l[34 + j] / s[34 + j];
+                for (int a = 0; a < 3; a++)
+                    for (int c = 0; c < 3; c++) w->PhiPos[a * 3 + c] += sg * A[3 * j + a] * A[3 * j + c];
+            }
+        }
+        /* ---- predictor ---- */
+        double ap, ad;
+        build_phi(&W, params, 0.0, 0);
+        if (kkt_solve(&W, xinit, 1)) { flag = ORC_FACTORIZATION_ERROR; break; }
+        slack_steps(&W, params, 0.0, 0, &ap, &ad);
+        ap = fmin(1.0, ap); ad = fmin(1.0, ad);
+        double gap_aff = 0;
+        for (int k = 0; k < N; k++)
+            for (int i = 0; i < 34 + W.nf[k]; i++) {
+                const size_t id = (size_t)k * mc + i;
+                gap_aff += (W.s[id] + ap * W.ds[id]) * (W.lam[id] + ad * W.dlam[id]);
+                W.corr[id] = W.ds[id] * W.dlam[id];
+            }
+        const double mu_aff = gap_aff / mtot;
+        double sigma = mu_aff / mu;
+        sigma = sigma * sigma * sigma;
+        if (sigma > 1.0) sigma = 1.0;
+        inf.mu_aff = mu_aff; inf.sigma = sigma; inf.step_aff = ap;
+        /* ---- corrector ---- */
+        build_phi(&W, params, sigma * mu, 1);
+        if (kkt_solve(&W, xinit, 0)) { flag = ORC_FACTORIZATION_ERROR; break; }
+        slack_steps(&W, params, sigma * mu, 1, &ap, &ad);
+        ap = fmin(1.0, opt.ftb * ap); ad = fmin(1.0, opt.ftb * ad);
+        inf.step_cc = ap;
+        for (int k = 0; k < N; k++) {
+            for (int i = 0; i < 17; i++) W.z[17 * k + i] += ap * W.dz[17 * k + i];
+            for (int i = 0; i < NS; i++) W.y[NS * k + i] += ap * (W.ynew[NS * k + i] - W.y[NS * k + i]);
+            for (int i = 0; i < 34 + W.nf[k]; i++) {
+                const size_t id = (size_t)k * mc + i;
+                W.s[id] += ap * W.ds[id];
+                W.lam[id] += ad * W.dlam[id];
+            }
+        }
+    }
+    memcpy(zout, W.z, sizeof(double) * 17 * N);
+    if (info) *info = inf;
+    free(W.st); free(buf); free(W.nf);
+    return flag;
+}
+
+void orc_solve_batch(int B, int N, int M, int model, const double *xinit, const double *z0,
+                     const double *params, const int *nfaces, const orc_options *opt,
+                     double *z, int *exitflag, orc_info *info, int nthreads)
+{
+    const size_t np = (size_t)N * (ORC_NPRE + 4 * M);
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int b = 0; b < B; b++) {
+        orc_info inf;
+        const int fl = orc_solve(N, M, model, xinit + 9 * (size_t)b, z0 + 17 * (size_t)N * b, params + np * b,
+                                 nfaces ? nfaces + (size_t)N * b : 0, opt, z + 17 * (size_t)N * b, &inf);
+        if (exitflag) exitflag[b] = fl;
+        if (info) info[b] = inf;
+    }
+}
