@@ -1,0 +1,50 @@
+"""Build the in-tree native pieces: the gfx950 solver library and (test infrastructure) the oracle."""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libfrp_nmpc_amd.so")
+SOURCES = ["frp_kernels.hip", "frp_capi.hip"]
+HEADERS = ["frp_kernels.h", "frp_model.hpp", "frp_adapter.hpp", os.path.join(ROOT, "include", "frp_nmpc.h")]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build_native(force=False, verbose=True):
+    """hipcc --offload-arch=gfx950 -> forces_resilient_planner_amd/libfrp_nmpc_amd.so (in-tree)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    if not force and not _stale(LIB, deps):
+        return LIB
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-Wall",
+           "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")] + srcs + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_oracle(verbose=True):
+    """Test infrastructure: oracle/liboracle.so and, when /root/reference is present, oracle/_ref."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "all"],
+                          stdout=None if verbose else subprocess.DEVNULL)
+
+
+if __name__ == "__main__":
+    build_native(force=True)
+    build_oracle()

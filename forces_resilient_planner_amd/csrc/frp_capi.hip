@@ -1,0 +1,346 @@
+// frp_capi.hip -- the C-ABI of libfrp_nmpc_amd.so (declared in include/frp_nmpc.h).
+//
+// Drop-in part: FORCESNLPsolver_normal_solve / FORCESNLPsolver_final_solve with the reference's
+// struct layouts (FORCESNLPsolver_normal.h:153-301,317-323), so plan_manage's adapters
+// (forces_normal.cpp:139, forces_final.cpp:138) link against this library unchanged.
+// Batched part: device-pointer API used by bench.py, the tests and the host-side adapter mirror.
+// There is NO CPU compute path in this file: without a HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cmath>
+#include <cstddef>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+#include "../../include/frp_nmpc.h"
+#include "frp_kernels.h"
+#include "frp_model.hpp"
+
+static_assert(sizeof(frp_forces_params) == 23600, "params layout must match FORCESNLPsolver_normal.h:153-168");
+static_assert(offsetof(frp_forces_params, x0) == 72, "x0 offset");
+static_assert(offsetof(frp_forces_params, all_parameters) == 2792, "all_parameters offset");
+static_assert(offsetof(frp_forces_params, num_of_threads) == 23592, "num_of_threads offset");
+static_assert(sizeof(frp_forces_output) == 2720, "output layout must match FORCESNLPsolver_normal.h:173-236");
+static_assert(sizeof(frp_forces_info) == 136, "info layout must match FORCESNLPsolver_normal.h:241-301");
+static_assert(offsetof(frp_forces_info, res_eq) == 8 && offsetof(frp_forces_info, lsit_aff) == 96 &&
+              offsetof(frp_forces_info, step_aff) == 104 && offsetof(frp_forces_info, fevalstime) == 128, "info offsets");
+
+namespace {
+
+#define FRP_HIP(call)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            fprintf(stderr, "[frp_nmpc] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return FRP_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+bool fill_args(const frp_nmpc_batch *b, const frp_nmpc_options *opt_in, void *ws, size_t ws_bytes, frp::KernelArgs *a)
+{
+    if (!b || b->B <= 0 || b->N < 2 || b->N > 64 || b->M < 0 || b->MF < 0 || b->MF > b->M) return false;
+    if (!b->xinit || !b->x0 || !b->params || !b->z || !b->exitflag || !b->iters || !ws) return false;
+    if (b->model != FRP_MODEL_NORMAL && b->model != FRP_MODEL_FINAL) return false;
+    if (ws_bytes < frp::ws_bytes(b->B, b->N, b->MF)) return false;
+    frp_nmpc_options o;
+    if (opt_in) o = *opt_in; else frp_nmpc_default_options(&o);
+    a->B = b->B; a->N = b->N; a->M = b->M; a->MF = b->MF; a->model = b->model; a->maxit = o.maxit;
+    a->tol_stat = o.tol_stat; a->tol_eq = o.tol_eq; a->tol_ineq = o.tol_ineq; a->tol_comp = o.tol_comp;
+    a->mu0 = o.mu0; a->ftb = o.ftb;
+    a->xinit = b->xinit; a->x0 = b->x0; a->params = b->params; a->nfaces = b->nfaces;
+    a->z = b->z; a->exitflag = b->exitflag; a->iters = b->iters; a->info = b->info;
+    a->ws = static_cast<double *>(ws);
+    return true;
+}
+
+// ---- single-problem context of the drop-in ABI: created lazily on first call, freed at unload
+// (the reference has no init/teardown call; SURVEY 8b "Ownership"). Serialised by a mutex: the
+// reference library is not re-entrant either (static work arrays).
+struct DropInCtx {
+    bool ready = false;
+    hipStream_t stream = nullptr;
+    double *d_xinit = nullptr, *d_x0 = nullptr, *d_par = nullptr, *d_z = nullptr, *d_info = nullptr, *d_ws = nullptr;
+    int *d_flag = nullptr, *d_it = nullptr;
+    size_t ws_bytes = 0;
+    bool probed[2] = {false, false};
+    bool probe_ok[2] = {false, false};
+    std::mutex mtx;
+    ~DropInCtx()
+    {
+        if (!ready) return;
+        (void)hipFree(d_xinit); (void)hipFree(d_x0); (void)hipFree(d_par); (void)hipFree(d_z); (void)hipFree(d_info); (void)hipFree(d_ws);
+        (void)hipFree(d_flag); (void)hipFree(d_it);
+        (void)hipStreamDestroy(stream);
+    }
+};
+DropInCtx g_ctx;
+
+int ctx_init()
+{
+    if (g_ctx.ready) return FRP_OK;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FRP_ERR_NO_DEVICE;
+    FRP_HIP(hipStreamCreate(&g_ctx.stream));
+    g_ctx.ws_bytes = frp::ws_bytes(1, FRP_N_REF, FRP_NH_REF);
+    FRP_HIP(hipMalloc(&g_ctx.d_xinit, 9 * sizeof(double)));
+    FRP_HIP(hipMalloc(&g_ctx.d_x0, 340 * sizeof(double)));
+    FRP_HIP(hipMalloc(&g_ctx.d_par, 2600 * sizeof(double)));
+    FRP_HIP(hipMalloc(&g_ctx.d_z, 340 * sizeof(double)));
+    FRP_HIP(hipMalloc(&g_ctx.d_info, FRP_INFO_STRIDE * sizeof(double)));
+    FRP_HIP(hipMalloc(&g_ctx.d_flag, sizeof(int)));
+    FRP_HIP(hipMalloc(&g_ctx.d_it, sizeof(int)));
+    FRP_HIP(hipMalloc(&g_ctx.d_ws, g_ctx.ws_bytes));
+    g_ctx.ready = true;
+    return FRP_OK;
+}
+
+// Probe a caller-supplied model callback against the built-in device model at fixed test points
+// (all three stage classes).  The callback is never used for the solve itself.
+bool probe_callback(frp_forces_extfunc fn, int model)
+{
+    const int stages[3] = {0, 7, 19};
+    for (int s = 0; s < 3; s++) {
+        double z[17] = {0.1, -0.05, 0.2, 7.5, 0.02, 0.01, -0.03, 7.3, 0.5, -0.3, 1.2, 0.4, 0.1, -0.2, 0.05, -0.1, 0.3};
+        double p[130];
+        std::memset(p, 0, sizeof p);
+        const double p10[10] = {1, 0, 1, 0.5, -1, 0.2, 15, 3, 80, 0.2};
+        std::memcpy(p, p10, sizeof p10);
+        p[10] = 1.0; p[11] = 0.5; p[12] = -0.25; p[100] = 2.0;
+        double y[13] = {0}, lam[64] = {0}, f = 0, g[17] = {0}, c[13] = {0}, J[221] = {0}, h[30] = {0}, Jh[510] = {0};
+        fn(z, y, lam, p, &f, g, c, J, h, Jh, nullptr, stages[s], 0, 0);
+        const int sc = frp::stage_class(stages[s], FRP_N_REF);
+        double g2[17];
+        const double f2 = frp::stage_cost(z, p, sc, model, g2);
+        if (std::fabs(f - f2) > 1e-9 * (1.0 + std::fabs(f2))) return false;
+        for (int i = 0; i < 17; i++)
+            if (std::fabs(g[i] - g2[i]) > 1e-9 * (1.0 + std::fabs(g2[i]))) return false;
+        if (sc != frp::STAGE_LAST) {
+            frp::Lin L;
+            double xn[9];
+            frp::rk2<true>(z + 8, z, p + 3, xn, &L);
+            for (int i = 0; i < 9; i++)
+                if (std::fabs(c[i] - xn[i]) > 1e-9 * (1.0 + std::fabs(xn[i]))) return false;
+            const double *Lc = reinterpret_cast<const double *>(&L);
+            for (int i = 0; i < 9; i++) {
+                for (int j = 0; j < 4; j++)
+                    if (std::fabs(J[j * 13 + i] - frp::lin_B(Lc, i, j)) > 1e-9) return false;
+                for (int j = 0; j < 9; j++)
+                    if (std::fabs(J[(8 + j) * 13 + i] - frp::lin_A(Lc, i, j)) > 1e-9) return false;
+            }
+        }
+        const double h0 = 1.0 * z[8] + 0.5 * z[9] - 0.25 * z[10] - 2.0;
+        if (std::fabs(h[0] - h0) > 1e-9) return false;
+    }
+    return true;
+}
+
+int forces_solve(int model, frp_forces_params *params, frp_forces_output *output, frp_forces_info *info, FILE *fs,
+                 frp_forces_extfunc fn)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!params || !output || !info) return FRP_EXIT_PARAM_VALUE;
+    std::lock_guard<std::mutex> lock(g_ctx.mtx);
+    std::memset(info, 0, sizeof *info);
+    if (ctx_init() != FRP_OK) {
+        if (fs) fprintf(fs, "frp_nmpc: no usable HIP device -- this library has no CPU path\n");
+        return FRP_EXIT_PARAM_VALUE;
+    }
+    if (fn) {
+        if (!g_ctx.probed[model]) {
+            g_ctx.probe_ok[model] = probe_callback(fn, model);
+            g_ctx.probed[model] = true;
+        }
+        if (!g_ctx.probe_ok[model]) {
+            if (fs) fprintf(fs, "frp_nmpc: the supplied model callback differs from the built-in device model\n");
+            return FRP_EXIT_PARAM_VALUE;
+        }
+    }
+    for (int i = 0; i < 9; i++) if (!std::isfinite(params->xinit[i])) return FRP_EXIT_PARAM_VALUE;
+    hipStream_t st = g_ctx.stream;
+    if (hipMemcpyAsync(g_ctx.d_xinit, params->xinit, 9 * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(g_ctx.d_x0, params->x0, 340 * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(g_ctx.d_par, params->all_parameters, 2600 * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+        return FRP_EXIT_PARAM_VALUE;
+    frp_nmpc_batch b;
+    std::memset(&b, 0, sizeof b);
+    b.B = 1; b.N = FRP_N_REF; b.M = FRP_NH_REF; b.MF = FRP_NH_REF; b.model = model;
+    b.xinit = g_ctx.d_xinit; b.x0 = g_ctx.d_x0; b.params = g_ctx.d_par; b.nfaces = nullptr;
+    b.z = g_ctx.d_z; b.exitflag = g_ctx.d_flag; b.iters = g_ctx.d_it; b.info = g_ctx.d_info;
+    frp::KernelArgs a;
+    if (!fill_args(&b, nullptr, g_ctx.d_ws, g_ctx.ws_bytes, &a)) return FRP_EXIT_PARAM_VALUE;
+    if (frp::launch_ipm(a, st) != hipSuccess) return FRP_EXIT_PARAM_VALUE;
+    int flag = FRP_EXIT_PARAM_VALUE, it = 0;
+    double inf[FRP_INFO_STRIDE];
+    if (hipMemcpyAsync(output->x, g_ctx.d_z, 340 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&flag, g_ctx.d_flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&it, g_ctx.d_it, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(inf, g_ctx.d_info, sizeof inf, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return FRP_EXIT_PARAM_VALUE;
+    info->it = it; info->it2opt = it;
+    info->res_eq = inf[0]; info->res_ineq = inf[1]; info->rsnorm = inf[2]; info->rcompnorm = inf[3];
+    info->pobj = inf[4]; info->mu = inf[5]; info->step_cc = inf[6]; info->sigma = inf[7];
+    info->dobj = inf[4]; info->dgap = 0.0; info->rdgap = 0.0;
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    info->solvetime = secs;
+    info->fevalstime = 0.0; /* model evaluation is fused into the device kernel */
+    if (fs) {
+        if (flag == FRP_EXIT_OPTIMAL)
+            fprintf(fs, "OPTIMAL (within EQTOL=%.1e, INEQTOL=%.1e, STATTOL=%.1e, COMPTOL=%.1e)\n", a.tol_eq, a.tol_ineq, a.tol_stat, a.tol_comp);
+        else if (flag == FRP_EXIT_MAXIT)
+            fprintf(fs, "MAXIT - Maximum number of iterations reached, exiting.\n");
+        else
+            fprintf(fs, "exit flag %d\n", flag);
+        fprintf(fs, "Solve time: %5.3f ms (%d iterations)\n", secs * 1e3, it);
+    }
+    return flag;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *frp_nmpc_version(void) { return "frp_nmpc_amd 0.1 (gfx950, FP64 wave-per-problem IPM)"; }
+
+int frp_nmpc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void frp_nmpc_default_options(frp_nmpc_options *o)
+{
+    o->maxit = 200;
+    o->tol_stat = 1e-4;
+    o->tol_eq = 1e-4;
+    o->tol_ineq = 1e-4;
+    o->tol_comp = 1e-4;
+    o->mu0 = 1.0;
+    o->ftb = 0.99;
+}
+
+size_t frp_nmpc_workspace_bytes(int B, int N, int MF) { return frp::ws_bytes(B, N, MF); }
+
+int frp_nmpc_solve_batch(const frp_nmpc_batch *batch, const frp_nmpc_options *opt, void *workspace,
+                         size_t workspace_bytes, void *stream)
+{
+    frp::KernelArgs a;
+    if (!fill_args(batch, opt, workspace, workspace_bytes, &a)) return FRP_ERR_ARG;
+    FRP_HIP(frp::launch_ipm(a, static_cast<hipStream_t>(stream)));
+    return FRP_OK;
+}
+
+int frp_nmpc_time_solve(const frp_nmpc_batch *batch, const frp_nmpc_options *opt, void *workspace,
+                        size_t workspace_bytes, void *stream, int reps, float *avg_ms)
+{
+    frp::KernelArgs a;
+    if (!fill_args(batch, opt, workspace, workspace_bytes, &a) || reps <= 0 || !avg_ms) return FRP_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    FRP_HIP(hipEventCreate(&e0));
+    FRP_HIP(hipEventCreate(&e1));
+    FRP_HIP(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; r++) FRP_HIP(frp::launch_ipm(a, st));
+    FRP_HIP(hipEventRecord(e1, st));
+    FRP_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    FRP_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return FRP_OK;
+}
+
+int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *opt)
+{
+    if (!h || h->B <= 0 || h->N < 2 || h->N > 64) return FRP_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FRP_ERR_NO_DEVICE;
+    const size_t B = h->B, N = h->N, np = FRP_NPAR(h->M);
+    double *d_xinit = nullptr, *d_x0 = nullptr, *d_par = nullptr, *d_z = nullptr, *d_info = nullptr;
+    int *d_nf = nullptr, *d_flag = nullptr, *d_it = nullptr;
+    void *d_ws = nullptr;
+    const size_t wsb = frp::ws_bytes(h->B, h->N, h->MF);
+    FRP_HIP(hipMalloc(&d_xinit, B * 9 * sizeof(double)));
+    FRP_HIP(hipMalloc(&d_x0, B * N * 17 * sizeof(double)));
+    FRP_HIP(hipMalloc(&d_par, B * N * np * sizeof(double)));
+    FRP_HIP(hipMalloc(&d_z, B * N * 17 * sizeof(double)));
+    FRP_HIP(hipMalloc(&d_info, B * FRP_INFO_STRIDE * sizeof(double)));
+    FRP_HIP(hipMalloc(&d_flag, B * sizeof(int)));
+    FRP_HIP(hipMalloc(&d_it, B * sizeof(int)));
+    FRP_HIP(hipMalloc(&d_ws, wsb));
+    FRP_HIP(hipMemcpy(d_xinit, h->xinit, B * 9 * sizeof(double), hipMemcpyHostToDevice));
+    FRP_HIP(hipMemcpy(d_x0, h->x0, B * N * 17 * sizeof(double), hipMemcpyHostToDevice));
+    FRP_HIP(hipMemcpy(d_par, h->params, B * N * np * sizeof(double), hipMemcpyHostToDevice));
+    if (h->nfaces) {
+        FRP_HIP(hipMalloc(&d_nf, B * N * sizeof(int)));
+        FRP_HIP(hipMemcpy(d_nf, h->nfaces, B * N * sizeof(int), hipMemcpyHostToDevice));
+    }
+    frp_nmpc_batch d = *h;
+    d.xinit = d_xinit; d.x0 = d_x0; d.params = d_par; d.nfaces = d_nf; d.z = d_z; d.exitflag = d_flag; d.iters = d_it; d.info = d_info;
+    int rc = frp_nmpc_solve_batch(&d, opt, d_ws, wsb, nullptr);
+    if (rc == FRP_OK) {
+        FRP_HIP(hipDeviceSynchronize());
+        FRP_HIP(hipMemcpy(h->z, d_z, B * N * 17 * sizeof(double), hipMemcpyDeviceToHost));
+        FRP_HIP(hipMemcpy(h->exitflag, d_flag, B * sizeof(int), hipMemcpyDeviceToHost));
+        FRP_HIP(hipMemcpy(h->iters, d_it, B * sizeof(int), hipMemcpyDeviceToHost));
+        if (h->info) FRP_HIP(hipMemcpy(h->info, d_info, B * FRP_INFO_STRIDE * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d_xinit); (void)hipFree(d_x0); (void)hipFree(d_par); (void)hipFree(d_z); (void)hipFree(d_info); (void)hipFree(d_flag); (void)hipFree(d_it);
+    (void)hipFree(d_ws); if (d_nf) (void)hipFree(d_nf);
+    return rc;
+}
+
+int frp_nmpc_stage_eval(int B, int N, int M, int model, const double *z, const double *params, double *f,
+                        double *grad_f, double *c, double *jac_c, double *h, void *stream)
+{
+    if (B <= 0 || N < 2 || M < 0 || !z || !params) return FRP_ERR_ARG;
+    FRP_HIP(frp::launch_stage_eval(B, N, M, model, z, params, f, grad_f, c, jac_c, h, static_cast<hipStream_t>(stream)));
+    return FRP_OK;
+}
+
+int frp_nmpc_stage_eval_host(int B, int N, int M, int model, const double *z, const double *params, double *f,
+                             double *grad_f, double *c, double *jac_c, double *h)
+{
+    if (B <= 0 || N < 2 || M < 0 || !z || !params) return FRP_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FRP_ERR_NO_DEVICE;
+    const size_t T = (size_t)B * N, np = FRP_NPAR(M);
+    double *d_z, *d_p, *d_f = nullptr, *d_g = nullptr, *d_c = nullptr, *d_J = nullptr, *d_h = nullptr;
+    FRP_HIP(hipMalloc(&d_z, T * 17 * sizeof(double)));
+    FRP_HIP(hipMalloc(&d_p, T * np * sizeof(double)));
+    FRP_HIP(hipMemcpy(d_z, z, T * 17 * sizeof(double), hipMemcpyHostToDevice));
+    FRP_HIP(hipMemcpy(d_p, params, T * np * sizeof(double), hipMemcpyHostToDevice));
+    if (f) FRP_HIP(hipMalloc(&d_f, T * sizeof(double)));
+    if (grad_f) FRP_HIP(hipMalloc(&d_g, T * 17 * sizeof(double)));
+    if (c) FRP_HIP(hipMalloc(&d_c, T * 13 * sizeof(double)));
+    if (jac_c) FRP_HIP(hipMalloc(&d_J, T * 221 * sizeof(double)));
+    if (h && M > 0) FRP_HIP(hipMalloc(&d_h, T * M * sizeof(double)));
+    int rc = frp_nmpc_stage_eval(B, N, M, model, d_z, d_p, d_f, d_g, d_c, d_J, d_h, nullptr);
+    if (rc == FRP_OK) {
+        FRP_HIP(hipDeviceSynchronize());
+        if (f) FRP_HIP(hipMemcpy(f, d_f, T * sizeof(double), hipMemcpyDeviceToHost));
+        if (grad_f) FRP_HIP(hipMemcpy(grad_f, d_g, T * 17 * sizeof(double), hipMemcpyDeviceToHost));
+        if (c) FRP_HIP(hipMemcpy(c, d_c, T * 13 * sizeof(double), hipMemcpyDeviceToHost));
+        if (jac_c) FRP_HIP(hipMemcpy(jac_c, d_J, T * 221 * sizeof(double), hipMemcpyDeviceToHost));
+        if (d_h) FRP_HIP(hipMemcpy(h, d_h, T * M * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d_z); (void)hipFree(d_p); (void)hipFree(d_f); (void)hipFree(d_g); (void)hipFree(d_c); (void)hipFree(d_J); (void)hipFree(d_h);
+    return rc;
+}
+
+int FORCESNLPsolver_normal_solve(frp_forces_params *params, frp_forces_output *output, frp_forces_info *info,
+                                 FILE *fs, frp_forces_extfunc evalextfunctions)
+{
+    return forces_solve(FRP_MODEL_NORMAL, params, output, info, fs, evalextfunctions);
+}
+
+int FORCESNLPsolver_final_solve(frp_forces_params *params, frp_forces_output *output, frp_forces_info *info,
+                                FILE *fs, frp_forces_extfunc evalextfunctions)
+{
+    return forces_solve(FRP_MODEL_FINAL, params, output, info, fs, evalextfunctions);
+}
+
+} // extern "C"

@@ -1,0 +1,877 @@
+// frp_kernels.hip -- gfx950 kernels of the batched NMPC solver (hand-written HIP, FP64).
+//
+// nmpc_ipm_kernel: one 64-lane wavefront == one workgroup == one NMPC problem, resident for the whole
+// interior-point solve (no host round trips, per-problem early exit; the hardware dispatcher
+// refills the slot with the next problem).  It replaces the reference's closed NLP solver
+//   FORCESNLPsolver_{normal,final}_solve  (FORCESNLPsolver_normal.h:323; forces_normal.cpp:139)
+// and its model callback FORCESNLPsolver_*_casadi2forces (casadi2forces.c:42-245).
+//
+// Iteration (same as the CPU oracle so both can be compared iterate by iterate):
+//   primal-dual interior point, Mehrotra predictor-corrector, exact (constant) cost Hessian,
+//   Newton KKT system solved by a Riccati recursion over the stage chain with
+//   state s = [w; x] (13) and control u (4):   s_{k+1} = [u_k; A_k x_k + B_k u_k] + d_k.
+// Work distribution inside the wavefront:
+//   * stage-parallel phases (model evaluation, residuals, barrier terms, step lengths): lane == stage,
+//     operands in [item][stage] arrays so that the 64 lanes read consecutive doubles;
+//   * the serial Riccati chain: the 64 lanes share every small dense product through LDS
+//     (P_{k+1}, [A|B], Q blocks staged in LDS; ~7 KB per problem), per-stage factors streamed
+//     to/from a 208-double HBM record with coalesced wave loads, next stage prefetched.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "frp_model.hpp"
+#include "../../include/frp_nmpc.h"
+#include "frp_kernels.h"
+
+namespace frp {
+
+// ------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// One wavefront per workgroup: __syncthreads() is the LDS producer/consumer fence between lanes.
+#define WSYNC() __syncthreads()
+
+// ------------------------------------------------------------------ LDS layout (doubles)
+constexpr int L_P0 = 0;                 // P buffer 0 (13x13)
+constexpr int L_P1 = L_P0 + 169;        // P buffer 1
+constexpr int L_AB = L_P1 + 169;        // [A | B] 9 x 13 row-major
+constexpr int L_D = L_AB + 117;         // d (13)
+constexpr int L_PA = L_D + 13;          // Pxx [A|B]  9 x 13
+constexpr int L_QUU = L_PA + 117;       // 4 x 4
+constexpr int L_QUS = L_QUU + 16;       // 4 x 13  (cols 0..3 = Quw, 4..12 = Qux)
+constexpr int L_Q = L_QUS + 52;         // q (17)
+constexpr int L_OUT = L_Q + 17;         // [Kb 52 | R 16 | Pd 13 | kb 4 | p 13] = record part 2 (98)
+constexpr int L_KB = L_OUT;
+constexpr int L_R = L_OUT + 52;
+constexpr int L_PD = L_OUT + 68;
+constexpr int L_KV = L_OUT + 81;
+constexpr int L_PV = L_OUT + 85;
+constexpr int L_PHI = L_OUT + 98;       // [PhiD 17 | PhiPos 9 | phi 17] = record part 3 (43)
+constexpr int L_PHID = L_PHI;
+constexpr int L_PHIPOS = L_PHI + 17;
+constexpr int L_PHIV = L_PHI + 26;
+constexpr int L_HC = L_PHI + 43;        // hc of the stage being processed
+constexpr int L_S0 = L_PHI + 44;        // stage-0 solve: [Rw 16 | Pwx 36]
+constexpr int L_DS = L_S0 + 52;         // ds (13)
+constexpr int L_DSN = L_DS + 13;        // next ds (13)
+constexpr int L_DU = L_DSN + 13;        // du (4)
+constexpr int L_YX = L_DU + 4;          // costate y_x (9) x 2
+constexpr int L_TOTAL = L_YX + 18;
+
+// ------------------------------------------------------------------ small device pieces
+__device__ __forceinline__ int lin_dst(int t)
+{
+    // destination (offset from L_AB) of compact-linearisation entry t (0..50) / d entry (51..63)
+    if (t < 9) return (t / 3) * 13 + 3 + t % 3;                     // Apv -> A[i][3+j]
+    if (t < 18) return ((t - 9) / 3) * 13 + 6 + (t - 9) % 3;        // Ape -> A[i][6+j]
+    if (t < 27) return (3 + (t - 18) / 3) * 13 + 3 + (t - 18) % 3;  // Avv
+    if (t < 36) return (3 + (t - 27) / 3) * 13 + 6 + (t - 27) % 3;  // Ave
+    if (t < 39) return (t - 36) * 13 + 12;                          // BpT -> B[i][3]
+    if (t < 42) return (3 + t - 39) * 13 + 12;                      // BvT -> B[3+i][3]
+    if (t < 51) return (3 + (t - 42) / 3) * 13 + 9 + (t - 42) % 3;  // Bvw -> B[3+i][j]
+    return 117 + (t - 51);                                          // d
+}
+
+// symmetric positive definite 4x4 inverse via LDL'; returns false if a pivot is not positive
+__device__ __forceinline__ bool spd4_inverse(const double *a /*row-major 4x4*/, double *r /*16*/)
+{
+    const double a00 = a[0], a10 = a[4], a11 = a[5], a20 = a[8], a21 = a[9], a22 = a[10];
+    const double a30 = a[12], a31 = a[13], a32 = a[14], a33 = a[15];
+    const double d0 = a00;
+    if (!(d0 > 0.0)) return false;
+    const double i0 = 1.0 / d0;
+    const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+    const double d1 = a11 - l10 * a10;
+    if (!(d1 > 0.0)) return false;
+    const double i1 = 1.0 / d1;
+    const double t21 = a21 - l20 * a10, t31 = a31 - l30 * a10;
+    const double l21 = t21 * i1, l31 = t31 * i1;
+    const double d2 = a22 - l20 * a20 - l21 * t21;
+    if (!(d2 > 0.0)) return false;
+    const double i2 = 1.0 / d2;
+    const double t32 = a32 - l30 * a20 - l31 * t21;
+    const double l32 = t32 * i2;
+    const double d3 = a33 - l30 * a30 - l31 * t31 - l32 * t32;
+    if (!(d3 > 0.0)) return false;
+    const double i3 = 1.0 / d3;
+    // inverse of unit lower L: m = L^-1
+    const double m10 = -l10, m21 = -l21, m32 = -l32;
+    const double m20 = -l20 - l21 * m10;
+    const double m31 = -l31 - l32 * m21;
+    const double m30 = -l30 - l31 * m10 - l32 * m20;
+    // R = m' D^-1 m
+    const double r33 = i3;
+    const double r32 = m32 * i3, r31 = m31 * i3, r30 = m30 * i3;
+    const double r22 = i2 + m32 * r32;
+    const double r21 = m21 * i2 + m32 * r31;
+    const double r20 = m20 * i2 + m32 * r30;
+    const double r11 = i1 + m21 * m21 * i2 + m31 * r31;
+    const double r10 = m10 * i1 + m21 * m20 * i2 + m31 * r30;
+    const double r00 = i0 + m10 * m10 * i1 + m20 * m20 * i2 + m30 * r30;
+    r[0] = r00; r[1] = r10; r[2] = r20; r[3] = r30;
+    r[4] = r10; r[5] = r11; r[6] = r21; r[7] = r31;
+    r[8] = r20; r[9] = r21; r[10] = r22; r[11] = r32;
+    r[12] = r30; r[13] = r31; r[14] = r32; r[15] = r33;
+    return true;
+}
+
+struct WsView {
+    double *rec, *z, *y, *dz, *s, *lam, *corr, *face;
+};
+
+__host__ __device__ inline size_t ws_doubles_per_problem(int N, int MF)
+{
+    const size_t mcf = 34 + MF;
+    return (size_t)N * (REC_STRIDE + 17 + 13 + 17 + 3 * mcf + 4 * (size_t)MF);
+}
+
+// ------------------------------------------------------------------ the solver kernel
+__global__ __launch_bounds__(64) void nmpc_ipm_kernel(KernelArgs a)
+{
+    __shared__ double sm[L_TOTAL];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int N = a.N, M = a.M, MF = a.MF, np = NPRE + 4 * M;
+    const int mcf = 34 + MF;
+    const bool act = lane < N; // lane == stage in the stage-parallel phases
+    const int k = lane;
+
+    WsView w;
+    {
+        double *base = a.ws + (size_t)b * ws_doubles_per_problem(N, MF);
+        w.rec = base;
+        w.z = w.rec + (size_t)N * REC_STRIDE;
+        w.y = w.z + 17 * N;
+        w.dz = w.y + 13 * N;
+        w.s = w.dz + 17 * N;
+        w.lam = w.s + (size_t)mcf * N;
+        w.corr = w.lam + (size_t)mcf * N;
+        w.face = w.corr + (size_t)mcf * N;
+    }
+    const double *xinit = a.xinit + (size_t)b * 9;
+
+    // ---------------------------------------------------------------- init (lane == stage)
+    double p10[NPRE];
+    int nf = 0;
+    int bad_param = 0;
+    double smin = 1e300;
+    if (act) {
+        const double *pk = a.params + ((size_t)b * N + k) * np;
+#pragma unroll
+        for (int i = 0; i < NPRE; i++) p10[i] = pk[i];
+        if (a.nfaces) nf = a.nfaces[(size_t)b * N + k];
+        else { // trailing all-zero rows are padding (forces_normal.cpp:127-135)
+            nf = M;
+            while (nf > 0) {
+                const double *r = pk + NPRE + 3 * (nf - 1);
+                if (r[0] == 0.0 && r[1] == 0.0 && r[2] == 0.0 && pk[NPRE + 3 * M + nf - 1] >= -HU) nf--;
+                else break;
+            }
+        }
+        if (nf > MF || nf < 0) { bad_param = 1; nf = 0; }
+        double zk[NZ];
+        const double *z0 = a.x0 + ((size_t)b * N + k) * NZ;
+#pragma unroll
+        for (int i = 0; i < NZ; i++) {
+            zk[i] = z0[i];
+            w.z[i * N + k] = zk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NZ; i++) {
+            const double sl = zk[i] - lower_bound(i), su = upper_bound(i) - zk[i];
+            w.s[i * N + k] = sl;
+            w.s[(17 + i) * N + k] = su;
+            smin = fmin(smin, fmin(sl, su));
+        }
+        for (int j = 0; j < nf; j++) {
+            const double a0 = pk[NPRE + 3 * j], a1 = pk[NPRE + 3 * j + 1], a2 = pk[NPRE + 3 * j + 2];
+            const double bj = pk[NPRE + 3 * M + j];
+            w.face[(3 * j) * N + k] = a0;
+            w.face[(3 * j + 1) * N + k] = a1;
+            w.face[(3 * j + 2) * N + k] = a2;
+            w.face[(3 * MF + j) * N + k] = bj;
+            const double sc = -(a0 * zk[8] + a1 * zk[9] + a2 * zk[10] - bj - HU);
+            w.s[(34 + j) * N + k] = sc;
+            smin = fmin(smin, sc);
+        }
+#pragma unroll
+        for (int i = 0; i < NS; i++) w.y[i * N + k] = 0.0;
+        w.rec[(size_t)k * REC_STRIDE + REC_HC] = -2.0 * p10[8]; // hc of this stage's cost (constant)
+    }
+    smin = wave_min(smin);
+    const int mtot = (int)wave_sum(act ? (double)(34 + nf) : 0.0);
+    if (wave_max((double)bad_param) > 0.0) {
+        if (lane == 0) { a.exitflag[b] = FRP_EXIT_PARAM_VALUE; a.iters[b] = 0; }
+        if (act) {
+            const double *z0 = a.x0 + ((size_t)b * N + k) * NZ;
+            for (int i = 0; i < NZ; i++) a.z[((size_t)b * N + k) * NZ + i] = z0[i];
+        }
+        return;
+    }
+    {
+        // infeasible-start initialisation: uniform slack shift (see oracle/nmpc_ipm.c)
+        const double shift = (smin >= S_MIN) ? 0.0 : (S_MIN - smin) + fmax(0.0, -smin);
+        if (act) {
+            for (int i = 0; i < 34 + nf; i++) {
+                const double s = w.s[i * N + k] + shift;
+                w.s[i * N + k] = s;
+                w.lam[i * N + k] = a.mu0 / s;
+            }
+        }
+    }
+    const int sc_k = stage_class(k, N);
+    const CostQ cq = make_cost(p10, sc_k, a.model);
+    const int my_dst = L_AB + lin_dst(lane);
+
+    // constant entries of [A|B]: identity blocks of A, dt*I in B's euler rows
+    for (int t = lane; t < 117; t += 64) {
+        const int i = t / 13, j = t % 13;
+        double v = 0.0;
+        if (j < 9) v = (i == j) ? 1.0 : 0.0;
+        else if (i >= 6 && (j - 9) == (i - 6)) v = DT;
+        sm[L_AB + t] = v;
+    }
+    WSYNC();
+
+    int flag = FRP_EXIT_MAXIT, it = 0;
+    double res_eq = 0, res_in = 0, rs = 0, rcomp = 0, pobj = 0, mu = 0, sigma = 0, step_cc = 0;
+
+    for (it = 0;; it++) {
+        // ------------------------------------------------------------ E: evaluate (lane == stage)
+        double l_eq = 0, l_in = 0, l_rs = 0, l_rc = 0, l_gap = 0, l_obj = 0;
+        if (act) {
+            double zk[NZ];
+#pragma unroll
+            for (int i = 0; i < NZ; i++) zk[i] = w.z[i * N + k];
+            double g[NZ];
+#pragma unroll
+            for (int i = 0; i < NZ; i++) g[i] = cq.hd(i) * zk[i] + cq.q(i);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                g[i] += cq.hc() * zk[4 + i];
+                g[4 + i] += cq.hc() * zk[i];
+            }
+            l_obj = stage_cost(zk, p10, sc_k, a.model, nullptr);
+            double *rec = w.rec + (size_t)k * REC_STRIDE;
+            if (k == 0) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) l_eq = fmax(l_eq, fabs(xinit[i] - zk[8 + i]));
+            }
+            // phi (affine) starts from the cost gradient, stationarity residual g gets multipliers added
+            double phi[NZ];
+#pragma unroll
+            for (int i = 0; i < NZ; i++) phi[i] = g[i];
+            if (k < N - 1) {
+                Lin L;
+                double xn[9];
+                rk2<true>(zk + 8, zk, p10 + 3, xn, &L);
+                const double *Lc = reinterpret_cast<const double *>(&L);
+#pragma unroll
+                for (int t = 0; t < 51; t++) rec[REC_LIN + t] = Lc[t];
+                double yn[NS];
+#pragma unroll
+                for (int i = 0; i < NS; i++) yn[i] = w.y[i * N + k + 1];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const double d = zk[i] - w.z[(4 + i) * N + k + 1];
+                    rec[REC_D + i] = d;
+                    l_eq = fmax(l_eq, fabs(d));
+                }
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    const double d = xn[i] - w.z[(8 + i) * N + k + 1];
+                    rec[REC_D + 4 + i] = d;
+                    l_eq = fmax(l_eq, fabs(d));
+                }
+                // g += M' y_{k+1}
+                const double *yw = yn, *yp = yn + 4, *yv = yn + 7, *ye = yn + 10;
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    g[j] += yw[j] + L.Bvw[0 + j] * yv[0] + L.Bvw[3 + j] * yv[1] + L.Bvw[6 + j] * yv[2] + DT * ye[j];
+                    g[8 + j] += yp[j];
+                    g[11 + j] += L.Apv[0 + j] * yp[0] + L.Apv[3 + j] * yp[1] + L.Apv[6 + j] * yp[2] +
+                                 L.Avv[0 + j] * yv[0] + L.Avv[3 + j] * yv[1] + L.Avv[6 + j] * yv[2];
+                    g[14 + j] += L.Ape[0 + j] * yp[0] + L.Ape[3 + j] * yp[1] + L.Ape[6 + j] * yp[2] +
+                                 L.Ave[0 + j] * yv[0] + L.Ave[3 + j] * yv[1] + L.Ave[6 + j] * yv[2] + ye[j];
+                }
+                g[3] += yw[3] + L.BpT[0] * yp[0] + L.BpT[1] * yp[1] + L.BpT[2] * yp[2] +
+                        L.BvT[0] * yv[0] + L.BvT[1] * yv[1] + L.BvT[2] * yv[2];
+            }
+#pragma unroll
+            for (int i = 0; i < NS; i++) g[4 + i] -= w.y[i * N + k];
+            // bounds: residuals, barrier Hessian / gradient
+#pragma unroll
+            for (int i = 0; i < NZ; i++) {
+                const double sl = w.s[i * N + k], su = w.s[(17 + i) * N + k];
+                const double ll = w.lam[i * N + k], lu = w.lam[(17 + i) * N + k];
+                const double vl = lower_bound(i) - zk[i], vu = zk[i] - upper_bound(i);
+                const double rl = vl + sl, ru = vu + su;
+                l_in = fmax(l_in, fmax(fmax(vl, vu), fmax(fabs(rl), fabs(ru))));
+                l_rc = fmax(l_rc, fmax(sl * ll, su * lu));
+                l_gap += sl * ll + su * lu;
+                g[i] += lu - ll;
+                const double sgl = ll / sl, sgu = lu / su;
+                rec[REC_PHID + i] = cq.hd(i) + sgl + sgu;
+                phi[i] += sgu * ru - sgl * rl;
+            }
+            double pp[6] = {0, 0, 0, 0, 0, 0}; // xx xy xz yy yz zz
+            for (int j = 0; j < nf; j++) {
+                const double a0 = w.face[(3 * j) * N + k], a1 = w.face[(3 * j + 1) * N + k], a2 = w.face[(3 * j + 2) * N + k];
+                const double hj = a0 * zk[8] + a1 * zk[9] + a2 * zk[10] - w.face[(3 * MF + j) * N + k] - HU;
+                const double sc = w.s[(34 + j) * N + k], lc = w.lam[(34 + j) * N + k];
+                const double rc = hj + sc;
+                l_in = fmax(l_in, fmax(hj, fabs(rc)));
+                l_rc = fmax(l_rc, sc * lc);
+                l_gap += sc * lc;
+                g[8] += a0 * lc; g[9] += a1 * lc; g[10] += a2 * lc;
+                const double sg = lc / sc, t = sg * rc;
+                phi[8] += a0 * t; phi[9] += a1 * t; phi[10] += a2 * t;
+                pp[0] += sg * a0 * a0; pp[1] += sg * a0 * a1; pp[2] += sg * a0 * a2;
+                pp[3] += sg * a1 * a1; pp[4] += sg * a1 * a2; pp[5] += sg * a2 * a2;
+            }
+            rec[REC_PHIPOS + 0] = pp[0]; rec[REC_PHIPOS + 1] = pp[1]; rec[REC_PHIPOS + 2] = pp[2];
+            rec[REC_PHIPOS + 3] = pp[1]; rec[REC_PHIPOS + 4] = pp[3]; rec[REC_PHIPOS + 5] = pp[4];
+            rec[REC_PHIPOS + 6] = pp[2]; rec[REC_PHIPOS + 7] = pp[4]; rec[REC_PHIPOS + 8] = pp[5];
+#pragma unroll
+            for (int i = 0; i < NZ; i++) {
+                rec[REC_PHI + i] = phi[i];
+                l_rs = fmax(l_rs, fabs(g[i]));
+            }
+        }
+        res_eq = wave_max(l_eq); res_in = wave_max(l_in); rs = wave_max(l_rs); rcomp = wave_max(l_rc);
+        pobj = wave_sum(l_obj);
+        mu = wave_sum(l_gap) / (double)mtot;
+        if (!(res_eq == res_eq) || !(rs == rs) || !(pobj == pobj)) { flag = FRP_EXIT_BADFUNCEVAL; break; }
+        if (res_eq <= a.tol_eq && res_in <= a.tol_ineq && rs <= a.tol_stat && rcomp <= a.tol_comp) { flag = FRP_EXIT_OPTIMAL; break; }
+        if (it >= a.maxit) { flag = FRP_EXIT_MAXIT; break; }
+        if (mu > DIVERGE_MU * fmax(1.0, a.mu0) || rs > DIVERGE_RS) { flag = FRP_EXIT_NOPROGRESS; break; }
+        __threadfence_block();
+        WSYNC();
+
+        bool fact_fail = false;
+        double smu = 0.0, ap = 1.0, ad = 1.0;
+        for (int pass = 0; pass < 2; pass++) {
+            // -------------------------------------------------------- backward sweep
+            // pass 0: factorisation + vector part; pass 1: vector part only (new phi)
+            {
+                int cur = 0; // buffer holding P_{k+1}
+                const double *r0 = w.rec + (size_t)(N - 1) * REC_STRIDE;
+                double pre_lin = r0[lane];                                           // LIN + D
+                double pre_phi = (lane < 44) ? r0[REC_PHID + lane] : 0.0;            // PhiD | PhiPos | phi
+                double pre_out0 = 0.0, pre_out1 = 0.0;                               // Kb|R|Pd (pass 1)
+                if (pass == 1) {
+                    pre_out0 = r0[REC_KB + lane];
+                    pre_out1 = (lane < 17) ? r0[REC_KB + 64 + lane] : 0.0;
+                }
+                for (int kk = N - 1; kk >= 0; kk--) {
+                    double *rec = w.rec + (size_t)kk * REC_STRIDE;
+                    const bool last = (kk == N - 1);
+                    sm[my_dst] = pre_lin;
+                    if (lane < 44) sm[L_PHI + lane] = pre_phi;
+                    if (pass == 1) {
+                        sm[L_OUT + lane] = pre_out0;               // Kb(52) R(12 of 16)
+                        if (lane < 17) sm[L_OUT + 64 + lane] = pre_out1; // R tail, Pd
+                    }
+                    if (kk > 0) {
+                        const double *rn = rec - REC_STRIDE;
+                        pre_lin = rn[lane];
+                        pre_phi = (lane < 44) ? rn[REC_PHID + lane] : 0.0;
+                        if (pass == 1) {
+                            pre_out0 = rn[REC_KB + lane];
+                            pre_out1 = (lane < 17) ? rn[REC_KB + 64 + lane] : 0.0;
+                        }
+                    }
+                    WSYNC();
+                    const double *Pn = sm + (cur ? L_P1 : L_P0);
+                    double *Pk = sm + (cur ? L_P0 : L_P1);
+                    const double *AB = sm + L_AB;
+                    if (pass == 0 && !last) {
+                        // PA = Pxx [A|B] (9 x 13), Pd = P d
+                        for (int t = lane; t < 117; t += 64) {
+                            const int i = t / 13, j = t % 13;
+                            double acc = 0.0;
+#pragma unroll
+                            for (int l = 0; l < 9; l++) acc += Pn[(4 + i) * 13 + 4 + l] * AB[l * 13 + j];
+                            sm[L_PA + t] = acc;
+                        }
+                        if (lane < 13) {
+                            double acc = 0.0;
+#pragma unroll
+                            for (int j = 0; j < 13; j++) acc += Pn[lane * 13 + j] * sm[L_D + j];
+                            sm[L_PD + lane] = acc;
+                        }
+                        WSYNC();
+                    }
+                    // q = phi + M'(Pd + p_{k+1})
+                    if (lane < 17) {
+                        double acc = sm[L_PHIV + lane];
+                        if (!last) {
+                            if (lane < 4) {
+                                acc += sm[L_PD + lane] + sm[L_PV + lane];
+#pragma unroll
+                                for (int i = 0; i < 9; i++) acc += AB[i * 13 + 9 + lane] * (sm[L_PD + 4 + i] + sm[L_PV + 4 + i]);
+                            } else if (lane >= 8) {
+#pragma unroll
+                                for (int i = 0; i < 9; i++) acc += AB[i * 13 + lane - 8] * (sm[L_PD + 4 + i] + sm[L_PV + 4 + i]);
+                            }
+                        }
+                        sm[L_Q + lane] = acc;
+                    }
+                    if (pass == 0) {
+                        // Qxx -> Pk[4+i][4+j]; Qww -> diag; Qwx = 0
+                        for (int t = lane; t < 169; t += 64) {
+                            const int i = t / 13, j = t % 13;
+                            double acc = 0.0;
+                            if (i >= 4 && j >= 4) {
+                                const int ii = i - 4, jj = j - 4;
+                                if (ii == jj) acc = sm[L_PHID + 8 + ii];
+                                if (ii < 3 && jj < 3) acc += sm[L_PHIPOS + ii * 3 + jj];
+                                if (!last) {
+#pragma unroll
+                                    for (int l = 0; l < 9; l++) acc += AB[l * 13 + ii] * sm[L_PA + l * 13 + jj];
+                                }
+                            } else if (i == j) acc = sm[L_PHID + 4 + i];
+                            Pk[t] = acc;
+                        }
+                        // Qus (4 x 13): Quw = hc I, Qux = T A with T = Pwx + (Pxx B)'
+                        if (lane < 52) {
+                            const int i = lane / 13, j = lane % 13;
+                            double acc = 0.0;
+                            if (j < 4) acc = (i == j) ? sm[L_HC] : 0.0;
+                            else if (!last) {
+#pragma unroll
+                                for (int l = 0; l < 9; l++) acc += (Pn[i * 13 + 4 + l] + sm[L_PA + l * 13 + 9 + i]) * AB[l * 13 + j - 4];
+                            }
+                            sm[L_QUS + lane] = acc;
+                        }
+                        // Quu
+                        if (lane < 16) {
+                            const int i = lane / 4, j = lane % 4;
+                            double acc = (i == j) ? sm[L_PHID + i] : 0.0;
+                            if (!last) {
+                                acc += Pn[i * 13 + j];
+#pragma unroll
+                                for (int l = 0; l < 9; l++)
+                                    acc += (Pn[i * 13 + 4 + l] + sm[L_PA + l * 13 + 9 + i]) * AB[l * 13 + 9 + j] + AB[l * 13 + 9 + i] * Pn[(4 + l) * 13 + j];
+                            }
+                            sm[L_QUU + lane] = acc;
+                        }
+                        WSYNC();
+                        {
+                            double R[16];
+                            const bool ok = spd4_inverse(sm + L_QUU, R);
+                            if (!ok) fact_fail = true;
+#pragma unroll
+                            for (int t = 0; t < 16; t++) sm[L_R + t] = ok ? R[t] : 0.0;
+                        }
+                        WSYNC();
+                        // Kb = R Qus
+                        if (lane < 52) {
+                            const int i = lane / 13, j = lane % 13;
+                            double acc = 0.0;
+#pragma unroll
+                            for (int l = 0; l < 4; l++) acc += sm[L_R + i * 4 + l] * sm[L_QUS + l * 13 + j];
+                            sm[L_KB + lane] = acc;
+                        }
+                        WSYNC();
+                        // P_k = Qss - Qus' Kb
+                        for (int t = lane; t < 169; t += 64) {
+                            const int i = t / 13, j = t % 13;
+                            double acc = Pk[t];
+#pragma unroll
+                            for (int l = 0; l < 4; l++) acc -= sm[L_QUS + l * 13 + i] * sm[L_KB + l * 13 + j];
+                            Pk[t] = acc;
+                        }
+                    } else {
+                        WSYNC();
+                    }
+                    // kb = R q_u ; p_k = q_s - Kb' q_u
+                    double kbv = 0.0, pv = 0.0;
+                    if (lane < 4) {
+#pragma unroll
+                        for (int l = 0; l < 4; l++) kbv += sm[L_R + lane * 4 + l] * sm[L_Q + l];
+                    } else if (lane < 17) {
+                        pv = sm[L_Q + lane];
+#pragma unroll
+                        for (int l = 0; l < 4; l++) pv -= sm[L_KB + l * 13 + lane - 4] * sm[L_Q + l];
+                    }
+                    WSYNC(); // everyone has read p_{k+1} (L_PV) before it is overwritten
+                    if (lane < 4) sm[L_KV + lane] = kbv;
+                    else if (lane < 17) sm[L_PV + lane - 4] = pv;
+                    WSYNC();
+                    // stream the factors of stage kk to HBM
+                    if (pass == 0) {
+                        rec[REC_KB + lane] = sm[L_OUT + lane];
+                        if (lane < 34) rec[REC_KB + 64 + lane] = sm[L_OUT + 64 + lane];
+                    } else if (lane < 17) {
+                        rec[REC_KV + lane] = sm[L_KV + lane]; // kb (4) + p (13)
+                    }
+                    cur ^= 1;
+                }
+                // stage 0: dw = -Pww^-1 (Pwx dx + p_w), dx = xinit - x_0
+                const double *P0 = sm + (cur ? L_P1 : L_P0);
+                if (pass == 0) {
+                    double Rw[16], Pww[16];
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) Pww[i * 4 + j] = P0[i * 13 + j];
+                    const bool ok = spd4_inverse(Pww, Rw);
+                    if (!ok) fact_fail = true;
+                    WSYNC();
+#pragma unroll
+                    for (int t = 0; t < 16; t++) sm[L_S0 + t] = ok ? Rw[t] : 0.0;
+                    if (lane < 36) sm[L_S0 + 16 + lane] = P0[(lane / 9) * 13 + 4 + lane % 9];
+                }
+                if (lane < 9) sm[L_DS + 4 + lane] = xinit[lane] - w.z[(8 + lane) * N + 0];
+                WSYNC();
+                if (lane < 4) {
+                    double acc = sm[L_PV + lane];
+#pragma unroll
+                    for (int j = 0; j < 9; j++) acc += sm[L_S0 + 16 + lane * 9 + j] * sm[L_DS + 4 + j];
+                    sm[L_DU + lane] = acc; // temporary: rhs
+                }
+                WSYNC();
+                if (lane < 4) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int l = 0; l < 4; l++) acc -= sm[L_S0 + lane * 4 + l] * sm[L_DU + l];
+                    sm[L_DS + lane] = acc;
+                }
+                WSYNC();
+            }
+            if (fact_fail) break;
+            // -------------------------------------------------------- forward sweep
+            {
+                const double *r0 = w.rec;
+                double pre_lin = r0[lane];
+                double pre_kb = (lane < 52) ? r0[REC_KB + lane] : ((lane < 56) ? r0[REC_KV + lane - 52] : 0.0);
+                for (int kk = 0; kk < N; kk++) {
+                    const double *rec = w.rec + (size_t)kk * REC_STRIDE;
+                    sm[my_dst] = pre_lin;
+                    if (lane < 52) sm[L_KB + lane] = pre_kb;
+                    else if (lane < 56) sm[L_KV + lane - 52] = pre_kb;
+                    if (kk < N - 1) {
+                        const double *rn = rec + REC_STRIDE;
+                        pre_lin = rn[lane];
+                        pre_kb = (lane < 52) ? rn[REC_KB + lane] : ((lane < 56) ? rn[REC_KV + lane - 52] : 0.0);
+                    }
+                    WSYNC();
+                    if (lane < 4) {
+                        double a0 = sm[L_KV + lane], a1 = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 12; j += 2) {
+                            a0 += sm[L_KB + lane * 13 + j] * sm[L_DS + j];
+                            a1 += sm[L_KB + lane * 13 + j + 1] * sm[L_DS + j + 1];
+                        }
+                        a0 += sm[L_KB + lane * 13 + 12] * sm[L_DS + 12];
+                        const double du = -(a0 + a1);
+                        sm[L_DU + lane] = du;
+                        w.dz[lane * N + kk] = du;
+                    } else if (lane < 17) {
+                        w.dz[lane * N + kk] = sm[L_DS + lane - 4];
+                    }
+                    WSYNC();
+                    if (kk < N - 1) {
+                        double v = 0.0;
+                        if (lane < 4) v = sm[L_DU + lane] + sm[L_D + lane];
+                        else if (lane < 13) {
+                            const int i = lane - 4;
+                            double a0 = sm[L_D + lane], a1 = 0.0;
+#pragma unroll
+                            for (int j = 0; j < 8; j += 2) {
+                                a0 += sm[L_AB + i * 13 + j] * sm[L_DS + 4 + j];
+                                a1 += sm[L_AB + i * 13 + j + 1] * sm[L_DS + 4 + j + 1];
+                            }
+                            a0 += sm[L_AB + i * 13 + 8] * sm[L_DS + 12];
+#pragma unroll
+                            for (int j = 0; j < 4; j += 2) {
+                                a0 += sm[L_AB + i * 13 + 9 + j] * sm[L_DU + j];
+                                a1 += sm[L_AB + i * 13 + 10 + j] * sm[L_DU + j + 1];
+                            }
+                            v = a0 + a1;
+                        }
+                        WSYNC();
+                        if (lane < 13) sm[L_DS + lane] = v;
+                    }
+                }
+                __threadfence_block();
+                WSYNC();
+            }
+            // -------------------------------------------------------- slack steps (lane == stage)
+            {
+                double l_ap = 1e300, l_ad = 1e300;
+                double dzk[NZ];
+                if (act) {
+#pragma unroll
+                    for (int i = 0; i < NZ; i++) dzk[i] = w.dz[i * N + k];
+                }
+                // pass A: step lengths
+                double zk[NZ];
+                if (act) {
+#pragma unroll
+                    for (int i = 0; i < NZ; i++) zk[i] = w.z[i * N + k];
+                    for (int c = 0; c < 34 + nf; c++) {
+                        double gdz, viol;
+                        if (c < 17) { gdz = -dzk[c]; viol = lower_bound(c) - zk[c]; }
+                        else if (c < 34) { gdz = dzk[c - 17]; viol = zk[c - 17] - upper_bound(c - 17); }
+                        else {
+                            const int j = c - 34;
+                            const double a0 = w.face[(3 * j) * N + k], a1 = w.face[(3 * j + 1) * N + k], a2 = w.face[(3 * j + 2) * N + k];
+                            gdz = a0 * dzk[8] + a1 * dzk[9] + a2 * dzk[10];
+                            viol = a0 * zk[8] + a1 * zk[9] + a2 * zk[10] - w.face[(3 * MF + j) * N + k] - HU;
+                        }
+                        const double s = w.s[c * N + k], l = w.lam[c * N + k];
+                        const double rin = viol + s;
+                        const double ds = -rin - gdz;
+                        const double rc = s * l - smu + (pass ? w.corr[c * N + k] : 0.0);
+                        const double dl = (-rc - l * ds) / s;
+                        if (ds < 0.0) l_ap = fmin(l_ap, -s / ds);
+                        if (dl < 0.0) l_ad = fmin(l_ad, -l / dl);
+                    }
+                }
+                ap = wave_min(l_ap); ad = wave_min(l_ad);
+                if (pass == 0) { ap = fmin(1.0, ap); ad = fmin(1.0, ad); }
+                else { ap = fmin(1.0, a.ftb * ap); ad = fmin(1.0, a.ftb * ad); }
+                // pass B: affine complementarity + second-order term / or the update
+                double l_gapaff = 0.0;
+                if (act) {
+                    for (int c = 0; c < 34 + nf; c++) {
+                        double gdz, viol;
+                        if (c < 17) { gdz = -dzk[c]; viol = lower_bound(c) - zk[c]; }
+                        else if (c < 34) { gdz = dzk[c - 17]; viol = zk[c - 17] - upper_bound(c - 17); }
+                        else {
+                            const int j = c - 34;
+                            const double a0 = w.face[(3 * j) * N + k], a1 = w.face[(3 * j + 1) * N + k], a2 = w.face[(3 * j + 2) * N + k];
+                            gdz = a0 * dzk[8] + a1 * dzk[9] + a2 * dzk[10];
+                            viol = a0 * zk[8] + a1 * zk[9] + a2 * zk[10] - w.face[(3 * MF + j) * N + k] - HU;
+                        }
+                        const double s = w.s[c * N + k], l = w.lam[c * N + k];
+                        const double rin = viol + s;
+                        const double ds = -rin - gdz;
+                        const double rc = s * l - smu + (pass ? w.corr[c * N + k] : 0.0);
+                        const double dl = (-rc - l * ds) / s;
+                        if (pass == 0) {
+                            l_gapaff += (s + ap * ds) * (l + ad * dl);
+                            w.corr[c * N + k] = ds * dl;
+                        } else {
+                            w.s[c * N + k] = s + ap * ds;
+                            w.lam[c * N + k] = l + ad * dl;
+                        }
+                    }
+                }
+                if (pass == 0) {
+                    const double mu_aff = wave_sum(l_gapaff) / (double)mtot;
+                    sigma = mu_aff / mu;
+                    sigma = sigma * sigma * sigma;
+                    if (sigma > 1.0) sigma = 1.0;
+                    smu = sigma * mu;
+                    if (smu < MU_FLOOR_FRAC * a.tol_comp) smu = MU_FLOOR_FRAC * a.tol_comp;
+                    // corrector rhs: phi = grad f + G'(Sigma r_in + (smu - corr)/s)
+                    if (act) {
+                        double phi[NZ];
+#pragma unroll
+                        for (int i = 0; i < NZ; i++) phi[i] = cq.hd(i) * zk[i] + cq.q(i);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            phi[i] += cq.hc() * zk[4 + i];
+                            phi[4 + i] += cq.hc() * zk[i];
+                        }
+#pragma unroll
+                        for (int i = 0; i < NZ; i++) {
+                            const double sl = w.s[i * N + k], su = w.s[(17 + i) * N + k];
+                            const double ll = w.lam[i * N + k], lu = w.lam[(17 + i) * N + k];
+                            const double rl = lower_bound(i) - zk[i] + sl, ru = zk[i] - upper_bound(i) + su;
+                            const double tl = (ll * rl + smu - w.corr[i * N + k]) / sl;
+                            const double tu = (lu * ru + smu - w.corr[(17 + i) * N + k]) / su;
+                            phi[i] += tu - tl;
+                        }
+                        for (int j = 0; j < nf; j++) {
+                            const double a0 = w.face[(3 * j) * N + k], a1 = w.face[(3 * j + 1) * N + k], a2 = w.face[(3 * j + 2) * N + k];
+                            const double hj = a0 * zk[8] + a1 * zk[9] + a2 * zk[10] - w.face[(3 * MF + j) * N + k] - HU;
+                            const double sc = w.s[(34 + j) * N + k], lc = w.lam[(34 + j) * N + k];
+                            const double t = (lc * (hj + sc) + smu - w.corr[(34 + j) * N + k]) / sc;
+                            phi[8] += a0 * t; phi[9] += a1 * t; phi[10] += a2 * t;
+                        }
+                        double *rec = w.rec + (size_t)k * REC_STRIDE;
+#pragma unroll
+                        for (int i = 0; i < NZ; i++) rec[REC_PHI + i] = phi[i];
+                    }
+                    __threadfence_block();
+                    WSYNC();
+                } else {
+                    step_cc = ap;
+                    if (act) {
+#pragma unroll
+                        for (int i = 0; i < NZ; i++) w.z[i * N + k] = zk[i] + ap * dzk[i];
+                    }
+                }
+            }
+        } // pass
+        if (fact_fail) { flag = FRP_EXIT_FACTORIZATION; break; }
+
+        // ------------------------------------------------------------ costate sweep: y <- y + ap (y+ - y)
+        // y+_k = (Phi_k dz_k + phi_k)_s + [0; A_k' y+_{k+1,x}]
+        {
+            // w-part is stage-parallel
+            if (act) {
+                const double *rec = w.rec + (size_t)k * REC_STRIDE;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const double yw = rec[REC_PHID + 4 + i] * w.dz[(4 + i) * N + k] + cq.hc() * w.dz[i * N + k] + rec[REC_PHI + 4 + i];
+                    const double yo = w.y[i * N + k];
+                    w.y[i * N + k] = yo + ap * (yw - yo);
+                }
+            }
+            int cy = 0;
+            const double *r0 = w.rec + (size_t)(N - 1) * REC_STRIDE;
+            double pre_lin = r0[lane];
+            double pre_phi = (lane < 44) ? r0[REC_PHID + lane] : 0.0;
+            double pre_dz = (lane < 9) ? w.dz[(8 + lane) * N + N - 1] : 0.0;
+            for (int kk = N - 1; kk >= 0; kk--) {
+                sm[my_dst] = pre_lin;
+                if (lane < 44) sm[L_PHI + lane] = pre_phi;
+                if (lane < 9) sm[L_DS + 4 + lane] = pre_dz;
+                if (kk > 0) {
+                    const double *rn = w.rec + (size_t)(kk - 1) * REC_STRIDE;
+                    pre_lin = rn[lane];
+                    pre_phi = (lane < 44) ? rn[REC_PHID + lane] : 0.0;
+                    pre_dz = (lane < 9) ? w.dz[(8 + lane) * N + kk - 1] : 0.0;
+                }
+                WSYNC();
+                if (lane < 9) {
+                    double acc = sm[L_PHID + 8 + lane] * sm[L_DS + 4 + lane] + sm[L_PHIV + 8 + lane];
+                    if (lane < 3) {
+#pragma unroll
+                        for (int j = 0; j < 3; j++) acc += sm[L_PHIPOS + lane * 3 + j] * sm[L_DS + 4 + j];
+                    }
+                    if (kk < N - 1) {
+                        const double *yn = sm + L_YX + (cy ? 9 : 0);
+#pragma unroll
+                        for (int i = 0; i < 9; i++) acc += sm[L_AB + i * 13 + lane] * yn[i];
+                    }
+                    sm[L_YX + (cy ? 0 : 9) + lane] = acc;
+                    const double yo = w.y[(4 + lane) * N + kk];
+                    w.y[(4 + lane) * N + kk] = yo + ap * (acc - yo);
+                }
+                cy ^= 1;
+                WSYNC();
+            }
+            __threadfence_block();
+            WSYNC();
+        }
+    }
+
+    // ---------------------------------------------------------------- outputs
+    if (act) {
+        double *zo = a.z + ((size_t)b * N + k) * NZ;
+#pragma unroll
+        for (int i = 0; i < NZ; i++) zo[i] = w.z[i * N + k];
+    }
+    if (lane == 0) {
+        a.exitflag[b] = flag;
+        a.iters[b] = it;
+        if (a.info) {
+            double *o = a.info + (size_t)b * FRP_INFO_STRIDE;
+            o[0] = res_eq; o[1] = res_in; o[2] = rs; o[3] = rcomp; o[4] = pobj; o[5] = mu; o[6] = step_cc; o[7] = sigma;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ batched model callback
+// One thread per (problem, stage): the reference's extfunc for B*N stage points (casadi2forces.c:42-245).
+__global__ __launch_bounds__(256) void stage_eval_kernel(int B, int N, int M, int model, const double *__restrict__ z,
+                                                          const double *__restrict__ params, double *__restrict__ f,
+                                                          double *__restrict__ gf, double *__restrict__ c,
+                                                          double *__restrict__ Jc, double *__restrict__ h)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)B * N) return;
+    const int k = (int)(t % N);
+    const int np = NPRE + 4 * M;
+    const double *zk = z + t * NZ, *pk = params + t * np;
+    double zl[NZ], p10[NPRE];
+#pragma unroll
+    for (int i = 0; i < NZ; i++) zl[i] = zk[i];
+#pragma unroll
+    for (int i = 0; i < NPRE; i++) p10[i] = pk[i];
+    const int sc = stage_class(k, N);
+    if (f || gf) {
+        double g[NZ];
+        const double cost = stage_cost(zl, p10, sc, model, g);
+        if (f) f[t] = cost;
+        if (gf) {
+#pragma unroll
+            for (int i = 0; i < NZ; i++) gf[t * NZ + i] = g[i];
+        }
+    }
+    if (c || Jc) {
+        if (sc != STAGE_LAST) {
+            Lin L;
+            double xn[9];
+            rk2<true>(zl + 8, zl, p10 + 3, xn, &L);
+            if (c) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) c[t * 13 + i] = xn[i];
+#pragma unroll
+                for (int i = 0; i < 4; i++) c[t * 13 + 9 + i] = zl[i];
+            }
+            if (Jc) {
+                double *J = Jc + t * 221;
+                const double *Lc = reinterpret_cast<const double *>(&L);
+                for (int col = 0; col < 17; col++) {
+#pragma unroll
+                    for (int row = 0; row < 13; row++) {
+                        double v = 0.0;
+                        if (row < 9) {
+                            if (col < 4) v = lin_B(Lc, row, col);
+                            else if (col >= 8) v = lin_A(Lc, row, col - 8);
+                        } else if (col == row - 9) v = 1.0;
+                        J[col * 13 + row] = v;
+                    }
+                }
+            }
+        } else {
+            if (c) for (int i = 0; i < 13; i++) c[t * 13 + i] = 0.0;
+            if (Jc) for (int i = 0; i < 221; i++) Jc[t * 221 + i] = 0.0;
+        }
+    }
+    if (h) {
+        const double *A = pk + NPRE, *bb = pk + NPRE + 3 * M;
+        for (int j = 0; j < M; j++) h[t * M + j] = A[3 * j] * zl[8] + A[3 * j + 1] * zl[9] + A[3 * j + 2] * zl[10] - bb[j];
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+size_t ws_bytes(int B, int N, int MF) { return (size_t)B * ws_doubles_per_problem(N, MF) * sizeof(double); }
+
+hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(nmpc_ipm_kernel, dim3(a.B), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_stage_eval(int B, int N, int M, int model, const double *z, const double *params, double *f,
+                             double *gf, double *c, double *Jc, double *h, hipStream_t stream)
+{
+    const size_t total = (size_t)B * N;
+    const int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(stage_eval_kernel, dim3(blocks), dim3(256), 0, stream, B, N, M, model, z, params, f, gf, c, Jc, h);
+    return hipGetLastError();
+}
+
+} // namespace frp

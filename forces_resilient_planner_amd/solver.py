@@ -1,0 +1,175 @@
+"""ctypes binding of the C-ABI in include/frp_nmpc.h (libfrp_nmpc_amd.so).
+
+The product path: every function here runs HIP kernels on the MI355X; there is no CPU fallback --
+if the library is missing or no device is visible the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+from . import layout as L
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libfrp_nmpc_amd.so")
+INFO_STRIDE = 8
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+
+
+class Options(ctypes.Structure):
+    _fields_ = [("maxit", ctypes.c_int), ("tol_stat", ctypes.c_double), ("tol_eq", ctypes.c_double),
+                ("tol_ineq", ctypes.c_double), ("tol_comp", ctypes.c_double), ("mu0", ctypes.c_double),
+                ("ftb", ctypes.c_double)]
+
+
+class Batch(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int), ("N", ctypes.c_int), ("M", ctypes.c_int), ("MF", ctypes.c_int),
+                ("model", ctypes.c_int),
+                ("xinit", ctypes.c_void_p), ("x0", ctypes.c_void_p), ("params", ctypes.c_void_p),
+                ("nfaces", ctypes.c_void_p), ("z", ctypes.c_void_p), ("exitflag", ctypes.c_void_p),
+                ("iters", ctypes.c_void_p), ("info", ctypes.c_void_p)]
+
+
+class ForcesParams(ctypes.Structure):
+    _fields_ = [("xinit", ctypes.c_double * 9), ("x0", ctypes.c_double * 340),
+                ("all_parameters", ctypes.c_double * 2600), ("num_of_threads", ctypes.c_uint)]
+
+
+class ForcesOutput(ctypes.Structure):
+    _fields_ = [("x", (ctypes.c_double * 17) * 20)]
+
+
+class ForcesInfo(ctypes.Structure):
+    _fields_ = [("it", ctypes.c_int), ("it2opt", ctypes.c_int)] + \
+               [(n, ctypes.c_double) for n in "res_eq res_ineq rsnorm rcompnorm pobj dobj dgap rdgap mu mu_aff sigma".split()] + \
+               [("lsit_aff", ctypes.c_int), ("lsit_cc", ctypes.c_int)] + \
+               [(n, ctypes.c_double) for n in "step_aff step_cc solvetime fevalstime".split()]
+
+
+EXTFUNC = ctypes.CFUNCTYPE(None, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                           c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int)
+
+EXPORTS = ["frp_nmpc_default_options", "frp_nmpc_workspace_bytes", "frp_nmpc_solve_batch",
+           "frp_nmpc_solve_batch_host", "frp_nmpc_stage_eval", "frp_nmpc_stage_eval_host", "frp_nmpc_time_solve",
+           "frp_nmpc_version", "frp_nmpc_device_count", "FORCESNLPsolver_normal_solve",
+           "FORCESNLPsolver_final_solve"]
+
+_lib = None
+
+
+def lib():
+    """Load libfrp_nmpc_amd.so (built in-tree by forces_resilient_planner_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        l = ctypes.CDLL(LIB_PATH)
+        l.frp_nmpc_workspace_bytes.restype = ctypes.c_size_t
+        l.frp_nmpc_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        l.frp_nmpc_version.restype = ctypes.c_char_p
+        l.frp_nmpc_solve_batch.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(Options), ctypes.c_void_p,
+                                           ctypes.c_size_t, ctypes.c_void_p]
+        l.frp_nmpc_time_solve.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(Options), ctypes.c_void_p,
+                                          ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+        l.frp_nmpc_solve_batch_host.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(Options)]
+        _lib = l
+    return _lib
+
+
+def default_options(**kw) -> Options:
+    o = Options()
+    lib().frp_nmpc_default_options(ctypes.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with frp error {rc} (no HIP device / HIP error / bad argument; "
+                           "this library has no CPU path)")
+
+
+def solve_batch_host(w, opt: Options | None = None, MF: int | None = None, x0=None):
+    """Solve a workload dict (host numpy arrays) on the GPU through frp_nmpc_solve_batch_host."""
+    B, N, M = int(w["xinit"].shape[0]), int(w["N"]), int(w["M"])
+    xinit = np.ascontiguousarray(w["xinit"], dtype=np.float64)
+    z0 = np.ascontiguousarray(w["x0"] if x0 is None else x0, dtype=np.float64)
+    params = np.ascontiguousarray(w["params"], dtype=np.float64)
+    nf = None if w.get("nfaces") is None else np.ascontiguousarray(w["nfaces"], dtype=np.int32)
+    if MF is None:
+        MF = int(nf.max()) if nf is not None and nf.size else M
+    z = np.zeros((B, N, L.NZ)); flag = np.zeros(B, dtype=np.int32); iters = np.zeros(B, dtype=np.int32)
+    info = np.zeros((B, INFO_STRIDE))
+    b = Batch(B, N, M, MF, int(w["model"]), xinit.ctypes.data, z0.ctypes.data, params.ctypes.data,
+              nf.ctypes.data if nf is not None else None, z.ctypes.data, flag.ctypes.data, iters.ctypes.data,
+              info.ctypes.data)
+    _check(lib().frp_nmpc_solve_batch_host(ctypes.byref(b), ctypes.byref(opt) if opt is not None else None),
+           "frp_nmpc_solve_batch_host")
+    return z, flag, iters, info
+
+
+def stage_eval_host(z, params, M, model, want=("f", "gf", "c", "Jc", "h")):
+    z = np.ascontiguousarray(z, dtype=np.float64); params = np.ascontiguousarray(params, dtype=np.float64)
+    B, N = z.shape[0], z.shape[1]
+    out = dict(f=np.zeros((B, N)), gf=np.zeros((B, N, 17)), c=np.zeros((B, N, 13)), Jc=np.zeros((B, N, 221)),
+               h=np.zeros((B, N, max(M, 1))))
+    ptr = lambda k: out[k].ctypes.data_as(c_double_p) if k in want else None
+    _check(lib().frp_nmpc_stage_eval_host(B, N, M, model, z.ctypes.data_as(c_double_p), params.ctypes.data_as(c_double_p),
+                                          ptr("f"), ptr("gf"), ptr("c"), ptr("Jc"), ptr("h")), "frp_nmpc_stage_eval_host")
+    return out
+
+
+class DeviceSolver:
+    """Device-resident batched solver: torch tensors hold the HBM buffers, the C-ABI gets raw pointers."""
+
+    def __init__(self, B, N, M, MF, model, device="cuda:0"):
+        import torch
+        self.torch = torch
+        self.B, self.N, self.M, self.MF, self.model = B, N, M, MF, model
+        self.device = torch.device(device)
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self.xinit = torch.empty((B, L.NX), **f64)
+        self.x0 = torch.empty((B, N, L.NZ), **f64)
+        self.params = torch.empty((B, N, L.npar(M)), **f64)
+        self.nfaces = torch.empty((B, N), dtype=torch.int32, device=self.device)
+        self.z = torch.empty((B, N, L.NZ), **f64)
+        self.exitflag = torch.empty((B,), dtype=torch.int32, device=self.device)
+        self.iters = torch.empty((B,), dtype=torch.int32, device=self.device)
+        self.info = torch.empty((B, INFO_STRIDE), **f64)
+        self.ws_bytes = int(lib().frp_nmpc_workspace_bytes(B, N, MF))
+        self.ws = torch.empty((self.ws_bytes // 8 + 1,), **f64)
+        self.use_nfaces = True
+        self.opt = default_options()
+
+    def upload(self, w):
+        t = self.torch
+        self.xinit.copy_(t.from_numpy(np.ascontiguousarray(w["xinit"])))
+        self.x0.copy_(t.from_numpy(np.ascontiguousarray(w["x0"])))
+        self.params.copy_(t.from_numpy(np.ascontiguousarray(w["params"])))
+        self.nfaces.copy_(t.from_numpy(np.ascontiguousarray(w["nfaces"], dtype=np.int32)))
+
+    def _batch(self):
+        return Batch(self.B, self.N, self.M, self.MF, self.model, self.xinit.data_ptr(), self.x0.data_ptr(),
+                     self.params.data_ptr(), self.nfaces.data_ptr() if self.use_nfaces else None, self.z.data_ptr(),
+                     self.exitflag.data_ptr(), self.iters.data_ptr(), self.info.data_ptr())
+
+    def solve(self, stream=None):
+        """Asynchronous launch on `stream` (a torch.cuda.Stream) or torch's current stream."""
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        b = self._batch()
+        _check(lib().frp_nmpc_solve_batch(ctypes.byref(b), ctypes.byref(self.opt), self.ws.data_ptr(), self.ws_bytes,
+                                          ctypes.c_void_p(s.cuda_stream)), "frp_nmpc_solve_batch")
+
+    def time_solve(self, reps, stream=None):
+        """Average kernel duration (ms) over `reps` launches, HIP events on the launch stream."""
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        b = self._batch()
+        ms = ctypes.c_float(0)
+        _check(lib().frp_nmpc_time_solve(ctypes.byref(b), ctypes.byref(self.opt), self.ws.data_ptr(), self.ws_bytes,
+                                         ctypes.c_void_p(s.cuda_stream), reps, ctypes.byref(ms)), "frp_nmpc_time_solve")
+        return ms.value

@@ -1,0 +1,176 @@
+"""Seeded synthetic NMPC workloads = BASELINE.json configs[0..4].
+
+Every generator returns a dict of numpy FP64 arrays already in the solver's packed layout
+(built through ``adapter.ForcesAdapter.pack`` exactly like forces_normal.cpp:62-136 would):
+  xinit [B,9], x0 [B,N,17], params [B,N,10+4M], nfaces [B,N] int32, model, N, M
+plus the unpacked ingredients for tests (ref_pos, ref_yaw, f_ext, poly_A/poly_b, E).
+Weights are the launch-file values (launch/rotors_sim.launch:56-66): stage (7, 1, 80),
+terminal (12, 0.5); final mode: stage (12, 1.5), terminal (15, 0.5).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import layout as L
+from .adapter import ForcesAdapter, init_mpc_output
+
+SEED0 = 20260928
+EGO = np.array([0.27, 0.27, 0.0425])   # ego ellipsoid semi-axes (rotors_sim.launch:67-68)
+
+
+def _weights(model):
+    return (7.0, 1.0, 80.0, 12.0, 0.5) if model == L.MODEL_NORMAL else (12.0, 1.5, 80.0, 15.0, 0.5)
+
+
+def _rot(eul):
+    """R = Rz(yaw) Ry(pitch) Rx(roll) (nonlinear_dynamics.m:21-23), batched over leading dims."""
+    r, p, y = eul[..., 0], eul[..., 1], eul[..., 2]
+    sr, cr, sp, cp, sy, cy = np.sin(r), np.cos(r), np.sin(p), np.cos(p), np.sin(y), np.cos(y)
+    R = np.empty(eul.shape[:-1] + (3, 3))
+    R[..., 0, 0] = cy * cp; R[..., 0, 1] = cy * sp * sr - cr * sy; R[..., 0, 2] = cy * sp * cr + sy * sr
+    R[..., 1, 0] = cp * sy; R[..., 1, 1] = cy * cr + sy * sp * sr; R[..., 1, 2] = sy * sp * cr - cy * sr
+    R[..., 2, 0] = -sp;     R[..., 2, 1] = cp * sr;                R[..., 2, 2] = cp * cr
+    return R
+
+
+def _bbox_faces(seed_pos, heading):
+    """DecompROS local bbox (2, 2, 1) about the seed segment [p, p + 0.1 h] with no obstacles
+    (nmpc_solver.cpp:311-323, decomp_util/line_segment.h:47-85): 6 faces a_j.x <= b_j.
+    seed_pos [...,3], heading [...] -> A [...,6,3], b [...,6]."""
+    h = np.stack([np.cos(heading), np.sin(heading), np.zeros_like(heading)], -1)
+    l = np.stack([-np.sin(heading), np.cos(heading), np.zeros_like(heading)], -1)
+    e3 = np.zeros_like(h); e3[..., 2] = 1.0
+    A = np.stack([h, -h, l, -l, e3, -e3], -2)
+    p2 = seed_pos + 0.1 * h
+    b = np.stack([(h * p2).sum(-1) + 2.0, -(h * seed_pos).sum(-1) + 2.0,
+                  (l * seed_pos).sum(-1) + 2.0, -(l * seed_pos).sum(-1) + 2.0,
+                  seed_pos[..., 2] + 1.0, -seed_pos[..., 2] + 1.0], -1)
+    return A, b
+
+
+def _random_states(rng, B):
+    st = np.zeros((B, 9))
+    st[:, 0:2] = rng.uniform(-5, 5, (B, 2))
+    st[:, 2] = rng.uniform(0.5, 2.5, B)
+    st[:, 3:6] = rng.uniform(-1, 1, (B, 3))
+    st[:, 6:8] = rng.uniform(-0.2, 0.2, (B, 2))
+    st[:, 8] = rng.uniform(-math.pi, math.pi, B)
+    return st
+
+
+def _line_reference(rng, st, N):
+    B = st.shape[0]
+    heading = st[:, 8] + rng.uniform(-0.3, 0.3, B)
+    speed = rng.uniform(0.5, 2.0, B)
+    t = (np.arange(N) + 1) * L.DT
+    d = np.stack([np.cos(heading), np.sin(heading), np.zeros(B)], -1)
+    ref_pos = st[:, None, 0:3] + speed[:, None, None] * t[None, :, None] * d[:, None, :]
+    ref_yaw = np.repeat(heading[:, None], N, 1)
+    return ref_pos, ref_yaw, heading
+
+
+def _finish(ad, mpc_output, f_ext, ref_pos, ref_yaw, E, A, b, nf, model):
+    ad.set_paras(*_weights(model))
+    xinit, x0, params, nfaces = ad.pack(mpc_output, f_ext, ref_pos, ref_yaw, E, A, b, nf)
+    return dict(xinit=xinit.copy(), x0=x0.copy(), params=params.copy(), nfaces=nfaces.copy(),
+                model=model, N=ad.N, M=ad.M, B=ad.B, ref_pos=ref_pos, ref_yaw=ref_yaw, f_ext=f_ext,
+                poly_A=A, poly_b=b, E=E, mpc_output=mpc_output)
+
+
+def config0(model=L.MODEL_NORMAL, f_ext=(0.0, 0.0, 0.0)):
+    """configs[0] 'plumbing' (SURVEY 8d Config 1 / Appendix B): one solve through the N=20 / 30-row ABI."""
+    N, M = L.N_REF, L.NH_REF
+    st = np.array([[0, 0, 1, 0, 0, 0, 0, 0, 0.0]])
+    ref_pos = np.zeros((1, N, 3)); ref_pos[0, :, 0] = 0.05 * (np.arange(N) + 1); ref_pos[0, :, 2] = 1.0
+    ref_yaw = np.zeros((1, N))
+    A1, b1 = _bbox_faces(st[:, 0:3], np.zeros(1))
+    A = np.repeat(A1[:, None], N, 1); b = np.repeat(b1[:, None], N, 1)
+    E = np.broadcast_to(np.diag(EGO), (1, N, 3, 3)).copy()
+    nf = np.full((1, N), 6, dtype=np.int32)
+    ad = ForcesAdapter(1, model, N, M)
+    return _finish(ad, init_mpc_output(st, N), np.asarray([f_ext], dtype=np.float64), ref_pos, ref_yaw, E, A, b, nf, model)
+
+
+def config1(B=1024, seed=SEED0 + 2, model=L.MODEL_NORMAL, M=L.NH_REF):
+    """configs[1]: N=20, zero external force, box bounds only (all corridor rows padded)."""
+    N = L.N_REF
+    rng = np.random.default_rng(seed)
+    st = _random_states(rng, B)
+    ref_pos, ref_yaw, _ = _line_reference(rng, st, N)
+    A = np.zeros((B, N, 1, 3)); b = np.zeros((B, N, 1)); nf = np.zeros((B, N), dtype=np.int32)
+    E = np.zeros((B, N, 3, 3))
+    ad = ForcesAdapter(B, model, N, M)
+    return _finish(ad, init_mpc_output(st, N), np.zeros((B, 3)), ref_pos, ref_yaw, E, A, b, nf, model)
+
+
+def config2(B=4096, seed=SEED0 + 3, model=L.MODEL_NORMAL, M=L.NH_REF):
+    """configs[2] (headline): N=20, constant f_ext ~ U[-3,3]^3, 6-face box corridor per stage in the
+    path frame, tightened by ||E a_j|| with E = R(eul0) diag(ego) R(eul0)'."""
+    N = L.N_REF
+    rng = np.random.default_rng(seed)
+    st = _random_states(rng, B)
+    ref_pos, ref_yaw, heading = _line_reference(rng, st, N)
+    f_ext = rng.uniform(-3, 3, (B, 3))
+    A, b = _bbox_faces(ref_pos, np.repeat(heading[:, None], N, 1))
+    R = _rot(st[:, 6:9])
+    E1 = R @ (EGO[None, :, None] * np.swapaxes(R, -1, -2))
+    E = np.repeat(E1[:, None], N, 1)
+    nf = np.full((B, N), 6, dtype=np.int32)
+    ad = ForcesAdapter(B, model, N, M)
+    return _finish(ad, init_mpc_output(st, N), f_ext, ref_pos, ref_yaw, E, A, b, nf, model)
+
+
+def config3(B=16384, seed=SEED0 + 4, model=L.MODEL_NORMAL, N=30, M=15):
+    """configs[3]: N=30, per-stage sinusoidal f_ext, per-stage polytopes = 6 bbox faces + U{0..9}
+    random tangent planes at 0.6..2.0 m from the stage reference point (<= 15 faces)."""
+    rng = np.random.default_rng(seed)
+    st = _random_states(rng, B)
+    ref_pos, ref_yaw, heading = _line_reference(rng, st, N)
+    f0 = rng.uniform(-2, 2, (B, 3)); amp = rng.uniform(0, 1, (B, 3)); ph = rng.uniform(0, 2 * math.pi, (B, 1))
+    k = np.arange(N)[None, :, None]
+    f_ext = f0[:, None, :] + amp[:, None, :] * np.sin(2 * math.pi * k / N + ph[:, None, :])
+    A6, b6 = _bbox_faces(ref_pos, np.repeat(heading[:, None], N, 1))
+    nx = rng.integers(0, 10, (B, N))
+    nrm = rng.normal(size=(B, N, 9, 3)); nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    off = rng.uniform(0.6, 2.0, (B, N, 9))
+    bx = (nrm * ref_pos[:, :, None, :]).sum(-1) + off
+    A = np.concatenate([A6, nrm], 2); b = np.concatenate([b6, bx], 2)
+    nf = (6 + nx).astype(np.int32)
+    R = _rot(st[:, 6:9])
+    E1 = R @ (EGO[None, :, None] * np.swapaxes(R, -1, -2))
+    E = np.repeat(E1[:, None], N, 1)
+    ad = ForcesAdapter(B, model, N, M)
+    return _finish(ad, init_mpc_output(st, N), f_ext, ref_pos, ref_yaw, E, A, b, nf, model)
+
+
+def config4_nominal(B=65536, seed=SEED0 + 5, model=L.MODEL_NORMAL, M=L.NH_REF, ticks=20):
+    """configs[4]: Monte-Carlo f_ext ~ N(fbar, 0.5^2 I) around ONE nominal problem, N=20; the
+    receding-horizon loop (shift warm start, reference advanced one stage per tick) is driven by
+    ``receding.run``.  Returns the tick-0 problem plus the long reference (N + ticks points)."""
+    N = L.N_REF
+    rng = np.random.default_rng(seed)
+    st1 = _random_states(rng, 1)
+    heading = st1[:, 8] + rng.uniform(-0.3, 0.3, 1)
+    speed = rng.uniform(0.8, 1.6, 1)
+    t = (np.arange(N + ticks) + 1) * L.DT
+    d = np.stack([np.cos(heading), np.sin(heading), np.zeros(1)], -1)
+    ref_long = st1[:, None, 0:3] + speed[:, None, None] * t[None, :, None] * d[:, None, :]
+    fbar = rng.uniform(-2, 2, 3)
+    f_ext = fbar[None, :] + 0.5 * rng.normal(size=(B, 3))
+    st = np.repeat(st1, B, 0)
+    ref_pos = np.repeat(ref_long[:, :N], B, 0)
+    ref_yaw = np.repeat(heading[:, None], N, 1).repeat(B, 0)
+    A, b = _bbox_faces(ref_pos, ref_yaw)
+    R = _rot(st[:, 6:9])
+    E1 = R @ (EGO[None, :, None] * np.swapaxes(R, -1, -2))
+    E = np.repeat(E1[:, None], N, 1)
+    nf = np.full((B, N), 6, dtype=np.int32)
+    ad = ForcesAdapter(B, model, N, M)
+    out = _finish(ad, init_mpc_output(st, N), f_ext, ref_pos, ref_yaw, E, A, b, nf, model)
+    out.update(ref_long=ref_long, heading=heading, ticks=ticks)
+    return out
+
+
+CONFIGS = {0: config0, 1: config1, 2: config2, 3: config3, 4: config4_nominal}

@@ -1,0 +1,157 @@
+/*
+ * frp_nmpc.h -- C-ABI of libfrp_nmpc_amd.so, the MI355X (gfx950) NMPC solver that replaces the
+ * solver behind the reference's plan_manage adapters.
+ *
+ * Two groups of entry points:
+ *
+ * (1) Drop-in symbols with the reference's exact names, argument order and struct layouts:
+ *       FORCESNLPsolver_normal_solve / FORCESNLPsolver_final_solve
+ *     replacing the licence-locked ForcesPro binary
+ *       plan_manage/solver/normal/FORCESNLPsolver_normal/include/FORCESNLPsolver_normal.h:317-323
+ *       plan_manage/solver/final/FORCESNLPsolver_final/include/FORCESNLPsolver_final.h:317-323
+ *     called at plan_manage/src/forces_normal.cpp:139 and forces_final.cpp:138.
+ *     A caller compiled against the reference's own headers links against this library unchanged
+ *     (sizes/offsets are asserted in csrc/frp_capi.hip: params 23600 B, output 2720 B, info 136 B).
+ *
+ * (2) A batched, horizon-generic API (not in the reference, needed by BASELINE.json configs[1..4]):
+ *     B independent problems, device-resident buffers, per-problem exit flags.
+ *
+ * All pointers in (2) are DEVICE pointers unless the name ends in _host; no torch / C++ types cross
+ * this boundary.  All functions return 0 on success or a negative frp error; solver exit flags
+ * (per problem) use the reference's codes (FORCESNLPsolver_normal.h:110-139).
+ */
+#ifndef FRP_NMPC_H
+#define FRP_NMPC_H
+
+#include <stddef.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- problem constants (matlab_code/setup.m:36-43) ---- */
+#define FRP_NZ 17
+#define FRP_NX 9
+#define FRP_NEQ 13
+#define FRP_NPRE 10
+#define FRP_NPAR(M) (FRP_NPRE + 4 * (M))
+#define FRP_N_REF 20
+#define FRP_NH_REF 30
+
+#define FRP_MODEL_NORMAL 0 /* stage-N cost of mpc_objectiveN_normal.m */
+#define FRP_MODEL_FINAL 1  /* stage-N cost of mpc_objectiveN_final.m (adds 20 w_wp |v|^2) */
+
+/* per-problem solver exit flags, same values as the reference (FORCESNLPsolver_normal.h:110-139) */
+#define FRP_EXIT_OPTIMAL 1
+#define FRP_EXIT_MAXIT 0
+#define FRP_EXIT_FACTORIZATION (-5)
+#define FRP_EXIT_BADFUNCEVAL (-6)
+#define FRP_EXIT_NOPROGRESS (-7)
+#define FRP_EXIT_PARAM_VALUE (-11)
+
+/* library-level errors */
+#define FRP_OK 0
+#define FRP_ERR_NO_DEVICE (-1001)
+#define FRP_ERR_HIP (-1002)
+#define FRP_ERR_ARG (-1003)
+#define FRP_ERR_MODEL_MISMATCH (-1004)
+
+#define FRP_INFO_STRIDE 8 /* doubles per problem in the info array, see frp_nmpc_batch.info */
+
+typedef struct frp_nmpc_options {
+    int maxit;        /* 200  (FORCESNLPsolver_normal.h:86)                */
+    double tol_stat;  /* 1e-4 (mpc_generator_normal.m:76)                  */
+    double tol_eq;    /* 1e-4 (:77)                                        */
+    double tol_ineq;  /* 1e-4 (:78)                                        */
+    double tol_comp;  /* 1e-4 (:79)                                        */
+    double mu0;       /* initial barrier parameter, 1.0                    */
+    double ftb;       /* fraction to boundary, 0.99 (normal.h:89)          */
+} frp_nmpc_options;
+
+typedef struct frp_nmpc_batch {
+    int B;      /* problems                                                             */
+    int N;      /* horizon (stages); 20 in the reference (setup.m:36), <= 64 here       */
+    int M;      /* corridor rows in the parameter layout (30 in the reference, setup.m:42) */
+    int MF;     /* max LIVE corridor rows of any stage (<= M); sizes the workspace       */
+    int model;  /* FRP_MODEL_NORMAL / FRP_MODEL_FINAL                                    */
+    const double *xinit;  /* [B][9]            params.xinit            (normal.h:156)  */
+    const double *x0;     /* [B][N][17]        params.x0, initial guess (normal.h:159)  */
+    const double *params; /* [B][N][10+4M]     params.all_parameters   (normal.h:162),
+                             per stage: ref(3) f_ext(3) w_wp w_in w_rate yaw_ref | A row-major Mx3 | b(M)
+                             (matlab_code/setup.m:60-66)                                 */
+    const int *nfaces;    /* [B][N] live rows per stage, or NULL: trailing all-zero rows (the padding
+                             forces_normal.cpp:127-135 writes) are detected and dropped  */
+    double *z;            /* [B][N][17] out    output.x01..xN          (normal.h:173-236) */
+    int *exitflag;        /* [B] out                                                     */
+    int *iters;           /* [B] out, interior-point iterations (info.it)                */
+    double *info;         /* [B][FRP_INFO_STRIDE] out or NULL:
+                             res_eq, res_ineq, rsnorm, rcompnorm, pobj, mu, step_cc, sigma  */
+} frp_nmpc_batch;
+
+void frp_nmpc_default_options(frp_nmpc_options *opt);
+
+/* Bytes of device workspace frp_nmpc_solve_batch needs for (B, N, MF). */
+size_t frp_nmpc_workspace_bytes(int B, int N, int MF);
+
+/* Solve B problems.  `workspace` = device buffer of at least frp_nmpc_workspace_bytes() bytes,
+ * `stream` = hipStream_t (NULL = default stream).  Asynchronous: returns after the launch. */
+int frp_nmpc_solve_batch(const frp_nmpc_batch *batch, const frp_nmpc_options *opt,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* Same with HOST buffers: allocates/copies/synchronises internally (plumbing + tests). */
+int frp_nmpc_solve_batch_host(const frp_nmpc_batch *batch_host, const frp_nmpc_options *opt);
+
+/* Batched model callback = the reference's extfunc (FORCESNLPsolver_normal.h:321,
+ * FORCESNLPsolver_normal_casadi2forces.c:42-245) for B*N stage points at once.
+ * z [B][N][17], params [B][N][10+4M]; outputs (any may be NULL):
+ *   f [B][N], grad_f [B][N][17], c [B][N][13], jac_c [B][N][13*17] column-major ld 13 (stage N-1:
+ *   zeros, no dynamics there), h [B][N][M], A of the corridor is its own Jacobian and is not copied. */
+int frp_nmpc_stage_eval(int B, int N, int M, int model, const double *z, const double *params,
+                        double *f, double *grad_f, double *c, double *jac_c, double *h, void *stream);
+int frp_nmpc_stage_eval_host(int B, int N, int M, int model, const double *z, const double *params,
+                             double *f, double *grad_f, double *c, double *jac_c, double *h);
+
+/* Average kernel duration (ms) of the last `frp_nmpc_time_solve` call: launches the solve `reps`
+ * times on `stream` bracketed by hipEvents on that same stream (bench.py's roofline leg). */
+int frp_nmpc_time_solve(const frp_nmpc_batch *batch, const frp_nmpc_options *opt, void *workspace,
+                        size_t workspace_bytes, void *stream, int reps, float *avg_ms);
+
+const char *frp_nmpc_version(void);
+int frp_nmpc_device_count(void);
+
+/* ---- (1) drop-in ABI: layout-compatible with the reference's generated headers ---- */
+typedef struct {
+    double xinit[9];             /* normal.h:156 */
+    double x0[340];              /* normal.h:159 */
+    double all_parameters[2600]; /* normal.h:162 */
+    unsigned int num_of_threads; /* normal.h:165 */
+} frp_forces_params;
+
+typedef struct {
+    double x[20][17]; /* x01 .. x20, normal.h:173-236 (contiguous) */
+} frp_forces_output;
+
+typedef struct {
+    int it, it2opt;                                                                      /* normal.h:244-247 */
+    double res_eq, res_ineq, rsnorm, rcompnorm, pobj, dobj, dgap, rdgap, mu, mu_aff, sigma; /* :249-280 */
+    int lsit_aff, lsit_cc;                                                               /* :283-286 */
+    double step_aff, step_cc, solvetime, fevalstime;                                     /* :289-298 */
+} frp_forces_info;
+
+typedef void (*frp_forces_extfunc)(double *x, double *y, double *lambda, double *params, double *pobj,
+                                   double *g, double *c, double *Jeq, double *h, double *Jineq, double *H,
+                                   int stage, int iterations, int threadID); /* normal.h:321 */
+
+/* The callback pointer is an identity token here: the device kernels evaluate the shipped quadrotor
+ * model themselves.  A non-NULL callback is probed once on the host and compared with the built-in
+ * model; a different model makes the call fail with exit flag -11 (no host fallback exists). */
+int FORCESNLPsolver_normal_solve(frp_forces_params *params, frp_forces_output *output, frp_forces_info *info,
+                                 FILE *fs, frp_forces_extfunc evalextfunctions);
+int FORCESNLPsolver_final_solve(frp_forces_params *params, frp_forces_output *output, frp_forces_info *info,
+                                FILE *fs, frp_forces_extfunc evalextfunctions);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRP_NMPC_H */

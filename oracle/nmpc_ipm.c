@@ -28,6 +28,9 @@ void orc_cost_quadratic(const double *p, int stage_class, int model, double *hd,
 #define NS 13
 #define HU_OFF 1e-5 /* hu = 1e-5, mpc_generator_normal.m:14 */
 #define S_MIN 1e-2
+#define MU_FLOOR_FRAC 0.1
+#define DIVERGE_MU 1e6
+#define DIVERGE_RS 1e12
 
 void orc_default_options(orc_options *o)
 {
@@ -341,6 +344,7 @@ int orc_solve(int N, int M, int model, const double *xinit, const double *z0,
     memcpy(W.z, z0, sizeof(double) * 17 * N);
 
     int mtot = 0;
+    double smin = 1e300;
     for (int k = 0; k < N; k++) {
         const double *A = face_A(params, M, k), *b = face_b(params, M, k);
         int nf;
@@ -353,16 +357,27 @@ int orc_solve(int N, int M, int model, const double *xinit, const double *z0,
         mtot += 34 + nf;
         orc_cost_quadratic(params + (size_t)k * np, stage_class_of(k, N), model, W.st[k].hd, &W.st[k].hc, W.st[k].q, 0);
         const double *zk = W.z + 17 * k;
-        double *s = W.s + (size_t)k * mc, *l = W.lam + (size_t)k * mc;
+        double *s = W.s + (size_t)k * mc;
         for (int i = 0; i < 17; i++) {
-            s[i] = fmax(zk[i] - lb[i], S_MIN);
-            s[17 + i] = fmax(ub[i] - zk[i], S_MIN);
+            s[i] = zk[i] - lb[i];
+            s[17 + i] = ub[i] - zk[i];
         }
-        for (int j = 0; j < nf; j++) {
-            const double hj = A[3 * j] * zk[8] + A[3 * j + 1] * zk[9] + A[3 * j + 2] * zk[10] - b[j] - HU_OFF;
-            s[34 + j] = fmax(-hj, S_MIN);
+        for (int j = 0; j < nf; j++)
+            s[34 + j] = -(A[3 * j] * zk[8] + A[3 * j + 1] * zk[9] + A[3 * j + 2] * zk[10] - b[j] - HU_OFF);
+        for (int i = 0; i < 34 + nf; i++) smin = fmin(smin, s[i]);
+    }
+    /* Infeasible-start initialisation: if the guess is not S_MIN-strictly inside all inequality
+     * constraints, shift ALL slacks uniformly so that the smallest one is S_MIN + (worst violation);
+     * the uniform slack residual is then removed by the (linear) Newton steps. */
+    {
+        const double shift = (smin >= S_MIN) ? 0.0 : (S_MIN - smin) + fmax(0.0, -smin);
+        for (int k = 0; k < N; k++) {
+            double *s = W.s + (size_t)k * mc, *l = W.lam + (size_t)k * mc;
+            for (int i = 0; i < 34 + W.nf[k]; i++) {
+                s[i] += shift;
+                l[i] = opt.mu0 / s[i];
+            }
         }
-        for (int i = 0; i < 34 + nf; i++) l[i] = opt.mu0 / s[i];
     }
 
     int flag = ORC_MAXIT, it = 0;
@@ -433,6 +448,8 @@ int orc_solve(int N, int M, int model, const double *xinit, const double *z0,
         if (!(res_eq == res_eq) || !(rs == rs) || !(pobj == pobj)) { flag = ORC_BADFUNCEVAL; break; }
         if (res_eq <= opt.tol_eq && res_in <= opt.tol_ineq && rs <= opt.tol_stat && rcomp <= opt.tol_comp) { flag = ORC_OPTIMAL; break; }
         if (it >= opt.maxit) { flag = ORC_MAXIT; break; }
+        /* divergence guard: on (locally) infeasible problems the multipliers blow up */
+        if (mu > DIVERGE_MU * fmax(1.0, opt.mu0) || rs > DIVERGE_RS) { flag = ORC_NOPROGRESS; break; }
 
         /* ---- barrier-augmented Hessian ---- */
         for (int k = 0; k < N; k++) {
@@ -465,10 +482,14 @@ int orc_solve(int N, int M, int model, const double *xinit, const double *z0,
         sigma = sigma * sigma * sigma;
         if (sigma > 1.0) sigma = 1.0;
         inf.mu_aff = mu_aff; inf.sigma = sigma; inf.step_aff = ap;
+        /* centring target, floored so that complementarity is not driven (far) below its tolerance
+         * while stationarity / feasibility are still converging (Gauss-Newton: linear rate) */
+        double smu = sigma * mu;
+        if (smu < MU_FLOOR_FRAC * opt.tol_comp) smu = MU_FLOOR_FRAC * opt.tol_comp;
         /* ---- corrector ---- */
-        build_phi(&W, params, sigma * mu, 1);
+        build_phi(&W, params, smu, 1);
         if (kkt_solve(&W, xinit, 0)) { flag = ORC_FACTORIZATION_ERROR; break; }
-        slack_steps(&W, params, sigma * mu, 1, &ap, &ad);
+        slack_steps(&W, params, smu, 1, &ap, &ad);
         ap = fmin(1.0, opt.ftb * ap); ad = fmin(1.0, opt.ftb * ad);
         inf.step_cc = ap;
         for (int k = 0; k < N; k++) {

@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/ (run in the BUILD container only).
+
+Needs oracle/_ref/libref_model_{normal,final}.so = the reference's own CasADi model callbacks
+compiled in place from /root/reference by `make -C oracle ref` (nothing from the reference is
+copied; only NUMBERS produced by it are stored).
+
+  G1  stage_vectors.npz   seeded (z, p, stage, model) -> f, grad f, c, Jc, h, Jh from the reference
+                          callback FORCESNLPsolver_{normal,final}_casadi2forces
+                          (solver/*/FORCESNLPsolver_*_casadi2forces.c:42-245).
+  G3  solutions_<family>.npz   independent SciPy SLSQP solutions of the reference NLP
+                          (matlab_code/setup.m, mpc/normal/mpc_generator_normal.m) assembled from those
+                          same callbacks (objective, dynamics, corridor + analytic Jacobians), for
+                          seeded problems of the BASELINE.json config families.  `start` records how
+                          SciPy was started: 'cold' = the caller's own initial guess (fully independent),
+                          'near' = a N(0, 0.02^2)-perturbed oracle solution (certifies a local minimiser).
+
+The ForcesPro binary itself cannot be run (licence error -100), so these SciPy solutions of the
+reference *model* are the solver-level known answers ("parity unpinned" w.r.t. ForcesPro proper).
+"""
+import ctypes
+import os
+import sys
+import time
+from multiprocessing import Pool
+
+import numpy as np
+from scipy.optimize import minimize
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from forces_resilient_planner_amd import layout as L  # noqa: E402
+from forces_resilient_planner_amd import workloads as W  # noqa: E402
+
+D = ctypes.POINTER(ctypes.c_double)
+_REF = {}
+
+
+def P(a):
+    return a.ctypes.data_as(D) if a is not None else None
+
+
+def ref_callback(model):
+    name = 'normal' if model == L.MODEL_NORMAL else 'final'
+    if name not in _REF:
+        lib = ctypes.CDLL(os.path.join(ROOT, 'oracle', '_ref', f'libref_model_{name}.so'))
+        _REF[name] = getattr(lib, f'FORCESNLPsolver_{name}_casadi2forces')
+    return _REF[name]
+
+
+def ref_stage(model, z, p130, stage20, want=('f', 'gf', 'c', 'Jc', 'h', 'Jh')):
+    """Call the reference callback for one stage (stage20 in 0..19, reference numbering)."""
+    fn = ref_callback(model)
+    out = dict(f=np.zeros(1), gf=np.zeros(17), c=np.zeros(13), Jc=np.zeros(13 * 17), h=np.zeros(30), Jh=np.zeros(30 * 17))
+    y = np.zeros(13)
+    lam = np.zeros(64)
+    z = np.ascontiguousarray(z, dtype=np.float64)
+    p130 = np.ascontiguousarray(p130, dtype=np.float64)
+    fn(P(z), P(y), P(lam), P(p130),
+       P(out['f']) if 'f' in want else None, P(out['gf']) if 'gf' in want else None,
+       P(out['c']) if 'c' in want else None, P(out['Jc']) if 'Jc' in want else None,
+       P(out['h']) if 'h' in want else None, P(out['Jh']) if 'Jh' in want else None,
+       None, ctypes.c_int(stage20), ctypes.c_int(0), ctypes.c_int(0))
+    return out
+
+
+def to_p130(p, M):
+    """Re-lay a (10+4M)-parameter stage vector into the reference's 130-slot layout (nh = 30)."""
+    if M == 30:
+        return p
+    q = np.zeros(130)
+    q[:10] = p[:10]
+    m = min(M, 30)
+    q[10:10 + 3 * m] = p[10:10 + 3 * m]
+    q[100:100 + m] = p[10 + 3 * M:10 + 3 * M + m]
+    return q
+
+
+def ref_stage_index(k, N):
+    return 0 if k == 0 else (19 if k == N - 1 else 1)
+
+
+class RefNLP:
+    """The reference NLP assembled from the reference callbacks, for SciPy."""
+
+    def __init__(self, N, M, model, xinit, params, nfaces):
+        self.N, self.M, self.model, self.xinit = N, M, model, xinit
+        self.p130 = [to_p130(params[k], M) for k in range(N)]
+        self.nf = nfaces
+        self.lb, self.ub = L.bounds()
+
+    def fun(self, Z):
+        z = Z.reshape(self.N, 17)
+        f = 0.0
+        g = np.zeros_like(z)
+        for k in range(self.N):
+            o = ref_stage(self.model, z[k], self.p130[k], ref_stage_index(k, self.N), ('f', 'gf'))
+            f += o['f'][0]
+            g[k] = o['gf']
+        return f, g.ravel()
+
+    def eq(self, Z):
+        z = Z.reshape(self.N, 17)
+        r = [z[0, 8:17] - self.xinit]
+        for k in range(self.N - 1):
+            o = ref_stage(self.model, z[k], self.p130[k], ref_stage_index(k, self.N), ('c',))
+            r.append(o['c'] - np.r_[z[k + 1, 8:17], z[k + 1, 4:8]])
+        return np.concatenate(r)
+
+    def eq_jac(self, Z):
+        z = Z.reshape(self.N, 17)
+        n = 17 * self.N
+        J = np.zeros((9 + 13 * (self.N - 1), n))
+        J[0:9, 8:17] = np.eye(9)
+        E = np.zeros((13, 17))
+        E[0:9, 8:17] = np.eye(9)
+        E[9:13, 4:8] = np.eye(4)
+        for k in range(self.N - 1):
+            o = ref_stage(self.model, z[k], self.p130[k], ref_stage_index(k, self.N), ('Jc',))
+            r0 = 9 + 13 * k
+            J[r0:r0 + 13, 17 * k:17 * k + 17] = o['Jc'].reshape(17, 13).T
+            J[r0:r0 + 13, 17 * (k + 1):17 * (k + 2)] = -E
+        return J
+
+    def ineq(self, Z):  # SciPy convention: >= 0
+        z = Z.reshape(self.N, 17)
+        r = []
+        for k in range(self.N):
+            o = ref_stage(self.model, z[k], self.p130[k], ref_stage_index(k, self.N), ('h',))
+            r.append(L.HU - o['h'][:self.nf[k]])
+        return np.concatenate(r) if r else np.zeros(0)
+
+    def ineq_jac(self, Z):
+        z = Z.reshape(self.N, 17)
+        rows = []
+        for k in range(self.N):
+            o = ref_stage(self.model, z[k], self.p130[k], ref_stage_index(k, self.N), ('Jh',))
+            Jh = o['Jh'].reshape(17, 30).T[:self.nf[k]]
+            blk = np.zeros((self.nf[k], 17 * self.N))
+            blk[:, 17 * k:17 * k + 17] = -Jh
+            rows.append(blk)
+        return np.concatenate(rows) if rows else np.zeros((0, 17 * self.N))
+
+    def solve(self, Z0, maxiter=400):
+        cons = [dict(type='eq', fun=self.eq, jac=self.eq_jac)]
+        if int(np.sum(self.nf)) > 0:
+            cons.append(dict(type='ineq', fun=self.ineq, jac=self.ineq_jac))
+        bnds = list(zip(np.tile(self.lb, self.N), np.tile(self.ub, self.N)))
+        Z0 = np.clip(Z0, np.tile(self.lb, self.N), np.tile(self.ub, self.N))
+        res = minimize(self.fun, Z0, jac=True, method='SLSQP', bounds=bnds, constraints=cons,
+                       options=dict(ftol=1e-13, maxiter=maxiter))
+        return res
+
+
+def oracle_solve(w, b):
+    import tests.oracle_lib as OL
+    return OL.solve_one(w, b)
+
+
+def _job(args):
+    fam, w1, start, seed = args
+    N, M, model = w1['N'], w1['M'], w1['model']
+    nlp = RefNLP(N, M, model, w1['xinit'], w1['params'], w1['nfaces'])
+    if start == 'cold':
+        Z0 = w1['x0'].ravel().copy()
+    else:
+        rng = np.random.default_rng(seed)
+        Z0 = w1['z_oracle'].ravel() + 0.02 * rng.normal(size=17 * N)
+    t = time.time()
+    res = nlp.solve(Z0)
+    eqn = float(np.max(np.abs(nlp.eq(res.x))))
+    return dict(z=res.x.reshape(N, 17), f=float(res.fun), status=int(res.status), nit=int(res.nit),
+                eq=eqn, secs=time.time() - t, start=start)
+
+
+def gen_stage_vectors(path, n=240, seed=W.SEED0):
+    rng = np.random.default_rng(seed)
+    lb, ub = L.bounds()
+    rec = dict(z=[], p=[], stage=[], model=[], f=[], gf=[], c=[], Jc=[], h=[], Jh=[])
+    for t in range(n):
+        model = t % 2
+        stage = [0, 7, 19][t % 3]
+        z = lb + (ub - lb) * rng.random(17)
+        p = np.zeros(130)
+        p[:3] = rng.uniform(-5, 5, 3)
+        p[3:6] = rng.uniform(-3, 3, 3)
+        p[6:9] = rng.uniform(0.5, 80, 3)
+        p[9] = rng.uniform(-3, 3)
+        nf = [0, 6, 15, 30][t % 4]
+        p[10:10 + 3 * nf] = rng.normal(size=3 * nf)
+        p[100:100 + nf] = rng.normal(size=nf)
+        o = ref_stage(model, z, p, stage)
+        rec['z'].append(z); rec['p'].append(p); rec['stage'].append(stage); rec['model'].append(model)
+        for k in ('f', 'gf', 'c', 'Jc', 'h', 'Jh'):
+            rec[k].append(o[k].copy())
+    np.savez_compressed(path, **{k: np.array(v) for k, v in rec.items()})
+    print('wrote', path)
+
+
+def gen_solutions(outdir, workers=8):
+    import tests.oracle_lib as OL
+    fams = {
+        'config0': [(W.config0(L.MODEL_NORMAL), [0]), (W.config0(L.MODEL_FINAL), [0]),
+                    (W.config0(L.MODEL_NORMAL, (1.5, -2.0, 0.5)), [0])],
+        'config1': [(W.config1(48), list(range(48)))],
+        'config2': [(W.config2(64), list(range(64))), (W.config2(16, model=L.MODEL_FINAL, seed=W.SEED0 + 33), list(range(16)))],
+        'config3': [(W.config3(24), list(range(24)))],
+    }
+    ncold = dict(config0=3, config1=8, config2=10, config3=4)
+    for fam, groups in fams.items():
+        jobs, meta = [], []
+        for w, idx in groups:
+            zo, fl, info = OL.solve_batch(w)
+            for b in idx:
+                w1 = dict(N=w['N'], M=w['M'], model=w['model'], xinit=w['xinit'][b], x0=w['x0'][b],
+                          params=w['params'][b], nfaces=w['nfaces'][b], z_oracle=zo[b])
+                start = 'cold' if len(jobs) < ncold[fam] or fl[b] != 1 else 'near'
+                jobs.append((fam, w1, start, 1000 + len(jobs)))
+                meta.append(w1)
+        t = time.time()
+        with Pool(workers) as pool:
+            res = pool.map(_job, jobs, chunksize=1)
+        keep = dict(xinit=[], x0=[], params=[], nfaces=[], model=[], z=[], f=[], status=[], start=[], eq=[])
+        for w1, r in zip(meta, res):
+            keep['xinit'].append(w1['xinit']); keep['x0'].append(w1['x0']); keep['params'].append(w1['params'])
+            keep['nfaces'].append(w1['nfaces']); keep['model'].append(w1['model'])
+            keep['z'].append(r['z']); keep['f'].append(r['f']); keep['status'].append(r['status'])
+            keep['start'].append(r['start']); keep['eq'].append(r['eq'])
+        path = os.path.join(outdir, f'solutions_{fam}.npz')
+        np.savez_compressed(path, N=meta[0]['N'], M=meta[0]['M'], **{k: np.array(v) for k, v in keep.items()})
+        st = np.array(keep['status'])
+        print(f'wrote {path}: {len(res)} problems, status0={np.sum(st == 0)}, other={np.sum(st != 0)}, {time.time() - t:.0f}s', flush=True)
+
+
+if __name__ == '__main__':
+    out = os.path.join(ROOT, 'tests', 'golden')
+    os.makedirs(out, exist_ok=True)
+    if len(sys.argv) < 2 or sys.argv[1] == 'stage':
+        gen_stage_vectors(os.path.join(out, 'stage_vectors.npz'))
+    if len(sys.argv) < 2 or sys.argv[1] == 'solutions':
+        gen_solutions(out)
