@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""bench.py -- NMPC solves/sec on MI355X (BASELINE.json metric), one process per GPU.
+
+A "step" = one pass of the hot path over one batch: solve B = 4096 independent N = 20 NMPC problems
+(BASELINE.json configs[2]: constant f_ext, 6-face tightened corridor per stage, cold start) with the
+HIP solver, inputs already resident in HBM, outputs left in HBM.  N GPUs -> each rank solves its own
+4096-problem shard (different seed), no data-path collective ("weak").
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the definition of every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic flops of one interior-point iteration of one N=20, m=6 problem
+F_STAGE = 31.5e3                 # flop per stage per iteration (textbook Schur-complement IPM definition)
+ALG_BYTES_PER_SOLVE = 26456.0    # dense ABI image: params 23600 + output 2720 + info 136
+FP64_PEAK_TFLOPS = 78.6          # MI355X FP64 vector == matrix peak (AMD datasheet)
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md
+
+
+def cpu_baseline(w, seconds_target=12.0):
+    """The CPU oracle (same algorithm, FP64, OpenMP over problems) timed on a bounded sample of the
+    same workload on this box's host cores.  Test infrastructure used only as the reported baseline."""
+    import tests.oracle_lib as OL
+    cores = os.cpu_count() or 1
+    B = w["xinit"].shape[0]
+    n0 = min(B, 256)
+    sub = {k: (v[:n0] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in w.items()}
+    OL.solve_batch(sub, nthreads=cores)  # warm up threads
+    t = time.perf_counter(); OL.solve_batch(sub, nthreads=cores); dt = time.perf_counter() - t
+    rate = n0 / dt
+    n = int(min(B, max(n0, rate * seconds_target)))
+    sub = {k: (v[:n] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in w.items()}
+    t = time.perf_counter(); z, fl, info = OL.solve_batch(sub, nthreads=cores); dt = time.perf_counter() - t
+    t1 = time.perf_counter(); OL.solve_batch({k: (v[:n0] if isinstance(v, np.ndarray) and v.shape[:1] == (n,) else v) for k, v in sub.items()}, nthreads=1); dt1 = time.perf_counter() - t1
+    return dict(value=n / dt, unit="solves/s", cores=cores, kind="port",
+                sample=f"first {n} problems of the same 4096-problem batch, oracle/liboracle.so (FP64 CPU restatement, "
+                       f"not ForcesPro: its binary is licence-locked), OpenMP over problems on {cores} threads, {dt:.1f} s; "
+                       f"single-thread {n0 / dt1:.0f} solves/s",
+                converged_frac=float((fl == 1).mean()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    from forces_resilient_planner_amd import solver, workloads
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path in the product)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    B = args.batch
+    w = workloads.config2(B, seed=workloads.SEED0 + 3 + 1000 * rank)
+    ds = solver.DeviceSolver(B, w["N"], w["M"], 6, w["model"], f"cuda:{local_rank}")
+    ds.upload(w)
+    stream = torch.cuda.current_stream(dev)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        ds.solve(stream)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ds.solve(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    fl = ds.exitflag.cpu().numpy(); it = ds.iters.cpu().numpy()
+    stats = torch.tensor([float((fl == 1).sum()), float(it.sum()), float(B)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)  # 3 scalars of summary statistics, not on the data path
+    conv_frac = float(stats[0] / stats[2]); mean_it = float(stats[1] / stats[2])
+
+    # dominant kernel: average duration over the same launches, HIP events on the launch stream
+    kernel_ms = ds.time_solve(max(1, args.steps), stream)
+    torch.cuda.synchronize(dev)
+
+    if rank == 0:
+        total = world * B * args.steps
+        value = total / elapsed
+        f_solve = mean_it * w["N"] * F_STAGE
+        achieved_tf = B * f_solve / (kernel_ms * 1e-3) / 1e12
+        achieved_gbs = B * ALG_BYTES_PER_SOLVE / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "NMPC solves/sec, batch=4096 horizons N=20", "value": value, "unit": "solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: batch=4096 per GPU, N=20, constant f_ext~U[-3,3]^3, "
+                                   "6-face tightened corridor per stage, cold start, reference 30-row parameter layout",
+                       "batch_per_gpu": B, "horizon": int(w["N"]), "converged_frac": conv_frac,
+                       "mean_ipm_iterations": mean_it, "p95_ipm_iterations": float(np.percentile(it, 95)),
+                       "max_ipm_iterations": int(it.max()), "tolerances": 1e-4},
+            "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "nmpc_ipm_kernel", "kernel_ms": kernel_ms,
+                         "flops_per_launch": B * f_solve,
+                         "note": "FP64 (vector == matrix peak 78.6 TFLOP/s); flops = SURVEY 8d definition "
+                                 "mean_it * N * 31.5 kflop per solve",
+                         "hbm_algorithmic": {"achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": achieved_gbs / HBM_PEAK_GBS}},
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(w)
+        elif not args.no_cpu:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

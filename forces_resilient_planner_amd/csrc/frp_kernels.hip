@@ -43,8 +43,18 @@ __device__ __forceinline__ double wave_sum(double v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
-// One wavefront per workgroup: __syncthreads() is the LDS producer/consumer fence between lanes.
-#define WSYNC() __syncthreads()
+// One wavefront per workgroup.  LDS operations of one wave are executed in issue order, so lanes can hand
+// data to each other through LDS with only a COMPILER ordering fence: WSYNC() emits no instruction and,
+// unlike __syncthreads(), does not drain the vector-memory counter -- prefetched global loads and
+// streamed stores stay in flight across it.  FULLSYNC() (= __syncthreads()) is used at phase boundaries
+// where lanes exchange data through global memory.
+#define WSYNC()                                                   \
+    do {                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+        __builtin_amdgcn_wave_barrier();                          \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+    } while (0)
+#define FULLSYNC() __syncthreads()
 
 // ------------------------------------------------------------------ LDS layout (doubles)
 constexpr int L_P0 = 0;                 // P buffer 0 (13x13)
@@ -130,20 +140,680 @@ __device__ __forceinline__ bool spd4_inverse(const double *a /*row-major 4x4*/, 
     return true;
 }
 
+
+// Explicit global address space: inside non-inlined device functions a plain double* is a GENERIC
+// pointer and compiles to flat_load/flat_store, which also count on lgkmcnt and therefore make every
+// LDS wait drain the in-flight prefetches.
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) const double cgdouble;
+
 struct WsView {
-    double *rec, *z, *y, *dz, *s, *lam, *corr, *face;
+    gdouble *rec, *z, *y, *dz, *s, *lam, *corr, *face;
 };
+
+__host__ __device__ inline int padded_stages(int N) { return N <= 32 ? 32 : 64; }
 
 __host__ __device__ inline size_t ws_doubles_per_problem(int N, int MF)
 {
-    const size_t mcf = 34 + MF;
-    return (size_t)N * (REC_STRIDE + 17 + 13 + 17 + 3 * mcf + 4 * (size_t)MF);
+    const size_t mcf = 34 + MF, NPs = padded_stages(N);
+    return (size_t)N * REC_STRIDE + NPs * (17 + 13 + 17 + 3 * mcf + 4 * (size_t)MF);
+}
+
+// The phases below are separate NON-inlined device functions on purpose: as one monolithic kernel
+// body the compiler hoists hundreds of loop-invariant values (addresses, constants, index maths)
+// across the solve loop and needs > 700 registers; as functions each phase is register-allocated on
+// its own.  Their arguments are wave-uniform; readfirstlane restores that knowledge (SGPRs, scalar
+// address arithmetic, uniform branches) on the callee side.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T *uni(T *p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double uni(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ WsView uni(WsView w)
+{
+    w.rec = uni(w.rec); w.z = uni(w.z); w.y = uni(w.y); w.dz = uni(w.dz);
+    w.s = uni(w.s); w.lam = uni(w.lam); w.corr = uni(w.corr); w.face = uni(w.face);
+    return w;
+}
+
+__shared__ double sm[L_TOTAL];
+
+struct EvalOut {
+    double eq, in, rs, rc, gap, obj;
+};
+
+// ------------------------------------------------------------------ E: evaluate (lane == stage)
+// model + linearisation -> record, residual norms, barrier Hessian/gradient (affine rhs) -> record
+template <int NP>
+__device__ __noinline__ EvalOut phase_eval(WsView w, cgdouble *pk, cgdouble *xinit, int N, int MF, int nf, int model)
+{
+    w = uni(w); xinit = uni(xinit); N = uni(N); MF = uni(MF); model = uni(model);
+    FULLSYNC(); // phase boundary: other lanes' global writes of the previous phase are visible
+    const int lane = threadIdx.x, k = lane;
+    const bool act = lane < N;
+    double l_eq = 0, l_in = 0, l_rs = 0, l_rc = 0, l_gap = 0, l_obj = 0;
+    double p10[NPRE];
+    if (act) {
+#pragma unroll
+        for (int i = 0; i < NPRE; i++) p10[i] = pk[i];
+    }
+    const int sc_k = stage_class(k, N);
+    const CostQ cq = make_cost(p10, sc_k, model);
+    if (act) {
+        double zk[NZ];
+#pragma unroll
+        for (int i = 0; i < NZ; i++) zk[i] = w.z[i * NP + k];
+        l_obj = stage_cost(zk, p10, sc_k, model, nullptr);
+        gdouble *rec = w.rec + (size_t)k * REC_STRIDE;
+        if (k == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) l_eq = fmax(l_eq, fabs(xinit[i] - zk[8 + i]));
+        }
+        // gm = M' y_{k+1} - [0; y_k]  (multiplier part of the stationarity residual)
+        double gm[NZ];
+#pragma unroll
+        for (int i = 0; i < 4; i++) gm[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NS; i++) gm[4 + i] = -w.y[i * NP + k];
+        if (k < N - 1) {
+            double yn[NS];
+#pragma unroll
+            for (int i = 0; i < NS; i++) yn[i] = w.y[i * NP + k + 1];
+            const double *yw = yn, *yp = yn + 4, *yv = yn + 7, *ye = yn + 10;
+            // one Heun step with its linearisation streamed out entry by entry (record + M'y)
+            AccJac J1, J2;
+            double a1[3], a2[3], vt[3], et[3];
+            accel<true>(zk + 11, zk + 14, zk[3], p10 + 3, a1, &J1);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                vt[i] = zk[11 + i] + DT * a1[i];
+                et[i] = zk[14 + i] + DT * zk[i];
+            }
+            accel<true>(vt, et, zk[3], p10 + 3, a2, &J2);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const double d = zk[i] - w.z[(4 + i) * NP + k + 1];
+                rec[REC_D + i] = d;
+                l_eq = fmax(l_eq, fabs(d));
+                gm[i] += yw[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const double xp = zk[8 + i] + 0.5 * DT * (zk[11 + i] + vt[i]);
+                const double xv = zk[11 + i] + 0.5 * DT * (a1[i] + a2[i]);
+                const double dp = xp - w.z[(8 + i) * NP + k + 1];
+                const double dv = xv - w.z[(11 + i) * NP + k + 1];
+                const double de = et[i] - w.z[(14 + i) * NP + k + 1];
+                rec[REC_D + 4 + i] = dp; rec[REC_D + 7 + i] = dv; rec[REC_D + 10 + i] = de;
+                l_eq = fmax(l_eq, fmax(fabs(dp), fmax(fabs(dv), fabs(de))));
+                gm[i] += DT * ye[i];
+                gm[8 + i] += yp[i];
+                gm[14 + i] += ye[i];
+            }
+            double gT = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                double sT = J2.gT[i];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    double sv = J2.Fvv[i * 3 + j], se = J2.Fve[i * 3 + j];
+#pragma unroll
+                    for (int l = 0; l < 3; l++) {
+                        sv += DT * J2.Fvv[i * 3 + l] * J1.Fvv[l * 3 + j];
+                        se += DT * J2.Fvv[i * 3 + l] * J1.Fve[l * 3 + j];
+                    }
+                    const double apv = (i == j ? DT : 0.0) + 0.5 * DT * DT * J1.Fvv[i * 3 + j];
+                    const double ape = 0.5 * DT * DT * J1.Fve[i * 3 + j];
+                    const double avv = (i == j ? 1.0 : 0.0) + 0.5 * DT * (J1.Fvv[i * 3 + j] + sv);
+                    const double ave = 0.5 * DT * (J1.Fve[i * 3 + j] + se);
+                    const double bvw = 0.5 * DT * DT * J2.Fve[i * 3 + j];
+                    rec[REC_LIN + i * 3 + j] = apv;
+                    rec[REC_LIN + 9 + i * 3 + j] = ape;
+                    rec[REC_LIN + 18 + i * 3 + j] = avv;
+                    rec[REC_LIN + 27 + i * 3 + j] = ave;
+                    rec[REC_LIN + 42 + i * 3 + j] = bvw;
+                    gm[j] += bvw * yv[i];
+                    gm[11 + j] += apv * yp[i] + avv * yv[i];
+                    gm[14 + j] += ape * yp[i] + ave * yv[i];
+                    sT += DT * J2.Fvv[i * 3 + j] * J1.gT[j];
+                }
+                const double bpt = 0.5 * DT * DT * J1.gT[i];
+                const double bvt = 0.5 * DT * (J1.gT[i] + sT);
+                rec[REC_LIN + 36 + i] = bpt;
+                rec[REC_LIN + 39 + i] = bvt;
+                gT += bpt * yp[i] + bvt * yv[i];
+            }
+            gm[3] += gT;
+        }
+        // corridor rows first (they touch the pos entries 8..10 only)
+        double gp[3] = {0, 0, 0}, fp[3] = {0, 0, 0};
+        double pp[6] = {0, 0, 0, 0, 0, 0}; // xx xy xz yy yz zz
+        for (int j = 0; j < nf; j++) {
+            const double a0 = w.face[(3 * j) * NP + k], a1 = w.face[(3 * j + 1) * NP + k], a2 = w.face[(3 * j + 2) * NP + k];
+            const double hj = a0 * zk[8] + a1 * zk[9] + a2 * zk[10] - w.face[(3 * MF + j) * NP + k] - HU;
+            const double sc = w.s[(34 + j) * NP + k], lc = w.lam[(34 + j) * NP + k];
+            const double rc = hj + sc;
+            l_in = fmax(l_in, fmax(hj, fabs(rc)));
+            l_rc = fmax(l_rc, sc * lc);
+            l_gap += sc * lc;
+            gp[0] += a0 * lc; gp[1] += a1 * lc; gp[2] += a2 * lc;
+            const double sg = lc / sc, t = sg * rc;
+            fp[0] += a0 * t; fp[1] += a1 * t; fp[2] += a2 * t;
+            pp[0] += sg * a0 * a0; pp[1] += sg * a0 * a1; pp[2] += sg * a0 * a2;
+            pp[3] += sg * a1 * a1; pp[4] += sg * a1 * a2; pp[5] += sg * a2 * a2;
+        }
+        rec[REC_PHIPOS + 0] = pp[0]; rec[REC_PHIPOS + 1] = pp[1]; rec[REC_PHIPOS + 2] = pp[2];
+        rec[REC_PHIPOS + 3] = pp[1]; rec[REC_PHIPOS + 4] = pp[3]; rec[REC_PHIPOS + 5] = pp[4];
+        rec[REC_PHIPOS + 6] = pp[2]; rec[REC_PHIPOS + 7] = pp[4]; rec[REC_PHIPOS + 8] = pp[5];
+        // bounds: residuals, barrier Hessian / gradient, finished entry by entry
+#pragma unroll
+        for (int i = 0; i < NZ; i++) {
+            double cg = cq.hd(i) * zk[i] + cq.q(i); // cost gradient
+            if (i < 4) cg += cq.hc() * zk[4 + i];
+            else if (i < 8) cg += cq.hc() * zk[i - 4];
+            const double sl = w.s[i * NP + k], su = w.s[(17 + i) * NP + k];
+            const double ll = w.lam[i * NP + k], lu = w.lam[(17 + i) * NP + k];
+            const double vl = lower_bound(i) - zk[i], vu = zk[i] - upper_bound(i);
+            const double rl = vl + sl, ru = vu + su;
+            l_in = fmax(l_in, fmax(fmax(vl, vu), fmax(fabs(rl), fabs(ru))));
+            l_rc = fmax(l_rc, fmax(sl * ll, su * lu));
+            l_gap += sl * ll + su * lu;
+            const double sgl = ll / sl, sgu = lu / su;
+            double gi = cg + gm[i] + lu - ll;
+            double ph = cg + sgu * ru - sgl * rl;
+            if (i >= 8 && i < 11) { gi += gp[i - 8]; ph += fp[i - 8]; }
+            rec[REC_PHID + i] = cq.hd(i) + sgl + sgu;
+            rec[REC_PHI + i] = ph;
+            l_rs = fmax(l_rs, fabs(gi));
+        }
+    }
+    FULLSYNC();
+    EvalOut o;
+    o.eq = l_eq; o.in = l_in; o.rs = l_rs; o.rc = l_rc; o.gap = l_gap; o.obj = l_obj;
+    return o;
+}
+
+// ------------------------------------------------------------------ backward Riccati sweep
+// pass 0: factorisation + vector part; pass 1: vector part only (new phi).  Ends with the stage-0
+// solve (ds_0 left in LDS).  Returns non-zero when a pivot block is not positive definite.
+template <int NP>
+__device__ __noinline__ int sweep_backward(WsView w, cgdouble *xinit, int N, int pass)
+{
+    w = uni(w); xinit = uni(xinit); N = uni(N); pass = uni(pass);
+    FULLSYNC(); // phase boundary: other lanes' global writes of the previous phase are visible
+    const int lane = threadIdx.x;
+    const int my_dst = L_AB + lin_dst(lane);
+    bool fact_fail = false;
+    {
+        int cur = 0; // buffer holding P_{k+1}
+        cgdouble *r0 = w.rec + (size_t)(N - 1) * REC_STRIDE;
+        double pre_lin = r0[lane];                                           // LIN + D
+        double pre_phi = (lane < 44) ? r0[REC_PHID + lane] : 0.0;            // PhiD | PhiPos | phi
+        double pre_out0 = 0.0, pre_out1 = 0.0;                               // Kb|R|Pd (pass 1)
+        if (pass == 1) {
+            pre_out0 = r0[REC_KB + lane];
+            pre_out1 = (lane < 17) ? r0[REC_KB + 64 + lane] : 0.0;
+        }
+        for (int kk = N - 1; kk >= 0; kk--) {
+            gdouble *rec = w.rec + (size_t)kk * REC_STRIDE;
+            const bool last = (kk == N - 1);
+            sm[my_dst] = pre_lin;
+            if (lane < 44) sm[L_PHI + lane] = pre_phi;
+            if (pass == 1) {
+                sm[L_OUT + lane] = pre_out0;               // Kb(52) R(12 of 16)
+                if (lane < 17) sm[L_OUT + 64 + lane] = pre_out1; // R tail, Pd
+            }
+            if (kk > 0) {
+                cgdouble *rn = rec - REC_STRIDE;
+                pre_lin = rn[lane];
+                pre_phi = (lane < 44) ? rn[REC_PHID + lane] : 0.0;
+                if (pass == 1) {
+                    pre_out0 = rn[REC_KB + lane];
+                    pre_out1 = (lane < 17) ? rn[REC_KB + 64 + lane] : 0.0;
+                }
+            }
+            WSYNC();
+            const double *Pn = sm + (cur ? L_P1 : L_P0);
+            double *Pk = sm + (cur ? L_P0 : L_P1);
+            const double *AB = sm + L_AB;
+            if (pass == 0 && !last) {
+                // PA = Pxx [A|B] (9 x 13), Pd = P d
+                for (int t = lane; t < 117; t += 64) {
+                    const int i = t / 13, j = t % 13;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int l = 0; l < 9; l++) acc += Pn[(4 + i) * 13 + 4 + l] * AB[l * 13 + j];
+                    sm[L_PA + t] = acc;
+                }
+                if (lane < 13) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 13; j++) acc += Pn[lane * 13 + j] * sm[L_D + j];
+                    sm[L_PD + lane] = acc;
+                }
+                WSYNC();
+            }
+            // q = phi + M'(Pd + p_{k+1})
+            if (lane < 17) {
+                double acc = sm[L_PHIV + lane];
+                if (!last) {
+                    if (lane < 4) {
+                        acc += sm[L_PD + lane] + sm[L_PV + lane];
+#pragma unroll
+                        for (int i = 0; i < 9; i++) acc += AB[i * 13 + 9 + lane] * (sm[L_PD + 4 + i] + sm[L_PV + 4 + i]);
+                    } else if (lane >= 8) {
+#pragma unroll
+                        for (int i = 0; i < 9; i++) acc += AB[i * 13 + lane - 8] * (sm[L_PD + 4 + i] + sm[L_PV + 4 + i]);
+                    }
+                }
+                sm[L_Q + lane] = acc;
+            }
+            if (pass == 0) {
+                // Qxx -> Pk[4+i][4+j]; Qww -> diag; Qwx = 0
+                for (int t = lane; t < 169; t += 64) {
+                    const int i = t / 13, j = t % 13;
+                    double acc = 0.0;
+                    if (i >= 4 && j >= 4) {
+                        const int ii = i - 4, jj = j - 4;
+                        if (ii == jj) acc = sm[L_PHID + 8 + ii];
+                        if (ii < 3 && jj < 3) acc += sm[L_PHIPOS + ii * 3 + jj];
+                        if (!last) {
+#pragma unroll
+                            for (int l = 0; l < 9; l++) acc += AB[l * 13 + ii] * sm[L_PA + l * 13 + jj];
+                        }
+                    } else if (i == j) acc = sm[L_PHID + 4 + i];
+                    Pk[t] = acc;
+                }
+                // Qus (4 x 13): Quw = hc I, Qux = T A with T = Pwx + (Pxx B)'
+                if (lane < 52) {
+                    const int i = lane / 13, j = lane % 13;
+                    double acc = 0.0;
+                    if (j < 4) acc = (i == j) ? sm[L_HC] : 0.0;
+                    else if (!last) {
+#pragma unroll
+                        for (int l = 0; l < 9; l++) acc += (Pn[i * 13 + 4 + l] + sm[L_PA + l * 13 + 9 + i]) * AB[l * 13 + j - 4];
+                    }
+                    sm[L_QUS + lane] = acc;
+                }
+                // Quu
+                if (lane < 16) {
+                    const int i = lane / 4, j = lane % 4;
+                    double acc = (i == j) ? sm[L_PHID + i] : 0.0;
+                    if (!last) {
+                        acc += Pn[i * 13 + j];
+#pragma unroll
+                        for (int l = 0; l < 9; l++)
+                            acc += (Pn[i * 13 + 4 + l] + sm[L_PA + l * 13 + 9 + i]) * AB[l * 13 + 9 + j] + AB[l * 13 + 9 + i] * Pn[(4 + l) * 13 + j];
+                    }
+                    sm[L_QUU + lane] = acc;
+                }
+                WSYNC();
+                {
+                    double R[16];
+                    const bool ok = spd4_inverse(sm + L_QUU, R);
+                    if (!ok) fact_fail = true;
+#pragma unroll
+                    for (int t = 0; t < 16; t++) sm[L_R + t] = ok ? R[t] : 0.0;
+                }
+                WSYNC();
+                // Kb = R Qus
+                if (lane < 52) {
+                    const int i = lane / 13, j = lane % 13;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int l = 0; l < 4; l++) acc += sm[L_R + i * 4 + l] * sm[L_QUS + l * 13 + j];
+                    sm[L_KB + lane] = acc;
+                }
+                WSYNC();
+                // P_k = Qss - Qus' Kb
+                for (int t = lane; t < 169; t += 64) {
+                    const int i = t / 13, j = t % 13;
+                    double acc = Pk[t];
+#pragma unroll
+                    for (int l = 0; l < 4; l++) acc -= sm[L_QUS + l * 13 + i] * sm[L_KB + l * 13 + j];
+                    Pk[t] = acc;
+                }
+            } else {
+                WSYNC();
+            }
+            // kb = R q_u ; p_k = q_s - Kb' q_u
+            double kbv = 0.0, pv = 0.0;
+            if (lane < 4) {
+#pragma unroll
+                for (int l = 0; l < 4; l++) kbv += sm[L_R + lane * 4 + l] * sm[L_Q + l];
+            } else if (lane < 17) {
+                pv = sm[L_Q + lane];
+#pragma unroll
+                for (int l = 0; l < 4; l++) pv -= sm[L_KB + l * 13 + lane - 4] * sm[L_Q + l];
+            }
+            WSYNC(); // everyone has read p_{k+1} (L_PV) before it is overwritten
+            if (lane < 4) sm[L_KV + lane] = kbv;
+            else if (lane < 17) sm[L_PV + lane - 4] = pv;
+            WSYNC();
+            // stream the factors of stage kk to HBM
+            if (pass == 0) {
+                rec[REC_KB + lane] = sm[L_OUT + lane];
+                if (lane < 34) rec[REC_KB + 64 + lane] = sm[L_OUT + 64 + lane];
+            } else if (lane < 17) {
+                rec[REC_KV + lane] = sm[L_KV + lane]; // kb (4) + p (13)
+            }
+            cur ^= 1;
+        }
+        // stage 0: dw = -Pww^-1 (Pwx dx + p_w), dx = xinit - x_0
+        const double *P0 = sm + (cur ? L_P1 : L_P0);
+        if (pass == 0) {
+            double Rw[16], Pww[16];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) Pww[i * 4 + j] = P0[i * 13 + j];
+            const bool ok = spd4_inverse(Pww, Rw);
+            if (!ok) fact_fail = true;
+            WSYNC();
+#pragma unroll
+            for (int t = 0; t < 16; t++) sm[L_S0 + t] = ok ? Rw[t] : 0.0;
+            if (lane < 36) sm[L_S0 + 16 + lane] = P0[(lane / 9) * 13 + 4 + lane % 9];
+        }
+        if (lane < 9) sm[L_DS + 4 + lane] = xinit[lane] - w.z[(8 + lane) * NP + 0];
+        WSYNC();
+        if (lane < 4) {
+            double acc = sm[L_PV + lane];
+#pragma unroll
+            for (int j = 0; j < 9; j++) acc += sm[L_S0 + 16 + lane * 9 + j] * sm[L_DS + 4 + j];
+            sm[L_DU + lane] = acc; // temporary: rhs
+        }
+        WSYNC();
+        if (lane < 4) {
+            double acc = 0.0;
+#pragma unroll
+            for (int l = 0; l < 4; l++) acc -= sm[L_S0 + lane * 4 + l] * sm[L_DU + l];
+            sm[L_DS + lane] = acc;
+        }
+        WSYNC();
+    }
+
+    FULLSYNC();
+    return fact_fail ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ forward sweep: dz for all stages
+template <int NP>
+__device__ __noinline__ void sweep_forward(WsView w, int N)
+{
+    w = uni(w); N = uni(N);
+    FULLSYNC(); // phase boundary: other lanes' global writes of the previous phase are visible
+    const int lane = threadIdx.x;
+    const int my_dst = L_AB + lin_dst(lane);
+    {
+        cgdouble *r0 = w.rec;
+        double pre_lin = r0[lane];
+        double pre_kb = (lane < 52) ? r0[REC_KB + lane] : ((lane < 56) ? r0[REC_KV + lane - 52] : 0.0);
+        for (int kk = 0; kk < N; kk++) {
+            cgdouble *rec = w.rec + (size_t)kk * REC_STRIDE;
+            sm[my_dst] = pre_lin;
+            if (lane < 52) sm[L_KB + lane] = pre_kb;
+            else if (lane < 56) sm[L_KV + lane - 52] = pre_kb;
+            if (kk < N - 1) {
+                cgdouble *rn = rec + REC_STRIDE;
+                pre_lin = rn[lane];
+                pre_kb = (lane < 52) ? rn[REC_KB + lane] : ((lane < 56) ? rn[REC_KV + lane - 52] : 0.0);
+            }
+            WSYNC();
+            if (lane < 4) {
+                double a0 = sm[L_KV + lane], a1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < 12; j += 2) {
+                    a0 += sm[L_KB + lane * 13 + j] * sm[L_DS + j];
+                    a1 += sm[L_KB + lane * 13 + j + 1] * sm[L_DS + j + 1];
+                }
+                a0 += sm[L_KB + lane * 13 + 12] * sm[L_DS + 12];
+                const double du = -(a0 + a1);
+                sm[L_DU + lane] = du;
+                w.dz[lane * NP + kk] = du;
+            } else if (lane < 17) {
+                w.dz[lane * NP + kk] = sm[L_DS + lane - 4];
+            }
+            WSYNC();
+            if (kk < N - 1) {
+                double v = 0.0;
+                if (lane < 4) v = sm[L_DU + lane] + sm[L_D + lane];
+                else if (lane < 13) {
+                    const int i = lane - 4;
+                    double a0 = sm[L_D + lane], a1 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        a0 += sm[L_AB + i * 13 + j] * sm[L_DS + 4 + j];
+                        a1 += sm[L_AB + i * 13 + j + 1] * sm[L_DS + 4 + j + 1];
+                    }
+                    a0 += sm[L_AB + i * 13 + 8] * sm[L_DS + 12];
+#pragma unroll
+                    for (int j = 0; j < 4; j += 2) {
+                        a0 += sm[L_AB + i * 13 + 9 + j] * sm[L_DU + j];
+                        a1 += sm[L_AB + i * 13 + 10 + j] * sm[L_DU + j + 1];
+                    }
+                    v = a0 + a1;
+                }
+                WSYNC();
+                if (lane < 13) sm[L_DS + lane] = v;
+            }
+        }
+                WSYNC();
+    }
+}
+
+struct SlackOut {
+    double ap, ad, sigma, smu;
+};
+
+// ------------------------------------------------------------------ slack / multiplier steps (lane == stage)
+// pass 0 (affine): step lengths, mu_aff -> sigma, second-order term, corrector rhs phi -> record
+// pass 1 (corrector): fraction-to-boundary step lengths, update z, s, lambda
+template <int NP>
+__device__ __noinline__ SlackOut phase_slack(WsView w, cgdouble *pk, int N, int MF, int nf, int model, int pass,
+                                             double smu, double mu, int mtot, double ftb, double tol_comp)
+{
+    w = uni(w); N = uni(N); MF = uni(MF); model = uni(model); pass = uni(pass); smu = uni(smu); mu = uni(mu);
+    mtot = uni(mtot); ftb = uni(ftb); tol_comp = uni(tol_comp);
+    FULLSYNC(); // phase boundary: other lanes' global writes of the previous phase are visible
+    const int lane = threadIdx.x, k = lane;
+    const bool act = lane < N;
+    double ap = 1.0, ad = 1.0, sigma = 0.0, step_cc = 0.0;
+    double p10[NPRE];
+    if (act) {
+#pragma unroll
+        for (int i = 0; i < NPRE; i++) p10[i] = pk[i];
+    }
+    const CostQ cq = make_cost(p10, stage_class(k, N), model);
+    {
+        double l_ap = 1e300, l_ad = 1e300;
+        double dzk[NZ];
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < NZ; i++) dzk[i] = w.dz[i * NP + k];
+        }
+        // pass A: step lengths
+        double zk[NZ];
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < NZ; i++) zk[i] = w.z[i * NP + k];
+            auto step_len = [&](int c, double gdz, double viol) {
+                const double s = w.s[c * NP + k], l = w.lam[c * NP + k];
+                const double ds = -(viol + s) - gdz;
+                const double rc = s * l - smu + (pass ? w.corr[c * NP + k] : 0.0);
+                const double dl = (-rc - l * ds) / s;
+                if (ds < 0.0) l_ap = fmin(l_ap, -s / ds);
+                if (dl < 0.0) l_ad = fmin(l_ad, -l / dl);
+            };
+#pragma unroll
+            for (int i = 0; i < NZ; i++) {
+                step_len(i, -dzk[i], lower_bound(i) - zk[i]);
+                step_len(17 + i, dzk[i], zk[i] - upper_bound(i));
+            }
+            for (int j = 0; j < nf; j++) {
+                const double a0 = w.face[(3 * j) * NP + k], a1 = w.face[(3 * j + 1) * NP + k], a2 = w.face[(3 * j + 2) * NP + k];
+                step_len(34 + j, a0 * dzk[8] + a1 * dzk[9] + a2 * dzk[10],
+                         a0 * zk[8] + a1 * zk[9] + a2 * zk[10] - w.face[(3 * MF + j) * NP + k] - HU);
+            }
+        }
+        ap = wave_min(l_ap); ad = wave_min(l_ad);
+        if (pass == 0) { ap = fmin(1.0, ap); ad = fmin(1.0, ad); }
+        else { ap = fmin(1.0, ftb * ap); ad = fmin(1.0, ftb * ad); }
+        // pass B: affine complementarity + second-order term / or the update
+        double l_gapaff = 0.0;
+        if (act) {
+            auto apply = [&](int c, double gdz, double viol) {
+                const double s = w.s[c * NP + k], l = w.lam[c * NP + k];
+                const double ds = -(viol + s) - gdz;
+                const double rc = s * l - smu + (pass ? w.corr[c * NP + k] : 0.0);
+                const double dl = (-rc - l * ds) / s;
+                if (pass == 0) {
+                    l_gapaff += (s + ap * ds) * (l + ad * dl);
+                    w.corr[c * NP + k] = ds * dl;
+                } else {
+                    w.s[c * NP + k] = s + ap * ds;
+                    w.lam[c * NP + k] = l + ad * dl;
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < NZ; i++) {
+                apply(i, -dzk[i], lower_bound(i) - zk[i]);
+                apply(17 + i, dzk[i], zk[i] - upper_bound(i));
+            }
+            for (int j = 0; j < nf; j++) {
+                const double a0 = w.face[(3 * j) * NP + k], a1 = w.face[(3 * j + 1) * NP + k], a2 = w.face[(3 * j + 2) * NP + k];
+                apply(34 + j, a0 * dzk[8] + a1 * dzk[9] + a2 * dzk[10],
+                      a0 * zk[8] + a1 * zk[9] + a2 * zk[10] - w.face[(3 * MF + j) * NP + k] - HU);
+            }
+        }
+        if (pass == 0) {
+            const double mu_aff = wave_sum(l_gapaff) / (double)mtot;
+            sigma = mu_aff / mu;
+            sigma = sigma * sigma * sigma;
+            if (sigma > 1.0) sigma = 1.0;
+            smu = sigma * mu;
+            if (smu < MU_FLOOR_FRAC * tol_comp) smu = MU_FLOOR_FRAC * tol_comp;
+            // corrector rhs: phi = grad f + G'(Sigma r_in + (smu - corr)/s)
+            if (act) {
+                double phi[NZ];
+#pragma unroll
+                for (int i = 0; i < NZ; i++) phi[i] = cq.hd(i) * zk[i] + cq.q(i);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    phi[i] += cq.hc() * zk[4 + i];
+                    phi[4 + i] += cq.hc() * zk[i];
+                }
+#pragma unroll
+                for (int i = 0; i < NZ; i++) {
+                    const double sl = w.s[i * NP + k], su = w.s[(17 + i) * NP + k];
+                    const double ll = w.lam[i * NP + k], lu = w.lam[(17 + i) * NP + k];
+                    const double rl = lower_bound(i) - zk[i] + sl, ru = zk[i] - upper_bound(i) + su;
+                    const double tl = (ll * rl + smu - w.corr[i * NP + k]) / sl;
+                    const double tu = (lu * ru + smu - w.corr[(17 + i) * NP + k]) / su;
+                    phi[i] += tu - tl;
+                }
+                for (int j = 0; j < nf; j++) {
+                    const double a0 = w.face[(3 * j) * NP + k], a1 = w.face[(3 * j + 1) * NP + k], a2 = w.face[(3 * j + 2) * NP + k];
+                    const double hj = a0 * zk[8] + a1 * zk[9] + a2 * zk[10] - w.face[(3 * MF + j) * NP + k] - HU;
+                    const double sc = w.s[(34 + j) * NP + k], lc = w.lam[(34 + j) * NP + k];
+                    const double t = (lc * (hj + sc) + smu - w.corr[(34 + j) * NP + k]) / sc;
+                    phi[8] += a0 * t; phi[9] += a1 * t; phi[10] += a2 * t;
+                }
+                gdouble *rec = w.rec + (size_t)k * REC_STRIDE;
+#pragma unroll
+                for (int i = 0; i < NZ; i++) rec[REC_PHI + i] = phi[i];
+            }
+                        WSYNC();
+        } else {
+            step_cc = ap;
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < NZ; i++) w.z[i * NP + k] = zk[i] + ap * dzk[i];
+            }
+        }
+    }
+
+    (void)step_cc;
+    FULLSYNC();
+    SlackOut o;
+    o.ap = ap; o.ad = ad; o.sigma = sigma; o.smu = smu;
+    return o;
+}
+
+// ------------------------------------------------------------------ costate sweep: y <- y + ap (y+ - y)
+// y+_k = (Phi_k dz_k + phi_k)_s + [0; A_k' y+_{k+1,x}]
+template <int NP>
+__device__ __noinline__ void sweep_costate(WsView w, cgdouble *pk, int N, double ap)
+{
+    w = uni(w); N = uni(N); ap = uni(ap);
+    FULLSYNC(); // phase boundary: other lanes' global writes of the previous phase are visible
+    const int lane = threadIdx.x, k = lane;
+    const bool act = lane < N;
+    const int my_dst = L_AB + lin_dst(lane);
+    const double hc_k = act ? -2.0 * pk[8] : 0.0;
+    {
+        // w-part is stage-parallel
+        if (act) {
+            cgdouble *rec = w.rec + (size_t)k * REC_STRIDE;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const double yw = rec[REC_PHID + 4 + i] * w.dz[(4 + i) * NP + k] + hc_k * w.dz[i * NP + k] + rec[REC_PHI + 4 + i];
+                const double yo = w.y[i * NP + k];
+                w.y[i * NP + k] = yo + ap * (yw - yo);
+            }
+        }
+        int cy = 0;
+        cgdouble *r0 = w.rec + (size_t)(N - 1) * REC_STRIDE;
+        double pre_lin = r0[lane];
+        double pre_phi = (lane < 44) ? r0[REC_PHID + lane] : 0.0;
+        double pre_dz = (lane < 9) ? w.dz[(8 + lane) * NP + N - 1] : 0.0;
+        for (int kk = N - 1; kk >= 0; kk--) {
+            sm[my_dst] = pre_lin;
+            if (lane < 44) sm[L_PHI + lane] = pre_phi;
+            if (lane < 9) sm[L_DS + 4 + lane] = pre_dz;
+            if (kk > 0) {
+                cgdouble *rn = w.rec + (size_t)(kk - 1) * REC_STRIDE;
+                pre_lin = rn[lane];
+                pre_phi = (lane < 44) ? rn[REC_PHID + lane] : 0.0;
+                pre_dz = (lane < 9) ? w.dz[(8 + lane) * NP + kk - 1] : 0.0;
+            }
+            WSYNC();
+            if (lane < 9) {
+                double acc = sm[L_PHID + 8 + lane] * sm[L_DS + 4 + lane] + sm[L_PHIV + 8 + lane];
+                if (lane < 3) {
+#pragma unroll
+                    for (int j = 0; j < 3; j++) acc += sm[L_PHIPOS + lane * 3 + j] * sm[L_DS + 4 + j];
+                }
+                if (kk < N - 1) {
+                    const double *yn = sm + L_YX + (cy ? 9 : 0);
+#pragma unroll
+                    for (int i = 0; i < 9; i++) acc += sm[L_AB + i * 13 + lane] * yn[i];
+                }
+                sm[L_YX + (cy ? 0 : 9) + lane] = acc;
+                const double yo = w.y[(4 + lane) * NP + kk];
+                w.y[(4 + lane) * NP + kk] = yo + ap * (acc - yo);
+            }
+            cy ^= 1;
+            WSYNC();
+        }
+                WSYNC();
+    }
 }
 
 // ------------------------------------------------------------------ the solver kernel
+template <int NP>
 __global__ __launch_bounds__(64) void nmpc_ipm_kernel(KernelArgs a)
 {
-    __shared__ double sm[L_TOTAL];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int N = a.N, M = a.M, MF = a.MF, np = NPRE + 4 * M;
     const int mcf = 34 + MF;
@@ -152,32 +822,29 @@ __global__ __launch_bounds__(64) void nmpc_ipm_kernel(KernelArgs a)
 
     WsView w;
     {
-        double *base = a.ws + (size_t)b * ws_doubles_per_problem(N, MF);
+        gdouble *base = (gdouble *)(a.ws + (size_t)b * ws_doubles_per_problem(N, MF));
         w.rec = base;
         w.z = w.rec + (size_t)N * REC_STRIDE;
-        w.y = w.z + 17 * N;
-        w.dz = w.y + 13 * N;
-        w.s = w.dz + 17 * N;
-        w.lam = w.s + (size_t)mcf * N;
-        w.corr = w.lam + (size_t)mcf * N;
-        w.face = w.corr + (size_t)mcf * N;
+        w.y = w.z + 17 * NP;
+        w.dz = w.y + 13 * NP;
+        w.s = w.dz + 17 * NP;
+        w.lam = w.s + (size_t)mcf * NP;
+        w.corr = w.lam + (size_t)mcf * NP;
+        w.face = w.corr + (size_t)mcf * NP;
     }
-    const double *xinit = a.xinit + (size_t)b * 9;
+    cgdouble *xinit = (cgdouble *)(a.xinit + (size_t)b * 9);
+    cgdouble *pk = (cgdouble *)(a.params + ((size_t)b * N + (act ? k : 0)) * np);
 
     // ---------------------------------------------------------------- init (lane == stage)
-    double p10[NPRE];
     int nf = 0;
     int bad_param = 0;
     double smin = 1e300;
     if (act) {
-        const double *pk = a.params + ((size_t)b * N + k) * np;
-#pragma unroll
-        for (int i = 0; i < NPRE; i++) p10[i] = pk[i];
         if (a.nfaces) nf = a.nfaces[(size_t)b * N + k];
         else { // trailing all-zero rows are padding (forces_normal.cpp:127-135)
             nf = M;
             while (nf > 0) {
-                const double *r = pk + NPRE + 3 * (nf - 1);
+                cgdouble *r = pk + NPRE + 3 * (nf - 1);
                 if (r[0] == 0.0 && r[1] == 0.0 && r[2] == 0.0 && pk[NPRE + 3 * M + nf - 1] >= -HU) nf--;
                 else break;
             }
@@ -188,29 +855,29 @@ __global__ __launch_bounds__(64) void nmpc_ipm_kernel(KernelArgs a)
 #pragma unroll
         for (int i = 0; i < NZ; i++) {
             zk[i] = z0[i];
-            w.z[i * N + k] = zk[i];
+            w.z[i * NP + k] = zk[i];
         }
 #pragma unroll
         for (int i = 0; i < NZ; i++) {
             const double sl = zk[i] - lower_bound(i), su = upper_bound(i) - zk[i];
-            w.s[i * N + k] = sl;
-            w.s[(17 + i) * N + k] = su;
+            w.s[i * NP + k] = sl;
+            w.s[(17 + i) * NP + k] = su;
             smin = fmin(smin, fmin(sl, su));
         }
         for (int j = 0; j < nf; j++) {
             const double a0 = pk[NPRE + 3 * j], a1 = pk[NPRE + 3 * j + 1], a2 = pk[NPRE + 3 * j + 2];
             const double bj = pk[NPRE + 3 * M + j];
-            w.face[(3 * j) * N + k] = a0;
-            w.face[(3 * j + 1) * N + k] = a1;
-            w.face[(3 * j + 2) * N + k] = a2;
-            w.face[(3 * MF + j) * N + k] = bj;
+            w.face[(3 * j) * NP + k] = a0;
+            w.face[(3 * j + 1) * NP + k] = a1;
+            w.face[(3 * j + 2) * NP + k] = a2;
+            w.face[(3 * MF + j) * NP + k] = bj;
             const double sc = -(a0 * zk[8] + a1 * zk[9] + a2 * zk[10] - bj - HU);
-            w.s[(34 + j) * N + k] = sc;
+            w.s[(34 + j) * NP + k] = sc;
             smin = fmin(smin, sc);
         }
 #pragma unroll
-        for (int i = 0; i < NS; i++) w.y[i * N + k] = 0.0;
-        w.rec[(size_t)k * REC_STRIDE + REC_HC] = -2.0 * p10[8]; // hc of this stage's cost (constant)
+        for (int i = 0; i < NS; i++) w.y[i * NP + k] = 0.0;
+        w.rec[(size_t)k * REC_STRIDE + REC_HC] = -2.0 * pk[8]; // hc of this stage's cost (constant)
     }
     smin = wave_min(smin);
     const int mtot = (int)wave_sum(act ? (double)(34 + nf) : 0.0);
@@ -227,16 +894,12 @@ __global__ __launch_bounds__(64) void nmpc_ipm_kernel(KernelArgs a)
         const double shift = (smin >= S_MIN) ? 0.0 : (S_MIN - smin) + fmax(0.0, -smin);
         if (act) {
             for (int i = 0; i < 34 + nf; i++) {
-                const double s = w.s[i * N + k] + shift;
-                w.s[i * N + k] = s;
-                w.lam[i * N + k] = a.mu0 / s;
+                const double s = w.s[i * NP + k] + shift;
+                w.s[i * NP + k] = s;
+                w.lam[i * NP + k] = a.mu0 / s;
             }
         }
     }
-    const int sc_k = stage_class(k, N);
-    const CostQ cq = make_cost(p10, sc_k, a.model);
-    const int my_dst = L_AB + lin_dst(lane);
-
     // constant entries of [A|B]: identity blocks of A, dt*I in B's euler rows
     for (int t = lane; t < 117; t += 64) {
         const int i = t / 13, j = t % 13;
@@ -250,537 +913,52 @@ __global__ __launch_bounds__(64) void nmpc_ipm_kernel(KernelArgs a)
     int flag = FRP_EXIT_MAXIT, it = 0;
     double res_eq = 0, res_in = 0, rs = 0, rcomp = 0, pobj = 0, mu = 0, sigma = 0, step_cc = 0;
 
+#ifdef FRP_PROFILE
+    long long tph[6] = {0, 0, 0, 0, 0, 0}, tc0, tc1;
+#define TICK() tc0 = clock64()
+#define TOCK(i) do { tc1 = clock64(); tph[i] += tc1 - tc0; tc0 = tc1; } while (0)
+#else
+#define TICK()
+#define TOCK(i)
+#endif
     for (it = 0;; it++) {
-        // ------------------------------------------------------------ E: evaluate (lane == stage)
-        double l_eq = 0, l_in = 0, l_rs = 0, l_rc = 0, l_gap = 0, l_obj = 0;
-        if (act) {
-            double zk[NZ];
-#pragma unroll
-            for (int i = 0; i < NZ; i++) zk[i] = w.z[i * N + k];
-            double g[NZ];
-#pragma unroll
-            for (int i = 0; i < NZ; i++) g[i] = cq.hd(i) * zk[i] + cq.q(i);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                g[i] += cq.hc() * zk[4 + i];
-                g[4 + i] += cq.hc() * zk[i];
-            }
-            l_obj = stage_cost(zk, p10, sc_k, a.model, nullptr);
-            double *rec = w.rec + (size_t)k * REC_STRIDE;
-            if (k == 0) {
-#pragma unroll
-                for (int i = 0; i < 9; i++) l_eq = fmax(l_eq, fabs(xinit[i] - zk[8 + i]));
-            }
-            // phi (affine) starts from the cost gradient, stationarity residual g gets multipliers added
-            double phi[NZ];
-#pragma unroll
-            for (int i = 0; i < NZ; i++) phi[i] = g[i];
-            if (k < N - 1) {
-                Lin L;
-                double xn[9];
-                rk2<true>(zk + 8, zk, p10 + 3, xn, &L);
-                const double *Lc = reinterpret_cast<const double *>(&L);
-#pragma unroll
-                for (int t = 0; t < 51; t++) rec[REC_LIN + t] = Lc[t];
-                double yn[NS];
-#pragma unroll
-                for (int i = 0; i < NS; i++) yn[i] = w.y[i * N + k + 1];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const double d = zk[i] - w.z[(4 + i) * N + k + 1];
-                    rec[REC_D + i] = d;
-                    l_eq = fmax(l_eq, fabs(d));
-                }
-#pragma unroll
-                for (int i = 0; i < 9; i++) {
-                    const double d = xn[i] - w.z[(8 + i) * N + k + 1];
-                    rec[REC_D + 4 + i] = d;
-                    l_eq = fmax(l_eq, fabs(d));
-                }
-                // g += M' y_{k+1}
-                const double *yw = yn, *yp = yn + 4, *yv = yn + 7, *ye = yn + 10;
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    g[j] += yw[j] + L.Bvw[0 + j] * yv[0] + L.Bvw[3 + j] * yv[1] + L.Bvw[6 + j] * yv[2] + DT * ye[j];
-                    g[8 + j] += yp[j];
-                    g[11 + j] += L.Apv[0 + j] * yp[0] + L.Apv[3 + j] * yp[1] + L.Apv[6 + j] * yp[2] +
-                                 L.Avv[0 + j] * yv[0] + L.Avv[3 + j] * yv[1] + L.Avv[6 + j] * yv[2];
-                    g[14 + j] += L.Ape[0 + j] * yp[0] + L.Ape[3 + j] * yp[1] + L.Ape[6 + j] * yp[2] +
-                                 L.Ave[0 + j] * yv[0] + L.Ave[3 + j] * yv[1] + L.Ave[6 + j] * yv[2] + ye[j];
-                }
-                g[3] += yw[3] + L.BpT[0] * yp[0] + L.BpT[1] * yp[1] + L.BpT[2] * yp[2] +
-                        L.BvT[0] * yv[0] + L.BvT[1] * yv[1] + L.BvT[2] * yv[2];
-            }
-#pragma unroll
-            for (int i = 0; i < NS; i++) g[4 + i] -= w.y[i * N + k];
-            // bounds: residuals, barrier Hessian / gradient
-#pragma unroll
-            for (int i = 0; i < NZ; i++) {
-                const double sl = w.s[i * N + k], su = w.s[(17 + i) * N + k];
-                const double ll = w.lam[i * N + k], lu = w.lam[(17 + i) * N + k];
-                const double vl = lower_bound(i) - zk[i], vu = zk[i] - upper_bound(i);
-                const double rl = vl + sl, ru = vu + su;
-                l_in = fmax(l_in, fmax(fmax(vl, vu), fmax(fabs(rl), fabs(ru))));
-                l_rc = fmax(l_rc, fmax(sl * ll, su * lu));
-                l_gap += sl * ll + su * lu;
-                g[i] += lu - ll;
-                const double sgl = ll / sl, sgu = lu / su;
-                rec[REC_PHID + i] = cq.hd(i) + sgl + sgu;
-                phi[i] += sgu * ru - sgl * rl;
-            }
-            double pp[6] = {0, 0, 0, 0, 0, 0}; // xx xy xz yy yz zz
-            for (int j = 0; j < nf; j++) {
-                const double a0 = w.face[(3 * j) * N + k], a1 = w.face[(3 * j + 1) * N + k], a2 = w.face[(3 * j + 2) * N + k];
-                const double hj = a0 * zk[8] + a1 * zk[9] + a2 * zk[10] - w.face[(3 * MF + j) * N + k] - HU;
-                const double sc = w.s[(34 + j) * N + k], lc = w.lam[(34 + j) * N + k];
-                const double rc = hj + sc;
-                l_in = fmax(l_in, fmax(hj, fabs(rc)));
-                l_rc = fmax(l_rc, sc * lc);
-                l_gap += sc * lc;
-                g[8] += a0 * lc; g[9] += a1 * lc; g[10] += a2 * lc;
-                const double sg = lc / sc, t = sg * rc;
-                phi[8] += a0 * t; phi[9] += a1 * t; phi[10] += a2 * t;
-                pp[0] += sg * a0 * a0; pp[1] += sg * a0 * a1; pp[2] += sg * a0 * a2;
-                pp[3] += sg * a1 * a1; pp[4] += sg * a1 * a2; pp[5] += sg * a2 * a2;
-            }
-            rec[REC_PHIPOS + 0] = pp[0]; rec[REC_PHIPOS + 1] = pp[1]; rec[REC_PHIPOS + 2] = pp[2];
-            rec[REC_PHIPOS + 3] = pp[1]; rec[REC_PHIPOS + 4] = pp[3]; rec[REC_PHIPOS + 5] = pp[4];
-            rec[REC_PHIPOS + 6] = pp[2]; rec[REC_PHIPOS + 7] = pp[4]; rec[REC_PHIPOS + 8] = pp[5];
-#pragma unroll
-            for (int i = 0; i < NZ; i++) {
-                rec[REC_PHI + i] = phi[i];
-                l_rs = fmax(l_rs, fabs(g[i]));
-            }
-        }
-        res_eq = wave_max(l_eq); res_in = wave_max(l_in); rs = wave_max(l_rs); rcomp = wave_max(l_rc);
-        pobj = wave_sum(l_obj);
-        mu = wave_sum(l_gap) / (double)mtot;
+        TICK();
+        const EvalOut e = phase_eval<NP>(w, pk, xinit, N, MF, nf, a.model);
+        res_eq = wave_max(e.eq); res_in = wave_max(e.in); rs = wave_max(e.rs); rcomp = wave_max(e.rc);
+        pobj = wave_sum(e.obj);
+        mu = wave_sum(e.gap) / (double)mtot;
         if (!(res_eq == res_eq) || !(rs == rs) || !(pobj == pobj)) { flag = FRP_EXIT_BADFUNCEVAL; break; }
         if (res_eq <= a.tol_eq && res_in <= a.tol_ineq && rs <= a.tol_stat && rcomp <= a.tol_comp) { flag = FRP_EXIT_OPTIMAL; break; }
         if (it >= a.maxit) { flag = FRP_EXIT_MAXIT; break; }
         if (mu > DIVERGE_MU * fmax(1.0, a.mu0) || rs > DIVERGE_RS) { flag = FRP_EXIT_NOPROGRESS; break; }
-        __threadfence_block();
         WSYNC();
+        TOCK(0);
 
-        bool fact_fail = false;
-        double smu = 0.0, ap = 1.0, ad = 1.0;
-        for (int pass = 0; pass < 2; pass++) {
-            // -------------------------------------------------------- backward sweep
-            // pass 0: factorisation + vector part; pass 1: vector part only (new phi)
-            {
-                int cur = 0; // buffer holding P_{k+1}
-                const double *r0 = w.rec + (size_t)(N - 1) * REC_STRIDE;
-                double pre_lin = r0[lane];                                           // LIN + D
-                double pre_phi = (lane < 44) ? r0[REC_PHID + lane] : 0.0;            // PhiD | PhiPos | phi
-                double pre_out0 = 0.0, pre_out1 = 0.0;                               // Kb|R|Pd (pass 1)
-                if (pass == 1) {
-                    pre_out0 = r0[REC_KB + lane];
-                    pre_out1 = (lane < 17) ? r0[REC_KB + 64 + lane] : 0.0;
-                }
-                for (int kk = N - 1; kk >= 0; kk--) {
-                    double *rec = w.rec + (size_t)kk * REC_STRIDE;
-                    const bool last = (kk == N - 1);
-                    sm[my_dst] = pre_lin;
-                    if (lane < 44) sm[L_PHI + lane] = pre_phi;
-                    if (pass == 1) {
-                        sm[L_OUT + lane] = pre_out0;               // Kb(52) R(12 of 16)
-                        if (lane < 17) sm[L_OUT + 64 + lane] = pre_out1; // R tail, Pd
-                    }
-                    if (kk > 0) {
-                        const double *rn = rec - REC_STRIDE;
-                        pre_lin = rn[lane];
-                        pre_phi = (lane < 44) ? rn[REC_PHID + lane] : 0.0;
-                        if (pass == 1) {
-                            pre_out0 = rn[REC_KB + lane];
-                            pre_out1 = (lane < 17) ? rn[REC_KB + 64 + lane] : 0.0;
-                        }
-                    }
-                    WSYNC();
-                    const double *Pn = sm + (cur ? L_P1 : L_P0);
-                    double *Pk = sm + (cur ? L_P0 : L_P1);
-                    const double *AB = sm + L_AB;
-                    if (pass == 0 && !last) {
-                        // PA = Pxx [A|B] (9 x 13), Pd = P d
-                        for (int t = lane; t < 117; t += 64) {
-                            const int i = t / 13, j = t % 13;
-                            double acc = 0.0;
-#pragma unroll
-                            for (int l = 0; l < 9; l++) acc += Pn[(4 + i) * 13 + 4 + l] * AB[l * 13 + j];
-                            sm[L_PA + t] = acc;
-                        }
-                        if (lane < 13) {
-                            double acc = 0.0;
-#pragma unroll
-                            for (int j = 0; j < 13; j++) acc += Pn[lane * 13 + j] * sm[L_D + j];
-                            sm[L_PD + lane] = acc;
-                        }
-                        WSYNC();
-                    }
-                    // q = phi + M'(Pd + p_{k+1})
-                    if (lane < 17) {
-                        double acc = sm[L_PHIV + lane];
-                        if (!last) {
-                            if (lane < 4) {
-                                acc += sm[L_PD + lane] + sm[L_PV + lane];
-#pragma unroll
-                                for (int i = 0; i < 9; i++) acc += AB[i * 13 + 9 + lane] * (sm[L_PD + 4 + i] + sm[L_PV + 4 + i]);
-                            } else if (lane >= 8) {
-#pragma unroll
-                                for (int i = 0; i < 9; i++) acc += AB[i * 13 + lane - 8] * (sm[L_PD + 4 + i] + sm[L_PV + 4 + i]);
-                            }
-                        }
-                        sm[L_Q + lane] = acc;
-                    }
-                    if (pass == 0) {
-                        // Qxx -> Pk[4+i][4+j]; Qww -> diag; Qwx = 0
-                        for (int t = lane; t < 169; t += 64) {
-                            const int i = t / 13, j = t % 13;
-                            double acc = 0.0;
-                            if (i >= 4 && j >= 4) {
-                                const int ii = i - 4, jj = j - 4;
-                                if (ii == jj) acc = sm[L_PHID + 8 + ii];
-                                if (ii < 3 && jj < 3) acc += sm[L_PHIPOS + ii * 3 + jj];
-                                if (!last) {
-#pragma unroll
-                                    for (int l = 0; l < 9; l++) acc += AB[l * 13 + ii] * sm[L_PA + l * 13 + jj];
-                                }
-                            } else if (i == j) acc = sm[L_PHID + 4 + i];
-                            Pk[t] = acc;
-                        }
-                        // Qus (4 x 13): Quw = hc I, Qux = T A with T = Pwx + (Pxx B)'
-                        if (lane < 52) {
-                            const int i = lane / 13, j = lane % 13;
-                            double acc = 0.0;
-                            if (j < 4) acc = (i == j) ? sm[L_HC] : 0.0;
-                            else if (!last) {
-#pragma unroll
-                                for (int l = 0; l < 9; l++) acc += (Pn[i * 13 + 4 + l] + sm[L_PA + l * 13 + 9 + i]) * AB[l * 13 + j - 4];
-                            }
-                            sm[L_QUS + lane] = acc;
-                        }
-                        // Quu
-                        if (lane < 16) {
-                            const int i = lane / 4, j = lane % 4;
-                            double acc = (i == j) ? sm[L_PHID + i] : 0.0;
-                            if (!last) {
-                                acc += Pn[i * 13 + j];
-#pragma unroll
-                                for (int l = 0; l < 9; l++)
-                                    acc += (Pn[i * 13 + 4 + l] + sm[L_PA + l * 13 + 9 + i]) * AB[l * 13 + 9 + j] + AB[l * 13 + 9 + i] * Pn[(4 + l) * 13 + j];
-                            }
-                            sm[L_QUU + lane] = acc;
-                        }
-                        WSYNC();
-                        {
-                            double R[16];
-                            const bool ok = spd4_inverse(sm + L_QUU, R);
-                            if (!ok) fact_fail = true;
-#pragma unroll
-                            for (int t = 0; t < 16; t++) sm[L_R + t] = ok ? R[t] : 0.0;
-                        }
-                        WSYNC();
-                        // Kb = R Qus
-                        if (lane < 52) {
-                            const int i = lane / 13, j = lane % 13;
-                            double acc = 0.0;
-#pragma unroll
-                            for (int l = 0; l < 4; l++) acc += sm[L_R + i * 4 + l] * sm[L_QUS + l * 13 + j];
-                            sm[L_KB + lane] = acc;
-                        }
-                        WSYNC();
-                        // P_k = Qss - Qus' Kb
-                        for (int t = lane; t < 169; t += 64) {
-                            const int i = t / 13, j = t % 13;
-                            double acc = Pk[t];
-#pragma unroll
-                            for (int l = 0; l < 4; l++) acc -= sm[L_QUS + l * 13 + i] * sm[L_KB + l * 13 + j];
-                            Pk[t] = acc;
-                        }
-                    } else {
-                        WSYNC();
-                    }
-                    // kb = R q_u ; p_k = q_s - Kb' q_u
-                    double kbv = 0.0, pv = 0.0;
-                    if (lane < 4) {
-#pragma unroll
-                        for (int l = 0; l < 4; l++) kbv += sm[L_R + lane * 4 + l] * sm[L_Q + l];
-                    } else if (lane < 17) {
-                        pv = sm[L_Q + lane];
-#pragma unroll
-                        for (int l = 0; l < 4; l++) pv -= sm[L_KB + l * 13 + lane - 4] * sm[L_Q + l];
-                    }
-                    WSYNC(); // everyone has read p_{k+1} (L_PV) before it is overwritten
-                    if (lane < 4) sm[L_KV + lane] = kbv;
-                    else if (lane < 17) sm[L_PV + lane - 4] = pv;
-                    WSYNC();
-                    // stream the factors of stage kk to HBM
-                    if (pass == 0) {
-                        rec[REC_KB + lane] = sm[L_OUT + lane];
-                        if (lane < 34) rec[REC_KB + 64 + lane] = sm[L_OUT + 64 + lane];
-                    } else if (lane < 17) {
-                        rec[REC_KV + lane] = sm[L_KV + lane]; // kb (4) + p (13)
-                    }
-                    cur ^= 1;
-                }
-                // stage 0: dw = -Pww^-1 (Pwx dx + p_w), dx = xinit - x_0
-                const double *P0 = sm + (cur ? L_P1 : L_P0);
-                if (pass == 0) {
-                    double Rw[16], Pww[16];
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-#pragma unroll
-                        for (int j = 0; j < 4; j++) Pww[i * 4 + j] = P0[i * 13 + j];
-                    const bool ok = spd4_inverse(Pww, Rw);
-                    if (!ok) fact_fail = true;
-                    WSYNC();
-#pragma unroll
-                    for (int t = 0; t < 16; t++) sm[L_S0 + t] = ok ? Rw[t] : 0.0;
-                    if (lane < 36) sm[L_S0 + 16 + lane] = P0[(lane / 9) * 13 + 4 + lane % 9];
-                }
-                if (lane < 9) sm[L_DS + 4 + lane] = xinit[lane] - w.z[(8 + lane) * N + 0];
-                WSYNC();
-                if (lane < 4) {
-                    double acc = sm[L_PV + lane];
-#pragma unroll
-                    for (int j = 0; j < 9; j++) acc += sm[L_S0 + 16 + lane * 9 + j] * sm[L_DS + 4 + j];
-                    sm[L_DU + lane] = acc; // temporary: rhs
-                }
-                WSYNC();
-                if (lane < 4) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int l = 0; l < 4; l++) acc -= sm[L_S0 + lane * 4 + l] * sm[L_DU + l];
-                    sm[L_DS + lane] = acc;
-                }
-                WSYNC();
-            }
-            if (fact_fail) break;
-            // -------------------------------------------------------- forward sweep
-            {
-                const double *r0 = w.rec;
-                double pre_lin = r0[lane];
-                double pre_kb = (lane < 52) ? r0[REC_KB + lane] : ((lane < 56) ? r0[REC_KV + lane - 52] : 0.0);
-                for (int kk = 0; kk < N; kk++) {
-                    const double *rec = w.rec + (size_t)kk * REC_STRIDE;
-                    sm[my_dst] = pre_lin;
-                    if (lane < 52) sm[L_KB + lane] = pre_kb;
-                    else if (lane < 56) sm[L_KV + lane - 52] = pre_kb;
-                    if (kk < N - 1) {
-                        const double *rn = rec + REC_STRIDE;
-                        pre_lin = rn[lane];
-                        pre_kb = (lane < 52) ? rn[REC_KB + lane] : ((lane < 56) ? rn[REC_KV + lane - 52] : 0.0);
-                    }
-                    WSYNC();
-                    if (lane < 4) {
-                        double a0 = sm[L_KV + lane], a1 = 0.0;
-#pragma unroll
-                        for (int j = 0; j < 12; j += 2) {
-                            a0 += sm[L_KB + lane * 13 + j] * sm[L_DS + j];
-                            a1 += sm[L_KB + lane * 13 + j + 1] * sm[L_DS + j + 1];
-                        }
-                        a0 += sm[L_KB + lane * 13 + 12] * sm[L_DS + 12];
-                        const double du = -(a0 + a1);
-                        sm[L_DU + lane] = du;
-                        w.dz[lane * N + kk] = du;
-                    } else if (lane < 17) {
-                        w.dz[lane * N + kk] = sm[L_DS + lane - 4];
-                    }
-                    WSYNC();
-                    if (kk < N - 1) {
-                        double v = 0.0;
-                        if (lane < 4) v = sm[L_DU + lane] + sm[L_D + lane];
-                        else if (lane < 13) {
-                            const int i = lane - 4;
-                            double a0 = sm[L_D + lane], a1 = 0.0;
-#pragma unroll
-                            for (int j = 0; j < 8; j += 2) {
-                                a0 += sm[L_AB + i * 13 + j] * sm[L_DS + 4 + j];
-                                a1 += sm[L_AB + i * 13 + j + 1] * sm[L_DS + 4 + j + 1];
-                            }
-                            a0 += sm[L_AB + i * 13 + 8] * sm[L_DS + 12];
-#pragma unroll
-                            for (int j = 0; j < 4; j += 2) {
-                                a0 += sm[L_AB + i * 13 + 9 + j] * sm[L_DU + j];
-                                a1 += sm[L_AB + i * 13 + 10 + j] * sm[L_DU + j + 1];
-                            }
-                            v = a0 + a1;
-                        }
-                        WSYNC();
-                        if (lane < 13) sm[L_DS + lane] = v;
-                    }
-                }
-                __threadfence_block();
-                WSYNC();
-            }
-            // -------------------------------------------------------- slack steps (lane == stage)
-            {
-                double l_ap = 1e300, l_ad = 1e300;
-                double dzk[NZ];
-                if (act) {
-#pragma unroll
-                    for (int i = 0; i < NZ; i++) dzk[i] = w.dz[i * N + k];
-                }
-                // pass A: step lengths
-                double zk[NZ];
-                if (act) {
-#pragma unroll
-                    for (int i = 0; i < NZ; i++) zk[i] = w.z[i * N + k];
-                    for (int c = 0; c < 34 + nf; c++) {
-                        double gdz, viol;
-                        if (c < 17) { gdz = -dzk[c]; viol = lower_bound(c) - zk[c]; }
-                        else if (c < 34) { gdz = dzk[c - 17]; viol = zk[c - 17] - upper_bound(c - 17); }
-                        else {
-                            const int j = c - 34;
-                            const double a0 = w.face[(3 * j) * N + k], a1 = w.face[(3 * j + 1) * N + k], a2 = w.face[(3 * j + 2) * N + k];
-                            gdz = a0 * dzk[8] + a1 * dzk[9] + a2 * dzk[10];
-                            viol = a0 * zk[8] + a1 * zk[9] + a2 * zk[10] - w.face[(3 * MF + j) * N + k] - HU;
-                        }
-                        const double s = w.s[c * N + k], l = w.lam[c * N + k];
-                        const double rin = viol + s;
-                        const double ds = -rin - gdz;
-                        const double rc = s * l - smu + (pass ? w.corr[c * N + k] : 0.0);
-                        const double dl = (-rc - l * ds) / s;
-                        if (ds < 0.0) l_ap = fmin(l_ap, -s / ds);
-                        if (dl < 0.0) l_ad = fmin(l_ad, -l / dl);
-                    }
-                }
-                ap = wave_min(l_ap); ad = wave_min(l_ad);
-                if (pass == 0) { ap = fmin(1.0, ap); ad = fmin(1.0, ad); }
-                else { ap = fmin(1.0, a.ftb * ap); ad = fmin(1.0, a.ftb * ad); }
-                // pass B: affine complementarity + second-order term / or the update
-                double l_gapaff = 0.0;
-                if (act) {
-                    for (int c = 0; c < 34 + nf; c++) {
-                        double gdz, viol;
-                        if (c < 17) { gdz = -dzk[c]; viol = lower_bound(c) - zk[c]; }
-                        else if (c < 34) { gdz = dzk[c - 17]; viol = zk[c - 17] - upper_bound(c - 17); }
-                        else {
-                            const int j = c - 34;
-                            const double a0 = w.face[(3 * j) * N + k], a1 = w.face[(3 * j + 1) * N + k], a2 = w.face[(3 * j + 2) * N + k];
-                            gdz = a0 * dzk[8] + a1 * dzk[9] + a2 * dzk[10];
-                            viol = a0 * zk[8] + a1 * zk[9] + a2 * zk[10] - w.face[(3 * MF + j) * N + k] - HU;
-                        }
-                        const double s = w.s[c * N + k], l = w.lam[c * N + k];
-                        const double rin = viol + s;
-                        const double ds = -rin - gdz;
-                        const double rc = s * l - smu + (pass ? w.corr[c * N + k] : 0.0);
-                        const double dl = (-rc - l * ds) / s;
-                        if (pass == 0) {
-                            l_gapaff += (s + ap * ds) * (l + ad * dl);
-                            w.corr[c * N + k] = ds * dl;
-                        } else {
-                            w.s[c * N + k] = s + ap * ds;
-                            w.lam[c * N + k] = l + ad * dl;
-                        }
-                    }
-                }
-                if (pass == 0) {
-                    const double mu_aff = wave_sum(l_gapaff) / (double)mtot;
-                    sigma = mu_aff / mu;
-                    sigma = sigma * sigma * sigma;
-                    if (sigma > 1.0) sigma = 1.0;
-                    smu = sigma * mu;
-                    if (smu < MU_FLOOR_FRAC * a.tol_comp) smu = MU_FLOOR_FRAC * a.tol_comp;
-                    // corrector rhs: phi = grad f + G'(Sigma r_in + (smu - corr)/s)
-                    if (act) {
-                        double phi[NZ];
-#pragma unroll
-                        for (int i = 0; i < NZ; i++) phi[i] = cq.hd(i) * zk[i] + cq.q(i);
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            phi[i] += cq.hc() * zk[4 + i];
-                            phi[4 + i] += cq.hc() * zk[i];
-                        }
-#pragma unroll
-                        for (int i = 0; i < NZ; i++) {
-                            const double sl = w.s[i * N + k], su = w.s[(17 + i) * N + k];
-                            const double ll = w.lam[i * N + k], lu = w.lam[(17 + i) * N + k];
-                            const double rl = lower_bound(i) - zk[i] + sl, ru = zk[i] - upper_bound(i) + su;
-                            const double tl = (ll * rl + smu - w.corr[i * N + k]) / sl;
-                            const double tu = (lu * ru + smu - w.corr[(17 + i) * N + k]) / su;
-                            phi[i] += tu - tl;
-                        }
-                        for (int j = 0; j < nf; j++) {
-                            const double a0 = w.face[(3 * j) * N + k], a1 = w.face[(3 * j + 1) * N + k], a2 = w.face[(3 * j + 2) * N + k];
-                            const double hj = a0 * zk[8] + a1 * zk[9] + a2 * zk[10] - w.face[(3 * MF + j) * N + k] - HU;
-                            const double sc = w.s[(34 + j) * N + k], lc = w.lam[(34 + j) * N + k];
-                            const double t = (lc * (hj + sc) + smu - w.corr[(34 + j) * N + k]) / sc;
-                            phi[8] += a0 * t; phi[9] += a1 * t; phi[10] += a2 * t;
-                        }
-                        double *rec = w.rec + (size_t)k * REC_STRIDE;
-#pragma unroll
-                        for (int i = 0; i < NZ; i++) rec[REC_PHI + i] = phi[i];
-                    }
-                    __threadfence_block();
-                    WSYNC();
-                } else {
-                    step_cc = ap;
-                    if (act) {
-#pragma unroll
-                        for (int i = 0; i < NZ; i++) w.z[i * N + k] = zk[i] + ap * dzk[i];
-                    }
-                }
-            }
-        } // pass
-        if (fact_fail) { flag = FRP_EXIT_FACTORIZATION; break; }
-
-        // ------------------------------------------------------------ costate sweep: y <- y + ap (y+ - y)
-        // y+_k = (Phi_k dz_k + phi_k)_s + [0; A_k' y+_{k+1,x}]
-        {
-            // w-part is stage-parallel
-            if (act) {
-                const double *rec = w.rec + (size_t)k * REC_STRIDE;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const double yw = rec[REC_PHID + 4 + i] * w.dz[(4 + i) * N + k] + cq.hc() * w.dz[i * N + k] + rec[REC_PHI + 4 + i];
-                    const double yo = w.y[i * N + k];
-                    w.y[i * N + k] = yo + ap * (yw - yo);
-                }
-            }
-            int cy = 0;
-            const double *r0 = w.rec + (size_t)(N - 1) * REC_STRIDE;
-            double pre_lin = r0[lane];
-            double pre_phi = (lane < 44) ? r0[REC_PHID + lane] : 0.0;
-            double pre_dz = (lane < 9) ? w.dz[(8 + lane) * N + N - 1] : 0.0;
-            for (int kk = N - 1; kk >= 0; kk--) {
-                sm[my_dst] = pre_lin;
-                if (lane < 44) sm[L_PHI + lane] = pre_phi;
-                if (lane < 9) sm[L_DS + 4 + lane] = pre_dz;
-                if (kk > 0) {
-                    const double *rn = w.rec + (size_t)(kk - 1) * REC_STRIDE;
-                    pre_lin = rn[lane];
-                    pre_phi = (lane < 44) ? rn[REC_PHID + lane] : 0.0;
-                    pre_dz = (lane < 9) ? w.dz[(8 + lane) * N + kk - 1] : 0.0;
-                }
-                WSYNC();
-                if (lane < 9) {
-                    double acc = sm[L_PHID + 8 + lane] * sm[L_DS + 4 + lane] + sm[L_PHIV + 8 + lane];
-                    if (lane < 3) {
-#pragma unroll
-                        for (int j = 0; j < 3; j++) acc += sm[L_PHIPOS + lane * 3 + j] * sm[L_DS + 4 + j];
-                    }
-                    if (kk < N - 1) {
-                        const double *yn = sm + L_YX + (cy ? 9 : 0);
-#pragma unroll
-                        for (int i = 0; i < 9; i++) acc += sm[L_AB + i * 13 + lane] * yn[i];
-                    }
-                    sm[L_YX + (cy ? 0 : 9) + lane] = acc;
-                    const double yo = w.y[(4 + lane) * N + kk];
-                    w.y[(4 + lane) * N + kk] = yo + ap * (acc - yo);
-                }
-                cy ^= 1;
-                WSYNC();
-            }
-            __threadfence_block();
-            WSYNC();
-        }
+        // predictor (affine) solve
+        if (sweep_backward<NP>(w, xinit, N, 0)) { flag = FRP_EXIT_FACTORIZATION; break; }
+        TOCK(1);
+        sweep_forward<NP>(w, N);
+        TOCK(2);
+        const SlackOut s0 = phase_slack<NP>(w, pk, N, MF, nf, a.model, 0, 0.0, mu, mtot, a.ftb, a.tol_comp);
+        sigma = s0.sigma;
+        TOCK(3);
+        // corrector solve (same factorisation, new rhs)
+        sweep_backward<NP>(w, xinit, N, 1);
+        TOCK(4);
+        sweep_forward<NP>(w, N);
+        TOCK(2);
+        const SlackOut s1 = phase_slack<NP>(w, pk, N, MF, nf, a.model, 1, s0.smu, mu, mtot, a.ftb, a.tol_comp);
+        step_cc = s1.ap;
+        TOCK(3);
+        sweep_costate<NP>(w, pk, N, s1.ap);
+        TOCK(5);
     }
 
     // ---------------------------------------------------------------- outputs
     if (act) {
         double *zo = a.z + ((size_t)b * N + k) * NZ;
 #pragma unroll
-        for (int i = 0; i < NZ; i++) zo[i] = w.z[i * N + k];
+        for (int i = 0; i < NZ; i++) zo[i] = w.z[i * NP + k];
     }
     if (lane == 0) {
         a.exitflag[b] = flag;
@@ -788,6 +966,9 @@ __global__ __launch_bounds__(64) void nmpc_ipm_kernel(KernelArgs a)
         if (a.info) {
             double *o = a.info + (size_t)b * FRP_INFO_STRIDE;
             o[0] = res_eq; o[1] = res_in; o[2] = rs; o[3] = rcomp; o[4] = pobj; o[5] = mu; o[6] = step_cc; o[7] = sigma;
+#ifdef FRP_PROFILE
+            for (int i = 0; i < 6; i++) o[i] = (double)tph[i]; // cycles: eval, factor, forward(x2), slack(x2), backvec, costate
+#endif
         }
     }
 }
@@ -861,7 +1042,8 @@ size_t ws_bytes(int B, int N, int MF) { return (size_t)B * ws_doubles_per_proble
 
 hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(nmpc_ipm_kernel, dim3(a.B), dim3(64), 0, stream, a);
+    if (padded_stages(a.N) == 32) hipLaunchKernelGGL(nmpc_ipm_kernel<32>, dim3(a.B), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL(nmpc_ipm_kernel<64>, dim3(a.B), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 

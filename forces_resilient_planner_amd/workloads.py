@@ -17,6 +17,7 @@ from . import layout as L
 from .adapter import ForcesAdapter, init_mpc_output
 
 SEED0 = 20260928
+NORMAL_WEIGHTS = (7.0, 1.0, 80.0, 12.0, 0.5)
 EGO = np.array([0.27, 0.27, 0.0425])   # ego ellipsoid semi-axes (rotors_sim.launch:67-68)
 
 
@@ -71,16 +72,18 @@ def _line_reference(rng, st, N):
     return ref_pos, ref_yaw, heading
 
 
-def _finish(ad, mpc_output, f_ext, ref_pos, ref_yaw, E, A, b, nf, model):
-    ad.set_paras(*_weights(model))
+def _finish(ad, mpc_output, f_ext, ref_pos, ref_yaw, E, A, b, nf, model, weights=None):
+    ad.set_paras(*(weights if weights is not None else _weights(model)))
     xinit, x0, params, nfaces = ad.pack(mpc_output, f_ext, ref_pos, ref_yaw, E, A, b, nf)
     return dict(xinit=xinit.copy(), x0=x0.copy(), params=params.copy(), nfaces=nfaces.copy(),
                 model=model, N=ad.N, M=ad.M, B=ad.B, ref_pos=ref_pos, ref_yaw=ref_yaw, f_ext=f_ext,
                 poly_A=A, poly_b=b, E=E, mpc_output=mpc_output)
 
 
-def config0(model=L.MODEL_NORMAL, f_ext=(0.0, 0.0, 0.0)):
-    """configs[0] 'plumbing' (SURVEY 8d Config 1 / Appendix B): one solve through the N=20 / 30-row ABI."""
+def config0(model=L.MODEL_NORMAL, f_ext=(0.0, 0.0, 0.0), weights=None):
+    """configs[0] 'plumbing' (SURVEY 8d Config 1 / Appendix B): one solve through the N=20 / 30-row ABI.
+    SURVEY Appendix B used the normal-mode weights (7, 1, 80, 12, 0.5) for BOTH models: pass
+    weights=NORMAL_WEIGHTS to reproduce its B-2 known answer with the final model."""
     N, M = L.N_REF, L.NH_REF
     st = np.array([[0, 0, 1, 0, 0, 0, 0, 0, 0.0]])
     ref_pos = np.zeros((1, N, 3)); ref_pos[0, :, 0] = 0.05 * (np.arange(N) + 1); ref_pos[0, :, 2] = 1.0
@@ -90,7 +93,7 @@ def config0(model=L.MODEL_NORMAL, f_ext=(0.0, 0.0, 0.0)):
     E = np.broadcast_to(np.diag(EGO), (1, N, 3, 3)).copy()
     nf = np.full((1, N), 6, dtype=np.int32)
     ad = ForcesAdapter(1, model, N, M)
-    return _finish(ad, init_mpc_output(st, N), np.asarray([f_ext], dtype=np.float64), ref_pos, ref_yaw, E, A, b, nf, model)
+    return _finish(ad, init_mpc_output(st, N), np.asarray([f_ext], dtype=np.float64), ref_pos, ref_yaw, E, A, b, nf, model, weights)
 
 
 def config1(B=1024, seed=SEED0 + 2, model=L.MODEL_NORMAL, M=L.NH_REF):

@@ -62,7 +62,7 @@ def _forces_call(w0, model):
 def test_dropin_abi_config0_known_answers(model, fext, fstar, golden_dir):
     """configs[0] through FORCESNLPsolver_{normal,final}_solve; f* from SURVEY Appendix B (SciPy on the
     reference callbacks), z* from the committed fixture."""
-    w0 = workloads.config0(model, fext)
+    w0 = workloads.config0(model, fext, workloads.NORMAL_WEIGHTS)
     flag, z, info = _forces_call(w0, model)
     assert flag == 1
     assert abs(info.pobj - fstar) / fstar < 1e-4

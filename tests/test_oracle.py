@@ -1,0 +1,111 @@
+"""CPU tests (no GPU): pin the oracle.
+
+ * orc_stage_eval vs the golden vectors produced by the reference's own CasADi callbacks (G1), and --
+   when oracle/_ref was built in this container -- vs the live reference callbacks on fresh points;
+ * orc_solve vs the committed SciPy SLSQP solutions of the reference NLP (G3) and SURVEY Appendix B.
+The ForcesPro binary itself is licence-locked (-100): solver-level parity with it is unpinned.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from forces_resilient_planner_amd import layout as L
+from forces_resilient_planner_amd import workloads
+
+from . import oracle_lib as OL
+
+
+def _sc(st):
+    return 0 if st == 0 else (2 if st == 19 else 1)
+
+
+def test_stage_functions_match_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "stage_vectors.npz"))
+    assert g["z"].shape[0] >= 200
+    for i in range(g["z"].shape[0]):
+        st = int(g["stage"][i])
+        o = OL.stage_eval(g["z"][i], g["p"][i], 30, _sc(st), int(g["model"][i]))
+        keys = ["f", "gf", "h", "Jh"] + ([] if st == 19 else ["c", "Jc"])
+        for key in keys:
+            ref = g[key][i] if key != "f" else g[key][i, 0]
+            assert np.max(np.abs(o[key] - ref) / (1 + np.abs(ref))) < 1e-12, (i, key)
+
+
+@pytest.mark.skipif(not OL.ref_model_available(), reason="oracle/_ref not built (reference tree absent)")
+def test_stage_functions_match_live_reference_callbacks():
+    rng = np.random.default_rng(7)
+    lb, ub = L.bounds()
+    D = ctypes.POINTER(ctypes.c_double)
+    for model, name in ((0, "normal"), (1, "final")):
+        lib = ctypes.CDLL(os.path.join(OL.ORC_DIR, "_ref", f"libref_model_{name}.so"))
+        fn = getattr(lib, f"FORCESNLPsolver_{name}_casadi2forces")
+        for t in range(300):
+            st = [0, 3, 19][t % 3]
+            z = lb + (ub - lb) * rng.random(17)
+            p = np.zeros(130); p[:10] = rng.uniform(-3, 3, 10); p[6:9] = rng.uniform(0.1, 90, 3)
+            nf = int(rng.integers(0, 31))
+            p[10:10 + 3 * nf] = rng.normal(size=3 * nf); p[100:100 + nf] = rng.normal(size=nf)
+            f = np.zeros(1); gf = np.zeros(17); c = np.zeros(13); Jc = np.zeros(221); h = np.zeros(30); Jh = np.zeros(510)
+            y = np.zeros(13); lam = np.zeros(64)
+            fn(*[a.ctypes.data_as(D) for a in (z, y, lam, p, f, gf, c, Jc, h, Jh)], None, st, 0, 0)
+            o = OL.stage_eval(z, p, 30, _sc(st), model)
+            assert abs(o["f"] - f[0]) / (1 + abs(f[0])) < 1e-12
+            for key, ref in (("gf", gf), ("h", h), ("Jh", Jh)) + ((() if st == 19 else (("c", c), ("Jc", Jc)))):
+                assert np.max(np.abs(o[key] - ref) / (1 + np.abs(ref))) < 1e-12, (t, key)
+
+
+@pytest.mark.parametrize("model,fext,fstar", [(0, (0, 0, 0), 23.1594329641), (1, (0, 0, 0), 48.4610568794),
+                                              (0, (1.5, -2.0, 0.5), 16.3615772657)])
+def test_solver_known_answers_appendix_b(model, fext, fstar):
+    w = workloads.config0(model, fext, workloads.NORMAL_WEIGHTS)
+    z, fl, info = OL.solve_batch(w)
+    assert fl[0] == 1
+    assert abs(info[0].pobj - fstar) / fstar < 1e-6
+    if model == 0 and fext[0] == 0:
+        assert np.allclose(z[0, 0, :8], [0, 0.573693778, 0, 7.4752233435, 0, 0.5099500276, 0, 7.4752233456], atol=1e-4)
+        assert abs(z[0, 19, 11] - 2.0) < 1e-4  # vx at its bound on the last stage
+
+
+@pytest.mark.parametrize("fam", ["config0", "config1", "config2", "config3"])
+def test_solver_matches_scipy_fixtures(fam, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"solutions_{fam}.npz"))
+    N, M = int(g["N"]), int(g["M"])
+    n = g["z"].shape[0]
+    nconv = 0
+    for i in range(n):
+        z, fl, info = OL.solve_one(g["xinit"][i], g["x0"][i], g["params"][i], g["nfaces"][i], N, M, int(g["model"][i]))
+        if g["status"][i] != 0:
+            # SLSQP could not solve it either (infeasible corridor/dynamics combination): the oracle must
+            # report a non-optimal flag or a point SciPy simply missed -- never a NaN
+            assert np.all(np.isfinite(z))
+            continue
+        assert fl == 1, (fam, i, fl)
+        nconv += 1
+        assert np.max(np.abs(z - g["z"][i])) < 1e-3, (fam, i, np.max(np.abs(z - g["z"][i])))
+        assert abs(info.pobj - g["f"][i]) / max(1e-9, abs(g["f"][i])) < 1e-4
+        assert info.res_eq <= 1e-4 and info.rsnorm <= 1e-4 and info.rcompnorm <= 1e-4 and info.res_ineq <= 1e-4
+    assert nconv >= 0.7 * n
+
+
+def test_padding_detection_equals_explicit_face_counts():
+    w = workloads.config2(16)
+    za, fa, _ = OL.solve_batch(w)
+    w2 = dict(w); w2["nfaces"] = None
+    zb = np.zeros_like(za)
+    for b in range(16):
+        zb[b], fl, _ = OL.solve_one(w["xinit"][b], w["x0"][b], w["params"][b], None, w["N"], w["M"], w["model"])
+        assert fl == fa[b]
+    assert np.max(np.abs(za - zb)) == 0.0
+
+
+def test_infeasible_problem_reports_failure_not_nan():
+    w = workloads.config2(4)
+    # shrink the corridor of stage 10 to an empty set: x <= -1 and -x <= -1 in the path frame
+    p = w["params"].copy()
+    p[:, 10, L.NPRE + 3 * 30 + 0] = p[:, 10, L.NPRE + 3 * 30 + 1] * -1.0 - 5.0
+    w["params"] = p
+    z, fl, info = OL.solve_batch(w)
+    assert np.all(fl != 1)
+    assert np.all(np.isfinite(z))

@@ -152,11 +152,6 @@ class RefNLP:
         return res
 
 
-def oracle_solve(w, b):
-    import tests.oracle_lib as OL
-    return OL.solve_one(w, b)
-
-
 def _job(args):
     fam, w1, start, seed = args
     N, M, model = w1['N'], w1['M'], w1['model']
@@ -200,14 +195,17 @@ def gen_stage_vectors(path, n=240, seed=W.SEED0):
 def gen_solutions(outdir, workers=8):
     import tests.oracle_lib as OL
     fams = {
-        'config0': [(W.config0(L.MODEL_NORMAL), [0]), (W.config0(L.MODEL_FINAL), [0]),
-                    (W.config0(L.MODEL_NORMAL, (1.5, -2.0, 0.5)), [0])],
+        'config0': [(W.config0(L.MODEL_NORMAL), [0]), (W.config0(L.MODEL_FINAL, weights=W.NORMAL_WEIGHTS), [0]),
+                    (W.config0(L.MODEL_NORMAL, (1.5, -2.0, 0.5)), [0]), (W.config0(L.MODEL_FINAL), [0])],
         'config1': [(W.config1(48), list(range(48)))],
         'config2': [(W.config2(64), list(range(64))), (W.config2(16, model=L.MODEL_FINAL, seed=W.SEED0 + 33), list(range(16)))],
         'config3': [(W.config3(24), list(range(24)))],
     }
-    ncold = dict(config0=3, config1=8, config2=10, config3=4)
+    ncold = dict(config0=4, config1=8, config2=10, config3=4)
+    only = sys.argv[2:] if len(sys.argv) > 2 else None
     for fam, groups in fams.items():
+        if only and fam not in only:
+            continue
         jobs, meta = [], []
         for w, idx in groups:
             zo, fl, info = OL.solve_batch(w)
