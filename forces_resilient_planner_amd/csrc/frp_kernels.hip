@@ -24,6 +24,12 @@
 
 namespace frp {
 
+// occupancy target: waves per SIMD the register allocator must leave room for (propagates to the
+// non-inlined phase functions)
+#ifndef FRP_WAVES_PER_EU
+#define FRP_WAVES_PER_EU 4
+#endif
+
 // ------------------------------------------------------------------ wave helpers
 __device__ __forceinline__ double wave_max(double v)
 {
@@ -193,24 +199,48 @@ struct EvalOut {
     double eq, in, rs, rc, gap, obj;
 };
 
-// ------------------------------------------------------------------ E: evaluate (lane == stage)
-// model + linearisation -> record, residual norms, barrier Hessian/gradient (affine rhs) -> record
+// Staging area of the element-wise phases (aliases the Riccati working set, which is dead then):
+// gm[17][NP] multiplier part of the stationarity residual, gf[6][NP] corridor sums for pos entries.
+__shared__ double sm_big[23 * 64]; // only referenced (hence only allocated) by the NP = 64 instantiation
 template <int NP>
-__device__ __noinline__ EvalOut phase_eval(WsView w, cgdouble *pk, cgdouble *xinit, int N, int MF, int nf, int model)
+__device__ __forceinline__ double *stage_area() { return NP == 32 ? sm : sm_big; }
+static_assert(23 * 32 <= L_PHI, "element-wise staging must fit below the persistent LDS fields");
+
+__device__ __forceinline__ void init_ab_constants(int lane)
 {
-    w = uni(w); xinit = uni(xinit); N = uni(N); MF = uni(MF); model = uni(model);
+    // constant entries of [A|B]: identity blocks of A, dt*I in B's euler rows (the variable entries are
+    // scattered over them stage by stage)
+    for (int t = lane; t < 117; t += 64) {
+        const int i = t / 13, j = t % 13;
+        double v = 0.0;
+        if (j < 9) v = (i == j) ? 1.0 : 0.0;
+        else if (i >= 6 && (j - 9) == (i - 6)) v = DT;
+        sm[L_AB + t] = v;
+    }
+}
+
+__device__ __forceinline__ double xhalf_sum(double v) { return v + __shfl_xor(v, 32); }
+
+// ------------------------------------------------------------------ E: evaluate
+// part 1 (lane == stage): model + linearisation -> record, equality residuals, M'y -> LDS
+// part 2 (lane == (row pair, stage), all 64 lanes): corridor rows, then bounds: residual norms,
+//        barrier Hessian / affine rhs -> record
+template <int NP>
+__device__ __noinline__ EvalOut phase_eval(WsView w, cgdouble *pbase, int np, cgdouble *xinit, int N, int MF, int nfk, int model)
+{
+    w = uni(w); pbase = uni(pbase); np = uni(np); xinit = uni(xinit); N = uni(N); MF = uni(MF); model = uni(model);
     FULLSYNC(); // phase boundary: other lanes' global writes of the previous phase are visible
-    const int lane = threadIdx.x, k = lane;
-    const bool act = lane < N;
+    constexpr int H = 64 / NP;
+    const int lane = threadIdx.x;
+    double *stg = stage_area<NP>();
     double l_eq = 0, l_in = 0, l_rs = 0, l_rc = 0, l_gap = 0, l_obj = 0;
-    double p10[NPRE];
-    if (act) {
+    if (lane < N) {
+        const int k = lane;
+        cgdouble *pk = pbase + (size_t)k * np;
+        double p10[NPRE];
 #pragma unroll
         for (int i = 0; i < NPRE; i++) p10[i] = pk[i];
-    }
-    const int sc_k = stage_class(k, N);
-    const CostQ cq = make_cost(p10, sc_k, model);
-    if (act) {
+        const int sc_k = stage_class(k, N);
         double zk[NZ];
 #pragma unroll
         for (int i = 0; i < NZ; i++) zk[i] = w.z[i * NP + k];
@@ -296,44 +326,82 @@ __device__ __noinline__ EvalOut phase_eval(WsView w, cgdouble *pk, cgdouble *xin
             }
             gm[3] += gT;
         }
-        // corridor rows first (they touch the pos entries 8..10 only)
-        double gp[3] = {0, 0, 0}, fp[3] = {0, 0, 0};
-        double pp[6] = {0, 0, 0, 0, 0, 0}; // xx xy xz yy yz zz
-        for (int j = 0; j < nf; j++) {
-            const double a0 = w.face[(3 * j) * NP + k], a1 = w.face[(3 * j + 1) * NP + k], a2 = w.face[(3 * j + 2) * NP + k];
-            const double hj = a0 * zk[8] + a1 * zk[9] + a2 * zk[10] - w.face[(3 * MF + j) * NP + k] - HU;
-            const double sc = w.s[(34 + j) * NP + k], lc = w.lam[(34 + j) * NP + k];
-            const double rc = hj + sc;
-            l_in = fmax(l_in, fmax(hj, fabs(rc)));
-            l_rc = fmax(l_rc, sc * lc);
-            l_gap += sc * lc;
-            gp[0] += a0 * lc; gp[1] += a1 * lc; gp[2] += a2 * lc;
-            const double sg = lc / sc, t = sg * rc;
-            fp[0] += a0 * t; fp[1] += a1 * t; fp[2] += a2 * t;
-            pp[0] += sg * a0 * a0; pp[1] += sg * a0 * a1; pp[2] += sg * a0 * a2;
-            pp[3] += sg * a1 * a1; pp[4] += sg * a1 * a2; pp[5] += sg * a2 * a2;
-        }
-        rec[REC_PHIPOS + 0] = pp[0]; rec[REC_PHIPOS + 1] = pp[1]; rec[REC_PHIPOS + 2] = pp[2];
-        rec[REC_PHIPOS + 3] = pp[1]; rec[REC_PHIPOS + 4] = pp[3]; rec[REC_PHIPOS + 5] = pp[4];
-        rec[REC_PHIPOS + 6] = pp[2]; rec[REC_PHIPOS + 7] = pp[4]; rec[REC_PHIPOS + 8] = pp[5];
-        // bounds: residuals, barrier Hessian / gradient, finished entry by entry
 #pragma unroll
-        for (int i = 0; i < NZ; i++) {
-            double cg = cq.hd(i) * zk[i] + cq.q(i); // cost gradient
-            if (i < 4) cg += cq.hc() * zk[4 + i];
-            else if (i < 8) cg += cq.hc() * zk[i - 4];
+        for (int i = 0; i < NZ; i++) stg[i * NP + k] = gm[i];
+    }
+    // ---- part 2: all 64 lanes, lane = (half, stage k); rows handled in pairs
+    const int k = lane % NP, half = lane / NP;
+    const bool kact = k < N;
+    // corridor rows: sums over the faces of a stage (pos entries 8..10 only)
+    {
+        double gp0 = 0, gp1 = 0, gp2 = 0, fp0 = 0, fp1 = 0, fp2 = 0, p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0;
+        if (kact) {
+            const double z8 = w.z[8 * NP + k], z9 = w.z[9 * NP + k], z10 = w.z[10 * NP + k];
+            for (int j = half; j < nfk; j += H) {
+                const double a0 = w.face[(3 * j) * NP + k], a1 = w.face[(3 * j + 1) * NP + k], a2 = w.face[(3 * j + 2) * NP + k];
+                const double hj = a0 * z8 + a1 * z9 + a2 * z10 - w.face[(3 * MF + j) * NP + k] - HU;
+                const double sc = w.s[(34 + j) * NP + k], lc = w.lam[(34 + j) * NP + k];
+                const double rc = hj + sc;
+                l_in = fmax(l_in, fmax(hj, fabs(rc)));
+                l_rc = fmax(l_rc, sc * lc);
+                l_gap += sc * lc;
+                gp0 += a0 * lc; gp1 += a1 * lc; gp2 += a2 * lc;
+                const double sg = lc * (1.0 / sc), t = sg * rc;
+                fp0 += a0 * t; fp1 += a1 * t; fp2 += a2 * t;
+                p0 += sg * a0 * a0; p1 += sg * a0 * a1; p2 += sg * a0 * a2;
+                p3 += sg * a1 * a1; p4 += sg * a1 * a2; p5 += sg * a2 * a2;
+            }
+        }
+        if (H == 2) {
+            gp0 = xhalf_sum(gp0); gp1 = xhalf_sum(gp1); gp2 = xhalf_sum(gp2);
+            fp0 = xhalf_sum(fp0); fp1 = xhalf_sum(fp1); fp2 = xhalf_sum(fp2);
+            p0 = xhalf_sum(p0); p1 = xhalf_sum(p1); p2 = xhalf_sum(p2);
+            p3 = xhalf_sum(p3); p4 = xhalf_sum(p4); p5 = xhalf_sum(p5);
+        }
+        if (kact && half == 0) {
+            gdouble *rec = w.rec + (size_t)k * REC_STRIDE;
+            rec[REC_PHIPOS + 0] = p0; rec[REC_PHIPOS + 1] = p1; rec[REC_PHIPOS + 2] = p2;
+            rec[REC_PHIPOS + 3] = p1; rec[REC_PHIPOS + 4] = p3; rec[REC_PHIPOS + 5] = p4;
+            rec[REC_PHIPOS + 6] = p2; rec[REC_PHIPOS + 7] = p4; rec[REC_PHIPOS + 8] = p5;
+            stg[(17 + 0) * NP + k] = gp0; stg[(17 + 1) * NP + k] = gp1; stg[(17 + 2) * NP + k] = gp2;
+            stg[(17 + 3) * NP + k] = fp0; stg[(17 + 4) * NP + k] = fp1; stg[(17 + 5) * NP + k] = fp2;
+        }
+    }
+    WSYNC();
+    // bounds: residuals, barrier Hessian / gradient, finished entry by entry
+    if (kact) {
+        cgdouble *pk = pbase + (size_t)k * np;
+        double pc[NPRE];
+        pc[0] = pk[0]; pc[1] = pk[1]; pc[2] = pk[2]; pc[6] = pk[6]; pc[7] = pk[7]; pc[8] = pk[8]; pc[9] = pk[9];
+        const CostQ cq = make_cost(pc, stage_class(k, N), model);
+        gdouble *rec = w.rec + (size_t)k * REC_STRIDE;
+        constexpr int R = (NZ + H - 1) / H;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i0 = r * H, i1 = (H == 2) ? i0 + 1 : i0;
+            if (H == 2 && i1 >= NZ && half) continue;
+            const int i = half ? i1 : i0;
+            const double hd = half ? cq.hd(i1 < NZ ? i1 : i0) : cq.hd(i0);
+            const double qi = half ? cq.q(i1 < NZ ? i1 : i0) : cq.q(i0);
+            const double lb = half ? lower_bound(i1 < NZ ? i1 : i0) : lower_bound(i0);
+            const double ub = half ? upper_bound(i1 < NZ ? i1 : i0) : upper_bound(i0);
+            const double zi = w.z[i * NP + k];
+            double cg = hd * zi + qi; // cost gradient
+            if (i0 < 8) cg += cq.hc() * w.z[(i < 4 ? i + 4 : i - 4) * NP + k];
             const double sl = w.s[i * NP + k], su = w.s[(17 + i) * NP + k];
             const double ll = w.lam[i * NP + k], lu = w.lam[(17 + i) * NP + k];
-            const double vl = lower_bound(i) - zk[i], vu = zk[i] - upper_bound(i);
+            const double vl = lb - zi, vu = zi - ub;
             const double rl = vl + sl, ru = vu + su;
             l_in = fmax(l_in, fmax(fmax(vl, vu), fmax(fabs(rl), fabs(ru))));
             l_rc = fmax(l_rc, fmax(sl * ll, su * lu));
             l_gap += sl * ll + su * lu;
-            const double sgl = ll / sl, sgu = lu / su;
-            double gi = cg + gm[i] + lu - ll;
+            const double sgl = ll * (1.0 / sl), sgu = lu * (1.0 / su);
+            double gi = cg + stg[i * NP + k] + lu - ll;
             double ph = cg + sgu * ru - sgl * rl;
-            if (i >= 8 && i < 11) { gi += gp[i - 8]; ph += fp[i - 8]; }
-            rec[REC_PHID + i] = cq.hd(i) + sgl + sgu;
+            if (i0 + H > 8 && i0 < 11) {
+                if (i >= 8 && i < 11) { gi += stg[(17 + i - 8) * NP + k]; ph += stg[(17 + 3 + i - 8) * NP + k]; }
+            }
+            rec[REC_PHID + i] = hd + sgl + sgu;
             rec[REC_PHI + i] = ph;
             l_rs = fmax(l_rs, fabs(gi));
         }
@@ -355,6 +423,8 @@ __device__ __noinline__ int sweep_backward(WsView w, cgdouble *xinit, int N, int
     const int lane = threadIdx.x;
     const int my_dst = L_AB + lin_dst(lane);
     bool fact_fail = false;
+    init_ab_constants(lane);
+    WSYNC();
     {
         int cur = 0; // buffer holding P_{k+1}
         cgdouble *r0 = w.rec + (size_t)(N - 1) * REC_STRIDE;
@@ -555,6 +625,8 @@ __device__ __noinline__ void sweep_forward(WsView w, int N)
     FULLSYNC(); // phase boundary: other lanes' global writes of the previous phase are visible
     const int lane = threadIdx.x;
     const int my_dst = L_AB + lin_dst(lane);
+    init_ab_constants(lane);
+    WSYNC();
     {
         cgdouble *r0 = w.rec;
         double pre_lin = r0[lane];
@@ -616,134 +688,182 @@ struct SlackOut {
     double ap, ad, sigma, smu;
 };
 
-// ------------------------------------------------------------------ slack / multiplier steps (lane == stage)
+// ------------------------------------------------------------------ slack / multiplier steps
+// All 64 lanes, lane = (half, stage k), constraints handled in pairs (flattened [row][stage] arrays).
 // pass 0 (affine): step lengths, mu_aff -> sigma, second-order term, corrector rhs phi -> record
 // pass 1 (corrector): fraction-to-boundary step lengths, update z, s, lambda
+// Per constraint:  ds = -(G z - g + s) - G dz,  dl = (-(s l - smu + corr) - l ds) / s.
+// Ratios -ds/s and -dl/l are formed with ONE reciprocal u = 1/(s l) per constraint.
 template <int NP>
-__device__ __noinline__ SlackOut phase_slack(WsView w, cgdouble *pk, int N, int MF, int nf, int model, int pass,
+__device__ __noinline__ SlackOut phase_slack(WsView w, cgdouble *pbase, int np, int N, int MF, int nfk, int model, int pass,
                                              double smu, double mu, int mtot, double ftb, double tol_comp)
 {
-    w = uni(w); N = uni(N); MF = uni(MF); model = uni(model); pass = uni(pass); smu = uni(smu); mu = uni(mu);
-    mtot = uni(mtot); ftb = uni(ftb); tol_comp = uni(tol_comp);
-    FULLSYNC(); // phase boundary: other lanes' global writes of the previous phase are visible
-    const int lane = threadIdx.x, k = lane;
-    const bool act = lane < N;
-    double ap = 1.0, ad = 1.0, sigma = 0.0, step_cc = 0.0;
-    double p10[NPRE];
-    if (act) {
-#pragma unroll
-        for (int i = 0; i < NPRE; i++) p10[i] = pk[i];
-    }
-    const CostQ cq = make_cost(p10, stage_class(k, N), model);
-    {
-        double l_ap = 1e300, l_ad = 1e300;
-        double dzk[NZ];
-        if (act) {
-#pragma unroll
-            for (int i = 0; i < NZ; i++) dzk[i] = w.dz[i * NP + k];
-        }
-        // pass A: step lengths
-        double zk[NZ];
-        if (act) {
-#pragma unroll
-            for (int i = 0; i < NZ; i++) zk[i] = w.z[i * NP + k];
-            auto step_len = [&](int c, double gdz, double viol) {
-                const double s = w.s[c * NP + k], l = w.lam[c * NP + k];
-                const double ds = -(viol + s) - gdz;
-                const double rc = s * l - smu + (pass ? w.corr[c * NP + k] : 0.0);
-                const double dl = (-rc - l * ds) / s;
-                if (ds < 0.0) l_ap = fmin(l_ap, -s / ds);
-                if (dl < 0.0) l_ad = fmin(l_ad, -l / dl);
-            };
-#pragma unroll
-            for (int i = 0; i < NZ; i++) {
-                step_len(i, -dzk[i], lower_bound(i) - zk[i]);
-                step_len(17 + i, dzk[i], zk[i] - upper_bound(i));
-            }
-            for (int j = 0; j < nf; j++) {
-                const double a0 = w.face[(3 * j) * NP + k], a1 = w.face[(3 * j + 1) * NP + k], a2 = w.face[(3 * j + 2) * NP + k];
-                step_len(34 + j, a0 * dzk[8] + a1 * dzk[9] + a2 * dzk[10],
-                         a0 * zk[8] + a1 * zk[9] + a2 * zk[10] - w.face[(3 * MF + j) * NP + k] - HU);
-            }
-        }
-        ap = wave_min(l_ap); ad = wave_min(l_ad);
-        if (pass == 0) { ap = fmin(1.0, ap); ad = fmin(1.0, ad); }
-        else { ap = fmin(1.0, ftb * ap); ad = fmin(1.0, ftb * ad); }
-        // pass B: affine complementarity + second-order term / or the update
-        double l_gapaff = 0.0;
-        if (act) {
-            auto apply = [&](int c, double gdz, double viol) {
-                const double s = w.s[c * NP + k], l = w.lam[c * NP + k];
-                const double ds = -(viol + s) - gdz;
-                const double rc = s * l - smu + (pass ? w.corr[c * NP + k] : 0.0);
-                const double dl = (-rc - l * ds) / s;
-                if (pass == 0) {
-                    l_gapaff += (s + ap * ds) * (l + ad * dl);
-                    w.corr[c * NP + k] = ds * dl;
-                } else {
-                    w.s[c * NP + k] = s + ap * ds;
-                    w.lam[c * NP + k] = l + ad * dl;
-                }
-            };
-#pragma unroll
-            for (int i = 0; i < NZ; i++) {
-                apply(i, -dzk[i], lower_bound(i) - zk[i]);
-                apply(17 + i, dzk[i], zk[i] - upper_bound(i));
-            }
-            for (int j = 0; j < nf; j++) {
-                const double a0 = w.face[(3 * j) * NP + k], a1 = w.face[(3 * j + 1) * NP + k], a2 = w.face[(3 * j + 2) * NP + k];
-                apply(34 + j, a0 * dzk[8] + a1 * dzk[9] + a2 * dzk[10],
-                      a0 * zk[8] + a1 * zk[9] + a2 * zk[10] - w.face[(3 * MF + j) * NP + k] - HU);
-            }
-        }
-        if (pass == 0) {
-            const double mu_aff = wave_sum(l_gapaff) / (double)mtot;
-            sigma = mu_aff / mu;
-            sigma = sigma * sigma * sigma;
-            if (sigma > 1.0) sigma = 1.0;
-            smu = sigma * mu;
-            if (smu < MU_FLOOR_FRAC * tol_comp) smu = MU_FLOOR_FRAC * tol_comp;
-            // corrector rhs: phi = grad f + G'(Sigma r_in + (smu - corr)/s)
-            if (act) {
-                double phi[NZ];
-#pragma unroll
-                for (int i = 0; i < NZ; i++) phi[i] = cq.hd(i) * zk[i] + cq.q(i);
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    phi[i] += cq.hc() * zk[4 + i];
-                    phi[4 + i] += cq.hc() * zk[i];
-                }
-#pragma unroll
-                for (int i = 0; i < NZ; i++) {
-                    const double sl = w.s[i * NP + k], su = w.s[(17 + i) * NP + k];
-                    const double ll = w.lam[i * NP + k], lu = w.lam[(17 + i) * NP + k];
-                    const double rl = lower_bound(i) - zk[i] + sl, ru = zk[i] - upper_bound(i) + su;
-                    const double tl = (ll * rl + smu - w.corr[i * NP + k]) / sl;
-                    const double tu = (lu * ru + smu - w.corr[(17 + i) * NP + k]) / su;
-                    phi[i] += tu - tl;
-                }
-                for (int j = 0; j < nf; j++) {
-                    const double a0 = w.face[(3 * j) * NP + k], a1 = w.face[(3 * j + 1) * NP + k], a2 = w.face[(3 * j + 2) * NP + k];
-                    const double hj = a0 * zk[8] + a1 * zk[9] + a2 * zk[10] - w.face[(3 * MF + j) * NP + k] - HU;
-                    const double sc = w.s[(34 + j) * NP + k], lc = w.lam[(34 + j) * NP + k];
-                    const double t = (lc * (hj + sc) + smu - w.corr[(34 + j) * NP + k]) / sc;
-                    phi[8] += a0 * t; phi[9] += a1 * t; phi[10] += a2 * t;
-                }
-                gdouble *rec = w.rec + (size_t)k * REC_STRIDE;
-#pragma unroll
-                for (int i = 0; i < NZ; i++) rec[REC_PHI + i] = phi[i];
-            }
-                        WSYNC();
-        } else {
-            step_cc = ap;
-            if (act) {
-#pragma unroll
-                for (int i = 0; i < NZ; i++) w.z[i * NP + k] = zk[i] + ap * dzk[i];
-            }
-        }
-    }
+    w = uni(w); pbase = uni(pbase); np = uni(np); N = uni(N); MF = uni(MF); model = uni(model); pass = uni(pass);
+    smu = uni(smu); mu = uni(mu); mtot = uni(mtot); ftb = uni(ftb); tol_comp = uni(tol_comp);
+    FULLSYNC(); // phase boundary: dz of the forward sweep is visible
+    constexpr int H = 64 / NP;
+    constexpr int R = (NZ + H - 1) / H;
+    const int lane = threadIdx.x;
+    const int k = lane % NP, half = lane / NP;
+    const bool kact = k < N;
+    double *stg = stage_area<NP>();
+    double sigma = 0.0;
 
-    (void)step_cc;
+    // one constraint: returns ds, dl and the two ratios
+    auto cstep = [&](int c, double gdz, double viol, double &ds, double &dl, double &rp, double &rd, double &s, double &l) {
+        s = w.s[c * NP + k];
+        l = w.lam[c * NP + k];
+        const double u = 1.0 / (s * l);
+        const double sinv = u * l, linv = u * s;
+        ds = -(viol + s) - gdz;
+        const double rc = s * l - smu + (pass ? w.corr[c * NP + k] : 0.0);
+        dl = (-rc - l * ds) * sinv;
+        rp = -ds * sinv;
+        rd = -dl * linv;
+    };
+
+    // ---- A: largest ratios -> step lengths
+    double m_p = 0.0, m_d = 0.0;
+    double z8 = 0, z9 = 0, z10 = 0, d8 = 0, d9 = 0, d10 = 0;
+    if (kact) {
+        z8 = w.z[8 * NP + k]; z9 = w.z[9 * NP + k]; z10 = w.z[10 * NP + k];
+        d8 = w.dz[8 * NP + k]; d9 = w.dz[9 * NP + k]; d10 = w.dz[10 * NP + k];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i0 = r * H, i1 = (H == 2) ? i0 + 1 : i0;
+            if (H == 2 && i1 >= NZ && half) continue;
+            const int i = half ? i1 : i0;
+            const double lb = half ? lower_bound(i1 < NZ ? i1 : i0) : lower_bound(i0);
+            const double ub = half ? upper_bound(i1 < NZ ? i1 : i0) : upper_bound(i0);
+            const double zi = w.z[i * NP + k], dzi = w.dz[i * NP + k];
+            double ds, dl, rp, rd, sv, lv;
+            cstep(i, -dzi, lb - zi, ds, dl, rp, rd, sv, lv);
+            m_p = fmax(m_p, rp); m_d = fmax(m_d, rd);
+            cstep(17 + i, dzi, zi - ub, ds, dl, rp, rd, sv, lv);
+            m_p = fmax(m_p, rp); m_d = fmax(m_d, rd);
+        }
+        for (int j = half; j < nfk; j += H) {
+            const double a0 = w.face[(3 * j) * NP + k], a1 = w.face[(3 * j + 1) * NP + k], a2 = w.face[(3 * j + 2) * NP + k];
+            double ds, dl, rp, rd, sv, lv;
+            cstep(34 + j, a0 * d8 + a1 * d9 + a2 * d10, a0 * z8 + a1 * z9 + a2 * z10 - w.face[(3 * MF + j) * NP + k] - HU,
+                  ds, dl, rp, rd, sv, lv);
+            m_p = fmax(m_p, rp); m_d = fmax(m_d, rd);
+        }
+    }
+    m_p = wave_max(m_p); m_d = wave_max(m_d);
+    const double lim = pass ? ftb : 1.0;
+    const double ap = (m_p > lim) ? lim / m_p : 1.0;
+    const double ad = (m_d > lim) ? lim / m_d : 1.0;
+
+    // ---- B: corridor rows: affine complementarity + second-order term (pass 0) / update (pass 1)
+    double l_gapaff = 0.0;
+    if (pass == 0) {
+        if (kact) {
+            for (int j = half; j < nfk; j += H) {
+                const double a0 = w.face[(3 * j) * NP + k], a1 = w.face[(3 * j + 1) * NP + k], a2 = w.face[(3 * j + 2) * NP + k];
+                double ds, dl, rp, rd, sv, lv;
+                cstep(34 + j, a0 * d8 + a1 * d9 + a2 * d10, a0 * z8 + a1 * z9 + a2 * z10 - w.face[(3 * MF + j) * NP + k] - HU,
+                      ds, dl, rp, rd, sv, lv);
+                l_gapaff += (sv + ap * ds) * (lv + ad * dl);
+                w.corr[(34 + j) * NP + k] = ds * dl;
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int i0 = r * H, i1 = (H == 2) ? i0 + 1 : i0;
+                if (H == 2 && i1 >= NZ && half) continue;
+                const int i = half ? i1 : i0;
+                const double lb = half ? lower_bound(i1 < NZ ? i1 : i0) : lower_bound(i0);
+                const double ub = half ? upper_bound(i1 < NZ ? i1 : i0) : upper_bound(i0);
+                const double zi = w.z[i * NP + k], dzi = w.dz[i * NP + k];
+                double ds, dl, rp, rd, sv, lv;
+                cstep(i, -dzi, lb - zi, ds, dl, rp, rd, sv, lv);
+                l_gapaff += (sv + ap * ds) * (lv + ad * dl);
+                w.corr[i * NP + k] = ds * dl;
+                cstep(17 + i, dzi, zi - ub, ds, dl, rp, rd, sv, lv);
+                l_gapaff += (sv + ap * ds) * (lv + ad * dl);
+                w.corr[(17 + i) * NP + k] = ds * dl;
+            }
+        }
+        const double mu_aff = wave_sum(l_gapaff) / (double)mtot;
+        sigma = mu_aff / mu;
+        sigma = sigma * sigma * sigma;
+        if (sigma > 1.0) sigma = 1.0;
+        smu = sigma * mu;
+        if (smu < MU_FLOOR_FRAC * tol_comp) smu = MU_FLOOR_FRAC * tol_comp;
+        FULLSYNC(); // corr written above is re-read below by the same lanes; also orders LDS staging
+        // corrector rhs: phi = grad f + G'(Sigma r_in + (smu - corr)/s)
+        {
+            double fp0 = 0, fp1 = 0, fp2 = 0;
+            if (kact) {
+                for (int j = half; j < nfk; j += H) {
+                    const double a0 = w.face[(3 * j) * NP + k], a1 = w.face[(3 * j + 1) * NP + k], a2 = w.face[(3 * j + 2) * NP + k];
+                    const double hj = a0 * z8 + a1 * z9 + a2 * z10 - w.face[(3 * MF + j) * NP + k] - HU;
+                    const double sc = w.s[(34 + j) * NP + k], lc = w.lam[(34 + j) * NP + k];
+                    const double t = (lc * (hj + sc) + smu - w.corr[(34 + j) * NP + k]) * (1.0 / sc);
+                    fp0 += a0 * t; fp1 += a1 * t; fp2 += a2 * t;
+                }
+            }
+            if (H == 2) { fp0 = xhalf_sum(fp0); fp1 = xhalf_sum(fp1); fp2 = xhalf_sum(fp2); }
+            if (kact && half == 0) { stg[0 * NP + k] = fp0; stg[1 * NP + k] = fp1; stg[2 * NP + k] = fp2; }
+        }
+        WSYNC();
+        if (kact) {
+            cgdouble *pk = pbase + (size_t)k * np;
+            double pc[NPRE];
+            pc[0] = pk[0]; pc[1] = pk[1]; pc[2] = pk[2]; pc[6] = pk[6]; pc[7] = pk[7]; pc[8] = pk[8]; pc[9] = pk[9];
+            const CostQ cq = make_cost(pc, stage_class(k, N), model);
+            gdouble *rec = w.rec + (size_t)k * REC_STRIDE;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int i0 = r * H, i1 = (H == 2) ? i0 + 1 : i0;
+                if (H == 2 && i1 >= NZ && half) continue;
+                const int i = half ? i1 : i0;
+                const double hd = half ? cq.hd(i1 < NZ ? i1 : i0) : cq.hd(i0);
+                const double qi = half ? cq.q(i1 < NZ ? i1 : i0) : cq.q(i0);
+                const double lb = half ? lower_bound(i1 < NZ ? i1 : i0) : lower_bound(i0);
+                const double ub = half ? upper_bound(i1 < NZ ? i1 : i0) : upper_bound(i0);
+                const double zi = w.z[i * NP + k];
+                double ph = hd * zi + qi;
+                if (i0 < 8) ph += cq.hc() * w.z[(i < 4 ? i + 4 : i - 4) * NP + k];
+                const double sl = w.s[i * NP + k], su = w.s[(17 + i) * NP + k];
+                const double ll = w.lam[i * NP + k], lu = w.lam[(17 + i) * NP + k];
+                const double rl = lb - zi + sl, ru = zi - ub + su;
+                const double tl = (ll * rl + smu - w.corr[i * NP + k]) * (1.0 / sl);
+                const double tu = (lu * ru + smu - w.corr[(17 + i) * NP + k]) * (1.0 / su);
+                ph += tu - tl;
+                if (i0 + H > 8 && i0 < 11) {
+                    if (i >= 8 && i < 11) ph += stg[(i - 8) * NP + k];
+                }
+                rec[REC_PHI + i] = ph;
+            }
+        }
+    } else if (kact) {
+        for (int j = half; j < nfk; j += H) {
+            const double a0 = w.face[(3 * j) * NP + k], a1 = w.face[(3 * j + 1) * NP + k], a2 = w.face[(3 * j + 2) * NP + k];
+            double ds, dl, rp, rd, sv, lv;
+            cstep(34 + j, a0 * d8 + a1 * d9 + a2 * d10, a0 * z8 + a1 * z9 + a2 * z10 - w.face[(3 * MF + j) * NP + k] - HU,
+                  ds, dl, rp, rd, sv, lv);
+            w.s[(34 + j) * NP + k] = sv + ap * ds;
+            w.lam[(34 + j) * NP + k] = lv + ad * dl;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i0 = r * H, i1 = (H == 2) ? i0 + 1 : i0;
+            if (H == 2 && i1 >= NZ && half) continue;
+            const int i = half ? i1 : i0;
+            const double lb = half ? lower_bound(i1 < NZ ? i1 : i0) : lower_bound(i0);
+            const double ub = half ? upper_bound(i1 < NZ ? i1 : i0) : upper_bound(i0);
+            const double zi = w.z[i * NP + k], dzi = w.dz[i * NP + k];
+            double ds, dl, rp, rd, sv, lv;
+            cstep(i, -dzi, lb - zi, ds, dl, rp, rd, sv, lv);
+            w.s[i * NP + k] = sv + ap * ds;
+            w.lam[i * NP + k] = lv + ad * dl;
+            cstep(17 + i, dzi, zi - ub, ds, dl, rp, rd, sv, lv);
+            w.s[(17 + i) * NP + k] = sv + ap * ds;
+            w.lam[(17 + i) * NP + k] = lv + ad * dl;
+            w.z[i * NP + k] = zi + ap * dzi;
+        }
+    }
     FULLSYNC();
     SlackOut o;
     o.ap = ap; o.ad = ad; o.sigma = sigma; o.smu = smu;
@@ -761,6 +881,8 @@ __device__ __noinline__ void sweep_costate(WsView w, cgdouble *pk, int N, double
     const bool act = lane < N;
     const int my_dst = L_AB + lin_dst(lane);
     const double hc_k = act ? -2.0 * pk[8] : 0.0;
+    init_ab_constants(lane);
+    WSYNC();
     {
         // w-part is stage-parallel
         if (act) {
@@ -812,7 +934,7 @@ __device__ __noinline__ void sweep_costate(WsView w, cgdouble *pk, int N, double
 
 // ------------------------------------------------------------------ the solver kernel
 template <int NP>
-__global__ __launch_bounds__(64) void nmpc_ipm_kernel(KernelArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PER_EU, FRP_WAVES_PER_EU))) void nmpc_ipm_kernel(KernelArgs a)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int N = a.N, M = a.M, MF = a.MF, np = NPRE + 4 * M;
@@ -900,15 +1022,9 @@ __global__ __launch_bounds__(64) void nmpc_ipm_kernel(KernelArgs a)
             }
         }
     }
-    // constant entries of [A|B]: identity blocks of A, dt*I in B's euler rows
-    for (int t = lane; t < 117; t += 64) {
-        const int i = t / 13, j = t % 13;
-        double v = 0.0;
-        if (j < 9) v = (i == j) ? 1.0 : 0.0;
-        else if (i >= 6 && (j - 9) == (i - 6)) v = DT;
-        sm[L_AB + t] = v;
-    }
-    WSYNC();
+    cgdouble *pbase = (cgdouble *)(a.params + (size_t)b * N * np);
+    const int nfk = __shfl(nf, lane % NP); // face count of stage k = lane % NP for the (half, stage) lane mapping
+    FULLSYNC();
 
     int flag = FRP_EXIT_MAXIT, it = 0;
     double res_eq = 0, res_in = 0, rs = 0, rcomp = 0, pobj = 0, mu = 0, sigma = 0, step_cc = 0;
@@ -923,7 +1039,7 @@ __global__ __launch_bounds__(64) void nmpc_ipm_kernel(KernelArgs a)
 #endif
     for (it = 0;; it++) {
         TICK();
-        const EvalOut e = phase_eval<NP>(w, pk, xinit, N, MF, nf, a.model);
+        const EvalOut e = phase_eval<NP>(w, pbase, np, xinit, N, MF, nfk, a.model);
         res_eq = wave_max(e.eq); res_in = wave_max(e.in); rs = wave_max(e.rs); rcomp = wave_max(e.rc);
         pobj = wave_sum(e.obj);
         mu = wave_sum(e.gap) / (double)mtot;
@@ -939,7 +1055,7 @@ __global__ __launch_bounds__(64) void nmpc_ipm_kernel(KernelArgs a)
         TOCK(1);
         sweep_forward<NP>(w, N);
         TOCK(2);
-        const SlackOut s0 = phase_slack<NP>(w, pk, N, MF, nf, a.model, 0, 0.0, mu, mtot, a.ftb, a.tol_comp);
+        const SlackOut s0 = phase_slack<NP>(w, pbase, np, N, MF, nfk, a.model, 0, 0.0, mu, mtot, a.ftb, a.tol_comp);
         sigma = s0.sigma;
         TOCK(3);
         // corrector solve (same factorisation, new rhs)
@@ -947,7 +1063,7 @@ __global__ __launch_bounds__(64) void nmpc_ipm_kernel(KernelArgs a)
         TOCK(4);
         sweep_forward<NP>(w, N);
         TOCK(2);
-        const SlackOut s1 = phase_slack<NP>(w, pk, N, MF, nf, a.model, 1, s0.smu, mu, mtot, a.ftb, a.tol_comp);
+        const SlackOut s1 = phase_slack<NP>(w, pbase, np, N, MF, nfk, a.model, 1, s0.smu, mu, mtot, a.ftb, a.tol_comp);
         step_cc = s1.ap;
         TOCK(3);
         sweep_costate<NP>(w, pk, N, s1.ap);
