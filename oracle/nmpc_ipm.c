@@ -24,6 +24,7 @@
 
 void orc_rk2(const double *x, const double *u, const double *fext, double *xn, double *Ax, double *Bx);
 void orc_cost_quadratic(const double *p, int stage_class, int model, double *hd, double *hc, double *q, double *cst);
+void orc_rk2_hess(const double *x, const double *u, const double *fext, const double *yp, const double *yv, double *H);
 
 #define NS 13
 #define HU_OFF 1e-5 /* hu = 1e-5, mpc_generator_normal.m:14 */
@@ -31,6 +32,7 @@ void orc_cost_quadratic(const double *p, int stage_class, int model, double *hd,
 #define MU_FLOOR_FRAC 0.1
 #define DIVERGE_MU 1e6
 #define DIVERGE_RS 1e12
+#define EXACT_SWITCH_EQ 1e-1
 
 void orc_default_options(orc_options *o)
 {
@@ -41,6 +43,7 @@ void orc_default_options(orc_options *o)
     o->tol_comp = 1e-4;
     o->mu0 = 1.0;
     o->ftb = 0.99;
+    o->hessian = ORC_HESSIAN_DEFAULT;
 }
 
 typedef struct {
@@ -51,6 +54,8 @@ typedef struct {
     double L[16], Kt[4 * NS], kt[4], P[NS * NS], p[NS], Pd[NS];
     double phi[17];                /* rhs gradient of the current solve                             */
     double PhiD[17], PhiPos[9];    /* barrier-augmented Hessian: diagonal + pos 3x3 block           */
+    double Hd[100];                /* exact Hessian of y'c(z) over (rates, T, v, e), see orc_rk2_hess  */
+    int useH;
 } stage_ws;
 
 static int stage_class_of(int k, int N) { return k == 0 ? ORC_STAGE_FIRST : (k == N - 1 ? ORC_STAGE_LAST : ORC_STAGE_MID); }
@@ -89,6 +94,11 @@ static int riccati_step(stage_ws *w, const double *Pn, const double *pn, int ful
         for (int i = 0; i < 4; i++) Q[i * 17 + 4 + i] = Q[(4 + i) * 17 + i] = w->hc;
         for (int i = 0; i < 3; i++)
             for (int j = 0; j < 3; j++) Q[(8 + i) * 17 + 8 + j] += w->PhiPos[i * 3 + j];
+        if (w->useH) {
+            static const int zi[10] = {0, 1, 2, 3, 11, 12, 13, 14, 15, 16};
+            for (int i = 0; i < 10; i++)
+                for (int j = 0; j < 10; j++) Q[zi[i] * 17 + zi[j]] += w->Hd[i * 10 + j];
+        }
         if (Pn) {
             /* M = [I4 0 0; Bx 0 Ax] (rows [w;x] of stage k+1, cols [u w x] of stage k) */
             double PxxA[81], PxxB[36], T[36]; /* T = Pwx + Bx'Pxx  (4x9) */
@@ -380,7 +390,7 @@ int orc_solve(int N, int M, int model, const double *xinit, const double *z0,
         }
     }
 
-    int flag = ORC_MAXIT, it = 0;
+    int flag = ORC_MAXIT, it = 0, nfallback = 0;
     orc_info inf;
     memset(&inf, 0, sizeof inf);
     for (it = 0;; it++) {
@@ -464,10 +474,27 @@ int orc_solve(int N, int M, int model, const double *xinit, const double *z0,
                     for (int c = 0; c < 3; c++) w->PhiPos[a * 3 + c] += sg * A[3 * j + a] * A[3 * j + c];
             }
         }
+        /* ---- exact Lagrangian Hessian of the dynamics (optional), Gauss-Newton fallback ---- */
+        const int want_exact = (opt.hessian == 1) || (opt.hessian == 2 && res_eq <= EXACT_SWITCH_EQ);
+        for (int k = 0; k < N; k++) {
+            stage_ws *w = &W.st[k];
+            w->useH = 0;
+            if (want_exact && k < N - 1) {
+                const double *zk = W.z + 17 * k, *yn = W.y + NS * (k + 1);
+                orc_rk2_hess(zk + 8, zk, params + (size_t)k * np + 3, yn + 4, yn + 7, w->Hd);
+                w->useH = 1;
+            }
+        }
         /* ---- predictor ---- */
         double ap, ad;
         build_phi(&W, params, 0.0, 0);
-        if (kkt_solve(&W, xinit, 1)) { flag = ORC_FACTORIZATION_ERROR; break; }
+        int frc = kkt_solve(&W, xinit, 1);
+        if (frc && want_exact) { /* indefinite reduced Hessian: redo with the Gauss-Newton Hessian */
+            for (int k = 0; k < N; k++) W.st[k].useH = 0;
+            frc = kkt_solve(&W, xinit, 1);
+            nfallback++;
+        }
+        if (frc) { flag = ORC_FACTORIZATION_ERROR; break; }
         slack_steps(&W, params, 0.0, 0, &ap, &ad);
         ap = fmin(1.0, ap); ad = fmin(1.0, ad);
         double gap_aff = 0;
@@ -503,6 +530,7 @@ int orc_solve(int N, int M, int model, const double *xinit, const double *z0,
         }
     }
     memcpy(zout, W.z, sizeof(double) * 17 * N);
+    inf.nfallback = nfallback;
     if (info) *info = inf;
     free(W.st); free(buf); free(W.nf);
     return flag;

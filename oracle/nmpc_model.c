@@ -137,6 +137,106 @@ void orc_rk2(const double *x, const double *u, const double *fext, double *xn, d
     }
 }
 
+/* ---- second derivatives (exact Lagrangian Hessian of the dynamics) -------------------------------
+ * For a fixed contraction vector gam:  phi_gam(v, e, T) = gam . acc(v, e, T)
+ *   = a (gam.zB) - d gam.v + const,  a = T/m + d (zB.v).
+ * Its Hessian wrt (T, v, e) has only the blocks (T,e), (v,e), (e,e).  Also returns
+ * gv = d phi / d v = d zB (gam.zB) - d gam. */
+static void phi_hess(const double *gam, const double *v, const double *e, double T,
+                     double *hTe, double *Hve, double *Hee, double *gv)
+{
+    const double sr = sin(e[0]), cr = cos(e[0]), sp = sin(e[1]), cp = cos(e[1]), sy = sin(e[2]), cy = cos(e[2]);
+    const double zb[3] = {cy * sp * cr + sy * sr, sy * sp * cr - cy * sr, cp * cr};
+    double D1[3][3], D2[3][3][3];
+    D1[0][0] = -cy * sp * sr + sy * cr; D1[0][1] = -sy * sp * sr - cy * cr; D1[0][2] = -cp * sr;
+    D1[1][0] = cy * cp * cr;            D1[1][1] = sy * cp * cr;            D1[1][2] = -sp * cr;
+    D1[2][0] = -sy * sp * cr + cy * sr; D1[2][1] = cy * sp * cr + sy * sr;  D1[2][2] = 0.0;
+    const double rr[3] = {-zb[0], -zb[1], -zb[2]};
+    const double rp[3] = {-cy * cp * sr, -sy * cp * sr, sp * sr};
+    const double ry[3] = {sy * sp * sr + cy * cr, -cy * sp * sr + sy * cr, 0.0};
+    const double pp[3] = {-cy * sp * cr, -sy * sp * cr, -cp * cr};
+    const double py[3] = {-sy * cp * cr, cy * cp * cr, 0.0};
+    const double yy[3] = {-zb[0], -zb[1], 0.0};
+    for (int c = 0; c < 3; c++) {
+        D2[0][0][c] = rr[c]; D2[0][1][c] = D2[1][0][c] = rp[c]; D2[0][2][c] = D2[2][0][c] = ry[c];
+        D2[1][1][c] = pp[c]; D2[1][2][c] = D2[2][1][c] = py[c]; D2[2][2][c] = yy[c];
+    }
+    double s = 0, zv = 0, sj[3], aj[3];
+    for (int c = 0; c < 3; c++) { s += gam[c] * zb[c]; zv += zb[c] * v[c]; }
+    const double a = T / MASS + DRAG * zv;
+    for (int j = 0; j < 3; j++) {
+        sj[j] = 0; aj[j] = 0;
+        for (int c = 0; c < 3; c++) { sj[j] += gam[c] * D1[j][c]; aj[j] += DRAG * D1[j][c] * v[c]; }
+        hTe[j] = sj[j] / MASS;
+    }
+    for (int i = 0; i < 3; i++) {
+        gv[i] = DRAG * zb[i] * s - DRAG * gam[i];
+        for (int j = 0; j < 3; j++) Hve[i * 3 + j] = DRAG * (D1[j][i] * s + zb[i] * sj[j]);
+    }
+    for (int j = 0; j < 3; j++)
+        for (int l = 0; l < 3; l++) {
+            double sjl = 0, ajl = 0;
+            for (int c = 0; c < 3; c++) { sjl += gam[c] * D2[j][l][c]; ajl += DRAG * D2[j][l][c] * v[c]; }
+            Hee[j * 3 + l] = ajl * s + aj[j] * sj[l] + aj[l] * sj[j] + a * sjl;
+        }
+}
+
+/* Hessian of y_x' x+(x, u) wrt zt = (rates(3), T, v(3), e(3)) -- 10 x 10 symmetric, row-major.
+ * Only the position and velocity rows of x+ are non-linear: y enters through yp = y[0:3], yv = y[3:6].
+ * x+_p = p + dt v + dt^2/2 acc1,  x+_v = v + dt/2 (acc1 + acc2),  acc2 = acc(v + dt acc1, e + dt w, T). */
+void orc_rk2_hess(const double *x, const double *u, const double *fext, const double *yp, const double *yv, double *H)
+{
+    const double *v = x + 3, *e = x + 6;
+    const double T = u[3];
+    double a1[3], F1vv[9], F1ve[9], g1[3], vt[3], et[3];
+    accel(v, e, T, fext, a1, F1vv, F1ve, g1);
+    for (int i = 0; i < 3; i++) { vt[i] = v[i] + DT * a1[i]; et[i] = e[i] + DT * u[i]; }
+    double alpha[3], beta[3], gam1[3], gvt[3];
+    for (int i = 0; i < 3; i++) { alpha[i] = 0.5 * DT * DT * yp[i] + 0.5 * DT * yv[i]; beta[i] = 0.5 * DT * yv[i]; }
+    double h2Te[3], H2ve[9], H2ee[9];
+    phi_hess(beta, vt, et, T, h2Te, H2ve, H2ee, gvt);
+    for (int i = 0; i < 3; i++) gam1[i] = alpha[i] + DT * gvt[i];
+    double h1Te[3], H1ve[9], H1ee[9], dummy[3];
+    phi_hess(gam1, v, e, T, h1Te, H1ve, H1ee, dummy);
+    memset(H, 0, 100 * sizeof(double));
+    /* term 1: Hessian of phi_gam1 at (T, v, e), variable indices T=3, v=4..6, e=7..9 */
+    for (int j = 0; j < 3; j++) {
+        H[3 * 10 + 7 + j] += h1Te[j]; H[(7 + j) * 10 + 3] += h1Te[j];
+        for (int i = 0; i < 3; i++) { H[(4 + i) * 10 + 7 + j] += H1ve[i * 3 + j]; H[(7 + j) * 10 + 4 + i] += H1ve[i * 3 + j]; }
+        for (int l = 0; l < 3; l++) H[(7 + j) * 10 + 7 + l] += H1ee[j * 3 + l];
+    }
+    /* term 2: J' H2 J with J = d(T, vt, et)/d zt (7 x 10) */
+    double J[7 * 10], M2[7 * 7], W[7 * 10];
+    memset(J, 0, sizeof J); memset(M2, 0, sizeof M2);
+    J[0 * 10 + 3] = 1.0;
+    for (int i = 0; i < 3; i++) {
+        J[(1 + i) * 10 + 3] = DT * g1[i];
+        for (int j = 0; j < 3; j++) {
+            J[(1 + i) * 10 + 4 + j] = (i == j ? 1.0 : 0.0) + DT * F1vv[i * 3 + j];
+            J[(1 + i) * 10 + 7 + j] = DT * F1ve[i * 3 + j];
+        }
+        J[(4 + i) * 10 + i] = DT;
+        J[(4 + i) * 10 + 7 + i] = 1.0;
+    }
+    for (int j = 0; j < 3; j++) {
+        M2[0 * 7 + 4 + j] = M2[(4 + j) * 7 + 0] = h2Te[j];
+        for (int i = 0; i < 3; i++) M2[(1 + i) * 7 + 4 + j] = M2[(4 + j) * 7 + 1 + i] = H2ve[i * 3 + j];
+        for (int l = 0; l < 3; l++) M2[(4 + j) * 7 + 4 + l] = H2ee[j * 3 + l];
+    }
+    for (int i = 0; i < 7; i++)
+        for (int j = 0; j < 10; j++) {
+            double acc = 0;
+            for (int l = 0; l < 7; l++) acc += M2[i * 7 + l] * J[l * 10 + j];
+            W[i * 10 + j] = acc;
+        }
+    for (int i = 0; i < 10; i++)
+        for (int j = 0; j < 10; j++) {
+            double acc = 0;
+            for (int l = 0; l < 7; l++) acc += J[l * 10 + i] * W[l * 10 + j];
+            H[i * 10 + j] += acc;
+        }
+}
+
 /* Constant (Gauss-Newton == exact, the cost is quadratic) stage cost pieces:
  * f = 1/2 z'Hz + q'z + const with H diagonal except the (u_i, w_i) couplings.
  * hd[17] = diag(H), hc = the u_i/w_i off-diagonal entry (-2 w_rate), q[17] linear term. */

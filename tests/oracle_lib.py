@@ -15,12 +15,12 @@ IP = ctypes.POINTER(ctypes.c_int)
 
 class OrcInfo(ctypes.Structure):
     _fields_ = [("it", ctypes.c_int)] + [(n, ctypes.c_double) for n in
-                                         "res_eq res_ineq rsnorm rcompnorm pobj mu mu_aff sigma step_aff step_cc".split()]
+                                         "res_eq res_ineq rsnorm rcompnorm pobj mu mu_aff sigma step_aff step_cc".split()] + [("nfallback", ctypes.c_int)]
 
 
 class OrcOptions(ctypes.Structure):
     _fields_ = [("maxit", ctypes.c_int)] + [(n, ctypes.c_double) for n in
-                                            "tol_stat tol_eq tol_ineq tol_comp mu0 ftb".split()]
+                                            "tol_stat tol_eq tol_ineq tol_comp mu0 ftb".split()] + [("hessian", ctypes.c_int)]
 
 
 def P(a):
