@@ -47,7 +47,7 @@ bool fill_args(const frp_nmpc_batch *b, const frp_nmpc_options *opt_in, void *ws
     if (opt_in) o = *opt_in; else frp_nmpc_default_options(&o);
     a->B = b->B; a->N = b->N; a->M = b->M; a->MF = b->MF; a->model = b->model; a->maxit = o.maxit;
     a->tol_stat = o.tol_stat; a->tol_eq = o.tol_eq; a->tol_ineq = o.tol_ineq; a->tol_comp = o.tol_comp;
-    a->mu0 = o.mu0; a->ftb = o.ftb;
+    a->mu0 = o.mu0; a->ftb = o.ftb; a->hessian = o.hessian;
     a->xinit = b->xinit; a->x0 = b->x0; a->params = b->params; a->nfaces = b->nfaces;
     a->z = b->z; a->exitflag = b->exitflag; a->iters = b->iters; a->info = b->info;
     a->ws = static_cast<double *>(ws);
@@ -180,7 +180,7 @@ int forces_solve(int model, frp_forces_params *params, frp_forces_output *output
         return FRP_EXIT_PARAM_VALUE;
     info->it = it; info->it2opt = it;
     info->res_eq = inf[0]; info->res_ineq = inf[1]; info->rsnorm = inf[2]; info->rcompnorm = inf[3];
-    info->pobj = inf[4]; info->mu = inf[5]; info->step_cc = inf[6]; info->sigma = inf[7];
+    info->pobj = inf[4]; info->mu = inf[5]; info->step_cc = inf[6]; info->sigma = 0.0;
     info->dobj = inf[4]; info->dgap = 0.0; info->rdgap = 0.0;
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     info->solvetime = secs;
@@ -219,6 +219,7 @@ void frp_nmpc_default_options(frp_nmpc_options *o)
     o->tol_comp = 1e-4;
     o->mu0 = 1.0;
     o->ftb = 0.99;
+    o->hessian = 1;
 }
 
 size_t frp_nmpc_workspace_bytes(int B, int N, int MF) { return frp::ws_bytes(B, N, MF); }

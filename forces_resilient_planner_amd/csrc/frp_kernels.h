@@ -5,20 +5,21 @@
 
 namespace frp {
 
-// per-stage HBM record (doubles): everything the serial Riccati chain streams, laid out so that one
-// wavefront reads it with 64-lane coalesced loads.
+// Per-stage HBM record (doubles): everything the serial Riccati sweeps stream, laid out so that one
+// wavefront moves it with 64-lane coalesced loads/stores.
+//   E part (written by the evaluation / step phases, 208 doubles):
 constexpr int REC_LIN = 0;      // compact linearisation (51): Apv Ape Avv Ave BpT BvT Bvw
-constexpr int REC_D = 51;       // d = prev(z_k) - s_{k+1}  (13)
-constexpr int REC_KB = 64;      // Kb = Quu^-1 Qus (4 x 13)
-constexpr int REC_R = 116;      // R = Quu^-1 (4 x 4)
-constexpr int REC_PD = 132;     // P_{k+1} d (13)
-constexpr int REC_KV = 145;     // kb = R q_u (4)
-constexpr int REC_PV = 149;     // p_k (13)
-constexpr int REC_PHID = 162;   // diag of Phi = H + barrier (17)
-constexpr int REC_PHIPOS = 179; // corridor barrier block on pos (3 x 3)
-constexpr int REC_PHI = 188;    // rhs gradient phi (17)
-constexpr int REC_HC = 205;     // (u_i, w_i) cost coupling -2 w_rate of this stage
-constexpr int REC_STRIDE = 208;
+constexpr int REC_D = 51;       // d = prev(z_k) - s_{k+1}, s-order [w; x]  (13)
+constexpr int REC_PHID = 64;    // diag of Phi = cost Hessian + bound barriers (17)
+constexpr int REC_PHIPOS = 81;  // corridor barrier block on pos (3 x 3)
+constexpr int REC_PHI = 90;     // rhs gradient phi (17)
+constexpr int REC_HC = 107;     // (u_i, w_i) cost coupling -2 w_rate of this stage
+constexpr int REC_HD = 108;     // exact Hessian of y'c(z) over (rates, T, v, e), dense 10 x 10
+constexpr int REC_E_SIZE = 208;
+//   F part (written by the factorisation sweep, 80 doubles):
+constexpr int REC_T = 208;      // T' = [R | Kbar_x | kbar | hc] as tile register 0 (64): lane (g,c) <-> T'[g][c]
+constexpr int REC_PD = 272;     // P_{k+1} d (16, s-order rows)
+constexpr int REC_STRIDE = 288;
 
 constexpr double S_MIN = 1e-2;          // smallest initial slack (infeasible start shift)
 constexpr double MU_FLOOR_FRAC = 0.1;   // centring target floor = 0.1 * tol_comp
@@ -26,7 +27,7 @@ constexpr double DIVERGE_MU = 1e6;
 constexpr double DIVERGE_RS = 1e12;
 
 struct KernelArgs {
-    int B, N, M, MF, model, maxit;
+    int B, N, M, MF, model, maxit, hessian;
     double tol_stat, tol_eq, tol_ineq, tol_comp, mu0, ftb;
     const double *xinit, *x0, *params;
     const int *nfaces;

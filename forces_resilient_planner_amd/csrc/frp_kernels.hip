@@ -7,15 +7,21 @@
 // and its model callback FORCESNLPsolver_*_casadi2forces (casadi2forces.c:42-245).
 //
 // Iteration (same as the CPU oracle so both can be compared iterate by iterate):
-//   primal-dual interior point, Mehrotra predictor-corrector, exact (constant) cost Hessian,
+//   primal-dual interior point, Mehrotra predictor-corrector, stage Hessian = exact cost Hessian +
+//   exact Hessian of the RK2 dynamics (Gauss-Newton fallback when the reduced Hessian is indefinite),
 //   Newton KKT system solved by a Riccati recursion over the stage chain with
 //   state s = [w; x] (13) and control u (4):   s_{k+1} = [u_k; A_k x_k + B_k u_k] + d_k.
-// Work distribution inside the wavefront:
-//   * stage-parallel phases (model evaluation, residuals, barrier terms, step lengths): lane == stage,
-//     operands in [item][stage] arrays so that the 64 lanes read consecutive doubles;
-//   * the serial Riccati chain: the 64 lanes share every small dense product through LDS
-//     (P_{k+1}, [A|B], Q blocks staged in LDS; ~7 KB per problem), per-stage factors streamed
-//     to/from a 208-double HBM record with coalesced wave loads, next stage prefetched.
+//
+// Work distribution inside the wavefront
+//   * element-wise phases (residuals, barrier terms, step lengths, updates): all 64 lanes,
+//     lane = (row pair, stage), operands in [row][stage] arrays -> coalesced 64-lane accesses;
+//   * model evaluation (RK2 step, Jacobian, exact Hessian): lane == stage;
+//   * the serial Riccati sweeps: every 13x13(+1) block lives in REGISTERS as a 16x16 FP64 tile in the
+//     v_mfma_f64_16x16x4_f64 accumulator layout (lane (g,c), register r <-> element [4r+g][c]).  In that
+//     layout D = X'Y is four MFMAs with A := X, B := Y register for register, so the whole recursion
+//       X = P M,  G = M'X + Phi,  T = R G_u,  S = G - G_u' T,  P <- S (+ w blocks)
+//     runs on the matrix pipe with no cross-lane data movement; the right-hand side rides along as
+//     column 13 of the tiles.  Per stage the sweeps stream one 64-lane record row from/to HBM.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "frp_model.hpp"
@@ -27,7 +33,7 @@ namespace frp {
 // occupancy target: waves per SIMD the register allocator must leave room for (propagates to the
 // non-inlined phase functions)
 #ifndef FRP_WAVES_PER_EU
-#define FRP_WAVES_PER_EU 4
+#define FRP_WAVES_PER_EU 3
 #endif
 
 // ------------------------------------------------------------------ wave helpers
@@ -49,6 +55,20 @@ __device__ __forceinline__ double wave_sum(double v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// sum over the 16 lanes of one row group (lanes with equal lane >> 4)
+__device__ __forceinline__ double row16_sum(double v)
+{
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double lane_bcast(double v, int src) // wave-uniform src lane
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)b, src);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 // One wavefront per workgroup.  LDS operations of one wave are executed in issue order, so lanes can hand
 // data to each other through LDS with only a COMPILER ordering fence: WSYNC() emits no instruction and,
 // unlike __syncthreads(), does not drain the vector-memory counter -- prefetched global loads and
@@ -63,48 +83,21 @@ __device__ __forceinline__ double wave_sum(double v)
 #define FULLSYNC() __syncthreads()
 
 // ------------------------------------------------------------------ LDS layout (doubles)
-constexpr int L_P0 = 0;                 // P buffer 0 (13x13)
-constexpr int L_P1 = L_P0 + 169;        // P buffer 1
-constexpr int L_AB = L_P1 + 169;        // [A | B] 9 x 13 row-major
-constexpr int L_D = L_AB + 117;         // d (13)
-constexpr int L_PA = L_D + 13;          // Pxx [A|B]  9 x 13
-constexpr int L_QUU = L_PA + 117;       // 4 x 4
-constexpr int L_QUS = L_QUU + 16;       // 4 x 13  (cols 0..3 = Quw, 4..12 = Qux)
-constexpr int L_Q = L_QUS + 52;         // q (17)
-constexpr int L_OUT = L_Q + 17;         // [Kb 52 | R 16 | Pd 13 | kb 4 | p 13] = record part 2 (98)
-constexpr int L_KB = L_OUT;
-constexpr int L_R = L_OUT + 52;
-constexpr int L_PD = L_OUT + 68;
-constexpr int L_KV = L_OUT + 81;
-constexpr int L_PV = L_OUT + 85;
-constexpr int L_PHI = L_OUT + 98;       // [PhiD 17 | PhiPos 9 | phi 17] = record part 3 (43)
-constexpr int L_PHID = L_PHI;
-constexpr int L_PHIPOS = L_PHI + 17;
-constexpr int L_PHIV = L_PHI + 26;
-constexpr int L_HC = L_PHI + 43;        // hc of the stage being processed
-constexpr int L_S0 = L_PHI + 44;        // stage-0 solve: [Rw 16 | Pwx 36]
-constexpr int L_DS = L_S0 + 52;         // ds (13)
-constexpr int L_DSN = L_DS + 13;        // next ds (13)
-constexpr int L_DU = L_DSN + 13;        // du (4)
-constexpr int L_YX = L_DU + 4;          // costate y_x (9) x 2
-constexpr int L_TOTAL = L_YX + 18;
-
-// ------------------------------------------------------------------ small device pieces
-__device__ __forceinline__ int lin_dst(int t)
-{
-    // destination (offset from L_AB) of compact-linearisation entry t (0..50) / d entry (51..63)
-    if (t < 9) return (t / 3) * 13 + 3 + t % 3;                     // Apv -> A[i][3+j]
-    if (t < 18) return ((t - 9) / 3) * 13 + 6 + (t - 9) % 3;        // Ape -> A[i][6+j]
-    if (t < 27) return (3 + (t - 18) / 3) * 13 + 3 + (t - 18) % 3;  // Avv
-    if (t < 36) return (3 + (t - 27) / 3) * 13 + 6 + (t - 27) % 3;  // Ave
-    if (t < 39) return (t - 36) * 13 + 12;                          // BpT -> B[i][3]
-    if (t < 42) return (3 + t - 39) * 13 + 12;                      // BvT -> B[3+i][3]
-    if (t < 51) return (3 + (t - 42) / 3) * 13 + 9 + (t - 42) % 3;  // Bvw -> B[3+i][j]
-    return 117 + (t - 51);                                          // d
-}
+// [0, 736): staging.  Element-wise phases: gm[17][NP] + corridor sums[6][NP] (NP = 32).
+//           Riccati sweeps: the E part of the current stage record + constants + T' + R.
+// [736, ...): fields that live across phases of one iteration.
+constexpr int S_E = 0;                    // E part of the stage record (208)
+constexpr int S_ZERO = 208, S_ONE = 209, S_DTC = 210;
+constexpr int S_T = 216;                  // T' (64)
+constexpr int S_R = 280;                  // 4x4 inverse handed from uniform registers to lanes (16)
+constexpr int S_STAGING = 23 * 32;        // 736
+constexpr int S_RW = S_STAGING;           // stage-0 solve: Pww^-1 (16)
+constexpr int S_PWX = S_RW + 16;          // stage-0 solve: Pwx (4 x 9)
+constexpr int S_DS0 = S_PWX + 36;         // ds_0 = [dw_0; dx_0] (13, padded 16)
+constexpr int L_TOTAL = S_DS0 + 16;
 
 // symmetric positive definite 4x4 inverse via LDL'; returns false if a pivot is not positive
-__device__ __forceinline__ bool spd4_inverse(const double *a /*row-major 4x4*/, double *r /*16*/)
+__device__ __forceinline__ bool spd4_inverse(const double *a /*row-major 4x4, lower part used*/, double *r /*16*/)
 {
     const double a00 = a[0], a10 = a[4], a11 = a[5], a20 = a[8], a21 = a[9], a22 = a[10];
     const double a30 = a[12], a31 = a[13], a32 = a[14], a33 = a[15];
@@ -145,7 +138,6 @@ __device__ __forceinline__ bool spd4_inverse(const double *a /*row-major 4x4*/, 
     r[12] = r30; r[13] = r31; r[14] = r32; r[15] = r33;
     return true;
 }
-
 
 // Explicit global address space: inside non-inlined device functions a plain double* is a GENERIC
 // pointer and compiles to flat_load/flat_store, which also count on lgkmcnt and therefore make every
@@ -195,29 +187,74 @@ __device__ __forceinline__ WsView uni(WsView w)
 
 __shared__ double sm[L_TOTAL];
 
+// ------------------------------------------------------------------ 16x16 FP64 tiles in registers
+// Tile X: lane l = 16 g + c holds x[r] = X[4r + g][c], r = 0..3 (the C/D layout of
+// v_mfma_f64_16x16x4_f64; A operand of slice s = X'[.., 4s+g] i.e. again x[s], B operand = x[s]).
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// D = X' Y + C
+__device__ __forceinline__ d4 mm_tn(const d4 x, const d4 y, d4 c)
+{
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0], y[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1], y[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(x[2], y[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(x[3], y[3], c, 0, 0, 0);
+    return c;
+}
+// D = X[0:4,:]' Y[0:4,:] + C  (only the first four rows of X and Y contribute)
+__device__ __forceinline__ d4 mm_tn4(double x0, double y0, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y0, c, 0, 0, 0); }
+
+// LDS offset (within the staged E record) of Mt[row][col], the augmented transition matrix
+//   rows: s+ = [w+(0..3); x+(4..12)],  cols: [u(0..3); x(4..12); 13 = d]
+//   w+ = u + d_w,  x+ = A x + B u + d_x
+__device__ __forceinline__ int m_src(int row, int col)
+{
+    if (row > 12 || col > 13) return S_ZERO;
+    if (col == 13) return S_E + REC_D + row;
+    if (row < 4) return (col == row) ? S_ONE : S_ZERO;
+    const int i = row - 4, bi = i / 3, ii = i % 3;
+    if (col < 4) { // B[i][col]
+        if (col == 3) return bi == 0 ? S_E + REC_LIN + 36 + ii : (bi == 1 ? S_E + REC_LIN + 39 + ii : S_ZERO);
+        if (bi == 1) return S_E + REC_LIN + 42 + ii * 3 + col;
+        if (bi == 2) return ii == col ? S_DTC : S_ZERO;
+        return S_ZERO;
+    }
+    const int j = col - 4, bj = j / 3, jj = j % 3;
+    if (bi == 0) return bj == 0 ? (ii == jj ? S_ONE : S_ZERO) : S_E + REC_LIN + (bj == 1 ? 0 : 9) + ii * 3 + jj;
+    if (bi == 1) return bj == 0 ? S_ZERO : S_E + REC_LIN + (bj == 1 ? 18 : 27) + ii * 3 + jj;
+    return (bj == 2 && ii == jj) ? S_ONE : S_ZERO;
+}
+// z index of tile index a over (u, x):  u -> 0..3, x -> 8..16
+__device__ __forceinline__ int zi_of(int a) { return a < 4 ? a : a + 4; }
+// index into the 10 x 10 dynamics Hessian (rates, T, v, e) of tile index a, or -1
+__device__ __forceinline__ int hidx_of(int a) { return a < 4 ? a : (a >= 7 && a <= 12 ? a - 3 : -1); }
+// the three LDS sources summed into C~[row][col] = Phi~ (diag + corridor + Hessian) with phi in column 13
+__device__ __forceinline__ void c_src(int row, int col, int &o1, int &o2, int &o3)
+{
+    o1 = o2 = o3 = S_ZERO;
+    if (row > 12) return;
+    if (col == 13) { o1 = S_E + REC_PHI + zi_of(row); return; }
+    if (col > 12) return;
+    if (col == row) o1 = S_E + REC_PHID + zi_of(row);
+    if (row >= 4 && row <= 6 && col >= 4 && col <= 6) o2 = S_E + REC_PHIPOS + (row - 4) * 3 + (col - 4);
+    const int hr = hidx_of(row), hc_ = hidx_of(col);
+    if (hr >= 0 && hc_ >= 0) o3 = S_E + REC_HD + hr * 10 + hc_;
+}
+
+__device__ __forceinline__ void init_stage_constants(int lane)
+{
+    if (lane == 0) { sm[S_ZERO] = 0.0; sm[S_ONE] = 1.0; sm[S_DTC] = DT; }
+}
+
 struct EvalOut {
     double eq, in, rs, rc, gap, obj;
 };
 
-// Staging area of the element-wise phases (aliases the Riccati working set, which is dead then):
+// Staging area of the element-wise phases (aliases the sweep staging, which is dead then):
 // gm[17][NP] multiplier part of the stationarity residual, gf[6][NP] corridor sums for pos entries.
 __shared__ double sm_big[23 * 64]; // only referenced (hence only allocated) by the NP = 64 instantiation
 template <int NP>
 __device__ __forceinline__ double *stage_area() { return NP == 32 ? sm : sm_big; }
-static_assert(23 * 32 <= L_PHI, "element-wise staging must fit below the persistent LDS fields");
-
-__device__ __forceinline__ void init_ab_constants(int lane)
-{
-    // constant entries of [A|B]: identity blocks of A, dt*I in B's euler rows (the variable entries are
-    // scattered over them stage by stage)
-    for (int t = lane; t < 117; t += 64) {
-        const int i = t / 13, j = t % 13;
-        double v = 0.0;
-        if (j < 9) v = (i == j) ? 1.0 : 0.0;
-        else if (i >= 6 && (j - 9) == (i - 6)) v = DT;
-        sm[L_AB + t] = v;
-    }
-}
 
 __device__ __forceinline__ double xhalf_sum(double v) { return v + __shfl_xor(v, 32); }
 
@@ -226,9 +263,9 @@ __device__ __forceinline__ double xhalf_sum(double v) { return v + __shfl_xor(v,
 // part 2 (lane == (row pair, stage), all 64 lanes): corridor rows, then bounds: residual norms,
 //        barrier Hessian / affine rhs -> record
 template <int NP>
-__device__ __noinline__ EvalOut phase_eval(WsView w, cgdouble *pbase, int np, cgdouble *xinit, int N, int MF, int nfk, int model)
+__device__ __noinline__ EvalOut phase_eval(WsView w, cgdouble *pbase, int np, cgdouble *xinit, int N, int MF, int nfk, int model, int hess)
 {
-    w = uni(w); pbase = uni(pbase); np = uni(np); xinit = uni(xinit); N = uni(N); MF = uni(MF); model = uni(model);
+    w = uni(w); pbase = uni(pbase); np = uni(np); xinit = uni(xinit); N = uni(N); MF = uni(MF); model = uni(model); hess = uni(hess);
     FULLSYNC(); // phase boundary: other lanes' global writes of the previous phase are visible
     constexpr int H = 64 / NP;
     const int lane = threadIdx.x;
@@ -325,6 +362,13 @@ __device__ __noinline__ EvalOut phase_eval(WsView w, cgdouble *pbase, int np, cg
                 gT += bpt * yp[i] + bvt * yv[i];
             }
             gm[3] += gT;
+            if (hess) {
+                // exact Hessian of y_{k+1}' c(z_k): only the pos / vel rows of the RK2 step are non-linear
+                rk2_hessian(zk + 8, zk, p10 + 3, yp, yv, [&](int i, int j, double val) {
+                    rec[REC_HD + i * 10 + j] = val;
+                    if (i != j) rec[REC_HD + j * 10 + i] = val;
+                });
+            }
         }
 #pragma unroll
         for (int i = 0; i < NZ; i++) stg[i * NP + k] = gm[i];
@@ -412,276 +456,259 @@ __device__ __noinline__ EvalOut phase_eval(WsView w, cgdouble *pbase, int np, cg
     return o;
 }
 
-// ------------------------------------------------------------------ backward Riccati sweep
-// pass 0: factorisation + vector part; pass 1: vector part only (new phi).  Ends with the stage-0
-// solve (ds_0 left in LDS).  Returns non-zero when a pivot block is not positive definite.
+// ------------------------------------------------------------------ stage-0 solve (both passes)
+// dx_0 = xinit - x_0, dw_0 = -Pww^-1 (Pwx dx_0 + p_w); leaves ds_0 = [dw_0; dx_0] in LDS (S_DS0).
+// pw_here: p_w[g] in the lanes (g, 13).
 template <int NP>
-__device__ __noinline__ int sweep_backward(WsView w, cgdouble *xinit, int N, int pass)
+__device__ __forceinline__ void stage0_solve(const WsView &w, cgdouble *xinit, int lane, double pw_here)
 {
-    w = uni(w); xinit = uni(xinit); N = uni(N); pass = uni(pass);
-    FULLSYNC(); // phase boundary: other lanes' global writes of the previous phase are visible
-    const int lane = threadIdx.x;
-    const int my_dst = L_AB + lin_dst(lane);
-    bool fact_fail = false;
-    init_ab_constants(lane);
+    const int g = lane >> 4, c = lane & 15;
+    const bool xc = (c >= 4 && c <= 12);
+    const double dxc = xc ? xinit[c - 4] - w.z[(8 + c - 4) * NP + 0] : 0.0;
     WSYNC();
-    {
-        int cur = 0; // buffer holding P_{k+1}
-        cgdouble *r0 = w.rec + (size_t)(N - 1) * REC_STRIDE;
-        double pre_lin = r0[lane];                                           // LIN + D
-        double pre_phi = (lane < 44) ? r0[REC_PHID + lane] : 0.0;            // PhiD | PhiPos | phi
-        double pre_out0 = 0.0, pre_out1 = 0.0;                               // Kb|R|Pd (pass 1)
-        if (pass == 1) {
-            pre_out0 = r0[REC_KB + lane];
-            pre_out1 = (lane < 17) ? r0[REC_KB + 64 + lane] : 0.0;
-        }
-        for (int kk = N - 1; kk >= 0; kk--) {
-            gdouble *rec = w.rec + (size_t)kk * REC_STRIDE;
-            const bool last = (kk == N - 1);
-            sm[my_dst] = pre_lin;
-            if (lane < 44) sm[L_PHI + lane] = pre_phi;
-            if (pass == 1) {
-                sm[L_OUT + lane] = pre_out0;               // Kb(52) R(12 of 16)
-                if (lane < 17) sm[L_OUT + 64 + lane] = pre_out1; // R tail, Pd
-            }
-            if (kk > 0) {
-                cgdouble *rn = rec - REC_STRIDE;
-                pre_lin = rn[lane];
-                pre_phi = (lane < 44) ? rn[REC_PHID + lane] : 0.0;
-                if (pass == 1) {
-                    pre_out0 = rn[REC_KB + lane];
-                    pre_out1 = (lane < 17) ? rn[REC_KB + 64 + lane] : 0.0;
-                }
-            }
-            WSYNC();
-            const double *Pn = sm + (cur ? L_P1 : L_P0);
-            double *Pk = sm + (cur ? L_P0 : L_P1);
-            const double *AB = sm + L_AB;
-            if (pass == 0 && !last) {
-                // PA = Pxx [A|B] (9 x 13), Pd = P d
-                for (int t = lane; t < 117; t += 64) {
-                    const int i = t / 13, j = t % 13;
-                    double acc = 0.0;
-#pragma unroll
-                    for (int l = 0; l < 9; l++) acc += Pn[(4 + i) * 13 + 4 + l] * AB[l * 13 + j];
-                    sm[L_PA + t] = acc;
-                }
-                if (lane < 13) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int j = 0; j < 13; j++) acc += Pn[lane * 13 + j] * sm[L_D + j];
-                    sm[L_PD + lane] = acc;
-                }
-                WSYNC();
-            }
-            // q = phi + M'(Pd + p_{k+1})
-            if (lane < 17) {
-                double acc = sm[L_PHIV + lane];
-                if (!last) {
-                    if (lane < 4) {
-                        acc += sm[L_PD + lane] + sm[L_PV + lane];
-#pragma unroll
-                        for (int i = 0; i < 9; i++) acc += AB[i * 13 + 9 + lane] * (sm[L_PD + 4 + i] + sm[L_PV + 4 + i]);
-                    } else if (lane >= 8) {
-#pragma unroll
-                        for (int i = 0; i < 9; i++) acc += AB[i * 13 + lane - 8] * (sm[L_PD + 4 + i] + sm[L_PV + 4 + i]);
-                    }
-                }
-                sm[L_Q + lane] = acc;
-            }
-            if (pass == 0) {
-                // Qxx -> Pk[4+i][4+j]; Qww -> diag; Qwx = 0
-                for (int t = lane; t < 169; t += 64) {
-                    const int i = t / 13, j = t % 13;
-                    double acc = 0.0;
-                    if (i >= 4 && j >= 4) {
-                        const int ii = i - 4, jj = j - 4;
-                        if (ii == jj) acc = sm[L_PHID + 8 + ii];
-                        if (ii < 3 && jj < 3) acc += sm[L_PHIPOS + ii * 3 + jj];
-                        if (!last) {
-#pragma unroll
-                            for (int l = 0; l < 9; l++) acc += AB[l * 13 + ii] * sm[L_PA + l * 13 + jj];
-                        }
-                    } else if (i == j) acc = sm[L_PHID + 4 + i];
-                    Pk[t] = acc;
-                }
-                // Qus (4 x 13): Quw = hc I, Qux = T A with T = Pwx + (Pxx B)'
-                if (lane < 52) {
-                    const int i = lane / 13, j = lane % 13;
-                    double acc = 0.0;
-                    if (j < 4) acc = (i == j) ? sm[L_HC] : 0.0;
-                    else if (!last) {
-#pragma unroll
-                        for (int l = 0; l < 9; l++) acc += (Pn[i * 13 + 4 + l] + sm[L_PA + l * 13 + 9 + i]) * AB[l * 13 + j - 4];
-                    }
-                    sm[L_QUS + lane] = acc;
-                }
-                // Quu
-                if (lane < 16) {
-                    const int i = lane / 4, j = lane % 4;
-                    double acc = (i == j) ? sm[L_PHID + i] : 0.0;
-                    if (!last) {
-                        acc += Pn[i * 13 + j];
-#pragma unroll
-                        for (int l = 0; l < 9; l++)
-                            acc += (Pn[i * 13 + 4 + l] + sm[L_PA + l * 13 + 9 + i]) * AB[l * 13 + 9 + j] + AB[l * 13 + 9 + i] * Pn[(4 + l) * 13 + j];
-                    }
-                    sm[L_QUU + lane] = acc;
-                }
-                WSYNC();
-                {
-                    double R[16];
-                    const bool ok = spd4_inverse(sm + L_QUU, R);
-                    if (!ok) fact_fail = true;
-#pragma unroll
-                    for (int t = 0; t < 16; t++) sm[L_R + t] = ok ? R[t] : 0.0;
-                }
-                WSYNC();
-                // Kb = R Qus
-                if (lane < 52) {
-                    const int i = lane / 13, j = lane % 13;
-                    double acc = 0.0;
-#pragma unroll
-                    for (int l = 0; l < 4; l++) acc += sm[L_R + i * 4 + l] * sm[L_QUS + l * 13 + j];
-                    sm[L_KB + lane] = acc;
-                }
-                WSYNC();
-                // P_k = Qss - Qus' Kb
-                for (int t = lane; t < 169; t += 64) {
-                    const int i = t / 13, j = t % 13;
-                    double acc = Pk[t];
-#pragma unroll
-                    for (int l = 0; l < 4; l++) acc -= sm[L_QUS + l * 13 + i] * sm[L_KB + l * 13 + j];
-                    Pk[t] = acc;
-                }
-            } else {
-                WSYNC();
-            }
-            // kb = R q_u ; p_k = q_s - Kb' q_u
-            double kbv = 0.0, pv = 0.0;
-            if (lane < 4) {
-#pragma unroll
-                for (int l = 0; l < 4; l++) kbv += sm[L_R + lane * 4 + l] * sm[L_Q + l];
-            } else if (lane < 17) {
-                pv = sm[L_Q + lane];
-#pragma unroll
-                for (int l = 0; l < 4; l++) pv -= sm[L_KB + l * 13 + lane - 4] * sm[L_Q + l];
-            }
-            WSYNC(); // everyone has read p_{k+1} (L_PV) before it is overwritten
-            if (lane < 4) sm[L_KV + lane] = kbv;
-            else if (lane < 17) sm[L_PV + lane - 4] = pv;
-            WSYNC();
-            // stream the factors of stage kk to HBM
-            if (pass == 0) {
-                rec[REC_KB + lane] = sm[L_OUT + lane];
-                if (lane < 34) rec[REC_KB + 64 + lane] = sm[L_OUT + 64 + lane];
-            } else if (lane < 17) {
-                rec[REC_KV + lane] = sm[L_KV + lane]; // kb (4) + p (13)
-            }
-            cur ^= 1;
-        }
-        // stage 0: dw = -Pww^-1 (Pwx dx + p_w), dx = xinit - x_0
-        const double *P0 = sm + (cur ? L_P1 : L_P0);
-        if (pass == 0) {
-            double Rw[16], Pww[16];
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) Pww[i * 4 + j] = P0[i * 13 + j];
-            const bool ok = spd4_inverse(Pww, Rw);
-            if (!ok) fact_fail = true;
-            WSYNC();
-#pragma unroll
-            for (int t = 0; t < 16; t++) sm[L_S0 + t] = ok ? Rw[t] : 0.0;
-            if (lane < 36) sm[L_S0 + 16 + lane] = P0[(lane / 9) * 13 + 4 + lane % 9];
-        }
-        if (lane < 9) sm[L_DS + 4 + lane] = xinit[lane] - w.z[(8 + lane) * NP + 0];
-        WSYNC();
-        if (lane < 4) {
-            double acc = sm[L_PV + lane];
-#pragma unroll
-            for (int j = 0; j < 9; j++) acc += sm[L_S0 + 16 + lane * 9 + j] * sm[L_DS + 4 + j];
-            sm[L_DU + lane] = acc; // temporary: rhs
-        }
-        WSYNC();
-        if (lane < 4) {
-            double acc = 0.0;
-#pragma unroll
-            for (int l = 0; l < 4; l++) acc -= sm[L_S0 + lane * 4 + l] * sm[L_DU + l];
-            sm[L_DS + lane] = acc;
-        }
-        WSYNC();
+    const double prod = xc ? sm[S_PWX + g * 9 + c - 4] * dxc : (c == 13 ? pw_here : 0.0);
+    const double rhs = row16_sum(prod);
+    const double r0 = lane_bcast(rhs, 0), r1 = lane_bcast(rhs, 16), r2 = lane_bcast(rhs, 32), r3 = lane_bcast(rhs, 48);
+    if (lane < 4) {
+        sm[S_DS0 + lane] = -(sm[S_RW + lane * 4 + 0] * r0 + sm[S_RW + lane * 4 + 1] * r1 +
+                             sm[S_RW + lane * 4 + 2] * r2 + sm[S_RW + lane * 4 + 3] * r3);
+    } else if (lane <= 12) {
+        sm[S_DS0 + lane] = dxc; // g == 0: index 4 + (c - 4) = c
+    } else if (lane < 16) {
+        sm[S_DS0 + lane] = 0.0;
     }
+    WSYNC();
+}
 
+// ------------------------------------------------------------------ factorisation sweep (predictor)
+// Backward Riccati recursion with everything in register tiles (see the header).  Per stage:
+//   X = P M (col 13: P d + p+),  G = M'X + C~ (col 13: q~),  R = Guu^-1,
+//   T = R G_u (Kbar, kbar),  TT = G_u' R (Kbar'),  S = G - G_u' T,
+//   P <- [Phi_w - hc^2 R, -hc Kbar_x; -hc Kbar_x', S_xx],  p <- [phi_w - hc kbar; S_x,13].
+// Streams T' = [R | Kbar_x | kbar | hc] and P d to the stage record.  Returns 1 when a pivot block
+// is not positive definite (exact Hessian: the caller retries with theta = 0, Gauss-Newton).
+template <int NP>
+__device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, int theta_i)
+{
+    w = uni(w); xinit = uni(xinit); N = uni(N); theta_i = uni(theta_i);
+    FULLSYNC(); // phase boundary: the evaluation phase's record writes are visible
+    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    const double theta = theta_i ? 1.0 : 0.0;
+    int mo[4], c1[4], c2[4], c3[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        mo[r] = m_src(4 * r + g, c);
+        c_src(4 * r + g, c, c1[r], c2[r], c3[r]);
+    }
+    init_stage_constants(lane);
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    d4 P = zero, pv = zero;
+    bool fail = false;
+    cgdouble *rp = w.rec + (size_t)(N - 1) * REC_STRIDE;
+    double e0 = rp[lane], e1 = rp[64 + lane], e2 = rp[128 + lane], e3 = (lane < 16) ? rp[192 + lane] : 0.0;
+    for (int kk = N - 1; kk >= 0; kk--) {
+        gdouble *rec = w.rec + (size_t)kk * REC_STRIDE;
+        const bool last = (kk == N - 1);
+        WSYNC(); // every lane is done with the previous stage's staging
+        sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1; sm[S_E + 128 + lane] = e2;
+        if (lane < 16) sm[S_E + 192 + lane] = e3;
+        if (kk > 0) {
+            cgdouble *rn = rec - REC_STRIDE;
+            e0 = rn[lane]; e1 = rn[64 + lane]; e2 = rn[128 + lane]; e3 = (lane < 16) ? rn[192 + lane] : 0.0;
+        }
+        WSYNC();
+        const double hc = sm[S_E + REC_HC];
+        d4 C;
+#pragma unroll
+        for (int r = 0; r < 4; r++) C[r] = sm[c1[r]] + sm[c2[r]] + theta * sm[c3[r]];
+        d4 G = C;
+        if (!last) {
+            d4 M;
+#pragma unroll
+            for (int r = 0; r < 4; r++) M[r] = sm[mo[r]];
+            d4 X = mm_tn(P, M, zero);
+            if (c == 13) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    rec[REC_PD + 4 * r + g] = X[r];
+                    X[r] += pv[r];
+                }
+            }
+            G = mm_tn(M, X, C);
+        }
+        // R = Guu^-1 (4 x 4): gather the lower triangle to uniform registers, invert redundantly
+        double q[16], R[16];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) q[i * 4 + j] = lane_bcast(G[0], 16 * i + j);
+        if (!spd4_inverse(q, R)) { fail = true; break; }
+#pragma unroll
+        for (int t = 0; t < 16; t++) sm[S_R + t] = R[t];
+        WSYNC();
+        const double rt = (c < 4) ? sm[S_R + g * 4 + c] : 0.0;
+        const d4 T = mm_tn4(rt, G[0], zero);
+        const d4 TT = mm_tn4(G[0], rt, zero);
+        const d4 S = mm_tn4(-G[0], T[0], G);
+        rec[REC_T + lane] = (c < 4) ? rt : (c <= 13 ? T[0] : (lane == 14 ? hc : 0.0));
+        const double PhiDw = sm[S_E + REC_PHID + 4 + g], phiw = sm[S_E + REC_PHI + 4 + g];
+        d4 Pn, pn;
+        Pn[0] = (c < 4) ? ((g == c ? PhiDw : 0.0) - hc * hc * rt) : (c <= 12 ? -hc * T[0] : 0.0);
+        pn[0] = (c == 13) ? (phiw - hc * T[0]) : 0.0;
+#pragma unroll
+        for (int r = 1; r < 4; r++) {
+            const bool inb = (4 * r + g) <= 12;
+            Pn[r] = (inb && c <= 12) ? (c < 4 ? -hc * TT[r] : S[r]) : 0.0;
+            pn[r] = (inb && c == 13) ? S[r] : 0.0;
+        }
+        P = Pn;
+        pv = pn;
+    }
+    if (!fail) {
+        // stage 0: keep Pww^-1 and Pwx for the corrector pass, then solve for ds_0
+        double q[16], Rw[16];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) q[i * 4 + j] = lane_bcast(P[0], 16 * i + j);
+        if (!spd4_inverse(q, Rw)) fail = true;
+        else {
+            WSYNC();
+#pragma unroll
+            for (int t = 0; t < 16; t++) sm[S_RW + t] = Rw[t];
+            if (c >= 4 && c <= 12) sm[S_PWX + g * 9 + c - 4] = P[0];
+            stage0_solve<NP>(w, xinit, lane, pv[0]);
+        }
+    }
     FULLSYNC();
-    return fact_fail ? 1 : 0;
+    return fail ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ vector-only backward sweep (corrector)
+// Same factorisation, new rhs phi:  q~ = phi~ + M'(P d + p+),  [kbar; Kbar'q_u] = T'' q_u,
+// p_x = q~_x - Kbar' q_u,  p_w = phi_w - hc kbar.  Updates the kbar column of T'.
+template <int NP>
+__device__ __noinline__ void sweep_backvec(WsView w, cgdouble *xinit, int N)
+{
+    w = uni(w); xinit = uni(xinit); N = uni(N);
+    FULLSYNC(); // phase boundary: the corrector rhs written by the step phase is visible
+    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    int mo[4], po[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        mo[r] = m_src(4 * r + g, c);
+        po[r] = (c == 13 && 4 * r + g <= 12) ? S_E + REC_PHI + zi_of(4 * r + g) : S_ZERO;
+    }
+    init_stage_constants(lane);
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    d4 pv = zero;
+    cgdouble *rp = w.rec + (size_t)(N - 1) * REC_STRIDE;
+    double e0 = rp[lane], e1 = rp[64 + lane], tp = rp[REC_T + lane];
+    d4 pd = zero;
+    if (c == 13) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) pd[r] = rp[REC_PD + 4 * r + g];
+    }
+    for (int kk = N - 1; kk >= 0; kk--) {
+        gdouble *rec = w.rec + (size_t)kk * REC_STRIDE;
+        const bool last = (kk == N - 1);
+        WSYNC();
+        sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1;
+        const double tpc = tp;
+        const d4 pdc = pd;
+        if (kk > 0) {
+            cgdouble *rn = rec - REC_STRIDE;
+            e0 = rn[lane]; e1 = rn[64 + lane]; tp = rn[REC_T + lane];
+            if (c == 13) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) pd[r] = rn[REC_PD + 4 * r + g];
+            }
+        }
+        WSYNC();
+        const double hc = sm[S_E + REC_HC];
+        d4 Gp;
+#pragma unroll
+        for (int r = 0; r < 4; r++) Gp[r] = sm[po[r]];
+        if (!last) {
+            d4 M, X;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                M[r] = sm[mo[r]];
+                X[r] = (c == 13) ? pdc[r] + pv[r] : 0.0;
+            }
+            Gp = mm_tn(M, X, Gp);
+        }
+        const d4 E = mm_tn4(tpc, Gp[0], zero);
+        if (c == 13) rec[REC_T + 16 * g + 13] = E[0]; // kbar
+        const double phiw = sm[S_E + REC_PHI + 4 + g];
+        d4 pn;
+        pn[0] = (c == 13) ? (phiw - hc * E[0]) : 0.0;
+#pragma unroll
+        for (int r = 1; r < 4; r++) pn[r] = (c == 13 && 4 * r + g <= 12) ? Gp[r] - E[r] : 0.0;
+        pv = pn;
+    }
+    stage0_solve<NP>(w, xinit, lane, pv[0]);
+    FULLSYNC();
 }
 
 // ------------------------------------------------------------------ forward sweep: dz for all stages
+// du = -T' [hc dw; dx; 1],  ds+ = Mt [du; dx; 1]; the vectors stay in the column-0 lanes (row layout).
 template <int NP>
 __device__ __noinline__ void sweep_forward(WsView w, int N)
 {
     w = uni(w); N = uni(N);
-    FULLSYNC(); // phase boundary: other lanes' global writes of the previous phase are visible
-    const int lane = threadIdx.x;
-    const int my_dst = L_AB + lin_dst(lane);
-    init_ab_constants(lane);
-    WSYNC();
-    {
-        cgdouble *r0 = w.rec;
-        double pre_lin = r0[lane];
-        double pre_kb = (lane < 52) ? r0[REC_KB + lane] : ((lane < 56) ? r0[REC_KV + lane - 52] : 0.0);
-        for (int kk = 0; kk < N; kk++) {
-            cgdouble *rec = w.rec + (size_t)kk * REC_STRIDE;
-            sm[my_dst] = pre_lin;
-            if (lane < 52) sm[L_KB + lane] = pre_kb;
-            else if (lane < 56) sm[L_KV + lane - 52] = pre_kb;
-            if (kk < N - 1) {
-                cgdouble *rn = rec + REC_STRIDE;
-                pre_lin = rn[lane];
-                pre_kb = (lane < 52) ? rn[REC_KB + lane] : ((lane < 56) ? rn[REC_KV + lane - 52] : 0.0);
-            }
-            WSYNC();
-            if (lane < 4) {
-                double a0 = sm[L_KV + lane], a1 = 0.0;
+    FULLSYNC(); // phase boundary: T' / kbar of the backward sweep are visible
+    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    int mt[4];
 #pragma unroll
-                for (int j = 0; j < 12; j += 2) {
-                    a0 += sm[L_KB + lane * 13 + j] * sm[L_DS + j];
-                    a1 += sm[L_KB + lane * 13 + j + 1] * sm[L_DS + j + 1];
-                }
-                a0 += sm[L_KB + lane * 13 + 12] * sm[L_DS + 12];
-                const double du = -(a0 + a1);
-                sm[L_DU + lane] = du;
-                w.dz[lane * NP + kk] = du;
-            } else if (lane < 17) {
-                w.dz[lane * NP + kk] = sm[L_DS + lane - 4];
-            }
-            WSYNC();
-            if (kk < N - 1) {
-                double v = 0.0;
-                if (lane < 4) v = sm[L_DU + lane] + sm[L_D + lane];
-                else if (lane < 13) {
-                    const int i = lane - 4;
-                    double a0 = sm[L_D + lane], a1 = 0.0;
+    for (int s = 0; s < 4; s++) mt[s] = m_src(c, 4 * s + g);
+    init_stage_constants(lane);
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    d4 v;
 #pragma unroll
-                    for (int j = 0; j < 8; j += 2) {
-                        a0 += sm[L_AB + i * 13 + j] * sm[L_DS + 4 + j];
-                        a1 += sm[L_AB + i * 13 + j + 1] * sm[L_DS + 4 + j + 1];
-                    }
-                    a0 += sm[L_AB + i * 13 + 8] * sm[L_DS + 12];
-#pragma unroll
-                    for (int j = 0; j < 4; j += 2) {
-                        a0 += sm[L_AB + i * 13 + 9 + j] * sm[L_DU + j];
-                        a1 += sm[L_AB + i * 13 + 10 + j] * sm[L_DU + j + 1];
-                    }
-                    v = a0 + a1;
-                }
-                WSYNC();
-                if (lane < 13) sm[L_DS + lane] = v;
-            }
+    for (int r = 0; r < 4; r++) v[r] = (c == 0 && 4 * r + g <= 12) ? sm[S_DS0 + 4 * r + g] : 0.0;
+    cgdouble *rp = w.rec;
+    double e0 = rp[lane], tp = rp[REC_T + lane];
+    for (int kk = 0; kk < N; kk++) {
+        cgdouble *rec = w.rec + (size_t)kk * REC_STRIDE;
+        WSYNC();
+        sm[S_E + lane] = e0; sm[S_T + lane] = tp;
+        if (kk < N - 1) {
+            cgdouble *rn = rec + REC_STRIDE;
+            e0 = rn[lane]; tp = rn[REC_T + lane];
         }
-                WSYNC();
+        WSYNC();
+        const double hc = sm[S_T + 14];
+        d4 tt, v1 = v;
+#pragma unroll
+        for (int s = 0; s < 4; s++) tt[s] = (c < 4) ? sm[S_T + 16 * c + 4 * s + g] : 0.0;
+        if (c == 0) {
+            v1[0] = hc * v[0];
+            if (g == 1) v1[3] = 1.0; // row 13 multiplies the kbar column
+        }
+        const d4 D1 = mm_tn(tt, v1, zero);
+        const double du = -D1[0];
+        if (c == 0) {
+            w.dz[g * NP + kk] = du;
+            w.dz[(4 + g) * NP + kk] = v[0];
+#pragma unroll
+            for (int r = 1; r < 4; r++)
+                if (4 * r + g <= 12) w.dz[(4 + 4 * r + g) * NP + kk] = v[r];
+        }
+        if (kk < N - 1) {
+            d4 v2 = v, mtv;
+            if (c == 0) {
+                v2[0] = du;
+                if (g == 1) v2[3] = 1.0; // row 13 multiplies the d column
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++) mtv[s] = sm[mt[s]];
+            const d4 D2 = mm_tn(mtv, v2, zero);
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = (c == 0 && 4 * r + g <= 12) ? D2[r] : 0.0;
+        }
     }
+    WSYNC();
 }
 
 struct SlackOut {
@@ -871,66 +898,87 @@ __device__ __noinline__ SlackOut phase_slack(WsView w, cgdouble *pbase, int np, 
 }
 
 // ------------------------------------------------------------------ costate sweep: y <- y + ap (y+ - y)
-// y+_k = (Phi_k dz_k + phi_k)_s + [0; A_k' y+_{k+1,x}]
+// y+_k = (Phi_k dz_k + phi_k)_s + [0; A_k' y+_{k+1,x}]:  x rows = (C~' [du; dx] + M' y+)_x + phi_x,
+// w rows = Phi_w dw + hc du + phi_w.  Vectors in the column-0 lanes (row layout).
 template <int NP>
-__device__ __noinline__ void sweep_costate(WsView w, cgdouble *pk, int N, double ap)
+__device__ __noinline__ void sweep_costate(WsView w, int N, double ap, int theta_i)
 {
-    w = uni(w); N = uni(N); ap = uni(ap);
-    FULLSYNC(); // phase boundary: other lanes' global writes of the previous phase are visible
-    const int lane = threadIdx.x, k = lane;
-    const bool act = lane < N;
-    const int my_dst = L_AB + lin_dst(lane);
-    const double hc_k = act ? -2.0 * pk[8] : 0.0;
-    init_ab_constants(lane);
-    WSYNC();
-    {
-        // w-part is stage-parallel
-        if (act) {
-            cgdouble *rec = w.rec + (size_t)k * REC_STRIDE;
+    w = uni(w); N = uni(N); ap = uni(ap); theta_i = uni(theta_i);
+    FULLSYNC(); // phase boundary: dz of the forward sweep / updates of the step phase are visible
+    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    const double theta = theta_i ? 1.0 : 0.0;
+    int mo[4], c1[4], c2[4], c3[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const double yw = rec[REC_PHID + 4 + i] * w.dz[(4 + i) * NP + k] + hc_k * w.dz[i * NP + k] + rec[REC_PHI + 4 + i];
-                const double yo = w.y[i * NP + k];
-                w.y[i * NP + k] = yo + ap * (yw - yo);
-            }
-        }
-        int cy = 0;
-        cgdouble *r0 = w.rec + (size_t)(N - 1) * REC_STRIDE;
-        double pre_lin = r0[lane];
-        double pre_phi = (lane < 44) ? r0[REC_PHID + lane] : 0.0;
-        double pre_dz = (lane < 9) ? w.dz[(8 + lane) * NP + N - 1] : 0.0;
-        for (int kk = N - 1; kk >= 0; kk--) {
-            sm[my_dst] = pre_lin;
-            if (lane < 44) sm[L_PHI + lane] = pre_phi;
-            if (lane < 9) sm[L_DS + 4 + lane] = pre_dz;
-            if (kk > 0) {
-                cgdouble *rn = w.rec + (size_t)(kk - 1) * REC_STRIDE;
-                pre_lin = rn[lane];
-                pre_phi = (lane < 44) ? rn[REC_PHID + lane] : 0.0;
-                pre_dz = (lane < 9) ? w.dz[(8 + lane) * NP + kk - 1] : 0.0;
-            }
-            WSYNC();
-            if (lane < 9) {
-                double acc = sm[L_PHID + 8 + lane] * sm[L_DS + 4 + lane] + sm[L_PHIV + 8 + lane];
-                if (lane < 3) {
-#pragma unroll
-                    for (int j = 0; j < 3; j++) acc += sm[L_PHIPOS + lane * 3 + j] * sm[L_DS + 4 + j];
-                }
-                if (kk < N - 1) {
-                    const double *yn = sm + L_YX + (cy ? 9 : 0);
-#pragma unroll
-                    for (int i = 0; i < 9; i++) acc += sm[L_AB + i * 13 + lane] * yn[i];
-                }
-                sm[L_YX + (cy ? 0 : 9) + lane] = acc;
-                const double yo = w.y[(4 + lane) * NP + kk];
-                w.y[(4 + lane) * NP + kk] = yo + ap * (acc - yo);
-            }
-            cy ^= 1;
-            WSYNC();
-        }
-                WSYNC();
+    for (int r = 0; r < 4; r++) {
+        mo[r] = m_src(4 * r + g, c);
+        c_src(4 * r + g, c, c1[r], c2[r], c3[r]);
     }
+    init_stage_constants(lane);
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    d4 y = zero;
+    cgdouble *rp = w.rec + (size_t)(N - 1) * REC_STRIDE;
+    double e0 = rp[lane], e1 = rp[64 + lane], e2 = rp[128 + lane], e3 = (lane < 16) ? rp[192 + lane] : 0.0;
+    d4 nv = zero;
+    double ndw = 0.0;
+    if (c == 0) {
+        nv[0] = w.dz[g * NP + N - 1];
+        ndw = w.dz[(4 + g) * NP + N - 1];
+#pragma unroll
+        for (int r = 1; r < 4; r++)
+            if (4 * r + g <= 12) nv[r] = w.dz[(4 + 4 * r + g) * NP + N - 1];
+    }
+    for (int kk = N - 1; kk >= 0; kk--) {
+        const bool last = (kk == N - 1);
+        WSYNC();
+        sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1; sm[S_E + 128 + lane] = e2;
+        if (lane < 16) sm[S_E + 192 + lane] = e3;
+        const d4 v2 = nv;
+        const double dw = ndw;
+        if (kk > 0) {
+            cgdouble *rn = w.rec + (size_t)(kk - 1) * REC_STRIDE;
+            e0 = rn[lane]; e1 = rn[64 + lane]; e2 = rn[128 + lane]; e3 = (lane < 16) ? rn[192 + lane] : 0.0;
+            if (c == 0) {
+                nv[0] = w.dz[g * NP + kk - 1];
+                ndw = w.dz[(4 + g) * NP + kk - 1];
+#pragma unroll
+                for (int r = 1; r < 4; r++)
+                    if (4 * r + g <= 12) nv[r] = w.dz[(4 + 4 * r + g) * NP + kk - 1];
+            }
+        }
+        WSYNC();
+        const double hc = sm[S_E + REC_HC];
+        d4 C;
+#pragma unroll
+        for (int r = 0; r < 4; r++) C[r] = sm[c1[r]] + sm[c2[r]] + theta * sm[c3[r]];
+        d4 D = mm_tn(C, v2, zero);
+        if (!last) {
+            d4 M;
+#pragma unroll
+            for (int r = 0; r < 4; r++) M[r] = sm[mo[r]];
+            D = mm_tn(M, y, D);
+        }
+        d4 yn = zero;
+        if (c == 0) {
+            yn[0] = sm[S_E + REC_PHID + 4 + g] * dw + hc * v2[0] + sm[S_E + REC_PHI + 4 + g];
+            {
+                const double yo = w.y[g * NP + kk];
+                w.y[g * NP + kk] = yo + ap * (yn[0] - yo);
+            }
+#pragma unroll
+            for (int r = 1; r < 4; r++) {
+                const int row = 4 * r + g;
+                if (row <= 12) {
+                    yn[r] = D[r] + sm[S_E + REC_PHI + row + 4];
+                    const double yo = w.y[row * NP + kk];
+                    w.y[row * NP + kk] = yo + ap * (yn[r] - yo);
+                }
+            }
+        }
+        y = yn;
+    }
+    WSYNC();
 }
+
 
 // ------------------------------------------------------------------ the solver kernel
 template <int NP>
@@ -939,7 +987,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
     const int b = blockIdx.x, lane = threadIdx.x;
     const int N = a.N, M = a.M, MF = a.MF, np = NPRE + 4 * M;
     const int mcf = 34 + MF;
-    const bool act = lane < N; // lane == stage in the stage-parallel phases
+    const bool act = lane < N; // lane == stage in the initialisation
     const int k = lane;
 
     WsView w;
@@ -955,7 +1003,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
         w.face = w.corr + (size_t)mcf * NP;
     }
     cgdouble *xinit = (cgdouble *)(a.xinit + (size_t)b * 9);
-    cgdouble *pk = (cgdouble *)(a.params + ((size_t)b * N + (act ? k : 0)) * np);
+    cgdouble *pbase = (cgdouble *)(a.params + (size_t)b * N * np);
+    cgdouble *pk = pbase + (size_t)(act ? k : 0) * np;
 
     // ---------------------------------------------------------------- init (lane == stage)
     int nf = 0;
@@ -999,7 +1048,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
         }
 #pragma unroll
         for (int i = 0; i < NS; i++) w.y[i * NP + k] = 0.0;
-        w.rec[(size_t)k * REC_STRIDE + REC_HC] = -2.0 * pk[8]; // hc of this stage's cost (constant)
+        gdouble *rec = w.rec + (size_t)k * REC_STRIDE;
+        rec[REC_HC] = -2.0 * pk[8]; // (u_i, w_i) cost coupling of this stage (constant)
+        for (int i = 0; i < 100; i++) rec[REC_HD + i] = 0.0; // stays zero in Gauss-Newton mode / last stage
+        for (int i = 0; i < 64; i++) rec[i] = 0.0;           // linearisation of the last stage is never written
     }
     smin = wave_min(smin);
     const int mtot = (int)wave_sum(act ? (double)(34 + nf) : 0.0);
@@ -1022,11 +1074,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
             }
         }
     }
-    cgdouble *pbase = (cgdouble *)(a.params + (size_t)b * N * np);
     const int nfk = __shfl(nf, lane % NP); // face count of stage k = lane % NP for the (half, stage) lane mapping
+    const int hess = a.hessian ? 1 : 0;
     FULLSYNC();
 
-    int flag = FRP_EXIT_MAXIT, it = 0;
+    int flag = FRP_EXIT_MAXIT, it = 0, nfallback = 0;
     double res_eq = 0, res_in = 0, rs = 0, rcomp = 0, pobj = 0, mu = 0, sigma = 0, step_cc = 0;
 
 #ifdef FRP_PROFILE
@@ -1039,7 +1091,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
 #endif
     for (it = 0;; it++) {
         TICK();
-        const EvalOut e = phase_eval<NP>(w, pbase, np, xinit, N, MF, nfk, a.model);
+        const EvalOut e = phase_eval<NP>(w, pbase, np, xinit, N, MF, nfk, a.model, hess);
         res_eq = wave_max(e.eq); res_in = wave_max(e.in); rs = wave_max(e.rs); rcomp = wave_max(e.rc);
         pobj = wave_sum(e.obj);
         mu = wave_sum(e.gap) / (double)mtot;
@@ -1047,11 +1099,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
         if (res_eq <= a.tol_eq && res_in <= a.tol_ineq && rs <= a.tol_stat && rcomp <= a.tol_comp) { flag = FRP_EXIT_OPTIMAL; break; }
         if (it >= a.maxit) { flag = FRP_EXIT_MAXIT; break; }
         if (mu > DIVERGE_MU * fmax(1.0, a.mu0) || rs > DIVERGE_RS) { flag = FRP_EXIT_NOPROGRESS; break; }
-        WSYNC();
         TOCK(0);
 
-        // predictor (affine) solve
-        if (sweep_backward<NP>(w, xinit, N, 0)) { flag = FRP_EXIT_FACTORIZATION; break; }
+        // predictor (affine) solve; exact Hessian first, Gauss-Newton if the reduced Hessian is indefinite
+        int theta = hess;
+        int fr = sweep_factor<NP>(w, xinit, N, theta);
+        if (fr && theta) {
+            theta = 0;
+            nfallback++;
+            fr = sweep_factor<NP>(w, xinit, N, 0);
+        }
+        if (fr) { flag = FRP_EXIT_FACTORIZATION; break; }
         TOCK(1);
         sweep_forward<NP>(w, N);
         TOCK(2);
@@ -1059,18 +1117,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
         sigma = s0.sigma;
         TOCK(3);
         // corrector solve (same factorisation, new rhs)
-        sweep_backward<NP>(w, xinit, N, 1);
+        sweep_backvec<NP>(w, xinit, N);
         TOCK(4);
         sweep_forward<NP>(w, N);
         TOCK(2);
         const SlackOut s1 = phase_slack<NP>(w, pbase, np, N, MF, nfk, a.model, 1, s0.smu, mu, mtot, a.ftb, a.tol_comp);
         step_cc = s1.ap;
         TOCK(3);
-        sweep_costate<NP>(w, pk, N, s1.ap);
+        sweep_costate<NP>(w, N, s1.ap, theta);
         TOCK(5);
     }
 
     // ---------------------------------------------------------------- outputs
+    FULLSYNC();
     if (act) {
         double *zo = a.z + ((size_t)b * N + k) * NZ;
 #pragma unroll
@@ -1081,12 +1140,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
         a.iters[b] = it;
         if (a.info) {
             double *o = a.info + (size_t)b * FRP_INFO_STRIDE;
-            o[0] = res_eq; o[1] = res_in; o[2] = rs; o[3] = rcomp; o[4] = pobj; o[5] = mu; o[6] = step_cc; o[7] = sigma;
+            o[0] = res_eq; o[1] = res_in; o[2] = rs; o[3] = rcomp; o[4] = pobj; o[5] = mu; o[6] = step_cc; o[7] = (double)nfallback;
 #ifdef FRP_PROFILE
             for (int i = 0; i < 6; i++) o[i] = (double)tph[i]; // cycles: eval, factor, forward(x2), slack(x2), backvec, costate
 #endif
         }
     }
+    (void)sigma;
 }
 
 // ------------------------------------------------------------------ batched model callback

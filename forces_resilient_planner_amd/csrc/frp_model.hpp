@@ -147,6 +147,130 @@ __host__ __device__ inline void rk2(const double x[9], const double u[4], const 
     }
 }
 
+// ---- second derivatives: exact Lagrangian Hessian of the dynamics ---------------------------------
+// For a contraction vector gam: phi_gam(v, e, T) = gam . acc(v, e, T) = a (gam.zB) - d gam.v + const,
+// a = T/m + d (zB.v).  Its Hessian wrt (T, v, e) has only the (T,e), (v,e), (e,e) blocks.
+struct PhiHess {
+    double hTe[3], Hve[9], Hee[9], gv[3]; // gv = d phi / d v
+};
+
+__host__ __device__ inline void phi_hess(const double gam[3], const double v[3], const double e[3], double T, PhiHess *o)
+{
+    double sr, cr, sp, cp, sy, cy;
+    sincos(e[0], &sr, &cr);
+    sincos(e[1], &sp, &cp);
+    sincos(e[2], &sy, &cy);
+    const double zb[3] = {cy * sp * cr + sy * sr, sy * sp * cr - cy * sr, cp * cr};
+    // D1[j] = d zB / d e_j ; D2[j][l] = d2 zB / d e_j d e_l
+    const double D1[3][3] = {{-cy * sp * sr + sy * cr, -sy * sp * sr - cy * cr, -cp * sr},
+                             {cy * cp * cr, sy * cp * cr, -sp * cr},
+                             {-sy * sp * cr + cy * sr, cy * sp * cr + sy * sr, 0.0}};
+    const double rr[3] = {-zb[0], -zb[1], -zb[2]};
+    const double rp[3] = {-cy * cp * sr, -sy * cp * sr, sp * sr};
+    const double ry[3] = {sy * sp * sr + cy * cr, -cy * sp * sr + sy * cr, 0.0};
+    const double pp[3] = {-cy * sp * cr, -sy * sp * cr, -cp * cr};
+    const double py[3] = {-sy * cp * cr, cy * cp * cr, 0.0};
+    const double yy[3] = {-zb[0], -zb[1], 0.0};
+    const double *D2[3][3] = {{rr, rp, ry}, {rp, pp, py}, {ry, py, yy}};
+    double s = 0.0, zv = 0.0, sj[3], aj[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { s += gam[c] * zb[c]; zv += zb[c] * v[c]; }
+    const double a = T * (1.0 / MASS) + DRAG * zv;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        sj[j] = gam[0] * D1[j][0] + gam[1] * D1[j][1] + gam[2] * D1[j][2];
+        aj[j] = DRAG * (D1[j][0] * v[0] + D1[j][1] * v[1] + D1[j][2] * v[2]);
+        o->hTe[j] = sj[j] * (1.0 / MASS);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        o->gv[i] = DRAG * zb[i] * s - DRAG * gam[i];
+#pragma unroll
+        for (int j = 0; j < 3; j++) o->Hve[i * 3 + j] = DRAG * (D1[j][i] * s + zb[i] * sj[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int l = 0; l < 3; l++) {
+            const double *d2 = D2[j][l];
+            const double sjl = gam[0] * d2[0] + gam[1] * d2[1] + gam[2] * d2[2];
+            const double ajl = DRAG * (d2[0] * v[0] + d2[1] * v[1] + d2[2] * v[2]);
+            o->Hee[j * 3 + l] = ajl * s + aj[j] * sj[l] + aj[l] * sj[j] + a * sjl;
+        }
+}
+
+// Hessian of y_x' x+(x,u) wrt (rates(3), T, v(3), e(3)), 10 x 10 symmetric; only the position and
+// velocity rows of x+ are non-linear (multipliers yp, yv).  Sink(i, j, value) receives every entry of
+// the upper triangle (i <= j) exactly once.
+//   x+_p = p + dt v + dt^2/2 acc1,  x+_v = v + dt/2 (acc1 + acc2),  acc2 = acc(v + dt acc1, e + dt w, T).
+template <typename Sink>
+__host__ __device__ inline void rk2_hessian(const double x[9], const double u[4], const double fext[3],
+                                            const double yp[3], const double yv[3], Sink sink)
+{
+    const double *v = x + 3, *e = x + 6;
+    const double T = u[3];
+    AccJac J1;
+    double a1[3], vt[3], et[3], alpha[3], beta[3], gam1[3];
+    accel<true>(v, e, T, fext, a1, &J1);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        vt[i] = v[i] + DT * a1[i];
+        et[i] = e[i] + DT * u[i];
+        alpha[i] = 0.5 * DT * DT * yp[i] + 0.5 * DT * yv[i];
+        beta[i] = 0.5 * DT * yv[i];
+    }
+    PhiHess h2, h1;
+    phi_hess(beta, vt, et, T, &h2);
+#pragma unroll
+    for (int i = 0; i < 3; i++) gam1[i] = alpha[i] + DT * h2.gv[i];
+    phi_hess(gam1, v, e, T, &h1);
+    // K = Jv' H2ve (+ h2Te on the T row): rows T, v(3), e(3); columns = e~ index
+    double KT[3], Kv[9], Ke[9];
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        KT[l] = h2.hTe[l] + DT * (J1.gT[0] * h2.Hve[0 * 3 + l] + J1.gT[1] * h2.Hve[1 * 3 + l] + J1.gT[2] * h2.Hve[2 * 3 + l]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            double kv = h2.Hve[i * 3 + l], ke = 0.0;
+#pragma unroll
+            for (int m = 0; m < 3; m++) {
+                kv += DT * J1.Fvv[m * 3 + i] * h2.Hve[m * 3 + l];
+                ke += DT * J1.Fve[m * 3 + i] * h2.Hve[m * 3 + l];
+            }
+            Kv[i * 3 + l] = kv;
+            Ke[i * 3 + l] = ke;
+        }
+    }
+    // variable order: w0 w1 w2 (0..2), T (3), v (4..6), e (7..9)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+#pragma unroll
+        for (int l = j; l < 3; l++) sink(j, l, DT * DT * h2.Hee[j * 3 + l]);                  // (w,w)
+        sink(j, 3, DT * KT[j]);                                                              // (w,T)
+#pragma unroll
+        for (int i = 0; i < 3; i++) sink(j, 4 + i, DT * Kv[i * 3 + j]);                      // (w,v)
+#pragma unroll
+        for (int l = 0; l < 3; l++) sink(j, 7 + l, DT * (Ke[l * 3 + j] + h2.Hee[j * 3 + l])); // (w,e)
+    }
+    sink(3, 3, 0.0);
+#pragma unroll
+    for (int i = 0; i < 3; i++) sink(3, 4 + i, 0.0);                                         // (T,v)
+#pragma unroll
+    for (int l = 0; l < 3; l++) sink(3, 7 + l, h1.hTe[l] + KT[l]);                            // (T,e)
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = i; j < 3; j++) sink(4 + i, 4 + j, 0.0);                                 // (v,v)
+#pragma unroll
+        for (int l = 0; l < 3; l++) sink(4 + i, 7 + l, h1.Hve[i * 3 + l] + Kv[i * 3 + l]);    // (v,e)
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int l = j; l < 3; l++)
+            sink(7 + j, 7 + l, h1.Hee[j * 3 + l] + Ke[j * 3 + l] + Ke[l * 3 + j] + h2.Hee[j * 3 + l]); // (e,e)
+}
+
 // Dense entries of Ax = dx+/dx (9x9) and Bx = dx+/du (9x4) from the compact form.
 __host__ __device__ inline double lin_A(const double *c /*Lin as 51 doubles*/, int i, int j)
 {

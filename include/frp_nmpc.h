@@ -67,6 +67,8 @@ typedef struct frp_nmpc_options {
     double tol_comp;  /* 1e-4 (:79)                                        */
     double mu0;       /* initial barrier parameter, 1.0                    */
     double ftb;       /* fraction to boundary, 0.99 (normal.h:89)          */
+    int hessian;      /* 1 (default): exact Lagrangian Hessian of the RK2 dynamics with Gauss-Newton
+                         fallback when the reduced Hessian is indefinite; 0: Gauss-Newton only   */
 } frp_nmpc_options;
 
 typedef struct frp_nmpc_batch {
@@ -86,7 +88,7 @@ typedef struct frp_nmpc_batch {
     int *exitflag;        /* [B] out                                                     */
     int *iters;           /* [B] out, interior-point iterations (info.it)                */
     double *info;         /* [B][FRP_INFO_STRIDE] out or NULL:
-                             res_eq, res_ineq, rsnorm, rcompnorm, pobj, mu, step_cc, sigma  */
+                             res_eq, res_ineq, rsnorm, rcompnorm, pobj, mu, step_cc, n_gn_fallback */
 } frp_nmpc_batch;
 
 void frp_nmpc_default_options(frp_nmpc_options *opt);
