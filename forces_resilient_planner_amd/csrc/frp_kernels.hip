@@ -900,9 +900,19 @@ __device__ __noinline__ SlackOut phase_slack(WsView w, cgdouble *pbase, int np, 
 // ------------------------------------------------------------------ costate sweep: y <- y + ap (y+ - y)
 // y+_k = (Phi_k dz_k + phi_k)_s + [0; A_k' y+_{k+1,x}]:  x rows = (C~' [du; dx] + M' y+)_x + phi_x,
 // w rows = Phi_w dw + hc du + phi_w.  Vectors in the column-0 lanes (row layout).
+#ifdef FRP_PROFILE
+__device__ long long g_wait_cycles;
+__device__ long long g_seg[6];
+#endif
 template <int NP>
 __device__ __noinline__ void sweep_costate(WsView w, int N, double ap, int theta_i)
 {
+#ifdef FRP_PROFILE
+    long long waitc = 0, seg[6] = {0, 0, 0, 0, 0, 0}, ts;
+#define SEG(i) do { const long long tn_ = clock64(); seg[i] += tn_ - ts; ts = tn_; } while (0)
+#else
+#define SEG(i)
+#endif
     w = uni(w); N = uni(N); ap = uni(ap); theta_i = uni(theta_i);
     FULLSYNC(); // phase boundary: dz of the forward sweep / updates of the step phase are visible
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
@@ -918,21 +928,33 @@ __device__ __noinline__ void sweep_costate(WsView w, int N, double ap, int theta
     d4 y = zero;
     cgdouble *rp = w.rec + (size_t)(N - 1) * REC_STRIDE;
     double e0 = rp[lane], e1 = rp[64 + lane], e2 = rp[128 + lane], e3 = (lane < 16) ? rp[192 + lane] : 0.0;
-    d4 nv = zero;
+    d4 nv = zero, nyo = zero; // prefetched dz and old y of the next stage to be processed (column-0 lanes)
     double ndw = 0.0;
     if (c == 0) {
         nv[0] = w.dz[g * NP + N - 1];
         ndw = w.dz[(4 + g) * NP + N - 1];
+        nyo[0] = w.y[g * NP + N - 1];
 #pragma unroll
         for (int r = 1; r < 4; r++)
-            if (4 * r + g <= 12) nv[r] = w.dz[(4 + 4 * r + g) * NP + N - 1];
+            if (4 * r + g <= 12) {
+                nv[r] = w.dz[(4 + 4 * r + g) * NP + N - 1];
+                nyo[r] = w.y[(4 * r + g) * NP + N - 1];
+            }
     }
     for (int kk = N - 1; kk >= 0; kk--) {
         const bool last = (kk == N - 1);
         WSYNC();
+#ifdef FRP_PROFILE
+        const long long tw0 = clock64();
+        ts = tw0;
+#endif
         sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1; sm[S_E + 128 + lane] = e2;
         if (lane < 16) sm[S_E + 192 + lane] = e3;
-        const d4 v2 = nv;
+#ifdef FRP_PROFILE
+        __builtin_amdgcn_s_waitcnt(0);
+        waitc += clock64() - tw0;
+#endif
+        const d4 v2 = nv, yo = nyo;
         const double dw = ndw;
         if (kk > 0) {
             cgdouble *rn = w.rec + (size_t)(kk - 1) * REC_STRIDE;
@@ -940,43 +962,51 @@ __device__ __noinline__ void sweep_costate(WsView w, int N, double ap, int theta
             if (c == 0) {
                 nv[0] = w.dz[g * NP + kk - 1];
                 ndw = w.dz[(4 + g) * NP + kk - 1];
+                nyo[0] = w.y[g * NP + kk - 1];
 #pragma unroll
                 for (int r = 1; r < 4; r++)
-                    if (4 * r + g <= 12) nv[r] = w.dz[(4 + 4 * r + g) * NP + kk - 1];
+                    if (4 * r + g <= 12) {
+                        nv[r] = w.dz[(4 + 4 * r + g) * NP + kk - 1];
+                        nyo[r] = w.y[(4 * r + g) * NP + kk - 1];
+                    }
             }
         }
         WSYNC();
+        SEG(0);
         const double hc = sm[S_E + REC_HC];
         d4 C;
 #pragma unroll
         for (int r = 0; r < 4; r++) C[r] = sm[c1[r]] + sm[c2[r]] + theta * sm[c3[r]];
+        SEG(1);
         d4 D = mm_tn(C, v2, zero);
+        SEG(2);
         if (!last) {
             d4 M;
 #pragma unroll
             for (int r = 0; r < 4; r++) M[r] = sm[mo[r]];
             D = mm_tn(M, y, D);
         }
+        SEG(3);
         d4 yn = zero;
         if (c == 0) {
             yn[0] = sm[S_E + REC_PHID + 4 + g] * dw + hc * v2[0] + sm[S_E + REC_PHI + 4 + g];
-            {
-                const double yo = w.y[g * NP + kk];
-                w.y[g * NP + kk] = yo + ap * (yn[0] - yo);
-            }
+            w.y[g * NP + kk] = yo[0] + ap * (yn[0] - yo[0]);
 #pragma unroll
             for (int r = 1; r < 4; r++) {
                 const int row = 4 * r + g;
                 if (row <= 12) {
                     yn[r] = D[r] + sm[S_E + REC_PHI + row + 4];
-                    const double yo = w.y[row * NP + kk];
-                    w.y[row * NP + kk] = yo + ap * (yn[r] - yo);
+                    w.y[row * NP + kk] = yo[r] + ap * (yn[r] - yo[r]);
                 }
             }
         }
         y = yn;
+        SEG(4);
     }
     WSYNC();
+#ifdef FRP_PROFILE
+    if (lane == 0) { g_wait_cycles = waitc; for (int i = 0; i < 6; i++) g_seg[i] = seg[i]; }
+#endif
 }
 
 
@@ -1143,6 +1173,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
             o[0] = res_eq; o[1] = res_in; o[2] = rs; o[3] = rcomp; o[4] = pobj; o[5] = mu; o[6] = step_cc; o[7] = (double)nfallback;
 #ifdef FRP_PROFILE
             for (int i = 0; i < 6; i++) o[i] = (double)tph[i]; // cycles: eval, factor, forward(x2), slack(x2), backvec, costate
+            o[6] = (double)g_wait_cycles; // load-wait cycles of the LAST costate sweep
+            o[0] = (double)g_seg[0]; o[1] = (double)g_seg[1]; o[2] = (double)g_seg[2]; o[3] = (double)g_seg[3]; o[4] = (double)g_seg[4];
 #endif
         }
     }

@@ -12,4 +12,5 @@ per_it = info[:, :6] / np.maximum(it[:, None], 1)
 print("B", B, "mean it", it.mean(), "host wall", dt)
 for i, n in enumerate(names):
     print(f"{n:12s} mean cycles/iter {per_it[:, i].mean():10.0f}   (problems with it>=20: {per_it[it >= 20, i].mean() if (it>=20).any() else 0:10.0f})")
+print("costate load-wait cycles in last sweep (mean):", info[:,6].mean())
 print("total cycles/iter", per_it.sum(1).mean(), " total cycles/solve", info[:, :6].sum(1).mean())
