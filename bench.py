@@ -36,20 +36,23 @@ def cpu_baseline(w, seconds_target=12.0):
     import tests.oracle_lib as OL
     cores = os.cpu_count() or 1
     B = w["xinit"].shape[0]
-    n0 = min(B, 256)
-    sub = {k: (v[:n0] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in w.items()}
-    OL.solve_batch(sub, nthreads=cores)  # warm up threads
-    t = time.perf_counter(); OL.solve_batch(sub, nthreads=cores); dt = time.perf_counter() - t
-    rate = n0 / dt
-    n = int(min(B, max(n0, rate * seconds_target)))
-    sub = {k: (v[:n] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in w.items()}
-    t = time.perf_counter(); z, fl, info = OL.solve_batch(sub, nthreads=cores); dt = time.perf_counter() - t
-    t1 = time.perf_counter(); OL.solve_batch({k: (v[:n0] if isinstance(v, np.ndarray) and v.shape[:1] == (n,) else v) for k, v in sub.items()}, nthreads=1); dt1 = time.perf_counter() - t1
-    return dict(value=n / dt, unit="solves/s", cores=cores, kind="port",
-                sample=f"first {n} problems of the same 4096-problem batch, oracle/liboracle.so (FP64 CPU restatement, "
-                       f"not ForcesPro: its binary is licence-locked), OpenMP over problems on {cores} threads, {dt:.1f} s; "
-                       f"single-thread {n0 / dt1:.0f} solves/s",
-                converged_frac=float((fl == 1).mean()))
+    OL.solve_batch(w, nthreads=cores)  # warm up threads / page in
+    reps, solved, t0 = 0, 0, time.perf_counter()
+    conv = 0
+    while True:
+        z, fl, info = OL.solve_batch(w, nthreads=cores)
+        reps += 1; solved += B; conv += int((fl == 1).sum())
+        dt = time.perf_counter() - t0
+        if dt >= seconds_target or reps >= 2000:
+            break
+    n1 = min(B, 512)
+    sub = {k: (v[:n1] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in w.items()}
+    t1 = time.perf_counter(); OL.solve_batch(sub, nthreads=1); dt1 = time.perf_counter() - t1
+    return dict(value=solved / dt, unit="solves/s", cores=cores, kind="port",
+                sample=f"the same {B}-problem batch solved {reps}x by oracle/liboracle.so (FP64 CPU restatement of the "
+                       f"same interior-point method, not ForcesPro: its binary is licence-locked), OpenMP over problems on "
+                       f"{cores} threads, {dt:.1f} s; single-thread {n1 / dt1:.0f} solves/s",
+                converged_frac=conv / solved)
 
 
 def main():

@@ -1,0 +1,157 @@
+"""CPU tests of the boundary: the C-ABI library loads and exports every symbol include/frp_nmpc.h declares,
+the drop-in structs have the reference's sizes, the host-side adapter mirrors pack identically in Python
+and C++, and -- with no GPU -- every compute entry point fails loudly instead of falling back."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from forces_resilient_planner_amd import adapter, layout as L, solver, workloads
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    try:
+        return solver.lib().frp_nmpc_device_count() > 0
+    except Exception:
+        return False
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "frp_nmpc.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(frp_nmpc_\w+|FORCESNLPsolver_\w+_solve)\s*\(", hdr))
+    declared -= {"frp_nmpc_options", "frp_nmpc_batch"}
+    assert {"FORCESNLPsolver_normal_solve", "FORCESNLPsolver_final_solve", "frp_nmpc_solve_batch"} <= declared
+    lib = solver.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/frp_nmpc.h but not exported"
+    assert set(solver.EXPORTS) <= declared
+    assert b"gfx950" in lib.frp_nmpc_version()
+
+
+def test_dropin_struct_layouts_match_reference_sizes():
+    # FORCESNLPsolver_normal.h:153-301 ([probed] sizes in SURVEY 8b): params 23600, output 2720, info 136
+    assert ctypes.sizeof(solver.ForcesParams) == 23600
+    assert solver.ForcesParams.x0.offset == 72 and solver.ForcesParams.all_parameters.offset == 2792
+    assert solver.ForcesParams.num_of_threads.offset == 23592
+    assert ctypes.sizeof(solver.ForcesOutput) == 2720
+    assert ctypes.sizeof(solver.ForcesInfo) == 136
+    assert solver.ForcesInfo.res_eq.offset == 8 and solver.ForcesInfo.solvetime.offset == 120
+
+
+def test_workspace_size_formula():
+    lib = solver.lib()
+    b1 = lib.frp_nmpc_workspace_bytes(1, 20, 6); b2 = lib.frp_nmpc_workspace_bytes(7, 20, 6)
+    assert b2 == 7 * b1 and b1 > 20 * 288 * 8
+    assert lib.frp_nmpc_workspace_bytes(1, 40, 6) > lib.frp_nmpc_workspace_bytes(1, 20, 6)
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-device behaviour")
+def test_no_device_means_loud_failure_not_cpu_fallback():
+    w = workloads.config2(2)
+    with pytest.raises(RuntimeError):
+        solver.solve_batch_host(w)
+    w0 = workloads.config0()
+    p = solver.ForcesParams(); o = solver.ForcesOutput(); info = solver.ForcesInfo()
+    p.xinit[:] = w0["xinit"][0]; p.x0[:] = w0["x0"][0].ravel(); p.all_parameters[:] = w0["params"][0].ravel()
+    flag = solver.lib().FORCESNLPsolver_normal_solve(ctypes.byref(p), ctypes.byref(o), ctypes.byref(info), None, None)
+    assert flag != 1 and flag < 0
+    assert np.all(np.array(o.x) == 0.0)
+
+
+def _harness():
+    exe = os.path.join(ROOT, "tests", "cpp", "adapter_harness")
+    src = exe + ".cpp"
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", src, "-o", exe, "-L" + os.path.dirname(solver.LIB_PATH),
+                               "-lfrp_nmpc_amd", "-Wl,-rpath," + os.path.dirname(solver.LIB_PATH),
+                               "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def _write_harness_input(path, w, weights, F):
+    B, N = w["B"], w["N"]
+    with open(path, "wb") as f:
+        np.array([B, N, F, w["model"]], dtype=np.int32).tofile(f)
+        np.asarray(weights, dtype=np.float64).tofile(f)
+        for key in ("mpc_output", "f_ext", "ref_pos", "ref_yaw", "E", "poly_A", "poly_b"):
+            np.ascontiguousarray(w[key], dtype=np.float64).tofile(f)
+        np.ascontiguousarray(w["nfaces"], dtype=np.int32).tofile(f)
+
+
+def test_cpp_adapter_packs_exactly_like_python_adapter(tmp_path):
+    """G2 packing vectors: forces_normal.cpp:62-136 restated twice (numpy, C++) must agree bit for bit,
+    including the robust tightening b - ||E a||, zero padding and the 30-row truncation."""
+    w = workloads.config2(5)
+    rng = np.random.default_rng(3)
+    # make it harder: 33 faces on some stages (the reference silently drops rows >= 30), ragged counts
+    B, N = 5, w["N"]
+    F = 33
+    A = rng.normal(size=(B, N, F, 3)); b = rng.uniform(1, 3, size=(B, N, F))
+    nf = rng.integers(0, F + 1, size=(B, N)).astype(np.int32)
+    w = dict(w, poly_A=A, poly_b=b, nfaces=nf)
+    weights = (7.0, 1.0, 80.0, 12.0, 0.5)
+    ad = adapter.ForcesAdapter(B, w["model"], N, 30)
+    ad.set_paras(*weights)
+    xinit, x0, params, nfo = ad.pack(w["mpc_output"], w["f_ext"], w["ref_pos"], w["ref_yaw"], w["E"], A, b, nf)
+    inp = tmp_path / "in.bin"; out = tmp_path / "out.bin"
+    _write_harness_input(inp, w, weights, F)
+    subprocess.check_call([_harness(), "pack", str(inp), str(out)])
+    raw = np.fromfile(out, dtype=np.uint8)
+    nd = B * 9 + B * N * 17 + B * N * 130
+    d = raw[:nd * 8].view(np.float64); ni = raw[nd * 8:].view(np.int32)
+    assert np.array_equal(d[:B * 9], xinit.ravel())
+    assert np.array_equal(d[B * 9:B * 9 + B * N * 17], x0.ravel())
+    pc = d[B * 9 + B * N * 17:]
+    assert np.array_equal(pc == 0, params.ravel() == 0)            # same padding pattern
+    assert np.max(np.abs(pc - params.ravel())) <= 4e-16 * 4        # b - ||E a||: summation order only
+    assert np.array_equal(ni, nfo.ravel())
+    assert nfo.max() == 30  # truncated
+    # padded rows are exactly zero, live rows carry the tightened offsets
+    p = params.reshape(B, N, 130)
+    for bb in range(B):
+        for k in range(N):
+            m = nfo[bb, k]
+            assert np.all(p[bb, k, 10 + 3 * m:100] == 0) and np.all(p[bb, k, 100 + m:] == 0)
+            if m:
+                Ea = w["E"][bb, k] @ A[bb, k, 0]
+                assert abs(p[bb, k, 100] - (b[bb, k, 0] - np.linalg.norm(Ea))) < 1e-15
+
+
+def test_adapter_shift_warm_start_and_yaw_wrap():
+    st = np.array([[0.1, 0.2, 1.0, 0, 0, 0, 0, 0, 0.3]])
+    mpc = adapter.init_mpc_output(st, 20)
+    assert mpc.shape == (1, 21, 17) and np.all(mpc[0, :, 3] == 7.3) and np.all(mpc[0, :, 7] == 7.3)
+    mpc[0, :, 16] = np.linspace(-4, 4, 21)
+    mpc[0, :, 0] = np.arange(21)
+    ad = adapter.ForcesAdapter(1)
+    A = np.zeros((1, 20, 1, 3)); b = np.zeros((1, 20, 1)); nf = np.zeros((1, 20), np.int32)
+    xinit, x0, params, _ = ad.pack(mpc, np.zeros((1, 3)), np.zeros((1, 20, 3)), np.zeros((1, 20)), np.zeros((1, 20, 3, 3)), A, b, nf)
+    assert np.array_equal(x0[0, :, 0], np.arange(1, 21))          # stage i <- previous plan stage i+1
+    assert np.array_equal(xinit[0], mpc[0, 1, 8:17])                # NOT row 0 / odometry (forces_normal.cpp:62-72)
+    out = adapter.update_forces_results(mpc.copy())
+    assert np.all(np.abs(out[0, :20, 16]) <= np.pi + 1e-12)
+    assert np.array_equal(out[0, 20], out[0, 19])
+
+
+def test_workloads_are_seeded_and_well_formed():
+    a = workloads.config2(16); b = workloads.config2(16)
+    assert np.array_equal(a["params"], b["params"]) and np.array_equal(a["xinit"], b["xinit"])
+    assert a["params"].shape == (16, 20, 130) and a["nfaces"].min() == 6 == a["nfaces"].max()
+    c = workloads.config3(8)
+    assert c["N"] == 30 and c["M"] == 15 and c["params"].shape == (8, 30, 70) and c["nfaces"].max() <= 15
+    # the stage reference point is strictly inside its tightened polytope
+    p = c["params"]
+    for bb in range(8):
+        for k in range(30):
+            m = c["nfaces"][bb, k]
+            A = p[bb, k, 10:10 + 3 * m].reshape(m, 3); bt = p[bb, k, 10 + 45:10 + 45 + m]
+            assert np.all(A @ c["ref_pos"][bb, k] < bt)
+    d = workloads.config1(4)
+    assert d["nfaces"].max() == 0 and np.all(d["params"][:, :, 10:] == 0)
