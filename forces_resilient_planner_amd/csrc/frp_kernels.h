@@ -7,19 +7,23 @@ namespace frp {
 
 // Per-stage HBM record (doubles): everything the serial Riccati sweeps stream, laid out so that one
 // wavefront moves it with 64-lane coalesced loads/stores.
-//   E part (written by the evaluation / step phases, 208 doubles):
+//   E part (written by the evaluation / step phases, 248 doubles = 64 + 64 + 64 + 56):
 constexpr int REC_LIN = 0;      // compact linearisation (51): Apv Ape Avv Ave BpT BvT Bvw
 constexpr int REC_D = 51;       // d = prev(z_k) - s_{k+1}, s-order [w; x]  (13)
 constexpr int REC_PHID = 64;    // diag of Phi = cost Hessian + bound barriers (17)
 constexpr int REC_PHIPOS = 81;  // corridor barrier block on pos (3 x 3)
-constexpr int REC_PHI = 90;     // rhs gradient phi (17)
+constexpr int REC_PHI = 90;     // predictor rhs gradient phi_aff (17)
 constexpr int REC_HC = 107;     // (u_i, w_i) cost coupling -2 w_rate of this stage
-constexpr int REC_HD = 108;     // exact Hessian of y'c(z) over (rates, T, v, e), dense 10 x 10
-constexpr int REC_E_SIZE = 208;
+constexpr int REC_PHIB = 108;   // corrector rhs: phi_cc = PHIB + (sigma mu) PHIC  (17 + 17)
+constexpr int REC_PHIC = 128;
+constexpr int REC_HD = 148;     // exact Hessian of y'c(z) over (rates, T, v, e), dense 10 x 10
+constexpr int REC_E_SIZE = 248;
 //   F part (written by the factorisation sweep, 80 doubles):
-constexpr int REC_T = 208;      // T' = [R | Kbar_x | kbar | hc] as tile register 0 (64): lane (g,c) <-> T'[g][c]
-constexpr int REC_PD = 272;     // P_{k+1} d (16, s-order rows)
-constexpr int REC_STRIDE = 288;
+constexpr int REC_T = 248;      // T' = [R | Kbar_x | kbar | hc] as tile register 0 (64): lane (g,c) <-> T'[g][c]
+constexpr int REC_PD = 312;     // P_{k+1} d (16, s-order rows)
+constexpr int REC_STRIDE = 328;
+constexpr int DZ_ROWS = 20;     // dz rows: du(4) + ds(13) + 3 pad rows (tile rows 13..15)
+constexpr int Y_ROWS = 16;      // y rows: 13 + 3 pad rows
 
 constexpr double S_MIN = 1e-2;          // smallest initial slack (infeasible start shift)
 constexpr double MU_FLOOR_FRAC = 0.1;   // centring target floor = 0.1 * tol_comp

@@ -33,7 +33,7 @@ namespace frp {
 // occupancy target: waves per SIMD the register allocator must leave room for (propagates to the
 // non-inlined phase functions)
 #ifndef FRP_WAVES_PER_EU
-#define FRP_WAVES_PER_EU 3
+#define FRP_WAVES_PER_EU 2
 #endif
 
 // ------------------------------------------------------------------ wave helpers
@@ -86,10 +86,10 @@ __device__ __forceinline__ double lane_bcast(double v, int src) // wave-uniform 
 // [0, 736): staging.  Element-wise phases: gm[17][NP] + corridor sums[6][NP] (NP = 32).
 //           Riccati sweeps: the E part of the current stage record + constants + T' + R.
 // [736, ...): fields that live across phases of one iteration.
-constexpr int S_E = 0;                    // E part of the stage record (208)
-constexpr int S_ZERO = 208, S_ONE = 209, S_DTC = 210;
-constexpr int S_T = 216;                  // T' (64)
-constexpr int S_R = 280;                  // 4x4 inverse handed from uniform registers to lanes (16)
+constexpr int S_E = 0;                    // E part of the stage record (248)
+constexpr int S_ZERO = 248, S_ONE = 249, S_DTC = 250;
+constexpr int S_T = 256;                  // T' (64)
+constexpr int S_R = 320;                  // 4x4 inverse handed from uniform registers to lanes (16)
 constexpr int S_STAGING = 23 * 32;        // 736
 constexpr int S_RW = S_STAGING;           // stage-0 solve: Pww^-1 (16)
 constexpr int S_PWX = S_RW + 16;          // stage-0 solve: Pwx (4 x 9)
@@ -146,7 +146,7 @@ typedef __attribute__((address_space(1))) double gdouble;
 typedef __attribute__((address_space(1))) const double cgdouble;
 
 struct WsView {
-    gdouble *rec, *z, *y, *dz, *s, *lam, *corr, *face;
+    gdouble *rec, *z, *y, *dz, *s, *lam, *corr, *face, *step;
 };
 
 __host__ __device__ inline int padded_stages(int N) { return N <= 32 ? 32 : 64; }
@@ -154,7 +154,7 @@ __host__ __device__ inline int padded_stages(int N) { return N <= 32 ? 32 : 64; 
 __host__ __device__ inline size_t ws_doubles_per_problem(int N, int MF)
 {
     const size_t mcf = 34 + MF, NPs = padded_stages(N);
-    return (size_t)N * REC_STRIDE + NPs * (17 + 13 + 17 + 3 * mcf + 4 * (size_t)MF);
+    return (size_t)N * REC_STRIDE + NPs * (17 + Y_ROWS + DZ_ROWS + 5 * mcf + 4 * (size_t)MF);
 }
 
 // The phases below are separate NON-inlined device functions on purpose: as one monolithic kernel
@@ -181,11 +181,30 @@ __device__ __forceinline__ double uni(double v)
 __device__ __forceinline__ WsView uni(WsView w)
 {
     w.rec = uni(w.rec); w.z = uni(w.z); w.y = uni(w.y); w.dz = uni(w.dz);
-    w.s = uni(w.s); w.lam = uni(w.lam); w.corr = uni(w.corr); w.face = uni(w.face);
+    w.s = uni(w.s); w.lam = uni(w.lam); w.corr = uni(w.corr); w.face = uni(w.face); w.step = uni(w.step);
     return w;
 }
 
 __shared__ double sm[L_TOTAL];
+// Newton step dz = [du(4); ds(13); 3 pad rows][NP]: written by the forward sweep, read by the step phases and the
+// costate sweep -- kept in LDS so that the sweeps carry no global stores for it (a store in the loop makes the
+// staging write of the next stage wait for vmcnt(0))
+__shared__ double sm_dz32[DZ_ROWS * 32];
+__shared__ double sm_dz64[DZ_ROWS * 64];
+template <int NP>
+__device__ __forceinline__ double *dz_area() { return NP == 32 ? sm_dz32 : sm_dz64; }
+
+#ifdef FRP_PROFILE
+__device__ long long g_prof[24];
+// per-function segment timers kept in registers, flushed once at the end of the function
+#define PROF_BEGIN() long long pacc_[6] = {0, 0, 0, 0, 0, 0}; long long pts_ = clock64()
+#define PROF_SEG(i) do { const long long tn_ = clock64(); pacc_[(i) % 6] += tn_ - pts_; pts_ = tn_; } while (0)
+#define PROF_END(base) do { if (threadIdx.x == 0) for (int q_ = 0; q_ < 6; q_++) g_prof[(base) + q_] += pacc_[q_]; } while (0)
+#else
+#define PROF_BEGIN()
+#define PROF_SEG(i)
+#define PROF_END(base)
+#endif
 
 // ------------------------------------------------------------------ 16x16 FP64 tiles in registers
 // Tile X: lane l = 16 g + c holds x[r] = X[4r + g][c], r = 0..3 (the C/D layout of
@@ -257,6 +276,95 @@ template <int NP>
 __device__ __forceinline__ double *stage_area() { return NP == 32 ? sm : sm_big; }
 
 __device__ __forceinline__ double xhalf_sum(double v) { return v + __shfl_xor(v, 32); }
+
+// part 2 of the evaluation phase (see phase_eval); arrays as __restrict__ parameters so that the loads of
+// several row rounds can be batched across the record stores
+template <int NP>
+__device__ __forceinline__ void eval_rows(cgdouble *__restrict__ ps, cgdouble *__restrict__ pl, cgdouble *__restrict__ pz,
+                                          cgdouble *__restrict__ pface, gdouble *__restrict__ prec, cgdouble *__restrict__ pbase,
+                                          int np, int N, int MF, int nfk, int model, double *stg,
+                                          double &l_in, double &l_rc, double &l_gap, double &l_rs)
+{
+    constexpr int H = 64 / NP;
+    const int lane = threadIdx.x;
+    // ---- part 2: all 64 lanes, lane = (half, stage k); rows handled in pairs
+    const int k = lane % NP, half = lane / NP;
+    const bool kact = k < N;
+    // corridor rows: sums over the faces of a stage (pos entries 8..10 only)
+    {
+        double gp0 = 0, gp1 = 0, gp2 = 0, fp0 = 0, fp1 = 0, fp2 = 0, p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0;
+        if (kact) {
+            const double z8 = pz[8 * NP + k], z9 = pz[9 * NP + k], z10 = pz[10 * NP + k];
+            for (int j = half; j < nfk; j += H) {
+                const double a0 = pface[(3 * j) * NP + k], a1 = pface[(3 * j + 1) * NP + k], a2 = pface[(3 * j + 2) * NP + k];
+                const double hj = a0 * z8 + a1 * z9 + a2 * z10 - pface[(3 * MF + j) * NP + k] - HU;
+                const double sc = ps[(34 + j) * NP + k], lc = pl[(34 + j) * NP + k];
+                const double rc = hj + sc;
+                l_in = fmax(l_in, fmax(hj, fabs(rc)));
+                l_rc = fmax(l_rc, sc * lc);
+                l_gap += sc * lc;
+                gp0 += a0 * lc; gp1 += a1 * lc; gp2 += a2 * lc;
+                const double sg = lc * (1.0 / sc), t = sg * rc;
+                fp0 += a0 * t; fp1 += a1 * t; fp2 += a2 * t;
+                p0 += sg * a0 * a0; p1 += sg * a0 * a1; p2 += sg * a0 * a2;
+                p3 += sg * a1 * a1; p4 += sg * a1 * a2; p5 += sg * a2 * a2;
+            }
+        }
+        if (H == 2) {
+            gp0 = xhalf_sum(gp0); gp1 = xhalf_sum(gp1); gp2 = xhalf_sum(gp2);
+            fp0 = xhalf_sum(fp0); fp1 = xhalf_sum(fp1); fp2 = xhalf_sum(fp2);
+            p0 = xhalf_sum(p0); p1 = xhalf_sum(p1); p2 = xhalf_sum(p2);
+            p3 = xhalf_sum(p3); p4 = xhalf_sum(p4); p5 = xhalf_sum(p5);
+        }
+        if (kact && half == 0) {
+            gdouble *rec = prec + (size_t)k * REC_STRIDE;
+            rec[REC_PHIPOS + 0] = p0; rec[REC_PHIPOS + 1] = p1; rec[REC_PHIPOS + 2] = p2;
+            rec[REC_PHIPOS + 3] = p1; rec[REC_PHIPOS + 4] = p3; rec[REC_PHIPOS + 5] = p4;
+            rec[REC_PHIPOS + 6] = p2; rec[REC_PHIPOS + 7] = p4; rec[REC_PHIPOS + 8] = p5;
+            stg[(17 + 0) * NP + k] = gp0; stg[(17 + 1) * NP + k] = gp1; stg[(17 + 2) * NP + k] = gp2;
+            stg[(17 + 3) * NP + k] = fp0; stg[(17 + 4) * NP + k] = fp1; stg[(17 + 5) * NP + k] = fp2;
+        }
+    }
+    WSYNC();
+    // bounds: residuals, barrier Hessian / gradient, finished entry by entry
+    if (kact) {
+        cgdouble *pk = pbase + (size_t)k * np;
+        double pc[NPRE];
+        pc[0] = pk[0]; pc[1] = pk[1]; pc[2] = pk[2]; pc[6] = pk[6]; pc[7] = pk[7]; pc[8] = pk[8]; pc[9] = pk[9];
+        const CostQ cq = make_cost(pc, stage_class(k, N), model);
+        gdouble *rec = prec + (size_t)k * REC_STRIDE;
+        constexpr int R = (NZ + H - 1) / H;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i0 = r * H, i1 = (H == 2) ? i0 + 1 : i0;
+            if (H == 2 && i1 >= NZ && half) continue;
+            const int i = half ? i1 : i0;
+            const double hd = half ? cq.hd(i1 < NZ ? i1 : i0) : cq.hd(i0);
+            const double qi = half ? cq.q(i1 < NZ ? i1 : i0) : cq.q(i0);
+            const double lb = half ? lower_bound(i1 < NZ ? i1 : i0) : lower_bound(i0);
+            const double ub = half ? upper_bound(i1 < NZ ? i1 : i0) : upper_bound(i0);
+            const double zi = pz[i * NP + k];
+            double cg = hd * zi + qi; // cost gradient
+            if (i0 < 8) cg += cq.hc() * pz[(i < 4 ? i + 4 : i - 4) * NP + k];
+            const double sl = ps[i * NP + k], su = ps[(17 + i) * NP + k];
+            const double ll = pl[i * NP + k], lu = pl[(17 + i) * NP + k];
+            const double vl = lb - zi, vu = zi - ub;
+            const double rl = vl + sl, ru = vu + su;
+            l_in = fmax(l_in, fmax(fmax(vl, vu), fmax(fabs(rl), fabs(ru))));
+            l_rc = fmax(l_rc, fmax(sl * ll, su * lu));
+            l_gap += sl * ll + su * lu;
+            const double sgl = ll * (1.0 / sl), sgu = lu * (1.0 / su);
+            double gi = cg + stg[i * NP + k] + lu - ll;
+            double ph = cg + sgu * ru - sgl * rl;
+            if (i0 + H > 8 && i0 < 11) {
+                if (i >= 8 && i < 11) { gi += stg[(17 + i - 8) * NP + k]; ph += stg[(17 + 3 + i - 8) * NP + k]; }
+            }
+            rec[REC_PHID + i] = hd + sgl + sgu;
+            rec[REC_PHI + i] = ph;
+            l_rs = fmax(l_rs, fabs(gi));
+        }
+    }
+}
 
 // ------------------------------------------------------------------ E: evaluate
 // part 1 (lane == stage): model + linearisation -> record, equality residuals, M'y -> LDS
@@ -374,82 +482,8 @@ __device__ __noinline__ EvalOut phase_eval(WsView w, cgdouble *pbase, int np, cg
         for (int i = 0; i < NZ; i++) stg[i * NP + k] = gm[i];
     }
     // ---- part 2: all 64 lanes, lane = (half, stage k); rows handled in pairs
-    const int k = lane % NP, half = lane / NP;
-    const bool kact = k < N;
-    // corridor rows: sums over the faces of a stage (pos entries 8..10 only)
-    {
-        double gp0 = 0, gp1 = 0, gp2 = 0, fp0 = 0, fp1 = 0, fp2 = 0, p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0;
-        if (kact) {
-            const double z8 = w.z[8 * NP + k], z9 = w.z[9 * NP + k], z10 = w.z[10 * NP + k];
-            for (int j = half; j < nfk; j += H) {
-                const double a0 = w.face[(3 * j) * NP + k], a1 = w.face[(3 * j + 1) * NP + k], a2 = w.face[(3 * j + 2) * NP + k];
-                const double hj = a0 * z8 + a1 * z9 + a2 * z10 - w.face[(3 * MF + j) * NP + k] - HU;
-                const double sc = w.s[(34 + j) * NP + k], lc = w.lam[(34 + j) * NP + k];
-                const double rc = hj + sc;
-                l_in = fmax(l_in, fmax(hj, fabs(rc)));
-                l_rc = fmax(l_rc, sc * lc);
-                l_gap += sc * lc;
-                gp0 += a0 * lc; gp1 += a1 * lc; gp2 += a2 * lc;
-                const double sg = lc * (1.0 / sc), t = sg * rc;
-                fp0 += a0 * t; fp1 += a1 * t; fp2 += a2 * t;
-                p0 += sg * a0 * a0; p1 += sg * a0 * a1; p2 += sg * a0 * a2;
-                p3 += sg * a1 * a1; p4 += sg * a1 * a2; p5 += sg * a2 * a2;
-            }
-        }
-        if (H == 2) {
-            gp0 = xhalf_sum(gp0); gp1 = xhalf_sum(gp1); gp2 = xhalf_sum(gp2);
-            fp0 = xhalf_sum(fp0); fp1 = xhalf_sum(fp1); fp2 = xhalf_sum(fp2);
-            p0 = xhalf_sum(p0); p1 = xhalf_sum(p1); p2 = xhalf_sum(p2);
-            p3 = xhalf_sum(p3); p4 = xhalf_sum(p4); p5 = xhalf_sum(p5);
-        }
-        if (kact && half == 0) {
-            gdouble *rec = w.rec + (size_t)k * REC_STRIDE;
-            rec[REC_PHIPOS + 0] = p0; rec[REC_PHIPOS + 1] = p1; rec[REC_PHIPOS + 2] = p2;
-            rec[REC_PHIPOS + 3] = p1; rec[REC_PHIPOS + 4] = p3; rec[REC_PHIPOS + 5] = p4;
-            rec[REC_PHIPOS + 6] = p2; rec[REC_PHIPOS + 7] = p4; rec[REC_PHIPOS + 8] = p5;
-            stg[(17 + 0) * NP + k] = gp0; stg[(17 + 1) * NP + k] = gp1; stg[(17 + 2) * NP + k] = gp2;
-            stg[(17 + 3) * NP + k] = fp0; stg[(17 + 4) * NP + k] = fp1; stg[(17 + 5) * NP + k] = fp2;
-        }
-    }
     WSYNC();
-    // bounds: residuals, barrier Hessian / gradient, finished entry by entry
-    if (kact) {
-        cgdouble *pk = pbase + (size_t)k * np;
-        double pc[NPRE];
-        pc[0] = pk[0]; pc[1] = pk[1]; pc[2] = pk[2]; pc[6] = pk[6]; pc[7] = pk[7]; pc[8] = pk[8]; pc[9] = pk[9];
-        const CostQ cq = make_cost(pc, stage_class(k, N), model);
-        gdouble *rec = w.rec + (size_t)k * REC_STRIDE;
-        constexpr int R = (NZ + H - 1) / H;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int i0 = r * H, i1 = (H == 2) ? i0 + 1 : i0;
-            if (H == 2 && i1 >= NZ && half) continue;
-            const int i = half ? i1 : i0;
-            const double hd = half ? cq.hd(i1 < NZ ? i1 : i0) : cq.hd(i0);
-            const double qi = half ? cq.q(i1 < NZ ? i1 : i0) : cq.q(i0);
-            const double lb = half ? lower_bound(i1 < NZ ? i1 : i0) : lower_bound(i0);
-            const double ub = half ? upper_bound(i1 < NZ ? i1 : i0) : upper_bound(i0);
-            const double zi = w.z[i * NP + k];
-            double cg = hd * zi + qi; // cost gradient
-            if (i0 < 8) cg += cq.hc() * w.z[(i < 4 ? i + 4 : i - 4) * NP + k];
-            const double sl = w.s[i * NP + k], su = w.s[(17 + i) * NP + k];
-            const double ll = w.lam[i * NP + k], lu = w.lam[(17 + i) * NP + k];
-            const double vl = lb - zi, vu = zi - ub;
-            const double rl = vl + sl, ru = vu + su;
-            l_in = fmax(l_in, fmax(fmax(vl, vu), fmax(fabs(rl), fabs(ru))));
-            l_rc = fmax(l_rc, fmax(sl * ll, su * lu));
-            l_gap += sl * ll + su * lu;
-            const double sgl = ll * (1.0 / sl), sgu = lu * (1.0 / su);
-            double gi = cg + stg[i * NP + k] + lu - ll;
-            double ph = cg + sgu * ru - sgl * rl;
-            if (i0 + H > 8 && i0 < 11) {
-                if (i >= 8 && i < 11) { gi += stg[(17 + i - 8) * NP + k]; ph += stg[(17 + 3 + i - 8) * NP + k]; }
-            }
-            rec[REC_PHID + i] = hd + sgl + sgu;
-            rec[REC_PHI + i] = ph;
-            l_rs = fmax(l_rs, fabs(gi));
-        }
-    }
+    eval_rows<NP>(w.s, w.lam, w.z, w.face, w.rec, pbase, np, N, MF, nfk, model, stg, l_in, l_rc, l_gap, l_rs);
     FULLSYNC();
     EvalOut o;
     o.eq = l_eq; o.in = l_in; o.rs = l_rs; o.rc = l_rc; o.gap = l_gap; o.obj = l_obj;
@@ -487,6 +521,13 @@ __device__ __forceinline__ void stage0_solve(const WsView &w, cgdouble *xinit, i
 //   P <- [Phi_w - hc^2 R, -hc Kbar_x; -hc Kbar_x', S_xx],  p <- [phi_w - hc kbar; S_x,13].
 // Streams T' = [R | Kbar_x | kbar | hc] and P d to the stage record.  Returns 1 when a pivot block
 // is not positive definite (exact Hessian: the caller retries with theta = 0, Gauss-Newton).
+// Software pipeline: while the MFMA chain of stage k executes, the wave stages the (prefetched) record of
+// stage k-1 through LDS and assembles its tiles, and issues the global prefetch of stage k-2.
+struct FactorTiles {
+    d4 C, M;
+    double hc, PhiDw, phiw;
+};
+
 template <int NP>
 __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, int theta_i)
 {
@@ -504,29 +545,36 @@ __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, int t
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     d4 P = zero, pv = zero;
     bool fail = false;
-    cgdouble *rp = w.rec + (size_t)(N - 1) * REC_STRIDE;
-    double e0 = rp[lane], e1 = rp[64 + lane], e2 = rp[128 + lane], e3 = (lane < 16) ? rp[192 + lane] : 0.0;
+    double e0, e1, e2, e3;
+    auto fetch = [&](int kk) {
+        cgdouble *rp = w.rec + (size_t)kk * REC_STRIDE;
+        e0 = rp[lane]; e1 = rp[64 + lane]; e2 = rp[128 + lane]; e3 = (lane < 56) ? rp[192 + lane] : 0.0;
+    };
+    auto stage = [&]() -> FactorTiles { // regs -> LDS -> tiles of that stage
+        WSYNC();
+        sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1; sm[S_E + 128 + lane] = e2;
+        if (lane < 56) sm[S_E + 192 + lane] = e3;
+        WSYNC();
+        FactorTiles t;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            t.C[r] = sm[c1[r]] + sm[c2[r]] + theta * sm[c3[r]];
+            t.M[r] = sm[mo[r]];
+        }
+        t.hc = sm[S_E + REC_HC];
+        t.PhiDw = sm[S_E + REC_PHID + 4 + g];
+        t.phiw = sm[S_E + REC_PHI + 4 + g];
+        return t;
+    };
+    fetch(N - 1);
+    FactorTiles cur = stage();
+    if (N > 1) fetch(N - 2);
     for (int kk = N - 1; kk >= 0; kk--) {
         gdouble *rec = w.rec + (size_t)kk * REC_STRIDE;
         const bool last = (kk == N - 1);
-        WSYNC(); // every lane is done with the previous stage's staging
-        sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1; sm[S_E + 128 + lane] = e2;
-        if (lane < 16) sm[S_E + 192 + lane] = e3;
-        if (kk > 0) {
-            cgdouble *rn = rec - REC_STRIDE;
-            e0 = rn[lane]; e1 = rn[64 + lane]; e2 = rn[128 + lane]; e3 = (lane < 16) ? rn[192 + lane] : 0.0;
-        }
-        WSYNC();
-        const double hc = sm[S_E + REC_HC];
-        d4 C;
-#pragma unroll
-        for (int r = 0; r < 4; r++) C[r] = sm[c1[r]] + sm[c2[r]] + theta * sm[c3[r]];
-        d4 G = C;
+        d4 G = cur.C;
         if (!last) {
-            d4 M;
-#pragma unroll
-            for (int r = 0; r < 4; r++) M[r] = sm[mo[r]];
-            d4 X = mm_tn(P, M, zero);
+            d4 X = mm_tn(P, cur.M, zero);
             if (c == 13) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -534,9 +582,15 @@ __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, int t
                     X[r] += pv[r];
                 }
             }
-            G = mm_tn(M, X, C);
+            G = mm_tn(cur.M, X, cur.C);
         }
-        // R = Guu^-1 (4 x 4): gather the lower triangle to uniform registers, invert redundantly
+        // ---- overlapped with the MFMA chain above: tiles of the next stage to be processed
+        FactorTiles nxt = cur;
+        if (kk > 0) {
+            nxt = stage();
+            if (kk > 1) fetch(kk - 2);
+        }
+        // ---- R = Guu^-1 (4 x 4): gather the lower triangle to uniform registers, invert redundantly
         double q[16], R[16];
 #pragma unroll
         for (int i = 0; i < 4; i++)
@@ -547,14 +601,14 @@ __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, int t
         for (int t = 0; t < 16; t++) sm[S_R + t] = R[t];
         WSYNC();
         const double rt = (c < 4) ? sm[S_R + g * 4 + c] : 0.0;
+        const double hc = cur.hc;
         const d4 T = mm_tn4(rt, G[0], zero);
         const d4 TT = mm_tn4(G[0], rt, zero);
         const d4 S = mm_tn4(-G[0], T[0], G);
         rec[REC_T + lane] = (c < 4) ? rt : (c <= 13 ? T[0] : (lane == 14 ? hc : 0.0));
-        const double PhiDw = sm[S_E + REC_PHID + 4 + g], phiw = sm[S_E + REC_PHI + 4 + g];
         d4 Pn, pn;
-        Pn[0] = (c < 4) ? ((g == c ? PhiDw : 0.0) - hc * hc * rt) : (c <= 12 ? -hc * T[0] : 0.0);
-        pn[0] = (c == 13) ? (phiw - hc * T[0]) : 0.0;
+        Pn[0] = (c < 4) ? ((g == c ? cur.PhiDw : 0.0) - hc * hc * rt) : (c <= 12 ? -hc * T[0] : 0.0);
+        pn[0] = (c == 13) ? (cur.phiw - hc * T[0]) : 0.0;
 #pragma unroll
         for (int r = 1; r < 4; r++) {
             const bool inb = (4 * r + g) <= 12;
@@ -563,6 +617,7 @@ __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, int t
         }
         P = Pn;
         pv = pn;
+        cur = nxt;
     }
     if (!fail) {
         // stage 0: keep Pww^-1 and Pwx for the corrector pass, then solve for ds_0
@@ -585,67 +640,83 @@ __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, int t
 }
 
 // ------------------------------------------------------------------ vector-only backward sweep (corrector)
-// Same factorisation, new rhs phi:  q~ = phi~ + M'(P d + p+),  [kbar; Kbar'q_u] = T'' q_u,
+// Same factorisation, new rhs phi_cc = PHIB + smu PHIC:  q~ = phi~ + M'(P d + p+),  [kbar; Kbar'q_u] = T'' q_u,
 // p_x = q~_x - Kbar' q_u,  p_w = phi_w - hc kbar.  Updates the kbar column of T'.
+struct BackvecTiles {
+    d4 M, Gp, pd;
+    double hc, phiw, tp;
+};
+
 template <int NP>
-__device__ __noinline__ void sweep_backvec(WsView w, cgdouble *xinit, int N)
+__device__ __noinline__ void sweep_backvec(WsView w, cgdouble *xinit, int N, double smu)
 {
-    w = uni(w); xinit = uni(xinit); N = uni(N);
+    w = uni(w); xinit = uni(xinit); N = uni(N); smu = uni(smu);
     FULLSYNC(); // phase boundary: the corrector rhs written by the step phase is visible
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
     int mo[4], po[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         mo[r] = m_src(4 * r + g, c);
-        po[r] = (c == 13 && 4 * r + g <= 12) ? S_E + REC_PHI + zi_of(4 * r + g) : S_ZERO;
+        po[r] = (c == 13 && 4 * r + g <= 12) ? zi_of(4 * r + g) : -1;
     }
     init_stage_constants(lane);
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     d4 pv = zero;
-    cgdouble *rp = w.rec + (size_t)(N - 1) * REC_STRIDE;
-    double e0 = rp[lane], e1 = rp[64 + lane], tp = rp[REC_T + lane];
-    d4 pd = zero;
-    if (c == 13) {
+    double e0, e1, e2, tpre;
+    d4 pdpre = zero;
+    auto fetch = [&](int kk) {
+        cgdouble *rp = w.rec + (size_t)kk * REC_STRIDE;
+        e0 = rp[lane]; e1 = rp[64 + lane]; e2 = (lane < 17) ? rp[REC_PHIC + lane] : 0.0; tpre = rp[REC_T + lane];
+        if (c == 13) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) pd[r] = rp[REC_PD + 4 * r + g];
-    }
+            for (int r = 0; r < 4; r++) pdpre[r] = rp[REC_PD + 4 * r + g];
+        }
+    };
+    auto stage = [&]() -> BackvecTiles {
+        WSYNC();
+        sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1;
+        if (lane < 17) sm[S_E + REC_PHIC + lane] = e2;
+        WSYNC();
+        BackvecTiles t;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            t.M[r] = sm[mo[r]];
+            const int o = po[r] >= 0 ? po[r] : 0;
+            const double ph = sm[S_E + REC_PHIB + o] + smu * sm[S_E + REC_PHIC + o];
+            t.Gp[r] = (po[r] >= 0) ? ph : 0.0;
+        }
+        t.hc = sm[S_E + REC_HC];
+        t.phiw = sm[S_E + REC_PHIB + 4 + g] + smu * sm[S_E + REC_PHIC + 4 + g];
+        t.tp = tpre;
+        t.pd = pdpre;
+        return t;
+    };
+    fetch(N - 1);
+    BackvecTiles cur = stage();
+    if (N > 1) fetch(N - 2);
     for (int kk = N - 1; kk >= 0; kk--) {
         gdouble *rec = w.rec + (size_t)kk * REC_STRIDE;
         const bool last = (kk == N - 1);
-        WSYNC();
-        sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1;
-        const double tpc = tp;
-        const d4 pdc = pd;
-        if (kk > 0) {
-            cgdouble *rn = rec - REC_STRIDE;
-            e0 = rn[lane]; e1 = rn[64 + lane]; tp = rn[REC_T + lane];
-            if (c == 13) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) pd[r] = rn[REC_PD + 4 * r + g];
-            }
-        }
-        WSYNC();
-        const double hc = sm[S_E + REC_HC];
-        d4 Gp;
-#pragma unroll
-        for (int r = 0; r < 4; r++) Gp[r] = sm[po[r]];
+        d4 Gp = cur.Gp;
         if (!last) {
-            d4 M, X;
+            d4 X;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                M[r] = sm[mo[r]];
-                X[r] = (c == 13) ? pdc[r] + pv[r] : 0.0;
-            }
-            Gp = mm_tn(M, X, Gp);
+            for (int r = 0; r < 4; r++) X[r] = (c == 13) ? cur.pd[r] + pv[r] : 0.0;
+            Gp = mm_tn(cur.M, X, Gp);
         }
-        const d4 E = mm_tn4(tpc, Gp[0], zero);
+        const d4 E = mm_tn4(cur.tp, Gp[0], zero);
+        BackvecTiles nxt = cur;
+        if (kk > 0) {
+            nxt = stage();
+            if (kk > 1) fetch(kk - 2);
+        }
         if (c == 13) rec[REC_T + 16 * g + 13] = E[0]; // kbar
-        const double phiw = sm[S_E + REC_PHI + 4 + g];
         d4 pn;
-        pn[0] = (c == 13) ? (phiw - hc * E[0]) : 0.0;
+        pn[0] = (c == 13) ? (cur.phiw - cur.hc * E[0]) : 0.0;
 #pragma unroll
         for (int r = 1; r < 4; r++) pn[r] = (c == 13 && 4 * r + g <= 12) ? Gp[r] - E[r] : 0.0;
         pv = pn;
+        cur = nxt;
     }
     stage0_solve<NP>(w, xinit, lane, pv[0]);
     FULLSYNC();
@@ -653,62 +724,116 @@ __device__ __noinline__ void sweep_backvec(WsView w, cgdouble *xinit, int N)
 
 // ------------------------------------------------------------------ forward sweep: dz for all stages
 // du = -T' [hc dw; dx; 1],  ds+ = Mt [du; dx; 1]; the vectors stay in the column-0 lanes (row layout).
+// Software pipeline, branch-free body: the record of stage k+1 is staged through LDS and its operand tiles
+// are read BETWEEN the chained MFMAs of stage k (each chained MFMA blocks the wave for 64 cycles anyway);
+// the global prefetch runs two stages ahead.  Two register sets (A/B) alternate, so no tile is ever copied.
+template <int NP>
+__device__ __forceinline__ void forward_step(const WsView &w, int N, int kk, int lane, int g, int c, const int (&tto)[4],
+                                             const int (&mto)[4], const d4 &ctt, const d4 &cmt, double chc, d4 &ntt, d4 &nmt,
+                                             double &nhc, double &e0, double &tp, d4 &v, long long *pacc_, long long &pts_)
+{
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    d4 v1 = v;
+    if (c == 0) {
+        v1[0] = chc * v[0];
+        if (g == 1) v1[3] = 1.0; // row 13 multiplies the kbar column
+    }
+    PROF_SEG(0);
+    d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ctt[0], v1[0], zero, 0, 0, 0);
+#ifdef FRP_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    PROF_SEG(1);
+    // stage the (already fetched) record of the next stage through LDS ...
+    WSYNC();
+    sm[S_E + lane] = e0; sm[S_T + lane] = tp;
+    WSYNC();
+    D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ctt[1], v1[1], D1, 0, 0, 0);
+    { // ... prefetch the one after it (clamped: the tail re-reads the last record, unused) ...
+        const int kf = (kk + 2 < N) ? kk + 2 : N - 1;
+        cgdouble *rp = w.rec + (size_t)kf * REC_STRIDE;
+        e0 = rp[lane]; tp = rp[REC_T + lane];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) ntt[s] = sm[tto[s]];
+    D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ctt[2], v1[2], D1, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; s++) nmt[s] = sm[mto[s]];
+    nhc = sm[S_T + 14];
+    D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ctt[3], v1[3], D1, 0, 0, 0);
+    PROF_SEG(2);
+    const double du = -D1[0];
+#ifdef FRP_PROFILE
+    asm volatile("s_nop 0" :: "v"(du));
+#endif
+    PROF_SEG(3);
+    if (c == 0) { // dz rows 17..19 are padding (tile rows 13..15)
+        double *dzl = dz_area<NP>();
+        dzl[g * NP + kk] = du;
+#pragma unroll
+        for (int r = 0; r < 4; r++) dzl[(4 + 4 * r + g) * NP + kk] = v[r];
+    }
+    d4 v2 = v;
+    if (c == 0) {
+        v2[0] = du;
+        if (g == 1) v2[3] = 1.0; // row 13 multiplies the d column
+    }
+    const d4 D2 = mm_tn(cmt, v2, zero);
+    PROF_SEG(4);
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = (c == 0 && 4 * r + g <= 12) ? D2[r] : 0.0;
+#ifdef FRP_PROFILE
+    asm volatile("s_nop 0" :: "v"(v[0]));
+#endif
+    PROF_SEG(5);
+}
+
 template <int NP>
 __device__ __noinline__ void sweep_forward(WsView w, int N)
 {
     w = uni(w); N = uni(N);
     FULLSYNC(); // phase boundary: T' / kbar of the backward sweep are visible
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-    int mt[4];
+    int mto[4], tto[4];
 #pragma unroll
-    for (int s = 0; s < 4; s++) mt[s] = m_src(c, 4 * s + g);
+    for (int s = 0; s < 4; s++) {
+        mto[s] = m_src(c, 4 * s + g);                           // Mt' tile: element [c][4s+g]
+        tto[s] = (c < 4) ? S_T + 16 * c + 4 * s + g : S_ZERO;   // T'' tile: element T'[c][4s+g]
+    }
     init_stage_constants(lane);
-    const d4 zero = {0.0, 0.0, 0.0, 0.0};
     d4 v;
 #pragma unroll
     for (int r = 0; r < 4; r++) v[r] = (c == 0 && 4 * r + g <= 12) ? sm[S_DS0 + 4 * r + g] : 0.0;
-    cgdouble *rp = w.rec;
-    double e0 = rp[lane], tp = rp[REC_T + lane];
-    for (int kk = 0; kk < N; kk++) {
-        cgdouble *rec = w.rec + (size_t)kk * REC_STRIDE;
-        WSYNC();
-        sm[S_E + lane] = e0; sm[S_T + lane] = tp;
-        if (kk < N - 1) {
-            cgdouble *rn = rec + REC_STRIDE;
-            e0 = rn[lane]; tp = rn[REC_T + lane];
-        }
-        WSYNC();
-        const double hc = sm[S_T + 14];
-        d4 tt, v1 = v;
-#pragma unroll
-        for (int s = 0; s < 4; s++) tt[s] = (c < 4) ? sm[S_T + 16 * c + 4 * s + g] : 0.0;
-        if (c == 0) {
-            v1[0] = hc * v[0];
-            if (g == 1) v1[3] = 1.0; // row 13 multiplies the kbar column
-        }
-        const d4 D1 = mm_tn(tt, v1, zero);
-        const double du = -D1[0];
-        if (c == 0) {
-            w.dz[g * NP + kk] = du;
-            w.dz[(4 + g) * NP + kk] = v[0];
-#pragma unroll
-            for (int r = 1; r < 4; r++)
-                if (4 * r + g <= 12) w.dz[(4 + 4 * r + g) * NP + kk] = v[r];
-        }
-        if (kk < N - 1) {
-            d4 v2 = v, mtv;
-            if (c == 0) {
-                v2[0] = du;
-                if (g == 1) v2[3] = 1.0; // row 13 multiplies the d column
-            }
-#pragma unroll
-            for (int s = 0; s < 4; s++) mtv[s] = sm[mt[s]];
-            const d4 D2 = mm_tn(mtv, v2, zero);
-#pragma unroll
-            for (int r = 0; r < 4; r++) v[r] = (c == 0 && 4 * r + g <= 12) ? D2[r] : 0.0;
-        }
+    double e0, tp;
+    {
+        cgdouble *rp = w.rec;
+        e0 = rp[lane]; tp = rp[REC_T + lane];
     }
     WSYNC();
+    sm[S_E + lane] = e0; sm[S_T + lane] = tp;
+    WSYNC();
+    d4 ttA, mtA, ttB, mtB;
+    double hcA, hcB = 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) { ttA[s] = sm[tto[s]]; mtA[s] = sm[mto[s]]; }
+    hcA = sm[S_T + 14];
+    {
+        cgdouble *rp = w.rec + (size_t)(N > 1 ? 1 : 0) * REC_STRIDE;
+        e0 = rp[lane]; tp = rp[REC_T + lane];
+    }
+#ifdef FRP_PROFILE
+    PROF_BEGIN();
+#else
+    long long pacc_[1], pts_ = 0;
+#endif
+    int kk = 0;
+    for (; kk + 1 < N; kk += 2) {
+        forward_step<NP>(w, N, kk, lane, g, c, tto, mto, ttA, mtA, hcA, ttB, mtB, hcB, e0, tp, v, pacc_, pts_);
+        forward_step<NP>(w, N, kk + 1, lane, g, c, tto, mto, ttB, mtB, hcB, ttA, mtA, hcA, e0, tp, v, pacc_, pts_);
+    }
+    if (kk < N) forward_step<NP>(w, N, kk, lane, g, c, tto, mto, ttA, mtA, hcA, ttB, mtB, hcB, e0, tp, v, pacc_, pts_);
+    WSYNC();
+    PROF_END(12);
 }
 
 struct SlackOut {
@@ -717,203 +842,248 @@ struct SlackOut {
 
 // ------------------------------------------------------------------ slack / multiplier steps
 // All 64 lanes, lane = (half, stage k), constraints handled in pairs (flattened [row][stage] arrays).
-// pass 0 (affine): step lengths, mu_aff -> sigma, second-order term, corrector rhs phi -> record
-// pass 1 (corrector): fraction-to-boundary step lengths, update z, s, lambda
 // Per constraint:  ds = -(G z - g + s) - G dz,  dl = (-(s l - smu + corr) - l ds) / s.
 // Ratios -ds/s and -dl/l are formed with ONE reciprocal u = 1/(s l) per constraint.
+//
+// phase_affine (predictor): ONE pass over the constraints gives the step lengths (max ratios), the
+// second-order term corr = ds dl, the pieces of the affine complementarity
+//     sum (s + ap ds)(l + ad dl) = sum s l + ad sum s dl + ap sum l ds + ap ad sum ds dl
+// and the corrector rhs split as  phi_cc = PHIB + (sigma mu) PHIC  (sigma mu is only known after the
+// wave-wide reductions, the sweeps apply it):
+//     PHIB = grad f + G'((l r_in - corr)/s),   PHIC = G'(1/s).
 template <int NP>
-__device__ __noinline__ SlackOut phase_slack(WsView w, cgdouble *pbase, int np, int N, int MF, int nfk, int model, int pass,
-                                             double smu, double mu, int mtot, double ftb, double tol_comp)
+__device__ __forceinline__ void affine_body(cgdouble *__restrict__ ps, cgdouble *__restrict__ pl, gdouble *__restrict__ pcorr,
+                                            cgdouble *__restrict__ pz, const double *__restrict__ pdz, cgdouble *__restrict__ pface,
+                                            gdouble *__restrict__ prec, cgdouble *__restrict__ pbase, int np, int N, int MF, int nfk,
+                                            int model, double &m_p, double &m_d, double &s_sdl, double &s_lds, double &s_dsdl)
 {
-    w = uni(w); pbase = uni(pbase); np = uni(np); N = uni(N); MF = uni(MF); model = uni(model); pass = uni(pass);
-    smu = uni(smu); mu = uni(mu); mtot = uni(mtot); ftb = uni(ftb); tol_comp = uni(tol_comp);
-    FULLSYNC(); // phase boundary: dz of the forward sweep is visible
     constexpr int H = 64 / NP;
     constexpr int R = (NZ + H - 1) / H;
     const int lane = threadIdx.x;
     const int k = lane % NP, half = lane / NP;
     const bool kact = k < N;
     double *stg = stage_area<NP>();
-    double sigma = 0.0;
 
-    // one constraint: returns ds, dl and the two ratios
-    auto cstep = [&](int c, double gdz, double viol, double &ds, double &dl, double &rp, double &rd, double &s, double &l) {
-        s = w.s[c * NP + k];
-        l = w.lam[c * NP + k];
+    // one constraint of the affine step (smu = 0, corr = 0): returns t1 = (l r_in - corr)/s, sinv = 1/s
+    auto cstep = [&](int c, double gdz, double viol, double &t1, double &sinv) {
+        const double s = ps[c * NP + k], l = pl[c * NP + k];
+        const double u = 1.0 / (s * l);
+        sinv = u * l;
+        const double linv = u * s;
+        const double rin = viol + s;
+        const double ds = -rin - gdz;
+        const double dl = -l * (1.0 + ds * sinv); // (-(s l) - l ds) / s
+        m_p = fmax(m_p, -ds * sinv);
+        m_d = fmax(m_d, -dl * linv);
+        s_sdl += s * dl; s_lds += l * ds;
+        const double cr = ds * dl;
+        s_dsdl += cr;
+        pcorr[c * NP + k] = cr;
+        t1 = (l * rin - cr) * sinv;
+    };
+    // corridor rows first: their sums go to the pos entries of PHIB / PHIC
+    {
+        double b0 = 0, b1 = 0, b2 = 0, c0 = 0, c1 = 0, c2 = 0;
+        if (kact) {
+            const double z8 = pz[8 * NP + k], z9 = pz[9 * NP + k], z10 = pz[10 * NP + k];
+            const double d8 = pdz[8 * NP + k], d9 = pdz[9 * NP + k], d10 = pdz[10 * NP + k];
+            for (int j = half; j < nfk; j += H) {
+                const double a0 = pface[(3 * j) * NP + k], a1 = pface[(3 * j + 1) * NP + k], a2 = pface[(3 * j + 2) * NP + k];
+                double t1, sinv;
+                cstep(34 + j, a0 * d8 + a1 * d9 + a2 * d10, a0 * z8 + a1 * z9 + a2 * z10 - pface[(3 * MF + j) * NP + k] - HU, t1, sinv);
+                b0 += a0 * t1; b1 += a1 * t1; b2 += a2 * t1;
+                c0 += a0 * sinv; c1 += a1 * sinv; c2 += a2 * sinv;
+            }
+        }
+        if (H == 2) {
+            b0 = xhalf_sum(b0); b1 = xhalf_sum(b1); b2 = xhalf_sum(b2);
+            c0 = xhalf_sum(c0); c1 = xhalf_sum(c1); c2 = xhalf_sum(c2);
+        }
+        if (kact && half == 0) {
+            stg[0 * NP + k] = b0; stg[1 * NP + k] = b1; stg[2 * NP + k] = b2;
+            stg[3 * NP + k] = c0; stg[4 * NP + k] = c1; stg[5 * NP + k] = c2;
+        }
+    }
+    WSYNC();
+    if (kact) {
+        cgdouble *pk = pbase + (size_t)k * np;
+        double pc[NPRE];
+        pc[0] = pk[0]; pc[1] = pk[1]; pc[2] = pk[2]; pc[6] = pk[6]; pc[7] = pk[7]; pc[8] = pk[8]; pc[9] = pk[9];
+        const CostQ cq = make_cost(pc, stage_class(k, N), model);
+        gdouble *rec = prec + (size_t)k * REC_STRIDE;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i0 = r * H, i1 = (H == 2) ? i0 + 1 : i0;
+            if (H == 2 && i1 >= NZ && half) continue;
+            const int i = half ? i1 : i0;
+            const double hd = half ? cq.hd(i1 < NZ ? i1 : i0) : cq.hd(i0);
+            const double qi = half ? cq.q(i1 < NZ ? i1 : i0) : cq.q(i0);
+            const double lb = half ? lower_bound(i1 < NZ ? i1 : i0) : lower_bound(i0);
+            const double ub = half ? upper_bound(i1 < NZ ? i1 : i0) : upper_bound(i0);
+            const double zi = pz[i * NP + k], dzi = pdz[i * NP + k];
+            double pb = hd * zi + qi; // cost gradient
+            if (i0 < 8) pb += cq.hc() * pz[(i < 4 ? i + 4 : i - 4) * NP + k];
+            double tl, tu, sil, siu;
+            cstep(i, -dzi, lb - zi, tl, sil);
+            cstep(17 + i, dzi, zi - ub, tu, siu);
+            pb += tu - tl;
+            double pcf = siu - sil;
+            if (i0 + H > 8 && i0 < 11) {
+                if (i >= 8 && i < 11) { pb += stg[(i - 8) * NP + k]; pcf += stg[(3 + i - 8) * NP + k]; }
+            }
+            rec[REC_PHIB + i] = pb;
+            rec[REC_PHIC + i] = pcf;
+        }
+    }
+}
+
+template <int NP>
+__device__ __noinline__ SlackOut phase_affine(WsView w, cgdouble *pbase, int np, int N, int MF, int nfk, int model,
+                                              double mu, int mtot, double tol_comp)
+{
+    w = uni(w); pbase = uni(pbase); np = uni(np); N = uni(N); MF = uni(MF); model = uni(model);
+    mu = uni(mu); mtot = uni(mtot); tol_comp = uni(tol_comp);
+    PROF_BEGIN();
+    FULLSYNC(); // phase boundary: dz of the forward sweep is visible
+    PROF_SEG(0);
+    double m_p = 0.0, m_d = 0.0, s_sdl = 0.0, s_lds = 0.0, s_dsdl = 0.0;
+    affine_body<NP>(w.s, w.lam, w.corr, w.z, dz_area<NP>(), w.face, w.rec, pbase, np, N, MF, nfk, model, m_p, m_d, s_sdl, s_lds, s_dsdl);
+    PROF_SEG(2);
+    m_p = wave_max(m_p); m_d = wave_max(m_d);
+    const double ap = (m_p > 1.0) ? 1.0 / m_p : 1.0;
+    const double ad = (m_d > 1.0) ? 1.0 / m_d : 1.0;
+    const double gap_aff = mu * (double)mtot + ad * wave_sum(s_sdl) + ap * wave_sum(s_lds) + ap * ad * wave_sum(s_dsdl);
+    double sigma = gap_aff / ((double)mtot * mu);
+    sigma = sigma * sigma * sigma;
+    if (sigma > 1.0) sigma = 1.0;
+    double smu = sigma * mu;
+    if (smu < MU_FLOOR_FRAC * tol_comp) smu = MU_FLOOR_FRAC * tol_comp;
+    PROF_SEG(3);
+    FULLSYNC();
+    PROF_SEG(4);
+    PROF_END(0);
+    SlackOut o;
+    o.ap = ap; o.ad = ad; o.sigma = sigma; o.smu = smu;
+    return o;
+}
+
+// phase_step (corrector): pass A computes ds, dl and the fraction-to-boundary step lengths, pass B applies
+// z += ap dz, s += ap ds, l += ad dl.  The arrays are passed as __restrict__ parameters of an inlined
+// helper so that the compiler may batch the loads of several constraint rounds across the stores (it
+// cannot prove on its own that the workspace arrays do not alias, which serialises every round on a
+// full memory round trip).
+template <int NP>
+__device__ __forceinline__ void step_body(gdouble *__restrict__ ps, gdouble *__restrict__ pl, cgdouble *__restrict__ pcorr,
+                                          gdouble *__restrict__ pz, const double *__restrict__ pdz, cgdouble *__restrict__ pface,
+                                          int N, int MF, int nfk, double smu, double ftb, double &ap_out, double &ad_out)
+{
+    constexpr int H = 64 / NP;
+    constexpr int R = (NZ + H - 1) / H;
+    constexpr int MAXF = 8; // corridor rounds kept in registers; further rounds are recomputed
+    const int lane = threadIdx.x;
+    const int k = lane % NP, half = lane / NP;
+    const bool kact = k < N;
+    double m_p = 0.0, m_d = 0.0;
+    double dsb[2 * R], dlb[2 * R], dsf[MAXF], dlf[MAXF];
+    double z8 = 0, z9 = 0, z10 = 0, d8 = 0, d9 = 0, d10 = 0;
+    auto cstep = [&](int c, double gdz, double viol, double &ds, double &dl) {
+        const double s = ps[c * NP + k], l = pl[c * NP + k];
         const double u = 1.0 / (s * l);
         const double sinv = u * l, linv = u * s;
         ds = -(viol + s) - gdz;
-        const double rc = s * l - smu + (pass ? w.corr[c * NP + k] : 0.0);
+        const double rc = s * l - smu + pcorr[c * NP + k];
         dl = (-rc - l * ds) * sinv;
-        rp = -ds * sinv;
-        rd = -dl * linv;
+        m_p = fmax(m_p, -ds * sinv);
+        m_d = fmax(m_d, -dl * linv);
     };
-
-    // ---- A: largest ratios -> step lengths
-    double m_p = 0.0, m_d = 0.0;
-    double z8 = 0, z9 = 0, z10 = 0, d8 = 0, d9 = 0, d10 = 0;
+    auto face = [&](int j, double &ds, double &dl) {
+        const double a0 = pface[(3 * j) * NP + k], a1 = pface[(3 * j + 1) * NP + k], a2 = pface[(3 * j + 2) * NP + k];
+        cstep(34 + j, a0 * d8 + a1 * d9 + a2 * d10, a0 * z8 + a1 * z9 + a2 * z10 - pface[(3 * MF + j) * NP + k] - HU, ds, dl);
+    };
     if (kact) {
-        z8 = w.z[8 * NP + k]; z9 = w.z[9 * NP + k]; z10 = w.z[10 * NP + k];
-        d8 = w.dz[8 * NP + k]; d9 = w.dz[9 * NP + k]; d10 = w.dz[10 * NP + k];
+        z8 = pz[8 * NP + k]; z9 = pz[9 * NP + k]; z10 = pz[10 * NP + k];
+        d8 = pdz[8 * NP + k]; d9 = pdz[9 * NP + k]; d10 = pdz[10 * NP + k];
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int i0 = r * H, i1 = (H == 2) ? i0 + 1 : i0;
+            dsb[2 * r] = dlb[2 * r] = dsb[2 * r + 1] = dlb[2 * r + 1] = 0.0;
             if (H == 2 && i1 >= NZ && half) continue;
             const int i = half ? i1 : i0;
             const double lb = half ? lower_bound(i1 < NZ ? i1 : i0) : lower_bound(i0);
             const double ub = half ? upper_bound(i1 < NZ ? i1 : i0) : upper_bound(i0);
-            const double zi = w.z[i * NP + k], dzi = w.dz[i * NP + k];
-            double ds, dl, rp, rd, sv, lv;
-            cstep(i, -dzi, lb - zi, ds, dl, rp, rd, sv, lv);
-            m_p = fmax(m_p, rp); m_d = fmax(m_d, rd);
-            cstep(17 + i, dzi, zi - ub, ds, dl, rp, rd, sv, lv);
-            m_p = fmax(m_p, rp); m_d = fmax(m_d, rd);
+            const double zi = pz[i * NP + k], dzi = pdz[i * NP + k];
+            cstep(i, -dzi, lb - zi, dsb[2 * r], dlb[2 * r]);
+            cstep(17 + i, dzi, zi - ub, dsb[2 * r + 1], dlb[2 * r + 1]);
         }
-        for (int j = half; j < nfk; j += H) {
-            const double a0 = w.face[(3 * j) * NP + k], a1 = w.face[(3 * j + 1) * NP + k], a2 = w.face[(3 * j + 2) * NP + k];
-            double ds, dl, rp, rd, sv, lv;
-            cstep(34 + j, a0 * d8 + a1 * d9 + a2 * d10, a0 * z8 + a1 * z9 + a2 * z10 - w.face[(3 * MF + j) * NP + k] - HU,
-                  ds, dl, rp, rd, sv, lv);
-            m_p = fmax(m_p, rp); m_d = fmax(m_d, rd);
+#pragma unroll
+        for (int t = 0; t < MAXF; t++) {
+            const int j = half + t * H;
+            dsf[t] = dlf[t] = 0.0;
+            if (j < nfk) face(j, dsf[t], dlf[t]);
         }
+        for (int j = half + MAXF * H; j < nfk; j += H) { double a, b; face(j, a, b); }
     }
     m_p = wave_max(m_p); m_d = wave_max(m_d);
-    const double lim = pass ? ftb : 1.0;
-    const double ap = (m_p > lim) ? lim / m_p : 1.0;
-    const double ad = (m_d > lim) ? lim / m_d : 1.0;
-
-    // ---- B: corridor rows: affine complementarity + second-order term (pass 0) / update (pass 1)
-    double l_gapaff = 0.0;
-    if (pass == 0) {
-        if (kact) {
-            for (int j = half; j < nfk; j += H) {
-                const double a0 = w.face[(3 * j) * NP + k], a1 = w.face[(3 * j + 1) * NP + k], a2 = w.face[(3 * j + 2) * NP + k];
-                double ds, dl, rp, rd, sv, lv;
-                cstep(34 + j, a0 * d8 + a1 * d9 + a2 * d10, a0 * z8 + a1 * z9 + a2 * z10 - w.face[(3 * MF + j) * NP + k] - HU,
-                      ds, dl, rp, rd, sv, lv);
-                l_gapaff += (sv + ap * ds) * (lv + ad * dl);
-                w.corr[(34 + j) * NP + k] = ds * dl;
-            }
+    const double ap = (m_p > ftb) ? ftb / m_p : 1.0;
+    const double ad = (m_d > ftb) ? ftb / m_d : 1.0;
+    if (kact) {
+        for (int j = half + MAXF * H; j < nfk; j += H) { // rare: more corridor rounds than kept in registers
+            double a, b;
+            face(j, a, b);
+            ps[(34 + j) * NP + k] += ap * a;
+            pl[(34 + j) * NP + k] += ad * b;
+        }
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int i0 = r * H, i1 = (H == 2) ? i0 + 1 : i0;
-                if (H == 2 && i1 >= NZ && half) continue;
-                const int i = half ? i1 : i0;
-                const double lb = half ? lower_bound(i1 < NZ ? i1 : i0) : lower_bound(i0);
-                const double ub = half ? upper_bound(i1 < NZ ? i1 : i0) : upper_bound(i0);
-                const double zi = w.z[i * NP + k], dzi = w.dz[i * NP + k];
-                double ds, dl, rp, rd, sv, lv;
-                cstep(i, -dzi, lb - zi, ds, dl, rp, rd, sv, lv);
-                l_gapaff += (sv + ap * ds) * (lv + ad * dl);
-                w.corr[i * NP + k] = ds * dl;
-                cstep(17 + i, dzi, zi - ub, ds, dl, rp, rd, sv, lv);
-                l_gapaff += (sv + ap * ds) * (lv + ad * dl);
-                w.corr[(17 + i) * NP + k] = ds * dl;
+        for (int t = 0; t < MAXF; t++) {
+            const int j = half + t * H;
+            if (j < nfk) {
+                ps[(34 + j) * NP + k] += ap * dsf[t];
+                pl[(34 + j) * NP + k] += ad * dlf[t];
             }
-        }
-        const double mu_aff = wave_sum(l_gapaff) / (double)mtot;
-        sigma = mu_aff / mu;
-        sigma = sigma * sigma * sigma;
-        if (sigma > 1.0) sigma = 1.0;
-        smu = sigma * mu;
-        if (smu < MU_FLOOR_FRAC * tol_comp) smu = MU_FLOOR_FRAC * tol_comp;
-        FULLSYNC(); // corr written above is re-read below by the same lanes; also orders LDS staging
-        // corrector rhs: phi = grad f + G'(Sigma r_in + (smu - corr)/s)
-        {
-            double fp0 = 0, fp1 = 0, fp2 = 0;
-            if (kact) {
-                for (int j = half; j < nfk; j += H) {
-                    const double a0 = w.face[(3 * j) * NP + k], a1 = w.face[(3 * j + 1) * NP + k], a2 = w.face[(3 * j + 2) * NP + k];
-                    const double hj = a0 * z8 + a1 * z9 + a2 * z10 - w.face[(3 * MF + j) * NP + k] - HU;
-                    const double sc = w.s[(34 + j) * NP + k], lc = w.lam[(34 + j) * NP + k];
-                    const double t = (lc * (hj + sc) + smu - w.corr[(34 + j) * NP + k]) * (1.0 / sc);
-                    fp0 += a0 * t; fp1 += a1 * t; fp2 += a2 * t;
-                }
-            }
-            if (H == 2) { fp0 = xhalf_sum(fp0); fp1 = xhalf_sum(fp1); fp2 = xhalf_sum(fp2); }
-            if (kact && half == 0) { stg[0 * NP + k] = fp0; stg[1 * NP + k] = fp1; stg[2 * NP + k] = fp2; }
-        }
-        WSYNC();
-        if (kact) {
-            cgdouble *pk = pbase + (size_t)k * np;
-            double pc[NPRE];
-            pc[0] = pk[0]; pc[1] = pk[1]; pc[2] = pk[2]; pc[6] = pk[6]; pc[7] = pk[7]; pc[8] = pk[8]; pc[9] = pk[9];
-            const CostQ cq = make_cost(pc, stage_class(k, N), model);
-            gdouble *rec = w.rec + (size_t)k * REC_STRIDE;
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int i0 = r * H, i1 = (H == 2) ? i0 + 1 : i0;
-                if (H == 2 && i1 >= NZ && half) continue;
-                const int i = half ? i1 : i0;
-                const double hd = half ? cq.hd(i1 < NZ ? i1 : i0) : cq.hd(i0);
-                const double qi = half ? cq.q(i1 < NZ ? i1 : i0) : cq.q(i0);
-                const double lb = half ? lower_bound(i1 < NZ ? i1 : i0) : lower_bound(i0);
-                const double ub = half ? upper_bound(i1 < NZ ? i1 : i0) : upper_bound(i0);
-                const double zi = w.z[i * NP + k];
-                double ph = hd * zi + qi;
-                if (i0 < 8) ph += cq.hc() * w.z[(i < 4 ? i + 4 : i - 4) * NP + k];
-                const double sl = w.s[i * NP + k], su = w.s[(17 + i) * NP + k];
-                const double ll = w.lam[i * NP + k], lu = w.lam[(17 + i) * NP + k];
-                const double rl = lb - zi + sl, ru = zi - ub + su;
-                const double tl = (ll * rl + smu - w.corr[i * NP + k]) * (1.0 / sl);
-                const double tu = (lu * ru + smu - w.corr[(17 + i) * NP + k]) * (1.0 / su);
-                ph += tu - tl;
-                if (i0 + H > 8 && i0 < 11) {
-                    if (i >= 8 && i < 11) ph += stg[(i - 8) * NP + k];
-                }
-                rec[REC_PHI + i] = ph;
-            }
-        }
-    } else if (kact) {
-        for (int j = half; j < nfk; j += H) {
-            const double a0 = w.face[(3 * j) * NP + k], a1 = w.face[(3 * j + 1) * NP + k], a2 = w.face[(3 * j + 2) * NP + k];
-            double ds, dl, rp, rd, sv, lv;
-            cstep(34 + j, a0 * d8 + a1 * d9 + a2 * d10, a0 * z8 + a1 * z9 + a2 * z10 - w.face[(3 * MF + j) * NP + k] - HU,
-                  ds, dl, rp, rd, sv, lv);
-            w.s[(34 + j) * NP + k] = sv + ap * ds;
-            w.lam[(34 + j) * NP + k] = lv + ad * dl;
         }
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const int i0 = r * H, i1 = (H == 2) ? i0 + 1 : i0;
-            if (H == 2 && i1 >= NZ && half) continue;
-            const int i = half ? i1 : i0;
-            const double lb = half ? lower_bound(i1 < NZ ? i1 : i0) : lower_bound(i0);
-            const double ub = half ? upper_bound(i1 < NZ ? i1 : i0) : upper_bound(i0);
-            const double zi = w.z[i * NP + k], dzi = w.dz[i * NP + k];
-            double ds, dl, rp, rd, sv, lv;
-            cstep(i, -dzi, lb - zi, ds, dl, rp, rd, sv, lv);
-            w.s[i * NP + k] = sv + ap * ds;
-            w.lam[i * NP + k] = lv + ad * dl;
-            cstep(17 + i, dzi, zi - ub, ds, dl, rp, rd, sv, lv);
-            w.s[(17 + i) * NP + k] = sv + ap * ds;
-            w.lam[(17 + i) * NP + k] = lv + ad * dl;
-            w.z[i * NP + k] = zi + ap * dzi;
+            const int i = r * H + half;
+            if (i >= NZ) continue;
+            ps[i * NP + k] += ap * dsb[2 * r];
+            pl[i * NP + k] += ad * dlb[2 * r];
+            ps[(17 + i) * NP + k] += ap * dsb[2 * r + 1];
+            pl[(17 + i) * NP + k] += ad * dlb[2 * r + 1];
+            pz[i * NP + k] += ap * pdz[i * NP + k];
         }
     }
+    ap_out = ap; ad_out = ad;
+}
+
+template <int NP>
+__device__ __noinline__ SlackOut phase_step(WsView w, int N, int MF, int nfk, double smu, double ftb)
+{
+    w = uni(w); N = uni(N); MF = uni(MF); smu = uni(smu); ftb = uni(ftb);
+    PROF_BEGIN();
+    FULLSYNC(); // phase boundary: dz of the forward sweep is visible
+    PROF_SEG(6);
+    double ap, ad;
+    step_body<NP>(w.s, w.lam, w.corr, w.z, dz_area<NP>(), w.face, N, MF, nfk, smu, ftb, ap, ad);
+    PROF_SEG(7);
     FULLSYNC();
+    PROF_SEG(8);
+    PROF_END(6);
     SlackOut o;
-    o.ap = ap; o.ad = ad; o.sigma = sigma; o.smu = smu;
+    o.ap = ap; o.ad = ad; o.sigma = 0.0; o.smu = smu;
     return o;
 }
 
 // ------------------------------------------------------------------ costate sweep: y <- y + ap (y+ - y)
 // y+_k = (Phi_k dz_k + phi_k)_s + [0; A_k' y+_{k+1,x}]:  x rows = (C~' [du; dx] + M' y+)_x + phi_x,
 // w rows = Phi_w dw + hc du + phi_w.  Vectors in the column-0 lanes (row layout).
-#ifdef FRP_PROFILE
-__device__ long long g_wait_cycles;
-__device__ long long g_seg[6];
-#endif
+// ------------------------------------------------------------------ costate sweep: y <- y + ap (y+ - y)
+// y+_k = (Phi_k dz_k + phi_k)_s + [0; A_k' y+_{k+1,x}]:  x rows = (C~' [du; dx] + M' y+)_x + phi_x,
+// w rows = Phi_w dw + hc du + phi_w, with phi = phi_cc = PHIB + smu PHIC.
+// Vectors in the column-0 lanes (row layout); dz / y have padding rows so that no row guards are needed.
 template <int NP>
-__device__ __noinline__ void sweep_costate(WsView w, int N, double ap, int theta_i)
+__device__ __noinline__ void sweep_costate(WsView w, int N, double ap, double smu, int theta_i)
 {
-#ifdef FRP_PROFILE
-    long long waitc = 0, seg[6] = {0, 0, 0, 0, 0, 0}, ts;
-#define SEG(i) do { const long long tn_ = clock64(); seg[i] += tn_ - ts; ts = tn_; } while (0)
-#else
-#define SEG(i)
-#endif
-    w = uni(w); N = uni(N); ap = uni(ap); theta_i = uni(theta_i);
+    w = uni(w); N = uni(N); ap = uni(ap); smu = uni(smu); theta_i = uni(theta_i);
     FULLSYNC(); // phase boundary: dz of the forward sweep / updates of the step phase are visible
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
     const double theta = theta_i ? 1.0 : 0.0;
@@ -927,88 +1097,67 @@ __device__ __noinline__ void sweep_costate(WsView w, int N, double ap, int theta
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     d4 y = zero;
     cgdouble *rp = w.rec + (size_t)(N - 1) * REC_STRIDE;
-    double e0 = rp[lane], e1 = rp[64 + lane], e2 = rp[128 + lane], e3 = (lane < 16) ? rp[192 + lane] : 0.0;
+    double e0 = rp[lane], e1 = rp[64 + lane], e2 = rp[128 + lane], e3 = (lane < 56) ? rp[192 + lane] : 0.0;
     d4 nv = zero, nyo = zero; // prefetched dz and old y of the next stage to be processed (column-0 lanes)
-    double ndw = 0.0;
+    double ndu = 0.0;
     if (c == 0) {
-        nv[0] = w.dz[g * NP + N - 1];
-        ndw = w.dz[(4 + g) * NP + N - 1];
-        nyo[0] = w.y[g * NP + N - 1];
+        const double *dzl = dz_area<NP>();
+        ndu = dzl[g * NP + N - 1];
 #pragma unroll
-        for (int r = 1; r < 4; r++)
-            if (4 * r + g <= 12) {
-                nv[r] = w.dz[(4 + 4 * r + g) * NP + N - 1];
-                nyo[r] = w.y[(4 * r + g) * NP + N - 1];
-            }
+        for (int r = 0; r < 4; r++) {
+            nv[r] = dzl[(4 + 4 * r + g) * NP + N - 1];
+            nyo[r] = w.y[(4 * r + g) * NP + N - 1];
+        }
     }
     for (int kk = N - 1; kk >= 0; kk--) {
         const bool last = (kk == N - 1);
         WSYNC();
-#ifdef FRP_PROFILE
-        const long long tw0 = clock64();
-        ts = tw0;
-#endif
         sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1; sm[S_E + 128 + lane] = e2;
-        if (lane < 16) sm[S_E + 192 + lane] = e3;
-#ifdef FRP_PROFILE
-        __builtin_amdgcn_s_waitcnt(0);
-        waitc += clock64() - tw0;
-#endif
-        const d4 v2 = nv, yo = nyo;
-        const double dw = ndw;
+        if (lane < 56) sm[S_E + 192 + lane] = e3;
+        const d4 ds = nv, yo = nyo;
+        const double du = ndu;
         if (kk > 0) {
             cgdouble *rn = w.rec + (size_t)(kk - 1) * REC_STRIDE;
-            e0 = rn[lane]; e1 = rn[64 + lane]; e2 = rn[128 + lane]; e3 = (lane < 16) ? rn[192 + lane] : 0.0;
+            e0 = rn[lane]; e1 = rn[64 + lane]; e2 = rn[128 + lane]; e3 = (lane < 56) ? rn[192 + lane] : 0.0;
             if (c == 0) {
-                nv[0] = w.dz[g * NP + kk - 1];
-                ndw = w.dz[(4 + g) * NP + kk - 1];
-                nyo[0] = w.y[g * NP + kk - 1];
+                const double *dzl = dz_area<NP>();
+                ndu = dzl[g * NP + kk - 1];
 #pragma unroll
-                for (int r = 1; r < 4; r++)
-                    if (4 * r + g <= 12) {
-                        nv[r] = w.dz[(4 + 4 * r + g) * NP + kk - 1];
-                        nyo[r] = w.y[(4 * r + g) * NP + kk - 1];
-                    }
+                for (int r = 0; r < 4; r++) {
+                    nv[r] = dzl[(4 + 4 * r + g) * NP + kk - 1];
+                    nyo[r] = w.y[(4 * r + g) * NP + kk - 1];
+                }
             }
         }
         WSYNC();
-        SEG(0);
         const double hc = sm[S_E + REC_HC];
-        d4 C;
+        d4 C, v2 = ds;
+        v2[0] = du; // [du; dx] over the (u, x) tile index; ds[0] = dw is used for the w rows below
 #pragma unroll
         for (int r = 0; r < 4; r++) C[r] = sm[c1[r]] + sm[c2[r]] + theta * sm[c3[r]];
-        SEG(1);
         d4 D = mm_tn(C, v2, zero);
-        SEG(2);
         if (!last) {
             d4 M;
 #pragma unroll
             for (int r = 0; r < 4; r++) M[r] = sm[mo[r]];
             D = mm_tn(M, y, D);
         }
-        SEG(3);
         d4 yn = zero;
         if (c == 0) {
-            yn[0] = sm[S_E + REC_PHID + 4 + g] * dw + hc * v2[0] + sm[S_E + REC_PHI + 4 + g];
-            w.y[g * NP + kk] = yo[0] + ap * (yn[0] - yo[0]);
+            const int zw = 4 + g;
+            yn[0] = sm[S_E + REC_PHID + zw] * ds[0] + hc * du + sm[S_E + REC_PHIB + zw] + smu * sm[S_E + REC_PHIC + zw];
 #pragma unroll
             for (int r = 1; r < 4; r++) {
-                const int row = 4 * r + g;
-                if (row <= 12) {
-                    yn[r] = D[r] + sm[S_E + REC_PHI + row + 4];
-                    w.y[row * NP + kk] = yo[r] + ap * (yn[r] - yo[r]);
-                }
+                const int zr = (4 * r + g <= 12) ? 4 * r + g + 4 : 16; // pad rows alias a valid slot, result discarded
+                yn[r] = (4 * r + g <= 12) ? D[r] + sm[S_E + REC_PHIB + zr] + smu * sm[S_E + REC_PHIC + zr] : 0.0;
             }
+#pragma unroll
+            for (int r = 0; r < 4; r++) w.y[(4 * r + g) * NP + kk] = yo[r] + ap * (yn[r] - yo[r]);
         }
         y = yn;
-        SEG(4);
     }
     WSYNC();
-#ifdef FRP_PROFILE
-    if (lane == 0) { g_wait_cycles = waitc; for (int i = 0; i < 6; i++) g_seg[i] = seg[i]; }
-#endif
 }
-
 
 // ------------------------------------------------------------------ the solver kernel
 template <int NP>
@@ -1026,11 +1175,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
         w.rec = base;
         w.z = w.rec + (size_t)N * REC_STRIDE;
         w.y = w.z + 17 * NP;
-        w.dz = w.y + 13 * NP;
-        w.s = w.dz + 17 * NP;
+        w.dz = w.y + Y_ROWS * NP;
+        w.s = w.dz + DZ_ROWS * NP;
         w.lam = w.s + (size_t)mcf * NP;
         w.corr = w.lam + (size_t)mcf * NP;
-        w.face = w.corr + (size_t)mcf * NP;
+        w.step = w.corr + (size_t)mcf * NP;       // ds | dlam of the corrector step ([2 mcf][NP])
+        w.face = w.step + 2 * (size_t)mcf * NP;
     }
     cgdouble *xinit = (cgdouble *)(a.xinit + (size_t)b * 9);
     cgdouble *pbase = (cgdouble *)(a.params + (size_t)b * N * np);
@@ -1082,6 +1232,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
         rec[REC_HC] = -2.0 * pk[8]; // (u_i, w_i) cost coupling of this stage (constant)
         for (int i = 0; i < 100; i++) rec[REC_HD + i] = 0.0; // stays zero in Gauss-Newton mode / last stage
         for (int i = 0; i < 64; i++) rec[i] = 0.0;           // linearisation of the last stage is never written
+        for (int i = 125; i < 128; i++) rec[i] = 0.0;        // padding slots of the E record
+        for (int i = 145; i < 148; i++) rec[i] = 0.0;
+        for (int i = 0; i < 3; i++) { // padding rows (tile rows 13..15) of dz and y
+            dz_area<NP>()[(17 + i) * NP + k] = 0.0;
+            w.y[(13 + i) * NP + k] = 0.0;
+        }
     }
     smin = wave_min(smin);
     const int mtot = (int)wave_sum(act ? (double)(34 + nf) : 0.0);
@@ -1143,18 +1299,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
         TOCK(1);
         sweep_forward<NP>(w, N);
         TOCK(2);
-        const SlackOut s0 = phase_slack<NP>(w, pbase, np, N, MF, nfk, a.model, 0, 0.0, mu, mtot, a.ftb, a.tol_comp);
+        const SlackOut s0 = phase_affine<NP>(w, pbase, np, N, MF, nfk, a.model, mu, mtot, a.tol_comp);
         sigma = s0.sigma;
         TOCK(3);
         // corrector solve (same factorisation, new rhs)
-        sweep_backvec<NP>(w, xinit, N);
+        sweep_backvec<NP>(w, xinit, N, s0.smu);
         TOCK(4);
         sweep_forward<NP>(w, N);
         TOCK(2);
-        const SlackOut s1 = phase_slack<NP>(w, pbase, np, N, MF, nfk, a.model, 1, s0.smu, mu, mtot, a.ftb, a.tol_comp);
+        const SlackOut s1 = phase_step<NP>(w, N, MF, nfk, s0.smu, a.ftb);
         step_cc = s1.ap;
         TOCK(3);
-        sweep_costate<NP>(w, N, s1.ap, theta);
+        sweep_costate<NP>(w, N, s1.ap, s0.smu, theta);
         TOCK(5);
     }
 
@@ -1173,8 +1329,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
             o[0] = res_eq; o[1] = res_in; o[2] = rs; o[3] = rcomp; o[4] = pobj; o[5] = mu; o[6] = step_cc; o[7] = (double)nfallback;
 #ifdef FRP_PROFILE
             for (int i = 0; i < 6; i++) o[i] = (double)tph[i]; // cycles: eval, factor, forward(x2), slack(x2), backvec, costate
-            o[6] = (double)g_wait_cycles; // load-wait cycles of the LAST costate sweep
-            o[0] = (double)g_seg[0]; o[1] = (double)g_seg[1]; o[2] = (double)g_seg[2]; o[3] = (double)g_seg[3]; o[4] = (double)g_seg[4];
 #endif
         }
     }
@@ -1264,4 +1418,17 @@ hipError_t launch_stage_eval(int B, int N, int M, int model, const double *z, co
     return hipGetLastError();
 }
 
+#ifdef FRP_PROFILE
+void debug_read_prof(long long *out)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(long long) * 24);
+    long long z[24] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z);
+}
+#endif
+
 } // namespace frp
+
+#ifdef FRP_PROFILE
+extern "C" void frp_debug_read_prof(long long *out) { frp::debug_read_prof(out); }
+#endif

@@ -343,12 +343,33 @@ int orc_solve(int N, int M, int model, const double *xinit, const double *z0,
     const int np = ORC_NPRE + 4 * M, mc = 34 + M;
     solver_ws W;
     W.N = N; W.M = M; W.mc = mc;
-    W.st = (stage_ws *)calloc(N, sizeof(stage_ws));
-    double *buf = (double *)calloc((size_t)N * (17 * 2 + NS * 2 + 6 * mc), sizeof(double));
+    /* per-thread scratch, grown on demand and reused across solves (a calloc/free pair per solve
+     * serialises 100+ OpenMP threads on the allocator) */
+    static __thread stage_ws *tl_st = 0;
+    static __thread double *tl_buf = 0;
+    static __thread int *tl_nf = 0;
+    static __thread size_t tl_nst = 0, tl_nbuf = 0;
+    const size_t need_buf = (size_t)N * (17 * 2 + NS * 2 + 6 * mc);
+    if (tl_nst < (size_t)N) {
+        free(tl_st); free(tl_nf);
+        tl_st = (stage_ws *)malloc((size_t)N * sizeof(stage_ws));
+        tl_nf = (int *)malloc((size_t)N * sizeof(int));
+        tl_nst = (size_t)N;
+    }
+    if (tl_nbuf < need_buf) {
+        free(tl_buf);
+        tl_buf = (double *)malloc(need_buf * sizeof(double));
+        tl_nbuf = need_buf;
+    }
+    memset(tl_st, 0, (size_t)N * sizeof(stage_ws));
+    memset(tl_buf, 0, need_buf * sizeof(double));
+    memset(tl_nf, 0, (size_t)N * sizeof(int));
+    W.st = tl_st;
+    double *buf = tl_buf;
     W.z = buf; W.dz = W.z + 17 * N; W.y = W.dz + 17 * N; W.ynew = W.y + NS * N;
     W.s = W.ynew + NS * N; W.lam = W.s + (size_t)N * mc; W.ds = W.lam + (size_t)N * mc;
     W.dlam = W.ds + (size_t)N * mc; W.rin = W.dlam + (size_t)N * mc; W.corr = W.rin + (size_t)N * mc;
-    W.nf = (int *)calloc(N, sizeof(int));
+    W.nf = tl_nf;
     double lb[17], ub[17];
     orc_bounds(lb, ub);
     memcpy(W.z, z0, sizeof(double) * 17 * N);
@@ -532,7 +553,6 @@ int orc_solve(int N, int M, int model, const double *xinit, const double *z0,
     memcpy(zout, W.z, sizeof(double) * 17 * N);
     inf.nfallback = nfallback;
     if (info) *info = inf;
-    free(W.st); free(buf); free(W.nf);
     return flag;
 }
 
@@ -544,7 +564,7 @@ void orc_solve_batch(int B, int N, int M, int model, const double *xinit, const 
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
-#pragma omp parallel for schedule(dynamic, 4)
+#pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < B; b++) {
         orc_info inf;
         const int fl = orc_solve(N, M, model, xinit + 9 * (size_t)b, z0 + 17 * (size_t)N * b, params + np * b,
