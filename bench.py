@@ -30,11 +30,33 @@ FP64_PEAK_TFLOPS = 78.6          # MI355X FP64 vector == matrix peak (AMD datash
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md
 
 
+def usable_cores():
+    """Host cores this process may actually use: min(cpu_count, affinity mask, cgroup CPU quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(w, seconds_target=12.0):
     """The CPU oracle (same algorithm, FP64, OpenMP over problems) timed on a bounded sample of the
     same workload on this box's host cores.  Test infrastructure used only as the reported baseline."""
     import tests.oracle_lib as OL
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     B = w["xinit"].shape[0]
     OL.solve_batch(w, nthreads=cores)  # warm up threads / page in
     reps, solved, t0 = 0, 0, time.perf_counter()
@@ -51,7 +73,8 @@ def cpu_baseline(w, seconds_target=12.0):
     return dict(value=solved / dt, unit="solves/s", cores=cores, kind="port",
                 sample=f"the same {B}-problem batch solved {reps}x by oracle/liboracle.so (FP64 CPU restatement of the "
                        f"same interior-point method, not ForcesPro: its binary is licence-locked), OpenMP over problems on "
-                       f"{cores} threads, {dt:.1f} s; single-thread {n1 / dt1:.0f} solves/s",
+                       f"{cores} threads (os.cpu_count()={os.cpu_count()}, affinity/cgroup-limited to {cores}), {dt:.1f} s; "
+                       f"single-thread {n1 / dt1:.0f} solves/s",
                 converged_frac=conv / solved)
 
 
