@@ -21,7 +21,10 @@ constexpr int REC_E_SIZE = 248;
 //   F part (written by the factorisation sweep, 80 doubles):
 constexpr int REC_T = 248;      // T' = [R | Kbar_x | kbar | hc] as tile register 0 (64): lane (g,c) <-> T'[g][c]
 constexpr int REC_PD = 312;     // P_{k+1} d (16, s-order rows)
-constexpr int REC_STRIDE = 328;
+constexpr int REC_PV = 328;     // p_k of the corrector solve (16, s-order rows)
+constexpr int REC_P = 344;      // P_k, packed lower triangle: (row, col <= row) -> row (row + 1) / 2 + col  (91, padded 96)
+constexpr int REC_STRIDE = 440;
+constexpr int REC_ZERO = 125;   // a slot of the record that always holds 0.0 (target of masked gathers)
 constexpr int DZ_ROWS = 20;     // dz rows: du(4) + ds(13) + 3 pad rows (tile rows 13..15)
 constexpr int Y_ROWS = 16;      // y rows: 13 + 3 pad rows
 
@@ -39,6 +42,7 @@ struct KernelArgs {
     int *exitflag, *iters;
     double *info;
     double *ws;
+    int *counter; // work-queue head (set by the launcher)
 };
 
 size_t ws_bytes(int B, int N, int MF);

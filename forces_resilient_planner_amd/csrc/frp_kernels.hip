@@ -35,6 +35,7 @@ namespace frp {
 #ifndef FRP_WAVES_PER_EU
 #define FRP_WAVES_PER_EU 2
 #endif
+#define FRP_MAX_SLOTS 4096 // upper bound of resident single-wave workgroups the workspace is sized for
 
 // ------------------------------------------------------------------ wave helpers
 __device__ __forceinline__ double wave_max(double v)
@@ -149,7 +150,8 @@ struct WsView {
     gdouble *rec, *z, *y, *dz, *s, *lam, *corr, *face, *step;
 };
 
-__host__ __device__ inline int padded_stages(int N) { return N <= 32 ? 32 : 64; }
+// stage stride NP of the [row][stage] arrays = lanes per row group of the element-wise phases (H = 64 / NP groups)
+__host__ __device__ inline int padded_stages(int N) { return N <= 16 ? 16 : (N <= 20 ? 20 : (N <= 32 ? 32 : 64)); }
 
 __host__ __device__ inline size_t ws_doubles_per_problem(int N, int MF)
 {
@@ -189,10 +191,12 @@ __shared__ double sm[L_TOTAL];
 // Newton step dz = [du(4); ds(13); 3 pad rows][NP]: written by the forward sweep, read by the step phases and the
 // costate sweep -- kept in LDS so that the sweeps carry no global stores for it (a store in the loop makes the
 // staging write of the next stage wait for vmcnt(0))
+__shared__ double sm_dz16[DZ_ROWS * 16];
+__shared__ double sm_dz20[DZ_ROWS * 20];
 __shared__ double sm_dz32[DZ_ROWS * 32];
 __shared__ double sm_dz64[DZ_ROWS * 64];
 template <int NP>
-__device__ __forceinline__ double *dz_area() { return NP == 32 ? sm_dz32 : sm_dz64; }
+__device__ __forceinline__ double *dz_area() { return NP == 16 ? sm_dz16 : (NP == 20 ? sm_dz20 : (NP == 32 ? sm_dz32 : sm_dz64)); }
 
 #ifdef FRP_PROFILE
 __device__ long long g_prof[24];
@@ -273,9 +277,32 @@ struct EvalOut {
 // gm[17][NP] multiplier part of the stationarity residual, gf[6][NP] corridor sums for pos entries.
 __shared__ double sm_big[23 * 64]; // only referenced (hence only allocated) by the NP = 64 instantiation
 template <int NP>
-__device__ __forceinline__ double *stage_area() { return NP == 32 ? sm : sm_big; }
+__device__ __forceinline__ double *stage_area() { return NP <= 32 ? sm : sm_big; }
 
-__device__ __forceinline__ double xhalf_sum(double v) { return v + __shfl_xor(v, 32); }
+// Lane groups of the element-wise phases: lane = sub * NP + k with sub in [0, H), H = 64 / NP (NP = 20: lanes
+// 60..63 idle).  xsub_sum adds the values of the H lanes that share a stage k (result valid in the sub == 0 lanes).
+template <int NP>
+__device__ __forceinline__ double xsub_sum(double v)
+{
+    constexpr int H = 64 / NP;
+    if (H == 2) return v + __shfl_xor(v, 32);
+    if (H == 4) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+    if (H == 3) {
+        const int lane = threadIdx.x;
+        const double a = __shfl(v, lane + NP < 64 ? lane + NP : lane), b = __shfl(v, lane + 2 * NP < 64 ? lane + 2 * NP : lane);
+        return v + a + b;
+    }
+    return v;
+}
+// value of a per-row constant for row i = r*H + sub, chosen among the H compile-time candidates of round r
+#define ROW_PICK(expr_of_i)                                                                         \
+    ([&]() {                                                                                          \
+        double v_ = [&](int i) { return (double)(expr_of_i); }(ib < NZ ? ib : NZ - 1);                 \
+        if (H > 1 && half == 1) v_ = [&](int i) { return (double)(expr_of_i); }(ib + 1 < NZ ? ib + 1 : NZ - 1); \
+        if (H > 2 && half == 2) v_ = [&](int i) { return (double)(expr_of_i); }(ib + 2 < NZ ? ib + 2 : NZ - 1); \
+        if (H > 3 && half == 3) v_ = [&](int i) { return (double)(expr_of_i); }(ib + 3 < NZ ? ib + 3 : NZ - 1); \
+        return v_;                                                                                    \
+    }())
 
 // part 2 of the evaluation phase (see phase_eval); arrays as __restrict__ parameters so that the loads of
 // several row rounds can be batched across the record stores
@@ -289,7 +316,7 @@ __device__ __forceinline__ void eval_rows(cgdouble *__restrict__ ps, cgdouble *_
     const int lane = threadIdx.x;
     // ---- part 2: all 64 lanes, lane = (half, stage k); rows handled in pairs
     const int k = lane % NP, half = lane / NP;
-    const bool kact = k < N;
+    const bool kact = k < N && half < H;
     // corridor rows: sums over the faces of a stage (pos entries 8..10 only)
     {
         double gp0 = 0, gp1 = 0, gp2 = 0, fp0 = 0, fp1 = 0, fp2 = 0, p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0;
@@ -310,11 +337,11 @@ __device__ __forceinline__ void eval_rows(cgdouble *__restrict__ ps, cgdouble *_
                 p3 += sg * a1 * a1; p4 += sg * a1 * a2; p5 += sg * a2 * a2;
             }
         }
-        if (H == 2) {
-            gp0 = xhalf_sum(gp0); gp1 = xhalf_sum(gp1); gp2 = xhalf_sum(gp2);
-            fp0 = xhalf_sum(fp0); fp1 = xhalf_sum(fp1); fp2 = xhalf_sum(fp2);
-            p0 = xhalf_sum(p0); p1 = xhalf_sum(p1); p2 = xhalf_sum(p2);
-            p3 = xhalf_sum(p3); p4 = xhalf_sum(p4); p5 = xhalf_sum(p5);
+        if (H > 1) {
+            gp0 = xsub_sum<NP>(gp0); gp1 = xsub_sum<NP>(gp1); gp2 = xsub_sum<NP>(gp2);
+            fp0 = xsub_sum<NP>(fp0); fp1 = xsub_sum<NP>(fp1); fp2 = xsub_sum<NP>(fp2);
+            p0 = xsub_sum<NP>(p0); p1 = xsub_sum<NP>(p1); p2 = xsub_sum<NP>(p2);
+            p3 = xsub_sum<NP>(p3); p4 = xsub_sum<NP>(p4); p5 = xsub_sum<NP>(p5);
         }
         if (kact && half == 0) {
             gdouble *rec = prec + (size_t)k * REC_STRIDE;
@@ -336,16 +363,15 @@ __device__ __forceinline__ void eval_rows(cgdouble *__restrict__ ps, cgdouble *_
         constexpr int R = (NZ + H - 1) / H;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const int i0 = r * H, i1 = (H == 2) ? i0 + 1 : i0;
-            if (H == 2 && i1 >= NZ && half) continue;
-            const int i = half ? i1 : i0;
-            const double hd = half ? cq.hd(i1 < NZ ? i1 : i0) : cq.hd(i0);
-            const double qi = half ? cq.q(i1 < NZ ? i1 : i0) : cq.q(i0);
-            const double lb = half ? lower_bound(i1 < NZ ? i1 : i0) : lower_bound(i0);
-            const double ub = half ? upper_bound(i1 < NZ ? i1 : i0) : upper_bound(i0);
+            const int ib = r * H, i = ib + half;
+            if (i >= NZ) continue;
+            const double hd = ROW_PICK(cq.hd(i));
+            const double qi = ROW_PICK(cq.q(i));
+            const double lb = ROW_PICK(lower_bound(i));
+            const double ub = ROW_PICK(upper_bound(i));
             const double zi = pz[i * NP + k];
             double cg = hd * zi + qi; // cost gradient
-            if (i0 < 8) cg += cq.hc() * pz[(i < 4 ? i + 4 : i - 4) * NP + k];
+            if (ib < 8) cg += (i < 8 ? cq.hc() : 0.0) * pz[(i < 4 ? i + 4 : (i < 8 ? i - 4 : i)) * NP + k];
             const double sl = ps[i * NP + k], su = ps[(17 + i) * NP + k];
             const double ll = pl[i * NP + k], lu = pl[(17 + i) * NP + k];
             const double vl = lb - zi, vu = zi - ub;
@@ -356,7 +382,7 @@ __device__ __forceinline__ void eval_rows(cgdouble *__restrict__ ps, cgdouble *_
             const double sgl = ll * (1.0 / sl), sgu = lu * (1.0 / su);
             double gi = cg + stg[i * NP + k] + lu - ll;
             double ph = cg + sgu * ru - sgl * rl;
-            if (i0 + H > 8 && i0 < 11) {
+            if (ib + H > 8 && ib < 11) {
                 if (i >= 8 && i < 11) { gi += stg[(17 + i - 8) * NP + k]; ph += stg[(17 + 3 + i - 8) * NP + k]; }
             }
             rec[REC_PHID + i] = hd + sgl + sgu;
@@ -521,12 +547,83 @@ __device__ __forceinline__ void stage0_solve(const WsView &w, cgdouble *xinit, i
 //   P <- [Phi_w - hc^2 R, -hc Kbar_x; -hc Kbar_x', S_xx],  p <- [phi_w - hc kbar; S_x,13].
 // Streams T' = [R | Kbar_x | kbar | hc] and P d to the stage record.  Returns 1 when a pivot block
 // is not positive definite (exact Hessian: the caller retries with theta = 0, Gauss-Newton).
-// Software pipeline: while the MFMA chain of stage k executes, the wave stages the (prefetched) record of
-// stage k-1 through LDS and assembles its tiles, and issues the global prefetch of stage k-2.
-struct FactorTiles {
-    d4 C, M;
-    double hc, PhiDw, phiw;
-};
+// Software pipeline as in the other sweeps: while the MFMA chain of stage k executes, the wave stages the
+// (prefetched) record of stage k-1 through LDS and assembles its tiles into the alternate register set, and issues
+// the global prefetch of stage k-2.
+template <int NP>
+__device__ __forceinline__ bool factor_step(const WsView &w, int kk, bool last, int lane, int g, int c, double theta,
+                                            const int (&mo)[4], const int (&c1)[4], const int (&c2)[4], const int (&c3)[4],
+                                            const d4 &cC, const d4 &cM, double chc, double cPhiDw, double cphiw,
+                                            d4 &nC, d4 &nM, double &nhc, double &nPhiDw, double &nphiw,
+                                            double &e0, double &e1, double &e2, double &e3, d4 &P, d4 &pv)
+{
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    gdouble *rec = w.rec + (size_t)kk * REC_STRIDE;
+    d4 G = cC;
+    if (!last) {
+        d4 X = mm_tn(P, cM, zero);
+        if (c == 13) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                rec[REC_PD + 4 * r + g] = X[r];
+                X[r] += pv[r];
+            }
+        }
+        G = mm_tn(cM, X, cC);
+    }
+    // ---- between / behind the MFMAs: tiles of stage kk-1 (clamped at 0: the tail re-stages stage 0, unused)
+    WSYNC();
+    sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1; sm[S_E + 128 + lane] = e2;
+    if (lane < 56) sm[S_E + 192 + lane] = e3;
+    WSYNC();
+    {
+        const int k2 = kk > 1 ? kk - 2 : 0;
+        cgdouble *r2 = w.rec + (size_t)k2 * REC_STRIDE;
+        e0 = r2[lane]; e1 = r2[64 + lane]; e2 = r2[128 + lane]; e3 = r2[192 + (lane < 56 ? lane : 0)];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        nC[r] = sm[c1[r]] + sm[c2[r]] + theta * sm[c3[r]];
+        nM[r] = sm[mo[r]];
+    }
+    nhc = sm[S_E + REC_HC];
+    nPhiDw = sm[S_E + REC_PHID + 4 + g];
+    nphiw = sm[S_E + REC_PHI + 4 + g];
+    // ---- R = Guu^-1 (4 x 4): gather the lower triangle to uniform registers, invert redundantly
+    double q[16], R[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) q[i * 4 + j] = lane_bcast(G[0], 16 * i + j);
+    if (!spd4_inverse(q, R)) return false;
+#pragma unroll
+    for (int t = 0; t < 16; t++) sm[S_R + t] = R[t];
+    WSYNC();
+    const double rt = (c < 4) ? sm[S_R + g * 4 + c] : 0.0;
+    const double hc = chc;
+    const d4 T = mm_tn4(rt, G[0], zero);
+    const d4 TT = mm_tn4(G[0], rt, zero);
+    const d4 S = mm_tn4(-G[0], T[0], G);
+    rec[REC_T + lane] = (c < 4) ? rt : (c <= 13 ? T[0] : (lane == 14 ? hc : 0.0));
+    d4 Pn, pn;
+    Pn[0] = (c < 4) ? ((g == c ? cPhiDw : 0.0) - hc * hc * rt) : (c <= 12 ? -hc * T[0] : 0.0);
+    pn[0] = (c == 13) ? (cphiw - hc * T[0]) : 0.0;
+#pragma unroll
+    for (int r = 1; r < 4; r++) {
+        const bool inb = (4 * r + g) <= 12;
+        Pn[r] = (inb && c <= 12) ? (c < 4 ? -hc * TT[r] : S[r]) : 0.0;
+        pn[r] = (inb && c == 13) ? S[r] : 0.0;
+    }
+    P = Pn;
+    pv = pn;
+    // P_k (packed lower triangle) for the multiplier recovery y_k = P_k ds_k + p_k in the forward sweep
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = 4 * r + g;
+        if (row <= 12 && c <= row) rec[REC_P + row * (row + 1) / 2 + c] = Pn[r];
+    }
+    return true;
+}
 
 template <int NP>
 __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, int theta_i)
@@ -544,81 +641,36 @@ __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, int t
     init_stage_constants(lane);
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     d4 P = zero, pv = zero;
-    bool fail = false;
+    bool ok = true;
     double e0, e1, e2, e3;
-    auto fetch = [&](int kk) {
-        cgdouble *rp = w.rec + (size_t)kk * REC_STRIDE;
-        e0 = rp[lane]; e1 = rp[64 + lane]; e2 = rp[128 + lane]; e3 = (lane < 56) ? rp[192 + lane] : 0.0;
-    };
-    auto stage = [&]() -> FactorTiles { // regs -> LDS -> tiles of that stage
+    d4 CA, MA, CB = zero, MB = zero;
+    double hcA, PhiDwA, phiwA, hcB = 0.0, PhiDwB = 0.0, phiwB = 0.0;
+    { // prologue: tiles of stage N-1 into set A, prefetch of stage N-2
+        cgdouble *rp = w.rec + (size_t)(N - 1) * REC_STRIDE;
+        e0 = rp[lane]; e1 = rp[64 + lane]; e2 = rp[128 + lane]; e3 = rp[192 + (lane < 56 ? lane : 0)];
         WSYNC();
         sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1; sm[S_E + 128 + lane] = e2;
         if (lane < 56) sm[S_E + 192 + lane] = e3;
         WSYNC();
-        FactorTiles t;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            t.C[r] = sm[c1[r]] + sm[c2[r]] + theta * sm[c3[r]];
-            t.M[r] = sm[mo[r]];
+            CA[r] = sm[c1[r]] + sm[c2[r]] + theta * sm[c3[r]];
+            MA[r] = sm[mo[r]];
         }
-        t.hc = sm[S_E + REC_HC];
-        t.PhiDw = sm[S_E + REC_PHID + 4 + g];
-        t.phiw = sm[S_E + REC_PHI + 4 + g];
-        return t;
-    };
-    fetch(N - 1);
-    FactorTiles cur = stage();
-    if (N > 1) fetch(N - 2);
-    for (int kk = N - 1; kk >= 0; kk--) {
-        gdouble *rec = w.rec + (size_t)kk * REC_STRIDE;
-        const bool last = (kk == N - 1);
-        d4 G = cur.C;
-        if (!last) {
-            d4 X = mm_tn(P, cur.M, zero);
-            if (c == 13) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    rec[REC_PD + 4 * r + g] = X[r];
-                    X[r] += pv[r];
-                }
-            }
-            G = mm_tn(cur.M, X, cur.C);
-        }
-        // ---- overlapped with the MFMA chain above: tiles of the next stage to be processed
-        FactorTiles nxt = cur;
-        if (kk > 0) {
-            nxt = stage();
-            if (kk > 1) fetch(kk - 2);
-        }
-        // ---- R = Guu^-1 (4 x 4): gather the lower triangle to uniform registers, invert redundantly
-        double q[16], R[16];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j <= i; j++) q[i * 4 + j] = lane_bcast(G[0], 16 * i + j);
-        if (!spd4_inverse(q, R)) { fail = true; break; }
-#pragma unroll
-        for (int t = 0; t < 16; t++) sm[S_R + t] = R[t];
-        WSYNC();
-        const double rt = (c < 4) ? sm[S_R + g * 4 + c] : 0.0;
-        const double hc = cur.hc;
-        const d4 T = mm_tn4(rt, G[0], zero);
-        const d4 TT = mm_tn4(G[0], rt, zero);
-        const d4 S = mm_tn4(-G[0], T[0], G);
-        rec[REC_T + lane] = (c < 4) ? rt : (c <= 13 ? T[0] : (lane == 14 ? hc : 0.0));
-        d4 Pn, pn;
-        Pn[0] = (c < 4) ? ((g == c ? cur.PhiDw : 0.0) - hc * hc * rt) : (c <= 12 ? -hc * T[0] : 0.0);
-        pn[0] = (c == 13) ? (cur.phiw - hc * T[0]) : 0.0;
-#pragma unroll
-        for (int r = 1; r < 4; r++) {
-            const bool inb = (4 * r + g) <= 12;
-            Pn[r] = (inb && c <= 12) ? (c < 4 ? -hc * TT[r] : S[r]) : 0.0;
-            pn[r] = (inb && c == 13) ? S[r] : 0.0;
-        }
-        P = Pn;
-        pv = pn;
-        cur = nxt;
+        hcA = sm[S_E + REC_HC];
+        PhiDwA = sm[S_E + REC_PHID + 4 + g];
+        phiwA = sm[S_E + REC_PHI + 4 + g];
+        cgdouble *r2 = w.rec + (size_t)(N > 1 ? N - 2 : 0) * REC_STRIDE;
+        e0 = r2[lane]; e1 = r2[64 + lane]; e2 = r2[128 + lane]; e3 = r2[192 + (lane < 56 ? lane : 0)];
     }
+    int kk = N - 1;
+    for (; kk >= 1 && ok; kk -= 2) {
+        ok = factor_step<NP>(w, kk, kk == N - 1, lane, g, c, theta, mo, c1, c2, c3, CA, MA, hcA, PhiDwA, phiwA, CB, MB, hcB, PhiDwB, phiwB, e0, e1, e2, e3, P, pv);
+        if (!ok) break;
+        ok = factor_step<NP>(w, kk - 1, false, lane, g, c, theta, mo, c1, c2, c3, CB, MB, hcB, PhiDwB, phiwB, CA, MA, hcA, PhiDwA, phiwA, e0, e1, e2, e3, P, pv);
+    }
+    if (ok && kk == 0) ok = factor_step<NP>(w, 0, N == 1, lane, g, c, theta, mo, c1, c2, c3, CA, MA, hcA, PhiDwA, phiwA, CB, MB, hcB, PhiDwB, phiwB, e0, e1, e2, e3, P, pv);
+    bool fail = !ok;
     if (!fail) {
         // stage 0: keep Pww^-1 and Pwx for the corrector pass, then solve for ds_0
         double q[16], Rw[16];
@@ -641,11 +693,59 @@ __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, int t
 
 // ------------------------------------------------------------------ vector-only backward sweep (corrector)
 // Same factorisation, new rhs phi_cc = PHIB + smu PHIC:  q~ = phi~ + M'(P d + p+),  [kbar; Kbar'q_u] = T'' q_u,
-// p_x = q~_x - Kbar' q_u,  p_w = phi_w - hc kbar.  Updates the kbar column of T'.
-struct BackvecTiles {
-    d4 M, Gp, pd;
-    double hc, phiw, tp;
-};
+// p_x = q~_x - Kbar' q_u,  p_w = phi_w - hc kbar.  Updates the kbar column of T' and stores p_k.
+// Same software pipeline as the forward sweep: LDS-staged operands (M, phi) are prepared one stage ahead between
+// the MFMAs, register operands (T', P d) are loaded one stage ahead straight into the alternate register set.
+template <int NP>
+__device__ __forceinline__ void backvec_step(const WsView &w, int kk, bool last, int lane, int g, int c, double smu,
+                                             const int (&mo)[4], const int (&po)[4],
+                                             const d4 &cM, const d4 &cGp, double chc, double cphiw, double ctp, const d4 &cpd,
+                                             d4 &nM, d4 &nGp, double &nhc, double &nphiw, double &ntp, d4 &npd,
+                                             double &e0, double &e1, double &e2, d4 &pv)
+{
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    gdouble *rec = w.rec + (size_t)kk * REC_STRIDE;
+    d4 Gp = cGp;
+    if (!last) {
+        d4 X;
+#pragma unroll
+        for (int r = 0; r < 4; r++) X[r] = (c == 13) ? cpd[r] + pv[r] : 0.0;
+        Gp = mm_tn(cM, X, Gp);
+    }
+    // ---- between the MFMAs: operands of stage kk-1 (clamped at 0: the tail re-stages stage 0, unused)
+    WSYNC();
+    sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1;
+    if (lane < 17) sm[S_E + REC_PHIC + lane] = e2;
+    WSYNC();
+    {
+        const int k1 = kk > 0 ? kk - 1 : 0, k2 = kk > 1 ? kk - 2 : 0;
+        cgdouble *r1 = w.rec + (size_t)k1 * REC_STRIDE, *r2 = w.rec + (size_t)k2 * REC_STRIDE;
+        ntp = r1[REC_T + lane];
+#pragma unroll
+        for (int r = 0; r < 4; r++) npd[r] = r1[(c == 13) ? REC_PD + 4 * r + g : REC_ZERO];
+        e0 = r2[lane]; e1 = r2[64 + lane]; e2 = r2[REC_PHIC + (lane < 17 ? lane : 0)];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        nM[r] = sm[mo[r]];
+        const int o = po[r] >= 0 ? po[r] : 0;
+        const double ph = sm[S_E + REC_PHIB + o] + smu * sm[S_E + REC_PHIC + o];
+        nGp[r] = (po[r] >= 0) ? ph : 0.0;
+    }
+    nhc = sm[S_E + REC_HC];
+    nphiw = sm[S_E + REC_PHIB + 4 + g] + smu * sm[S_E + REC_PHIC + 4 + g];
+    const d4 E = mm_tn4(ctp, Gp[0], zero);
+    d4 pn;
+    pn[0] = (c == 13) ? (cphiw - chc * E[0]) : 0.0;
+#pragma unroll
+    for (int r = 1; r < 4; r++) pn[r] = (c == 13 && 4 * r + g <= 12) ? Gp[r] - E[r] : 0.0;
+    if (c == 13) {
+        rec[REC_T + 16 * g + 13] = E[0]; // kbar
+#pragma unroll
+        for (int r = 0; r < 4; r++) rec[REC_PV + 4 * r + g] = pn[r]; // p_k for y_k = P_k ds_k + p_k
+    }
+    pv = pn;
+}
 
 template <int NP>
 __device__ __noinline__ void sweep_backvec(WsView w, cgdouble *xinit, int N, double smu)
@@ -662,75 +762,53 @@ __device__ __noinline__ void sweep_backvec(WsView w, cgdouble *xinit, int N, dou
     init_stage_constants(lane);
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     d4 pv = zero;
-    double e0, e1, e2, tpre;
-    d4 pdpre = zero;
-    auto fetch = [&](int kk) {
-        cgdouble *rp = w.rec + (size_t)kk * REC_STRIDE;
-        e0 = rp[lane]; e1 = rp[64 + lane]; e2 = (lane < 17) ? rp[REC_PHIC + lane] : 0.0; tpre = rp[REC_T + lane];
-        if (c == 13) {
+    double e0, e1, e2;
+    d4 MA, GpA, pdA = zero, MB = zero, GpB = zero, pdB = zero;
+    double hcA, phiwA, tpA, hcB = 0.0, phiwB = 0.0, tpB = 0.0;
+    { // prologue: operands of stage N-1 into set A, prefetch of stage N-2
+        cgdouble *rp = w.rec + (size_t)(N - 1) * REC_STRIDE;
+        e0 = rp[lane]; e1 = rp[64 + lane]; e2 = rp[REC_PHIC + (lane < 17 ? lane : 0)];
+        tpA = rp[REC_T + lane];
 #pragma unroll
-            for (int r = 0; r < 4; r++) pdpre[r] = rp[REC_PD + 4 * r + g];
-        }
-    };
-    auto stage = [&]() -> BackvecTiles {
+        for (int r = 0; r < 4; r++) pdA[r] = rp[(c == 13) ? REC_PD + 4 * r + g : REC_ZERO];
         WSYNC();
         sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1;
         if (lane < 17) sm[S_E + REC_PHIC + lane] = e2;
         WSYNC();
-        BackvecTiles t;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            t.M[r] = sm[mo[r]];
+            MA[r] = sm[mo[r]];
             const int o = po[r] >= 0 ? po[r] : 0;
             const double ph = sm[S_E + REC_PHIB + o] + smu * sm[S_E + REC_PHIC + o];
-            t.Gp[r] = (po[r] >= 0) ? ph : 0.0;
+            GpA[r] = (po[r] >= 0) ? ph : 0.0;
         }
-        t.hc = sm[S_E + REC_HC];
-        t.phiw = sm[S_E + REC_PHIB + 4 + g] + smu * sm[S_E + REC_PHIC + 4 + g];
-        t.tp = tpre;
-        t.pd = pdpre;
-        return t;
-    };
-    fetch(N - 1);
-    BackvecTiles cur = stage();
-    if (N > 1) fetch(N - 2);
-    for (int kk = N - 1; kk >= 0; kk--) {
-        gdouble *rec = w.rec + (size_t)kk * REC_STRIDE;
-        const bool last = (kk == N - 1);
-        d4 Gp = cur.Gp;
-        if (!last) {
-            d4 X;
-#pragma unroll
-            for (int r = 0; r < 4; r++) X[r] = (c == 13) ? cur.pd[r] + pv[r] : 0.0;
-            Gp = mm_tn(cur.M, X, Gp);
-        }
-        const d4 E = mm_tn4(cur.tp, Gp[0], zero);
-        BackvecTiles nxt = cur;
-        if (kk > 0) {
-            nxt = stage();
-            if (kk > 1) fetch(kk - 2);
-        }
-        if (c == 13) rec[REC_T + 16 * g + 13] = E[0]; // kbar
-        d4 pn;
-        pn[0] = (c == 13) ? (cur.phiw - cur.hc * E[0]) : 0.0;
-#pragma unroll
-        for (int r = 1; r < 4; r++) pn[r] = (c == 13 && 4 * r + g <= 12) ? Gp[r] - E[r] : 0.0;
-        pv = pn;
-        cur = nxt;
+        hcA = sm[S_E + REC_HC];
+        phiwA = sm[S_E + REC_PHIB + 4 + g] + smu * sm[S_E + REC_PHIC + 4 + g];
+        cgdouble *r2 = w.rec + (size_t)(N > 1 ? N - 2 : 0) * REC_STRIDE;
+        e0 = r2[lane]; e1 = r2[64 + lane]; e2 = r2[REC_PHIC + (lane < 17 ? lane : 0)];
     }
+    int kk = N - 1;
+    for (; kk >= 1; kk -= 2) {
+        backvec_step<NP>(w, kk, kk == N - 1, lane, g, c, smu, mo, po, MA, GpA, hcA, phiwA, tpA, pdA, MB, GpB, hcB, phiwB, tpB, pdB, e0, e1, e2, pv);
+        backvec_step<NP>(w, kk - 1, false, lane, g, c, smu, mo, po, MB, GpB, hcB, phiwB, tpB, pdB, MA, GpA, hcA, phiwA, tpA, pdA, e0, e1, e2, pv);
+    }
+    if (kk == 0) backvec_step<NP>(w, 0, N == 1, lane, g, c, smu, mo, po, MA, GpA, hcA, phiwA, tpA, pdA, MB, GpB, hcB, phiwB, tpB, pdB, e0, e1, e2, pv);
     stage0_solve<NP>(w, xinit, lane, pv[0]);
     FULLSYNC();
 }
 
 // ------------------------------------------------------------------ forward sweep: dz for all stages
 // du = -T' [hc dw; dx; 1],  ds+ = Mt [du; dx; 1]; the vectors stay in the column-0 lanes (row layout).
-// Software pipeline, branch-free body: the record of stage k+1 is staged through LDS and its operand tiles
-// are read BETWEEN the chained MFMAs of stage k (each chained MFMA blocks the wave for 64 cycles anyway);
-// the global prefetch runs two stages ahead.  Two register sets (A/B) alternate, so no tile is ever copied.
-template <int NP>
+// WITH_Y (corrector pass): also the multipliers of the Newton system  y+_k = P_k ds_k + p_k  (P_k gathered from its
+// packed lower triangle straight into the tile registers, prefetched one stage ahead), written to ynew.
+// Software pipeline, branch-free body: the record of stage k+1 is staged through LDS and its operand tiles are read
+// between the chained MFMAs of stage k; the global prefetch runs two stages ahead.  Two register sets (A/B)
+// alternate, so no tile is ever copied.
+template <int NP, bool WITH_Y>
 __device__ __forceinline__ void forward_step(const WsView &w, int N, int kk, int lane, int g, int c, const int (&tto)[4],
-                                             const int (&mto)[4], const d4 &ctt, const d4 &cmt, double chc, d4 &ntt, d4 &nmt,
-                                             double &nhc, double &e0, double &tp, d4 &v, long long *pacc_, long long &pts_)
+                                             const int (&mto)[4], const int (&pmo)[4], const d4 &ctt, const d4 &cmt, double chc,
+                                             const d4 &cP, const d4 &cpv, d4 &ntt, d4 &nmt, double &nhc, d4 &nP, d4 &npv,
+                                             double &e0, double &tp, d4 &v)
 {
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     d4 v1 = v;
@@ -738,12 +816,7 @@ __device__ __forceinline__ void forward_step(const WsView &w, int N, int kk, int
         v1[0] = chc * v[0];
         if (g == 1) v1[3] = 1.0; // row 13 multiplies the kbar column
     }
-    PROF_SEG(0);
     d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ctt[0], v1[0], zero, 0, 0, 0);
-#ifdef FRP_PROFILE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    PROF_SEG(1);
     // stage the (already fetched) record of the next stage through LDS ...
     WSYNC();
     sm[S_E + lane] = e0; sm[S_T + lane] = tp;
@@ -753,6 +826,15 @@ __device__ __forceinline__ void forward_step(const WsView &w, int N, int kk, int
         const int kf = (kk + 2 < N) ? kk + 2 : N - 1;
         cgdouble *rp = w.rec + (size_t)kf * REC_STRIDE;
         e0 = rp[lane]; tp = rp[REC_T + lane];
+        if (WITH_Y) { // P and p of the NEXT stage, straight into registers
+            const int kn = (kk + 1 < N) ? kk + 1 : N - 1;
+            cgdouble *rq = w.rec + (size_t)kn * REC_STRIDE;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                nP[r] = rq[pmo[r]];
+                npv[r] = rq[(c == 0) ? REC_PV + 4 * r + g : REC_ZERO];
+            }
+        }
     }
 #pragma unroll
     for (int s = 0; s < 4; s++) ntt[s] = sm[tto[s]];
@@ -761,12 +843,9 @@ __device__ __forceinline__ void forward_step(const WsView &w, int N, int kk, int
     for (int s = 0; s < 4; s++) nmt[s] = sm[mto[s]];
     nhc = sm[S_T + 14];
     D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ctt[3], v1[3], D1, 0, 0, 0);
-    PROF_SEG(2);
+    d4 Y = zero;
+    if (WITH_Y) Y = mm_tn(cP, v, cpv); // y+_k = P_k ds_k + p_k (P symmetric: A operand = the tile itself)
     const double du = -D1[0];
-#ifdef FRP_PROFILE
-    asm volatile("s_nop 0" :: "v"(du));
-#endif
-    PROF_SEG(3);
     if (c == 0) { // dz rows 17..19 are padding (tile rows 13..15)
         double *dzl = dz_area<NP>();
         dzl[g * NP + kk] = du;
@@ -779,35 +858,47 @@ __device__ __forceinline__ void forward_step(const WsView &w, int N, int kk, int
         if (g == 1) v2[3] = 1.0; // row 13 multiplies the d column
     }
     const d4 D2 = mm_tn(cmt, v2, zero);
-    PROF_SEG(4);
+    if (WITH_Y) {
+        if (c == 0) { // ynew rows 13..15 are padding
+#pragma unroll
+            for (int r = 0; r < 4; r++) w.step[(4 * r + g) * NP + kk] = Y[r];
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 4; r++) v[r] = (c == 0 && 4 * r + g <= 12) ? D2[r] : 0.0;
-#ifdef FRP_PROFILE
-    asm volatile("s_nop 0" :: "v"(v[0]));
-#endif
-    PROF_SEG(5);
 }
 
-template <int NP>
+template <int NP, bool WITH_Y>
 __device__ __noinline__ void sweep_forward(WsView w, int N)
 {
     w = uni(w); N = uni(N);
     FULLSYNC(); // phase boundary: T' / kbar of the backward sweep are visible
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-    int mto[4], tto[4];
+    int mto[4], tto[4], pmo[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         mto[s] = m_src(c, 4 * s + g);                           // Mt' tile: element [c][4s+g]
         tto[s] = (c < 4) ? S_T + 16 * c + 4 * s + g : S_ZERO;   // T'' tile: element T'[c][4s+g]
+        const int row = 4 * s + g, hi = row > c ? row : c, lo = row > c ? c : row;
+        pmo[s] = (row <= 12 && c <= 12) ? REC_P + hi * (hi + 1) / 2 + lo : REC_ZERO; // symmetric P_k from its packed triangle
     }
     init_stage_constants(lane);
     d4 v;
 #pragma unroll
     for (int r = 0; r < 4; r++) v[r] = (c == 0 && 4 * r + g <= 12) ? sm[S_DS0 + 4 * r + g] : 0.0;
     double e0, tp;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    d4 PA = zero, pvA = zero, PB = zero, pvB = zero;
     {
         cgdouble *rp = w.rec;
         e0 = rp[lane]; tp = rp[REC_T + lane];
+        if (WITH_Y) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                PA[r] = rp[pmo[r]];
+                pvA[r] = rp[(c == 0) ? REC_PV + 4 * r + g : REC_ZERO];
+            }
+        }
     }
     WSYNC();
     sm[S_E + lane] = e0; sm[S_T + lane] = tp;
@@ -821,19 +912,13 @@ __device__ __noinline__ void sweep_forward(WsView w, int N)
         cgdouble *rp = w.rec + (size_t)(N > 1 ? 1 : 0) * REC_STRIDE;
         e0 = rp[lane]; tp = rp[REC_T + lane];
     }
-#ifdef FRP_PROFILE
-    PROF_BEGIN();
-#else
-    long long pacc_[1], pts_ = 0;
-#endif
     int kk = 0;
     for (; kk + 1 < N; kk += 2) {
-        forward_step<NP>(w, N, kk, lane, g, c, tto, mto, ttA, mtA, hcA, ttB, mtB, hcB, e0, tp, v, pacc_, pts_);
-        forward_step<NP>(w, N, kk + 1, lane, g, c, tto, mto, ttB, mtB, hcB, ttA, mtA, hcA, e0, tp, v, pacc_, pts_);
+        forward_step<NP, WITH_Y>(w, N, kk, lane, g, c, tto, mto, pmo, ttA, mtA, hcA, PA, pvA, ttB, mtB, hcB, PB, pvB, e0, tp, v);
+        forward_step<NP, WITH_Y>(w, N, kk + 1, lane, g, c, tto, mto, pmo, ttB, mtB, hcB, PB, pvB, ttA, mtA, hcA, PA, pvA, e0, tp, v);
     }
-    if (kk < N) forward_step<NP>(w, N, kk, lane, g, c, tto, mto, ttA, mtA, hcA, ttB, mtB, hcB, e0, tp, v, pacc_, pts_);
+    if (kk < N) forward_step<NP, WITH_Y>(w, N, kk, lane, g, c, tto, mto, pmo, ttA, mtA, hcA, PA, pvA, ttB, mtB, hcB, PB, pvB, e0, tp, v);
     WSYNC();
-    PROF_END(12);
 }
 
 struct SlackOut {
@@ -861,7 +946,7 @@ __device__ __forceinline__ void affine_body(cgdouble *__restrict__ ps, cgdouble 
     constexpr int R = (NZ + H - 1) / H;
     const int lane = threadIdx.x;
     const int k = lane % NP, half = lane / NP;
-    const bool kact = k < N;
+    const bool kact = k < N && half < H;
     double *stg = stage_area<NP>();
 
     // one constraint of the affine step (smu = 0, corr = 0): returns t1 = (l r_in - corr)/s, sinv = 1/s
@@ -895,9 +980,9 @@ __device__ __forceinline__ void affine_body(cgdouble *__restrict__ ps, cgdouble 
                 c0 += a0 * sinv; c1 += a1 * sinv; c2 += a2 * sinv;
             }
         }
-        if (H == 2) {
-            b0 = xhalf_sum(b0); b1 = xhalf_sum(b1); b2 = xhalf_sum(b2);
-            c0 = xhalf_sum(c0); c1 = xhalf_sum(c1); c2 = xhalf_sum(c2);
+        if (H > 1) {
+            b0 = xsub_sum<NP>(b0); b1 = xsub_sum<NP>(b1); b2 = xsub_sum<NP>(b2);
+            c0 = xsub_sum<NP>(c0); c1 = xsub_sum<NP>(c1); c2 = xsub_sum<NP>(c2);
         }
         if (kact && half == 0) {
             stg[0 * NP + k] = b0; stg[1 * NP + k] = b1; stg[2 * NP + k] = b2;
@@ -913,22 +998,21 @@ __device__ __forceinline__ void affine_body(cgdouble *__restrict__ ps, cgdouble 
         gdouble *rec = prec + (size_t)k * REC_STRIDE;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const int i0 = r * H, i1 = (H == 2) ? i0 + 1 : i0;
-            if (H == 2 && i1 >= NZ && half) continue;
-            const int i = half ? i1 : i0;
-            const double hd = half ? cq.hd(i1 < NZ ? i1 : i0) : cq.hd(i0);
-            const double qi = half ? cq.q(i1 < NZ ? i1 : i0) : cq.q(i0);
-            const double lb = half ? lower_bound(i1 < NZ ? i1 : i0) : lower_bound(i0);
-            const double ub = half ? upper_bound(i1 < NZ ? i1 : i0) : upper_bound(i0);
+            const int ib = r * H, i = ib + half;
+            if (i >= NZ) continue;
+            const double hd = ROW_PICK(cq.hd(i));
+            const double qi = ROW_PICK(cq.q(i));
+            const double lb = ROW_PICK(lower_bound(i));
+            const double ub = ROW_PICK(upper_bound(i));
             const double zi = pz[i * NP + k], dzi = pdz[i * NP + k];
             double pb = hd * zi + qi; // cost gradient
-            if (i0 < 8) pb += cq.hc() * pz[(i < 4 ? i + 4 : i - 4) * NP + k];
+            if (ib < 8) pb += (i < 8 ? cq.hc() : 0.0) * pz[(i < 4 ? i + 4 : (i < 8 ? i - 4 : i)) * NP + k];
             double tl, tu, sil, siu;
             cstep(i, -dzi, lb - zi, tl, sil);
             cstep(17 + i, dzi, zi - ub, tu, siu);
             pb += tu - tl;
             double pcf = siu - sil;
-            if (i0 + H > 8 && i0 < 11) {
+            if (ib + H > 8 && ib < 11) {
                 if (i >= 8 && i < 11) { pb += stg[(i - 8) * NP + k]; pcf += stg[(3 + i - 8) * NP + k]; }
             }
             rec[REC_PHIB + i] = pb;
@@ -975,6 +1059,7 @@ __device__ __noinline__ SlackOut phase_affine(WsView w, cgdouble *pbase, int np,
 template <int NP>
 __device__ __forceinline__ void step_body(gdouble *__restrict__ ps, gdouble *__restrict__ pl, cgdouble *__restrict__ pcorr,
                                           gdouble *__restrict__ pz, const double *__restrict__ pdz, cgdouble *__restrict__ pface,
+                                          gdouble *__restrict__ py, cgdouble *__restrict__ pynew,
                                           int N, int MF, int nfk, double smu, double ftb, double &ap_out, double &ad_out)
 {
     constexpr int H = 64 / NP;
@@ -982,7 +1067,7 @@ __device__ __forceinline__ void step_body(gdouble *__restrict__ ps, gdouble *__r
     constexpr int MAXF = 8; // corridor rounds kept in registers; further rounds are recomputed
     const int lane = threadIdx.x;
     const int k = lane % NP, half = lane / NP;
-    const bool kact = k < N;
+    const bool kact = k < N && half < H;
     double m_p = 0.0, m_d = 0.0;
     double dsb[2 * R], dlb[2 * R], dsf[MAXF], dlf[MAXF];
     double z8 = 0, z9 = 0, z10 = 0, d8 = 0, d9 = 0, d10 = 0;
@@ -1005,12 +1090,11 @@ __device__ __forceinline__ void step_body(gdouble *__restrict__ ps, gdouble *__r
         d8 = pdz[8 * NP + k]; d9 = pdz[9 * NP + k]; d10 = pdz[10 * NP + k];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const int i0 = r * H, i1 = (H == 2) ? i0 + 1 : i0;
+            const int ib = r * H, i = ib + half;
             dsb[2 * r] = dlb[2 * r] = dsb[2 * r + 1] = dlb[2 * r + 1] = 0.0;
-            if (H == 2 && i1 >= NZ && half) continue;
-            const int i = half ? i1 : i0;
-            const double lb = half ? lower_bound(i1 < NZ ? i1 : i0) : lower_bound(i0);
-            const double ub = half ? upper_bound(i1 < NZ ? i1 : i0) : upper_bound(i0);
+            if (i >= NZ) continue;
+            const double lb = ROW_PICK(lower_bound(i));
+            const double ub = ROW_PICK(upper_bound(i));
             const double zi = pz[i * NP + k], dzi = pdz[i * NP + k];
             cstep(i, -dzi, lb - zi, dsb[2 * r], dlb[2 * r]);
             cstep(17 + i, dzi, zi - ub, dsb[2 * r + 1], dlb[2 * r + 1]);
@@ -1050,6 +1134,7 @@ __device__ __forceinline__ void step_body(gdouble *__restrict__ ps, gdouble *__r
             ps[(17 + i) * NP + k] += ap * dsb[2 * r + 1];
             pl[(17 + i) * NP + k] += ad * dlb[2 * r + 1];
             pz[i * NP + k] += ap * pdz[i * NP + k];
+            if (i < NS) py[i * NP + k] += ap * (pynew[i * NP + k] - py[i * NP + k]); // y <- y + ap (y+ - y)
         }
     }
     ap_out = ap; ad_out = ad;
@@ -1063,7 +1148,7 @@ __device__ __noinline__ SlackOut phase_step(WsView w, int N, int MF, int nfk, do
     FULLSYNC(); // phase boundary: dz of the forward sweep is visible
     PROF_SEG(6);
     double ap, ad;
-    step_body<NP>(w.s, w.lam, w.corr, w.z, dz_area<NP>(), w.face, N, MF, nfk, smu, ftb, ap, ad);
+    step_body<NP>(w.s, w.lam, w.corr, w.z, dz_area<NP>(), w.face, w.y, w.step, N, MF, nfk, smu, ftb, ap, ad);
     PROF_SEG(7);
     FULLSYNC();
     PROF_SEG(8);
@@ -1073,97 +1158,13 @@ __device__ __noinline__ SlackOut phase_step(WsView w, int N, int MF, int nfk, do
     return o;
 }
 
-// ------------------------------------------------------------------ costate sweep: y <- y + ap (y+ - y)
-// y+_k = (Phi_k dz_k + phi_k)_s + [0; A_k' y+_{k+1,x}]:  x rows = (C~' [du; dx] + M' y+)_x + phi_x,
-// w rows = Phi_w dw + hc du + phi_w.  Vectors in the column-0 lanes (row layout).
-// ------------------------------------------------------------------ costate sweep: y <- y + ap (y+ - y)
-// y+_k = (Phi_k dz_k + phi_k)_s + [0; A_k' y+_{k+1,x}]:  x rows = (C~' [du; dx] + M' y+)_x + phi_x,
-// w rows = Phi_w dw + hc du + phi_w, with phi = phi_cc = PHIB + smu PHIC.
-// Vectors in the column-0 lanes (row layout); dz / y have padding rows so that no row guards are needed.
-template <int NP>
-__device__ __noinline__ void sweep_costate(WsView w, int N, double ap, double smu, int theta_i)
-{
-    w = uni(w); N = uni(N); ap = uni(ap); smu = uni(smu); theta_i = uni(theta_i);
-    FULLSYNC(); // phase boundary: dz of the forward sweep / updates of the step phase are visible
-    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-    const double theta = theta_i ? 1.0 : 0.0;
-    int mo[4], c1[4], c2[4], c3[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        mo[r] = m_src(4 * r + g, c);
-        c_src(4 * r + g, c, c1[r], c2[r], c3[r]);
-    }
-    init_stage_constants(lane);
-    const d4 zero = {0.0, 0.0, 0.0, 0.0};
-    d4 y = zero;
-    cgdouble *rp = w.rec + (size_t)(N - 1) * REC_STRIDE;
-    double e0 = rp[lane], e1 = rp[64 + lane], e2 = rp[128 + lane], e3 = (lane < 56) ? rp[192 + lane] : 0.0;
-    d4 nv = zero, nyo = zero; // prefetched dz and old y of the next stage to be processed (column-0 lanes)
-    double ndu = 0.0;
-    if (c == 0) {
-        const double *dzl = dz_area<NP>();
-        ndu = dzl[g * NP + N - 1];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            nv[r] = dzl[(4 + 4 * r + g) * NP + N - 1];
-            nyo[r] = w.y[(4 * r + g) * NP + N - 1];
-        }
-    }
-    for (int kk = N - 1; kk >= 0; kk--) {
-        const bool last = (kk == N - 1);
-        WSYNC();
-        sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1; sm[S_E + 128 + lane] = e2;
-        if (lane < 56) sm[S_E + 192 + lane] = e3;
-        const d4 ds = nv, yo = nyo;
-        const double du = ndu;
-        if (kk > 0) {
-            cgdouble *rn = w.rec + (size_t)(kk - 1) * REC_STRIDE;
-            e0 = rn[lane]; e1 = rn[64 + lane]; e2 = rn[128 + lane]; e3 = (lane < 56) ? rn[192 + lane] : 0.0;
-            if (c == 0) {
-                const double *dzl = dz_area<NP>();
-                ndu = dzl[g * NP + kk - 1];
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    nv[r] = dzl[(4 + 4 * r + g) * NP + kk - 1];
-                    nyo[r] = w.y[(4 * r + g) * NP + kk - 1];
-                }
-            }
-        }
-        WSYNC();
-        const double hc = sm[S_E + REC_HC];
-        d4 C, v2 = ds;
-        v2[0] = du; // [du; dx] over the (u, x) tile index; ds[0] = dw is used for the w rows below
-#pragma unroll
-        for (int r = 0; r < 4; r++) C[r] = sm[c1[r]] + sm[c2[r]] + theta * sm[c3[r]];
-        d4 D = mm_tn(C, v2, zero);
-        if (!last) {
-            d4 M;
-#pragma unroll
-            for (int r = 0; r < 4; r++) M[r] = sm[mo[r]];
-            D = mm_tn(M, y, D);
-        }
-        d4 yn = zero;
-        if (c == 0) {
-            const int zw = 4 + g;
-            yn[0] = sm[S_E + REC_PHID + zw] * ds[0] + hc * du + sm[S_E + REC_PHIB + zw] + smu * sm[S_E + REC_PHIC + zw];
-#pragma unroll
-            for (int r = 1; r < 4; r++) {
-                const int zr = (4 * r + g <= 12) ? 4 * r + g + 4 : 16; // pad rows alias a valid slot, result discarded
-                yn[r] = (4 * r + g <= 12) ? D[r] + sm[S_E + REC_PHIB + zr] + smu * sm[S_E + REC_PHIC + zr] : 0.0;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r++) w.y[(4 * r + g) * NP + kk] = yo[r] + ap * (yn[r] - yo[r]);
-        }
-        y = yn;
-    }
-    WSYNC();
-}
-
 // ------------------------------------------------------------------ the solver kernel
+// One problem `b`, using workspace slot `slot` (slots are reused by successive problems of the same workgroup, so
+// the HBM footprint of the solver state is (#resident waves) x (state size), independent of the batch size).
 template <int NP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PER_EU, FRP_WAVES_PER_EU))) void nmpc_ipm_kernel(KernelArgs a)
+__device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, const int slot)
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     const int N = a.N, M = a.M, MF = a.MF, np = NPRE + 4 * M;
     const int mcf = 34 + MF;
     const bool act = lane < N; // lane == stage in the initialisation
@@ -1171,7 +1172,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
 
     WsView w;
     {
-        gdouble *base = (gdouble *)(a.ws + (size_t)b * ws_doubles_per_problem(N, MF));
+        gdouble *base = (gdouble *)(a.ws + (size_t)slot * ws_doubles_per_problem(N, MF));
         w.rec = base;
         w.z = w.rec + (size_t)N * REC_STRIDE;
         w.y = w.z + 17 * NP;
@@ -1297,7 +1298,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
         }
         if (fr) { flag = FRP_EXIT_FACTORIZATION; break; }
         TOCK(1);
-        sweep_forward<NP>(w, N);
+        sweep_forward<NP, false>(w, N);
         TOCK(2);
         const SlackOut s0 = phase_affine<NP>(w, pbase, np, N, MF, nfk, a.model, mu, mtot, a.tol_comp);
         sigma = s0.sigma;
@@ -1305,13 +1306,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
         // corrector solve (same factorisation, new rhs)
         sweep_backvec<NP>(w, xinit, N, s0.smu);
         TOCK(4);
-        sweep_forward<NP>(w, N);
-        TOCK(2);
+        sweep_forward<NP, true>(w, N);
+        TOCK(5);
         const SlackOut s1 = phase_step<NP>(w, N, MF, nfk, s0.smu, a.ftb);
         step_cc = s1.ap;
         TOCK(3);
-        sweep_costate<NP>(w, N, s1.ap, s0.smu, theta);
-        TOCK(5);
     }
 
     // ---------------------------------------------------------------- outputs
@@ -1328,11 +1327,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
             double *o = a.info + (size_t)b * FRP_INFO_STRIDE;
             o[0] = res_eq; o[1] = res_in; o[2] = rs; o[3] = rcomp; o[4] = pobj; o[5] = mu; o[6] = step_cc; o[7] = (double)nfallback;
 #ifdef FRP_PROFILE
-            for (int i = 0; i < 6; i++) o[i] = (double)tph[i]; // cycles: eval, factor, forward(x2), slack(x2), backvec, costate
+            for (int i = 0; i < 6; i++) o[i] = (double)tph[i]; // cycles: eval, factor, forward(affine), affine+step, backvec, forward(corrector, with y)
 #endif
         }
     }
     (void)sigma;
+}
+
+// Persistent workgroups: grid = min(B, resident slots); each wave pulls the next problem index from a device
+// counter (zeroed by the launcher) until the batch is exhausted -- natural load balancing over very different
+// iteration counts, and a bounded, cache-friendly workspace.
+template <int NP>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PER_EU, FRP_WAVES_PER_EU))) void nmpc_ipm_kernel(KernelArgs a)
+{
+    const int slot = blockIdx.x;
+    for (;;) {
+        int b = 0;
+        if (threadIdx.x == 0) b = atomicAdd(a.counter, 1);
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (b >= a.B) break;
+        solve_one<NP>(a, b, slot);
+        FULLSYNC();
+    }
 }
 
 // ------------------------------------------------------------------ batched model callback
@@ -1400,12 +1416,38 @@ __global__ __launch_bounds__(256) void stage_eval_kernel(int B, int N, int M, in
 }
 
 // ------------------------------------------------------------------ launchers
-size_t ws_bytes(int B, int N, int MF) { return (size_t)B * ws_doubles_per_problem(N, MF) * sizeof(double); }
+static int resident_slots()
+{
+    static int slots = 0;
+    if (slots == 0) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        slots = cus * 4 * FRP_WAVES_PER_EU; // one wave per workgroup, FRP_WAVES_PER_EU waves per SIMD
+        if (slots > FRP_MAX_SLOTS) slots = FRP_MAX_SLOTS;
+        if (slots < 1) slots = 1;
+    }
+    return slots;
+}
+
+size_t ws_bytes(int B, int N, int MF)
+{
+    const size_t slots = B < FRP_MAX_SLOTS ? B : FRP_MAX_SLOTS;
+    return slots * ws_doubles_per_problem(N, MF) * sizeof(double) + 256; // + the work-queue counter
+}
 
 hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
 {
-    if (padded_stages(a.N) == 32) hipLaunchKernelGGL(nmpc_ipm_kernel<32>, dim3(a.B), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL(nmpc_ipm_kernel<64>, dim3(a.B), dim3(64), 0, stream, a);
+    KernelArgs k = a;
+    const int slots = a.B < resident_slots() ? a.B : resident_slots();
+    k.counter = reinterpret_cast<int *>(a.ws + (size_t)slots * ws_doubles_per_problem(a.N, a.MF));
+    hipError_t e = hipMemsetAsync(k.counter, 0, sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    switch (padded_stages(a.N)) {
+    case 16: hipLaunchKernelGGL(nmpc_ipm_kernel<16>, dim3(slots), dim3(64), 0, stream, k); break;
+    case 20: hipLaunchKernelGGL(nmpc_ipm_kernel<20>, dim3(slots), dim3(64), 0, stream, k); break;
+    case 32: hipLaunchKernelGGL(nmpc_ipm_kernel<32>, dim3(slots), dim3(64), 0, stream, k); break;
+    default: hipLaunchKernelGGL(nmpc_ipm_kernel<64>, dim3(slots), dim3(64), 0, stream, k); break;
+    }
     return hipGetLastError();
 }
 

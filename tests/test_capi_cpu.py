@@ -46,10 +46,14 @@ def test_dropin_struct_layouts_match_reference_sizes():
 
 
 def test_workspace_size_formula():
+    """Workspace = (resident slots) x (per-problem solver state) + work-queue counter: grows with the batch only up
+    to the number of slots the library sizes for (4096), with the horizon and with the face count."""
     lib = solver.lib()
-    b1 = lib.frp_nmpc_workspace_bytes(1, 20, 6); b2 = lib.frp_nmpc_workspace_bytes(7, 20, 6)
-    assert b2 == 7 * b1 and b1 > 20 * 288 * 8
-    assert lib.frp_nmpc_workspace_bytes(1, 40, 6) > lib.frp_nmpc_workspace_bytes(1, 20, 6)
+    b1 = lib.frp_nmpc_workspace_bytes(1, 20, 6); b7 = lib.frp_nmpc_workspace_bytes(7, 20, 6)
+    per = b1 - 256
+    assert per > 20 * 328 * 8 and b7 == 7 * per + 256
+    assert lib.frp_nmpc_workspace_bytes(10 ** 6, 20, 6) == lib.frp_nmpc_workspace_bytes(4096, 20, 6)
+    assert lib.frp_nmpc_workspace_bytes(1, 40, 6) > b1 and lib.frp_nmpc_workspace_bytes(1, 20, 15) > b1
 
 
 @pytest.mark.skipif(_has_gpu(), reason="checks the no-device behaviour")

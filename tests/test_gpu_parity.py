@@ -206,3 +206,15 @@ def test_receding_horizon_warm_start_matches_oracle():
     assert np.max(np.abs(mg - mc)) < 1e-5
     # warm-started ticks need no more iterations than the cold-started first one
     assert ig[1:].mean() <= ig[0].mean() + 0.5
+
+
+@pytest.mark.parametrize("N", [8, 12, 20, 25, 33])
+def test_horizon_lengths_cover_every_lane_mapping(N):
+    """Stage strides 16 / 20 / 32 / 64 (4, 3, 2, 1 row groups per wavefront) against the oracle."""
+    w = workloads.config3(24, N=N, M=15)
+    z, fl, it, info = solver.solve_batch_host(w)
+    zo, flo, io = OL.solve_batch(w)
+    assert (fl == flo).mean() >= 0.9
+    ok = (fl == 1) & (flo == 1)
+    assert ok.sum() >= 12
+    assert np.max(np.abs(z[ok] - zo[ok])) < 1e-6

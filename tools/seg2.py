@@ -11,7 +11,7 @@ sym = ctypes.c_void_p(); sz = ctypes.c_size_t()
 get = getattr(lib, 'frp_debug_read_prof', None)
 buf = (ctypes.c_longlong * 24)()
 get(buf)
-names = ["aff:sync0", "aff:body", "aff:(unused)", "aff:reduce", "aff:sync1", "-", "step:sync0", "step:body", "step:sync1", "-", "-", "-", "fwd:v1 prep", "fwd:mfma0+vmwait", "fwd:stage+D1", "fwd:du wait", "fwd:dz+D2 issue", "fwd:v wait"]
+names = ["aff:sync0", "aff:body", "aff:(unused)", "aff:reduce", "aff:sync1", "-", "step:sync0", "step:body", "step:sync1", "-", "-", "-", "f0","f1","f2","f3","f4","f5","bv:looptop", "bv:X+G issue", "bv:E issue", "bv:stage next", "bv:E wait+pn+stores", "bv:vmcnt wait", "fwd:v1 prep", "fwd:mfma0+vmwait", "fwd:stage+D1", "fwd:du wait", "fwd:dz+D2 issue", "fwd:v wait"]
 print("iterations", it[0])
 for n, v in zip(names, buf):
     print(f"{n:12s} {v / max(it[0],1):10.0f} cycles/iter")
