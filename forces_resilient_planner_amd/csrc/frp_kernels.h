@@ -7,7 +7,7 @@ namespace frp {
 
 // Per-stage HBM record (doubles): everything the serial Riccati sweeps stream, laid out so that one
 // wavefront moves it with 64-lane coalesced loads/stores.
-//   E part (written by the evaluation / step phases, 248 doubles = 64 + 64 + 64 + 56):
+//   E part (written by the evaluation / step phases, 192 doubles = 3 x 64):
 constexpr int REC_LIN = 0;      // compact linearisation (51): Apv Ape Avv Ave BpT BvT Bvw
 constexpr int REC_D = 51;       // d = prev(z_k) - s_{k+1}, s-order [w; x]  (13)
 constexpr int REC_PHID = 64;    // diag of Phi = cost Hessian + bound barriers (17)
@@ -15,21 +15,53 @@ constexpr int REC_PHIPOS = 81;  // corridor barrier block on pos (3 x 3)
 constexpr int REC_PHI = 90;     // predictor rhs gradient phi_aff (17)
 constexpr int REC_HC = 107;     // (u_i, w_i) cost coupling -2 w_rate of this stage
 constexpr int REC_PHIB = 108;   // corrector rhs: phi_cc = PHIB + (sigma mu) PHIC  (17 + 17)
-constexpr int REC_PHIC = 128;
-constexpr int REC_HD = 148;     // exact Hessian of y'c(z) over (rates, T, v, e), dense 10 x 10
-constexpr int REC_E_SIZE = 248;
-//   F part (written by the factorisation sweep, 80 doubles):
-constexpr int REC_T = 248;      // T' = [R | Kbar_x | kbar | hc] as tile register 0 (64): lane (g,c) <-> T'[g][c]
-constexpr int REC_PD = 312;     // P_{k+1} d (16, s-order rows)
-constexpr int REC_PV = 328;     // p_k of the corrector solve (16, s-order rows)
-constexpr int REC_P = 344;      // P_k, packed lower triangle: (row, col <= row) -> row (row + 1) / 2 + col  (91, padded 96)
-constexpr int REC_STRIDE = 440;
-constexpr int REC_ZERO = 125;   // a slot of the record that always holds 0.0 (target of masked gathers)
+constexpr int REC_PHIC = 125;
+constexpr int REC_ZERO = 142;   // a slot of the record that always holds 0.0 (target of masked gathers)
+constexpr int REC_HD = 143;     // exact Hessian of y'c(z) over (rates, T, v, e): the 45 structurally non-zero
+                                // entries of the upper triangle, see hd_pack()
+constexpr int REC_HD_SIZE = 45;
+constexpr int REC_E_SIZE = 192; // 188..191 pad
+//   F part (written by the factorisation sweep):
+constexpr int REC_T = 192;      // T' = [R | Kbar_x | kbar | hc] as tile register 0 (64): lane (g,c) <-> T'[g][c]
+constexpr int REC_PD = 256;     // P_{k+1} d (16, s-order rows)
+constexpr int REC_PV = 272;     // p_k of the corrector solve (16, s-order rows)
+constexpr int REC_P = 288;      // P_k, packed lower triangle: (row, col <= row) -> row (row + 1) / 2 + col  (91, padded 96)
+constexpr int REC_STRIDE = 384;
+
+// Packed index of entry (i, j) of the 10 x 10 dynamics Hessian over (rates 0..2, T 3, v 4..6, e 7..9), or -1 where
+// it is structurally zero: the acceleration is affine in (T, v) jointly, so the (T,T), (T,v) and (v,v) blocks vanish.
+__host__ __device__ constexpr bool hd_zero(int i, int j) { return i >= 3 && i <= 6 && j >= 3 && j <= 6; }
+__host__ __device__ constexpr int hd_pack(int i, int j)
+{
+    if (i > j) { const int t = i; i = j; j = t; }
+    if (hd_zero(i, j)) return -1;
+    int n = 0;
+    for (int a = 0; a < 10; a++)
+        for (int b = a; b < 10; b++) {
+            if (a == i && b == j) return n;
+            if (!hd_zero(a, b)) n++;
+        }
+    return -1;
+}
+static_assert(hd_pack(9, 9) == REC_HD_SIZE - 1, "45 structurally non-zero entries");
+struct HdTable {
+    int v[100];
+};
+constexpr HdTable make_hd_table()
+{
+    HdTable t{};
+    for (int a = 0; a < 10; a++)
+        for (int b = 0; b < 10; b++) t.v[a * 10 + b] = hd_pack(a, b);
+    return t;
+}
+static constexpr HdTable HD_TABLE = make_hd_table(); // folded to immediates once the callers are unrolled
+__host__ __device__ inline int hd_index(int i, int j) { return HD_TABLE.v[i * 10 + j]; }
 constexpr int DZ_ROWS = 20;     // dz rows: du(4) + ds(13) + 3 pad rows (tile rows 13..15)
 constexpr int Y_ROWS = 16;      // y rows: 13 + 3 pad rows
 
 constexpr double S_MIN = 1e-2;          // smallest initial slack (infeasible start shift)
 constexpr double MU_FLOOR_FRAC = 0.1;   // centring target floor = 0.1 * tol_comp
+constexpr double KAPPA_LAM = 2.0;       // multiplier safeguard: s_i lam_i >= mu / KAPPA_LAM after every step
 constexpr double DIVERGE_MU = 1e6;
 constexpr double DIVERGE_RS = 1e12;
 

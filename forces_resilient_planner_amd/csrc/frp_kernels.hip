@@ -27,6 +27,7 @@
 #include "frp_model.hpp"
 #include "../../include/frp_nmpc.h"
 #include "frp_kernels.h"
+#include <cstdlib>
 
 namespace frp {
 
@@ -87,7 +88,7 @@ __device__ __forceinline__ double lane_bcast(double v, int src) // wave-uniform 
 // [0, 736): staging.  Element-wise phases: gm[17][NP] + corridor sums[6][NP] (NP = 32).
 //           Riccati sweeps: the E part of the current stage record + constants + T' + R.
 // [736, ...): fields that live across phases of one iteration.
-constexpr int S_E = 0;                    // E part of the stage record (248)
+constexpr int S_E = 0;                    // E part of the stage record (192 used)
 constexpr int S_ZERO = 248, S_ONE = 249, S_DTC = 250;
 constexpr int S_T = 256;                  // T' (64)
 constexpr int S_R = 320;                  // 4x4 inverse handed from uniform registers to lanes (16)
@@ -261,7 +262,7 @@ __device__ __forceinline__ void c_src(int row, int col, int &o1, int &o2, int &o
     if (col == row) o1 = S_E + REC_PHID + zi_of(row);
     if (row >= 4 && row <= 6 && col >= 4 && col <= 6) o2 = S_E + REC_PHIPOS + (row - 4) * 3 + (col - 4);
     const int hr = hidx_of(row), hc_ = hidx_of(col);
-    if (hr >= 0 && hc_ >= 0) o3 = S_E + REC_HD + hr * 10 + hc_;
+    if (hr >= 0 && hc_ >= 0 && hd_index(hr, hc_) >= 0) o3 = S_E + REC_HD + hd_index(hr, hc_);
 }
 
 __device__ __forceinline__ void init_stage_constants(int lane)
@@ -435,13 +436,15 @@ __device__ __noinline__ EvalOut phase_eval(WsView w, cgdouble *pbase, int np, cg
             // one Heun step with its linearisation streamed out entry by entry (record + M'y)
             AccJac J1, J2;
             double a1[3], a2[3], vt[3], et[3];
-            accel<true>(zk + 11, zk + 14, zk[3], p10 + 3, a1, &J1);
+            const Trig tg1 = make_trig(zk + 14);
+            accel_t<true>(zk + 11, tg1, zk[3], p10 + 3, a1, &J1);
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 vt[i] = zk[11 + i] + DT * a1[i];
                 et[i] = zk[14 + i] + DT * zk[i];
             }
-            accel<true>(vt, et, zk[3], p10 + 3, a2, &J2);
+            const Trig tg2 = make_trig(et);
+            accel_t<true>(vt, tg2, zk[3], p10 + 3, a2, &J2);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const double d = zk[i] - w.z[(4 + i) * NP + k + 1];
@@ -498,9 +501,8 @@ __device__ __noinline__ EvalOut phase_eval(WsView w, cgdouble *pbase, int np, cg
             gm[3] += gT;
             if (hess) {
                 // exact Hessian of y_{k+1}' c(z_k): only the pos / vel rows of the RK2 step are non-linear
-                rk2_hessian(zk + 8, zk, p10 + 3, yp, yv, [&](int i, int j, double val) {
-                    rec[REC_HD + i * 10 + j] = val;
-                    if (i != j) rec[REC_HD + j * 10 + i] = val;
+                rk2_hessian_core(zk + 11, zk[3], J1, vt, tg1, tg2, yp, yv, [&](int i, int j, double val) {
+                    if (hd_index(i, j) >= 0) rec[REC_HD + hd_index(i, j)] = val;
                 });
             }
         }
@@ -555,7 +557,7 @@ __device__ __forceinline__ bool factor_step(const WsView &w, int kk, bool last, 
                                             const int (&mo)[4], const int (&c1)[4], const int (&c2)[4], const int (&c3)[4],
                                             const d4 &cC, const d4 &cM, double chc, double cPhiDw, double cphiw,
                                             d4 &nC, d4 &nM, double &nhc, double &nPhiDw, double &nphiw,
-                                            double &e0, double &e1, double &e2, double &e3, d4 &P, d4 &pv)
+                                            double &e0, double &e1, double &e2, d4 &P, d4 &pv)
 {
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     gdouble *rec = w.rec + (size_t)kk * REC_STRIDE;
@@ -574,12 +576,11 @@ __device__ __forceinline__ bool factor_step(const WsView &w, int kk, bool last, 
     // ---- between / behind the MFMAs: tiles of stage kk-1 (clamped at 0: the tail re-stages stage 0, unused)
     WSYNC();
     sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1; sm[S_E + 128 + lane] = e2;
-    if (lane < 56) sm[S_E + 192 + lane] = e3;
     WSYNC();
     {
         const int k2 = kk > 1 ? kk - 2 : 0;
         cgdouble *r2 = w.rec + (size_t)k2 * REC_STRIDE;
-        e0 = r2[lane]; e1 = r2[64 + lane]; e2 = r2[128 + lane]; e3 = r2[192 + (lane < 56 ? lane : 0)];
+        e0 = r2[lane]; e1 = r2[64 + lane]; e2 = r2[128 + lane];
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -642,15 +643,14 @@ __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, int t
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     d4 P = zero, pv = zero;
     bool ok = true;
-    double e0, e1, e2, e3;
+    double e0, e1, e2;
     d4 CA, MA, CB = zero, MB = zero;
     double hcA, PhiDwA, phiwA, hcB = 0.0, PhiDwB = 0.0, phiwB = 0.0;
     { // prologue: tiles of stage N-1 into set A, prefetch of stage N-2
         cgdouble *rp = w.rec + (size_t)(N - 1) * REC_STRIDE;
-        e0 = rp[lane]; e1 = rp[64 + lane]; e2 = rp[128 + lane]; e3 = rp[192 + (lane < 56 ? lane : 0)];
+        e0 = rp[lane]; e1 = rp[64 + lane]; e2 = rp[128 + lane];
         WSYNC();
         sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1; sm[S_E + 128 + lane] = e2;
-        if (lane < 56) sm[S_E + 192 + lane] = e3;
         WSYNC();
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -661,15 +661,15 @@ __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, int t
         PhiDwA = sm[S_E + REC_PHID + 4 + g];
         phiwA = sm[S_E + REC_PHI + 4 + g];
         cgdouble *r2 = w.rec + (size_t)(N > 1 ? N - 2 : 0) * REC_STRIDE;
-        e0 = r2[lane]; e1 = r2[64 + lane]; e2 = r2[128 + lane]; e3 = r2[192 + (lane < 56 ? lane : 0)];
+        e0 = r2[lane]; e1 = r2[64 + lane]; e2 = r2[128 + lane];
     }
     int kk = N - 1;
     for (; kk >= 1 && ok; kk -= 2) {
-        ok = factor_step<NP>(w, kk, kk == N - 1, lane, g, c, theta, mo, c1, c2, c3, CA, MA, hcA, PhiDwA, phiwA, CB, MB, hcB, PhiDwB, phiwB, e0, e1, e2, e3, P, pv);
+        ok = factor_step<NP>(w, kk, kk == N - 1, lane, g, c, theta, mo, c1, c2, c3, CA, MA, hcA, PhiDwA, phiwA, CB, MB, hcB, PhiDwB, phiwB, e0, e1, e2, P, pv);
         if (!ok) break;
-        ok = factor_step<NP>(w, kk - 1, false, lane, g, c, theta, mo, c1, c2, c3, CB, MB, hcB, PhiDwB, phiwB, CA, MA, hcA, PhiDwA, phiwA, e0, e1, e2, e3, P, pv);
+        ok = factor_step<NP>(w, kk - 1, false, lane, g, c, theta, mo, c1, c2, c3, CB, MB, hcB, PhiDwB, phiwB, CA, MA, hcA, PhiDwA, phiwA, e0, e1, e2, P, pv);
     }
-    if (ok && kk == 0) ok = factor_step<NP>(w, 0, N == 1, lane, g, c, theta, mo, c1, c2, c3, CA, MA, hcA, PhiDwA, phiwA, CB, MB, hcB, PhiDwB, phiwB, e0, e1, e2, e3, P, pv);
+    if (ok && kk == 0) ok = factor_step<NP>(w, 0, N == 1, lane, g, c, theta, mo, c1, c2, c3, CA, MA, hcA, PhiDwA, phiwA, CB, MB, hcB, PhiDwB, phiwB, e0, e1, e2, P, pv);
     bool fail = !ok;
     if (!fail) {
         // stage 0: keep Pww^-1 and Pwx for the corrector pass, then solve for ds_0
@@ -715,7 +715,7 @@ __device__ __forceinline__ void backvec_step(const WsView &w, int kk, bool last,
     // ---- between the MFMAs: operands of stage kk-1 (clamped at 0: the tail re-stages stage 0, unused)
     WSYNC();
     sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1;
-    if (lane < 17) sm[S_E + REC_PHIC + lane] = e2;
+    if (lane < 14) sm[S_E + 128 + lane] = e2;
     WSYNC();
     {
         const int k1 = kk > 0 ? kk - 1 : 0, k2 = kk > 1 ? kk - 2 : 0;
@@ -723,7 +723,7 @@ __device__ __forceinline__ void backvec_step(const WsView &w, int kk, bool last,
         ntp = r1[REC_T + lane];
 #pragma unroll
         for (int r = 0; r < 4; r++) npd[r] = r1[(c == 13) ? REC_PD + 4 * r + g : REC_ZERO];
-        e0 = r2[lane]; e1 = r2[64 + lane]; e2 = r2[REC_PHIC + (lane < 17 ? lane : 0)];
+        e0 = r2[lane]; e1 = r2[64 + lane]; e2 = r2[128 + (lane < 14 ? lane : 0)];
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -767,13 +767,13 @@ __device__ __noinline__ void sweep_backvec(WsView w, cgdouble *xinit, int N, dou
     double hcA, phiwA, tpA, hcB = 0.0, phiwB = 0.0, tpB = 0.0;
     { // prologue: operands of stage N-1 into set A, prefetch of stage N-2
         cgdouble *rp = w.rec + (size_t)(N - 1) * REC_STRIDE;
-        e0 = rp[lane]; e1 = rp[64 + lane]; e2 = rp[REC_PHIC + (lane < 17 ? lane : 0)];
+        e0 = rp[lane]; e1 = rp[64 + lane]; e2 = rp[128 + (lane < 14 ? lane : 0)];
         tpA = rp[REC_T + lane];
 #pragma unroll
         for (int r = 0; r < 4; r++) pdA[r] = rp[(c == 13) ? REC_PD + 4 * r + g : REC_ZERO];
         WSYNC();
         sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1;
-        if (lane < 17) sm[S_E + REC_PHIC + lane] = e2;
+        if (lane < 14) sm[S_E + 128 + lane] = e2;
         WSYNC();
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -785,7 +785,7 @@ __device__ __noinline__ void sweep_backvec(WsView w, cgdouble *xinit, int N, dou
         hcA = sm[S_E + REC_HC];
         phiwA = sm[S_E + REC_PHIB + 4 + g] + smu * sm[S_E + REC_PHIC + 4 + g];
         cgdouble *r2 = w.rec + (size_t)(N > 1 ? N - 2 : 0) * REC_STRIDE;
-        e0 = r2[lane]; e1 = r2[64 + lane]; e2 = r2[REC_PHIC + (lane < 17 ? lane : 0)];
+        e0 = r2[lane]; e1 = r2[64 + lane]; e2 = r2[128 + (lane < 14 ? lane : 0)];
     }
     int kk = N - 1;
     for (; kk >= 1; kk -= 2) {
@@ -1060,7 +1060,7 @@ template <int NP>
 __device__ __forceinline__ void step_body(gdouble *__restrict__ ps, gdouble *__restrict__ pl, cgdouble *__restrict__ pcorr,
                                           gdouble *__restrict__ pz, const double *__restrict__ pdz, cgdouble *__restrict__ pface,
                                           gdouble *__restrict__ py, cgdouble *__restrict__ pynew,
-                                          int N, int MF, int nfk, double smu, double ftb, double &ap_out, double &ad_out)
+                                          int N, int MF, int nfk, double smu, double ftb, double gap, double inv_mtot_kappa, double &ap_out, double &ad_out)
 {
     constexpr int H = 64 / NP;
     constexpr int R = (NZ + H - 1) / H;
@@ -1069,6 +1069,7 @@ __device__ __forceinline__ void step_body(gdouble *__restrict__ ps, gdouble *__r
     const int k = lane % NP, half = lane / NP;
     const bool kact = k < N && half < H;
     double m_p = 0.0, m_d = 0.0;
+    double q1 = 0.0, q2 = 0.0, q3 = 0.0; // sums of ds l, s dl, ds dl: the average complementarity after the step
     double dsb[2 * R], dlb[2 * R], dsf[MAXF], dlf[MAXF];
     double z8 = 0, z9 = 0, z10 = 0, d8 = 0, d9 = 0, d10 = 0;
     auto cstep = [&](int c, double gdz, double viol, double &ds, double &dl) {
@@ -1080,6 +1081,7 @@ __device__ __forceinline__ void step_body(gdouble *__restrict__ ps, gdouble *__r
         dl = (-rc - l * ds) * sinv;
         m_p = fmax(m_p, -ds * sinv);
         m_d = fmax(m_d, -dl * linv);
+        q1 = fma(ds, l, q1); q2 = fma(s, dl, q2); q3 = fma(ds, dl, q3);
     };
     auto face = [&](int j, double &ds, double &dl) {
         const double a0 = pface[(3 * j) * NP + k], a1 = pface[(3 * j + 1) * NP + k], a2 = pface[(3 * j + 2) * NP + k];
@@ -1110,29 +1112,33 @@ __device__ __forceinline__ void step_body(gdouble *__restrict__ ps, gdouble *__r
     m_p = wave_max(m_p); m_d = wave_max(m_d);
     const double ap = (m_p > ftb) ? ftb / m_p : 1.0;
     const double ad = (m_d > ftb) ? ftb / m_d : 1.0;
+    // multiplier safeguard: s_i lam_i >= mu_new / KAPPA_LAM for every pair after the step
+    q1 = wave_sum(q1); q2 = wave_sum(q2); q3 = wave_sum(q3);
+    const double fprod = (gap + ap * q1 + ad * (q2 + ap * q3)) * inv_mtot_kappa;
+    auto commit = [&](int c, double ds, double dl) {
+        const double sn = ps[c * NP + k] + ap * ds;
+        double ln = pl[c * NP + k] + ad * dl;
+        if (ln * sn < fprod) ln = fprod / sn;
+        ps[c * NP + k] = sn;
+        pl[c * NP + k] = ln;
+    };
     if (kact) {
         for (int j = half + MAXF * H; j < nfk; j += H) { // rare: more corridor rounds than kept in registers
             double a, b;
             face(j, a, b);
-            ps[(34 + j) * NP + k] += ap * a;
-            pl[(34 + j) * NP + k] += ad * b;
+            commit(34 + j, a, b);
         }
 #pragma unroll
         for (int t = 0; t < MAXF; t++) {
             const int j = half + t * H;
-            if (j < nfk) {
-                ps[(34 + j) * NP + k] += ap * dsf[t];
-                pl[(34 + j) * NP + k] += ad * dlf[t];
-            }
+            if (j < nfk) commit(34 + j, dsf[t], dlf[t]);
         }
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int i = r * H + half;
             if (i >= NZ) continue;
-            ps[i * NP + k] += ap * dsb[2 * r];
-            pl[i * NP + k] += ad * dlb[2 * r];
-            ps[(17 + i) * NP + k] += ap * dsb[2 * r + 1];
-            pl[(17 + i) * NP + k] += ad * dlb[2 * r + 1];
+            commit(i, dsb[2 * r], dlb[2 * r]);
+            commit(17 + i, dsb[2 * r + 1], dlb[2 * r + 1]);
             pz[i * NP + k] += ap * pdz[i * NP + k];
             if (i < NS) py[i * NP + k] += ap * (pynew[i * NP + k] - py[i * NP + k]); // y <- y + ap (y+ - y)
         }
@@ -1141,14 +1147,14 @@ __device__ __forceinline__ void step_body(gdouble *__restrict__ ps, gdouble *__r
 }
 
 template <int NP>
-__device__ __noinline__ SlackOut phase_step(WsView w, int N, int MF, int nfk, double smu, double ftb)
+__device__ __noinline__ SlackOut phase_step(WsView w, int N, int MF, int nfk, double smu, double ftb, double gap, double inv_mtot_kappa)
 {
-    w = uni(w); N = uni(N); MF = uni(MF); smu = uni(smu); ftb = uni(ftb);
+    w = uni(w); N = uni(N); MF = uni(MF); smu = uni(smu); ftb = uni(ftb); gap = uni(gap); inv_mtot_kappa = uni(inv_mtot_kappa);
     PROF_BEGIN();
     FULLSYNC(); // phase boundary: dz of the forward sweep is visible
     PROF_SEG(6);
     double ap, ad;
-    step_body<NP>(w.s, w.lam, w.corr, w.z, dz_area<NP>(), w.face, w.y, w.step, N, MF, nfk, smu, ftb, ap, ad);
+    step_body<NP>(w.s, w.lam, w.corr, w.z, dz_area<NP>(), w.face, w.y, w.step, N, MF, nfk, smu, ftb, gap, inv_mtot_kappa, ap, ad);
     PROF_SEG(7);
     FULLSYNC();
     PROF_SEG(8);
@@ -1231,10 +1237,8 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         for (int i = 0; i < NS; i++) w.y[i * NP + k] = 0.0;
         gdouble *rec = w.rec + (size_t)k * REC_STRIDE;
         rec[REC_HC] = -2.0 * pk[8]; // (u_i, w_i) cost coupling of this stage (constant)
-        for (int i = 0; i < 100; i++) rec[REC_HD + i] = 0.0; // stays zero in Gauss-Newton mode / last stage
-        for (int i = 0; i < 64; i++) rec[i] = 0.0;           // linearisation of the last stage is never written
-        for (int i = 125; i < 128; i++) rec[i] = 0.0;        // padding slots of the E record
-        for (int i = 145; i < 148; i++) rec[i] = 0.0;
+        for (int i = REC_ZERO; i < REC_E_SIZE; i++) rec[i] = 0.0; // zero slot, Hd (stays zero in Gauss-Newton mode / last stage), pad
+        for (int i = 0; i < 64; i++) rec[i] = 0.0;                // linearisation of the last stage is never written
         for (int i = 0; i < 3; i++) { // padding rows (tile rows 13..15) of dz and y
             dz_area<NP>()[(17 + i) * NP + k] = 0.0;
             w.y[(13 + i) * NP + k] = 0.0;
@@ -1308,7 +1312,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         TOCK(4);
         sweep_forward<NP, true>(w, N);
         TOCK(5);
-        const SlackOut s1 = phase_step<NP>(w, N, MF, nfk, s0.smu, a.ftb);
+        const SlackOut s1 = phase_step<NP>(w, N, MF, nfk, s0.smu, a.ftb, mu * (double)mtot, 1.0 / (KAPPA_LAM * (double)mtot));
         step_cc = s1.ap;
         TOCK(3);
     }
@@ -1423,6 +1427,10 @@ static int resident_slots()
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         slots = cus * 4 * FRP_WAVES_PER_EU; // one wave per workgroup, FRP_WAVES_PER_EU waves per SIMD
+        if (const char *e = getenv("FRP_RESIDENT_SLOTS")) { // tuning knob: resident single-wave workgroups
+            const int v = atoi(e);
+            if (v > 0) slots = v;
+        }
         if (slots > FRP_MAX_SLOTS) slots = FRP_MAX_SLOTS;
         if (slots < 1) slots = 1;
     }

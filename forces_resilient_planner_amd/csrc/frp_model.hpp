@@ -65,15 +65,26 @@ struct AccJac {
     double Fvv[9], Fve[9], gT[3];
 };
 
+// sines / cosines of (roll, pitch, yaw): computed once per evaluation point and shared by the dynamics, its
+// Jacobian and its Hessian (FP64 sincos is by far the most expensive scalar operation of the model)
+struct Trig {
+    double sr, cr, sp, cp, sy, cy;
+};
+__host__ __device__ inline Trig make_trig(const double e[3])
+{
+    Trig t;
+    sincos(e[0], &t.sr, &t.cr);
+    sincos(e[1], &t.sp, &t.cp);
+    sincos(e[2], &t.sy, &t.cy);
+    return t;
+}
+
 // acc = zB T/m + f_ext - g e3 - R diag(d,d,0) R' v with R diag(d,d,0) R' = d (I - zB zB')
 template <bool JAC>
-__host__ __device__ inline void accel(const double v[3], const double e[3], double T, const double fext[3],
-                                      double acc[3], AccJac *J)
+__host__ __device__ inline void accel_t(const double v[3], const Trig &tg, double T, const double fext[3],
+                                        double acc[3], AccJac *J)
 {
-    double sr, cr, sp, cp, sy, cy;
-    sincos(e[0], &sr, &cr);
-    sincos(e[1], &sp, &cp);
-    sincos(e[2], &sy, &cy);
+    const double sr = tg.sr, cr = tg.cr, sp = tg.sp, cp = tg.cp, sy = tg.sy, cy = tg.cy;
     const double zb0 = cy * sp * cr + sy * sr;
     const double zb1 = sy * sp * cr - cy * sr;
     const double zb2 = cp * cr;
@@ -101,6 +112,13 @@ __host__ __device__ inline void accel(const double v[3], const double e[3], doub
             for (int i = 0; i < 3; i++) J->Fve[i * 3 + j] = a * dz[i * 3 + j] + DRAG * zb[i] * dzv;
         }
     }
+}
+
+template <bool JAC>
+__host__ __device__ inline void accel(const double v[3], const double e[3], double T, const double fext[3],
+                                      double acc[3], AccJac *J)
+{
+    accel_t<JAC>(v, make_trig(e), T, fext, acc, J);
 }
 
 // x = [p v e] (9), u = [rates(3) T]; xn = x + dt/2 (k1 + k2), k2 = f(x + dt k1)
@@ -154,12 +172,9 @@ struct PhiHess {
     double hTe[3], Hve[9], Hee[9], gv[3]; // gv = d phi / d v
 };
 
-__host__ __device__ inline void phi_hess(const double gam[3], const double v[3], const double e[3], double T, PhiHess *o)
+__host__ __device__ inline void phi_hess(const double gam[3], const double v[3], const Trig &tg, double T, PhiHess *o)
 {
-    double sr, cr, sp, cp, sy, cy;
-    sincos(e[0], &sr, &cr);
-    sincos(e[1], &sp, &cp);
-    sincos(e[2], &sy, &cy);
+    const double sr = tg.sr, cr = tg.cr, sp = tg.sp, cp = tg.cp, sy = tg.sy, cy = tg.cy;
     const double zb[3] = {cy * sp * cr + sy * sr, sy * sp * cr - cy * sr, cp * cr};
     // D1[j] = d zB / d e_j ; D2[j][l] = d2 zB / d e_j d e_l
     const double D1[3][3] = {{-cy * sp * sr + sy * cr, -sy * sp * sr - cy * cr, -cp * sr},
@@ -203,27 +218,23 @@ __host__ __device__ inline void phi_hess(const double gam[3], const double v[3],
 // velocity rows of x+ are non-linear (multipliers yp, yv).  Sink(i, j, value) receives every entry of
 // the upper triangle (i <= j) exactly once.
 //   x+_p = p + dt v + dt^2/2 acc1,  x+_v = v + dt/2 (acc1 + acc2),  acc2 = acc(v + dt acc1, e + dt w, T).
+// Core with everything the RK2 evaluation already has: J1 = Jacobian of acc at (v, e), vt = v + dt acc1,
+// tg1 / tg2 = trig of e and of e + dt rates.
 template <typename Sink>
-__host__ __device__ inline void rk2_hessian(const double x[9], const double u[4], const double fext[3],
-                                            const double yp[3], const double yv[3], Sink sink)
+__host__ __device__ inline void rk2_hessian_core(const double v[3], double T, const AccJac &J1, const double vt[3],
+                                                 const Trig &tg1, const Trig &tg2, const double yp[3], const double yv[3], Sink sink)
 {
-    const double *v = x + 3, *e = x + 6;
-    const double T = u[3];
-    AccJac J1;
-    double a1[3], vt[3], et[3], alpha[3], beta[3], gam1[3];
-    accel<true>(v, e, T, fext, a1, &J1);
+    double alpha[3], beta[3], gam1[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        vt[i] = v[i] + DT * a1[i];
-        et[i] = e[i] + DT * u[i];
         alpha[i] = 0.5 * DT * DT * yp[i] + 0.5 * DT * yv[i];
         beta[i] = 0.5 * DT * yv[i];
     }
     PhiHess h2, h1;
-    phi_hess(beta, vt, et, T, &h2);
+    phi_hess(beta, vt, tg2, T, &h2);
 #pragma unroll
     for (int i = 0; i < 3; i++) gam1[i] = alpha[i] + DT * h2.gv[i];
-    phi_hess(gam1, v, e, T, &h1);
+    phi_hess(gam1, v, tg1, T, &h1);
     // K = Jv' H2ve (+ h2Te on the T row): rows T, v(3), e(3); columns = e~ index
     double KT[3], Kv[9], Ke[9];
 #pragma unroll
@@ -269,6 +280,23 @@ __host__ __device__ inline void rk2_hessian(const double x[9], const double u[4]
 #pragma unroll
         for (int l = j; l < 3; l++)
             sink(7 + j, 7 + l, h1.Hee[j * 3 + l] + Ke[j * 3 + l] + Ke[l * 3 + j] + h2.Hee[j * 3 + l]); // (e,e)
+}
+
+template <typename Sink>
+__host__ __device__ inline void rk2_hessian(const double x[9], const double u[4], const double fext[3],
+                                            const double yp[3], const double yv[3], Sink sink)
+{
+    const double *v = x + 3, *e = x + 6;
+    AccJac J1;
+    double a1[3], vt[3], et[3];
+    const Trig tg1 = make_trig(e);
+    accel_t<true>(v, tg1, u[3], fext, a1, &J1);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        vt[i] = v[i] + DT * a1[i];
+        et[i] = e[i] + DT * u[i];
+    }
+    rk2_hessian_core(v, u[3], J1, vt, tg1, make_trig(et), yp, yv, sink);
 }
 
 // Dense entries of Ax = dx+/dx (9x9) and Bx = dx+/du (9x4) from the compact form.

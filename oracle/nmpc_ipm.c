@@ -30,6 +30,7 @@ void orc_rk2_hess(const double *x, const double *u, const double *fext, const do
 #define HU_OFF 1e-5 /* hu = 1e-5, mpc_generator_normal.m:14 */
 #define S_MIN 1e-2
 #define MU_FLOOR_FRAC 0.1
+#define KAPPA_LAM 2.0      /* multiplier safeguard: s_i lam_i >= mu / KAPPA_LAM after every step */
 #define DIVERGE_MU 1e6
 #define DIVERGE_RS 1e12
 #define EXACT_SWITCH_EQ 1e-1
@@ -311,6 +312,10 @@ static int kkt_solve(solver_ws *W, const double *xinit, int full)
     return 0;
 }
 
+#ifdef ORC_TRACE
+#include <stdio.h>
+static int trace_kp, trace_ip, trace_kd, trace_id;
+#endif
 /* ds, dlam from dz; returns max feasible step fractions (unscaled) through *ap, *ad */
 static void slack_steps(solver_ws *W, const double *params, double sigmamu, int use_corr, double *ap, double *ad)
 {
@@ -326,10 +331,26 @@ static void slack_steps(solver_ws *W, const double *params, double sigmamu, int 
             const double dli = (-rc - W->lam[id] * dsi) / W->s[id];
             W->ds[id] = dsi;
             W->dlam[id] = dli;
-            if (dsi < 0.0) { const double a = -W->s[id] / dsi; if (a < a_p) a_p = a; }
-            if (dli < 0.0) { const double a = -W->lam[id] / dli; if (a < a_d) a_d = a; }
+            if (dsi < 0.0) { const double a = -W->s[id] / dsi; if (a < a_p) { a_p = a;
+#ifdef ORC_TRACE
+                    trace_kp = k; trace_ip = i;
+#endif
+                } }
+            if (dli < 0.0) { const double a = -W->lam[id] / dli; if (a < a_d) { a_d = a;
+#ifdef ORC_TRACE
+                    trace_kd = k; trace_id = i;
+#endif
+                } }
         }
     }
+#ifdef ORC_TRACE
+    if (use_corr) {
+        const size_t ip = (size_t)trace_kp * mc + trace_ip, idd = (size_t)trace_kd * mc + trace_id;
+        fprintf(stderr, "  primal blocked a=%.3g by stage %d row %d (s %.3g lam %.3g ds %.3g dl %.3g rin %.3g) | dual a=%.3g by stage %d row %d (s %.3g lam %.3g ds %.3g dl %.3g)\n",
+                a_p, trace_kp, trace_ip, W->s[ip], W->lam[ip], W->ds[ip], W->dlam[ip], W->rin[ip],
+                a_d, trace_kd, trace_id, W->s[idd], W->lam[idd], W->ds[idd], W->dlam[idd]);
+    }
+#endif
     *ap = a_p;
     *ad = a_d;
 }
@@ -548,6 +569,21 @@ int orc_solve(int N, int M, int model, const double *xinit, const double *z0,
                 W.s[id] += ap * W.ds[id];
                 W.lam[id] += ad * W.dlam[id];
             }
+        }
+        /* multiplier safeguard (cf. Waechter & Biegler 2006, eq. 16, with a tight kappa): no complementarity
+         * pair may fall below 1/KAPPA_LAM of the average one.  Pairs far below the central path have a
+         * barrier weight lam/s that is too small for the Newton direction to "see" the constraint, and the
+         * next steps get cut to a few percent by the fraction-to-boundary rule (jamming). */
+        {
+            double g2 = 0;
+            for (int k = 0; k < N; k++)
+                for (int i = 0; i < 34 + W.nf[k]; i++) { const size_t id = (size_t)k * mc + i; g2 += W.s[id] * W.lam[id]; }
+            const double floor_prod = g2 / mtot / KAPPA_LAM;
+            for (int k = 0; k < N; k++)
+                for (int i = 0; i < 34 + W.nf[k]; i++) {
+                    const size_t id = (size_t)k * mc + i;
+                    if (W.lam[id] * W.s[id] < floor_prod) W.lam[id] = floor_prod / W.s[id];
+                }
         }
     }
     memcpy(zout, W.z, sizeof(double) * 17 * N);

@@ -4,7 +4,8 @@ Tolerances (FP64 end to end, like the reference -- FORCESNLPsolver_normal.h:55-5
   stage functions : <= 1e-12 relative vs the reference-callback golden vectors
   solver          : same interior-point iteration as the oracle -> identical exit flags, iteration counts
                     equal on >= 95 % of the problems (identical math, different summation order) and
-                    |z_gpu - z_oracle|_inf <= 1e-6; vs the SciPy fixtures |dz|_inf <= 1e-3, |df|/f <= 1e-4
+                    |z_gpu - z_oracle|_inf <= 1e-6; vs the SciPy fixtures |df|/f <= 1e-4 and |dz|_inf <= 5e-3 at the
+                    reference's 1e-4 tolerances, <= 3e-4 (SLSQP's own accuracy) when solved to 1e-8
 """
 import ctypes
 import os
@@ -101,8 +102,14 @@ def test_batch_matches_scipy_fixtures(fam, golden_dir):
         assert conv.mean() > 0.9
         dz = np.max(np.abs(z[conv] - g["z"][sel][conv]), axis=(1, 2))
         df = np.abs(info[conv, 4] - g["f"][sel][conv]) / np.maximum(1e-9, np.abs(g["f"][sel][conv]))
-        assert np.max(dz) < 1e-3, np.max(dz)
+        # reference tolerances (1e-4): weakly active bounds are resolved to ~sqrt(tol_comp) only (see test_oracle.py)
+        assert np.max(dz) < 5e-3, np.max(dz)
         assert np.max(df) < 1e-4, np.max(df)
+        opt = solver.default_options()
+        opt.tol_stat = opt.tol_eq = opt.tol_ineq = opt.tol_comp = 1e-8
+        zt, flt, _, _ = solver.solve_batch_host(w, opt)
+        assert np.all(flt[conv] == 1)
+        assert np.max(np.abs(zt[conv] - g["z"][sel][conv])) < 3e-4
 
 
 def test_full_size_properties():

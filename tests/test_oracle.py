@@ -83,7 +83,12 @@ def test_solver_matches_scipy_fixtures(fam, golden_dir):
             continue
         assert fl == 1, (fam, i, fl)
         nconv += 1
-        assert np.max(np.abs(z - g["z"][i])) < 1e-3, (fam, i, np.max(np.abs(z - g["z"][i])))
+        # at the reference's tolerances (1e-4) a weakly active bound (multiplier ~ 0) is only resolved to
+        # ~sqrt(tol_comp) ~ 3e-3 by any interior-point method; the tight-tolerance solve below must hit SLSQP's point
+        assert np.max(np.abs(z - g["z"][i])) < 5e-3, (fam, i, np.max(np.abs(z - g["z"][i])))
+        zt, flt, _ = OL.solve_one(g["xinit"][i], g["x0"][i], g["params"][i], g["nfaces"][i], N, M, int(g["model"][i]),
+                                  OL.default_options(tol_stat=1e-8, tol_eq=1e-8, tol_ineq=1e-8, tol_comp=1e-8))
+        assert flt == 1 and np.max(np.abs(zt - g["z"][i])) < 3e-4, (fam, i, flt, np.max(np.abs(zt - g["z"][i])))
         assert abs(info.pobj - g["f"][i]) / max(1e-9, abs(g["f"][i])) < 1e-4
         assert info.res_eq <= 1e-4 and info.rsnorm <= 1e-4 and info.rcompnorm <= 1e-4 and info.res_ineq <= 1e-4
     assert nconv >= 0.7 * n
