@@ -240,6 +240,31 @@ __device__ __forceinline__ d4 mm_tn(const d4 x, const d4 y, d4 c)
 // D = X[0:4,:]' Y[0:4,:] + C  (only the first four rows of X and Y contribute)
 __device__ __forceinline__ d4 mm_tn4(double x0, double y0, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y0, c, 0, 0, 0); }
 
+// ---- mat-vec products on v_mfma_f64_4x4x4_4b (4 independent 4x4x4 blocks, 24 cycles instead of the 64 of the
+// 16x16x4 instruction; layout probed in tools/ubench/mfma_f64_4x4.hip): for block b
+//     A[i][k] in lane 16k + 4b + i,   B[k][j] in lane 16k + 4b + j,   D[i][j] in lane 16i + 4b + j.
+// "V layout" of a 16-vector: lane l holds x[4 qI + qk] with qk = l >> 4, qI = (l >> 2) & 3 (replicated over qj = l & 3).
+// y = A x + c with block b = output rows 4b..4b+3; in step m block b contracts columns 4((b+m)&3).. with the input
+// rotated by m quads inside each 16-lane row (DPP row_ror), so that the output comes out in V layout again:
+//     A-operand register m, lane l  <->  A[4 qI + qj][4 ((qI + m) & 3) + qk]      (gather tables TAB4_*)
+template <int M>
+__device__ __forceinline__ double quad_rot(double v) // result in quad q <- quad (q + M) & 3 of the same 16-lane row
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x120 + (16 - 4 * M), 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x120 + (16 - 4 * M), 0xF, 0xF, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+__device__ __forceinline__ double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ double matvec4(const d4 &A, double x, double c)
+{
+    const double x1 = quad_rot<1>(x), x2 = quad_rot<2>(x), x3 = quad_rot<3>(x);
+    double d = mfma4(A[0], x, c);
+    d = mfma4(A[1], x1, d);
+    d = mfma4(A[2], x2, d);
+    return mfma4(A[3], x3, d);
+}
+
 // LDS offset (within the staged E record) of Mt[row][col], the augmented transition matrix
 //   rows: s+ = [w+(0..3); x+(4..12)],  cols: [u(0..3); x(4..12); 13 = d]
 //   w+ = u + d_w,  x+ = A x + B u + d_x
@@ -285,21 +310,30 @@ __device__ __forceinline__ void init_stage_constants(int lane)
 // Per-lane gather offsets of the register tiles (which LDS / record slot feeds tile element (4r+g, c)): they depend
 // on the lane only, so the persistent workgroup computes them once into LDS and every sweep reloads its 4..16
 // entries with a few ds_reads instead of re-deriving them with ~700 branchy integer instructions per sweep.
-constexpr int TAB_M = 0, TAB_C1 = 4, TAB_C2 = 8, TAB_C3 = 12, TAB_MT = 16, TAB_PM = 20, TAB_ROWS = 24;
-__shared__ int sm_tab[TAB_ROWS * 64];
+constexpr int TAB_M = 0, TAB_C1 = 4, TAB_C2 = 8, TAB_C3 = 12; // 16x16 tiles of the factorisation sweep: element (4r+g, c)
+constexpr int TAB4_MT = 16;  // 4x4x4 A-operand layout: Mt[row][col]            (forward sweep, ds+ = Mt [du; dx; 1])
+constexpr int TAB4_MTT = 20; //                         Mt[col][row]            (vector backward sweep, q~ = phi~ + Mt' x)
+constexpr int TAB4_TT = 24;  //                         T'[row][col], row < 4   (forward sweep, du = -T' [hc dw; dx; 1])
+constexpr int TAB4_P = 28;   //                         P_k[row][col] from its packed lower triangle (record offset)
+constexpr int TAB_ROWS = 32;
+__shared__ unsigned short sm_tab[TAB_ROWS * 64];
 __device__ __noinline__ void init_lane_tables()
 {
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    const int qk = lane >> 4, qI = (lane >> 2) & 3, qj = lane & 3;
     for (int r = 0; r < 4; r++) {
         int o1, o2, o3;
         c_src(4 * r + g, c, o1, o2, o3);
-        sm_tab[(TAB_M + r) * 64 + lane] = m_src(4 * r + g, c);
-        sm_tab[(TAB_C1 + r) * 64 + lane] = o1;
-        sm_tab[(TAB_C2 + r) * 64 + lane] = o2;
-        sm_tab[(TAB_C3 + r) * 64 + lane] = o3;
-        sm_tab[(TAB_MT + r) * 64 + lane] = m_src(c, 4 * r + g); // Mt' tile: element [c][4r+g]
-        const int row = 4 * r + g, hi = row > c ? row : c, lo = row > c ? c : row;
-        sm_tab[(TAB_PM + r) * 64 + lane] = (row <= 12 && c <= 12) ? REC_P + hi * (hi + 1) / 2 + lo : REC_ZERO; // symmetric P_k from its packed triangle
+        sm_tab[(TAB_M + r) * 64 + lane] = (unsigned short)m_src(4 * r + g, c);
+        sm_tab[(TAB_C1 + r) * 64 + lane] = (unsigned short)o1;
+        sm_tab[(TAB_C2 + r) * 64 + lane] = (unsigned short)o2;
+        sm_tab[(TAB_C3 + r) * 64 + lane] = (unsigned short)o3;
+        const int row = 4 * qI + qj, col = 4 * ((qI + r) & 3) + qk;
+        sm_tab[(TAB4_MT + r) * 64 + lane] = (unsigned short)m_src(row, col);
+        sm_tab[(TAB4_MTT + r) * 64 + lane] = (unsigned short)m_src(col, row);
+        sm_tab[(TAB4_TT + r) * 64 + lane] = (unsigned short)(row < 4 ? S_T + 16 * row + col : S_ZERO);
+        const int hi = row > col ? row : col, lo = row > col ? col : row;
+        sm_tab[(TAB4_P + r) * 64 + lane] = (unsigned short)((row <= 12 && col <= 12) ? REC_P + hi * (hi + 1) / 2 + lo : REC_ZERO);
     }
     __syncthreads();
 }
@@ -730,25 +764,22 @@ __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, int t
 // ------------------------------------------------------------------ vector-only backward sweep (corrector)
 // Same factorisation, new rhs phi_cc = PHIB + smu PHIC:  q~ = phi~ + M'(P d + p+),  [kbar; Kbar'q_u] = T'' q_u,
 // p_x = q~_x - Kbar' q_u,  p_w = phi_w - hc kbar.  Updates the kbar column of T' and stores p_k.
-// Same software pipeline as the forward sweep: LDS-staged operands (M, phi) are prepared one stage ahead between
-// the MFMAs, register operands (T', P d) are loaded one stage ahead straight into the alternate register set.
+// All mat-vec products on the 4x4x4 MFMA, vectors in V layout: q~ = matvec4(Mt', x, phi~); the second product
+// contracts over the 4 inputs only, i.e. ONE MFMA whose A operand is the T' record exactly as it is stored
+// (lane 16k + c <-> T'[k][c]) and whose B operand is q_u broadcast from quad 0 to all quads of each row.
+// Same software pipeline as the forward sweep: LDS-staged operands (Mt', phi) are gathered one stage ahead while the
+// MFMAs execute, register operands (T', P d) are loaded one stage ahead straight into the alternate register set.
 template <int NP>
-__device__ __forceinline__ void backvec_step(const WsView &w, int kk, bool last, int lane, int g, int c, double smu,
-                                             const int (&mo)[4], const int (&po)[4],
-                                             const d4 &cM, const d4 &cGp, double chc, double cphiw, double ctp, const d4 &cpd,
-                                             d4 &nM, d4 &nGp, double &nhc, double &nphiw, double &ntp, d4 &npd,
-                                             double &e0, double &e1, double &e2, d4 &pv)
+__device__ __forceinline__ void backvec_step(const WsView &w, int kk, bool last, int lane, int idx, double smu,
+                                             const int (&mo)[4], int pho, int pwo, int pdo,
+                                             const d4 &cM, double cphi, double chc, double cphiw, double ctp, double cpd,
+                                             d4 &nM, double &nphi, double &nhc, double &nphiw, double &ntp, double &npd,
+                                             double &e0, double &e1, double &e2, double &pv)
 {
-    const d4 zero = {0.0, 0.0, 0.0, 0.0};
     gdouble *rec = w.rec + (size_t)kk * REC_STRIDE;
-    d4 Gp = cGp;
-    if (!last) {
-        d4 X;
-#pragma unroll
-        for (int r = 0; r < 4; r++) X[r] = (c == 13) ? cpd[r] + pv[r] : 0.0;
-        Gp = mm_tn(cM, X, Gp);
-    }
-    // ---- between the MFMAs: operands of stage kk-1 (clamped at 0: the tail re-stages stage 0, unused)
+    double q = cphi;
+    if (!last) q = matvec4(cM, cpd + pv, cphi);
+    // ---- while the MFMAs execute: operands of stage kk-1 (clamped at 0: the tail re-stages stage 0, unused)
     WSYNC();
     sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1;
     if (lane < 14) sm[S_E + 128 + lane] = e2;
@@ -757,28 +788,25 @@ __device__ __forceinline__ void backvec_step(const WsView &w, int kk, bool last,
         const int k1 = kk > 0 ? kk - 1 : 0, k2 = kk > 1 ? kk - 2 : 0;
         cgdouble *r1 = w.rec + (size_t)k1 * REC_STRIDE, *r2 = w.rec + (size_t)k2 * REC_STRIDE;
         ntp = r1[REC_T + lane];
-#pragma unroll
-        for (int r = 0; r < 4; r++) npd[r] = r1[(c == 13) ? REC_PD + 4 * r + g : REC_ZERO];
+        npd = r1[pdo];
         e0 = r2[lane]; e1 = r2[64 + lane]; e2 = r2[128 + (lane < 14 ? lane : 0)];
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        nM[r] = sm[mo[r]];
-        const int o = po[r] >= 0 ? po[r] : 0;
-        const double ph = sm[S_E + REC_PHIB + o] + smu * sm[S_E + REC_PHIC + o];
-        nGp[r] = (po[r] >= 0) ? ph : 0.0;
-    }
+    for (int r = 0; r < 4; r++) nM[r] = sm[mo[r]];
+    nphi = sm[S_E + REC_PHIB + pho] + smu * sm[S_E + REC_PHIC + pho];
+    nphi = (idx <= 12) ? nphi : 0.0;
+    nphiw = sm[S_E + REC_PHIB + pwo] + smu * sm[S_E + REC_PHIC + pwo];
     nhc = sm[S_E + REC_HC];
-    nphiw = sm[S_E + REC_PHIB + 4 + g] + smu * sm[S_E + REC_PHIC + 4 + g];
-    const d4 E = mm_tn4(ctp, Gp[0], zero);
-    d4 pn;
-    pn[0] = (c == 13) ? (cphiw - chc * E[0]) : 0.0;
-#pragma unroll
-    for (int r = 1; r < 4; r++) pn[r] = (c == 13 && 4 * r + g <= 12) ? Gp[r] - E[r] : 0.0;
-    if (c == 13) {
-        rec[REC_T + 16 * g + 13] = E[0]; // kbar
-#pragma unroll
-        for (int r = 0; r < 4; r++) rec[REC_PV + 4 * r + g] = pn[r]; // p_k for y_k = P_k ds_k + p_k
+    // q_u (rows 0..3, quad 0) to every quad of its row, then E[c] = sum_k T'[k][c] q_u[k]
+    const int qI = (lane >> 2) & 3;
+    const double r1 = quad_rot<1>(q), r2 = quad_rot<2>(q), r3 = quad_rot<3>(q);
+    const double qu = qI == 0 ? q : (qI == 1 ? r3 : (qI == 2 ? r2 : r1));
+    const double E = mfma4(ctp, qu, 0.0);
+    const bool q0 = idx < 4;
+    const double pn = q0 ? cphiw - chc * E : (idx <= 12 ? q - E : 0.0);
+    if ((lane & 3) == 0) {
+        if (q0) rec[REC_T + 16 * idx + 13] = E; // kbar
+        rec[REC_PV + idx] = pn;                 // p_k for y_k = P_k ds_k + p_k (rows 13..15: zero padding)
     }
     pv = pn;
 }
@@ -788,76 +816,70 @@ __device__ __noinline__ void sweep_backvec(WsView w, cgdouble *xinit, int N, dou
 {
     w = uni(w); xinit = uni(xinit); N = uni(N); smu = uni(smu);
     FULLSYNC(); // phase boundary: the corrector rhs written by the step phase is visible
-    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-    int mo[4], po[4];
+    const int lane = threadIdx.x;
+    const int idx = 4 * ((lane >> 2) & 3) + (lane >> 4); // V layout: the vector row this lane holds
+    int mo[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        mo[r] = sm_tab[(TAB_M + r) * 64 + lane];
-        po[r] = (c == 13 && 4 * r + g <= 12) ? zi_of(4 * r + g) : -1;
-    }
+    for (int r = 0; r < 4; r++) mo[r] = sm_tab[(TAB4_MTT + r) * 64 + lane];
+    const int pho = idx <= 12 ? zi_of(idx) : 0;  // q~ rows [u; x] -> z index
+    const int pwo = 4 + (idx & 3);               // p_w rows -> z index of w
+    const int pdo = idx <= 12 ? REC_PD + idx : REC_ZERO;
     init_stage_constants(lane);
-    const d4 zero = {0.0, 0.0, 0.0, 0.0};
-    d4 pv = zero;
+    double pv = 0.0;
     double e0, e1, e2;
-    d4 MA, GpA, pdA = zero, MB = zero, GpB = zero, pdB = zero;
-    double hcA, phiwA, tpA, hcB = 0.0, phiwB = 0.0, tpB = 0.0;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    d4 MA, MB = zero;
+    double phiA, hcA, phiwA, tpA, pdA, phiB = 0.0, hcB = 0.0, phiwB = 0.0, tpB = 0.0, pdB = 0.0;
     { // prologue: operands of stage N-1 into set A, prefetch of stage N-2
         cgdouble *rp = w.rec + (size_t)(N - 1) * REC_STRIDE;
         e0 = rp[lane]; e1 = rp[64 + lane]; e2 = rp[128 + (lane < 14 ? lane : 0)];
         tpA = rp[REC_T + lane];
-#pragma unroll
-        for (int r = 0; r < 4; r++) pdA[r] = rp[(c == 13) ? REC_PD + 4 * r + g : REC_ZERO];
+        pdA = rp[pdo];
         WSYNC();
         sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1;
         if (lane < 14) sm[S_E + 128 + lane] = e2;
         WSYNC();
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            MA[r] = sm[mo[r]];
-            const int o = po[r] >= 0 ? po[r] : 0;
-            const double ph = sm[S_E + REC_PHIB + o] + smu * sm[S_E + REC_PHIC + o];
-            GpA[r] = (po[r] >= 0) ? ph : 0.0;
-        }
+        for (int r = 0; r < 4; r++) MA[r] = sm[mo[r]];
+        phiA = sm[S_E + REC_PHIB + pho] + smu * sm[S_E + REC_PHIC + pho];
+        phiA = (idx <= 12) ? phiA : 0.0;
+        phiwA = sm[S_E + REC_PHIB + pwo] + smu * sm[S_E + REC_PHIC + pwo];
         hcA = sm[S_E + REC_HC];
-        phiwA = sm[S_E + REC_PHIB + 4 + g] + smu * sm[S_E + REC_PHIC + 4 + g];
         cgdouble *r2 = w.rec + (size_t)(N > 1 ? N - 2 : 0) * REC_STRIDE;
         e0 = r2[lane]; e1 = r2[64 + lane]; e2 = r2[128 + (lane < 14 ? lane : 0)];
     }
     int kk = N - 1;
     for (; kk >= 1; kk -= 2) {
-        backvec_step<NP>(w, kk, kk == N - 1, lane, g, c, smu, mo, po, MA, GpA, hcA, phiwA, tpA, pdA, MB, GpB, hcB, phiwB, tpB, pdB, e0, e1, e2, pv);
-        backvec_step<NP>(w, kk - 1, false, lane, g, c, smu, mo, po, MB, GpB, hcB, phiwB, tpB, pdB, MA, GpA, hcA, phiwA, tpA, pdA, e0, e1, e2, pv);
+        backvec_step<NP>(w, kk, kk == N - 1, lane, idx, smu, mo, pho, pwo, pdo, MA, phiA, hcA, phiwA, tpA, pdA, MB, phiB, hcB, phiwB, tpB, pdB, e0, e1, e2, pv);
+        backvec_step<NP>(w, kk - 1, false, lane, idx, smu, mo, pho, pwo, pdo, MB, phiB, hcB, phiwB, tpB, pdB, MA, phiA, hcA, phiwA, tpA, pdA, e0, e1, e2, pv);
     }
-    if (kk == 0) backvec_step<NP>(w, 0, N == 1, lane, g, c, smu, mo, po, MA, GpA, hcA, phiwA, tpA, pdA, MB, GpB, hcB, phiwB, tpB, pdB, e0, e1, e2, pv);
-    stage0_solve<NP>(w, xinit, lane, pv[0]);
+    if (kk == 0) backvec_step<NP>(w, 0, N == 1, lane, idx, smu, mo, pho, pwo, pdo, MA, phiA, hcA, phiwA, tpA, pdA, MB, phiB, hcB, phiwB, tpB, pdB, e0, e1, e2, pv);
+    // p_w[g] sits in the quad-0 lanes of row g; the stage-0 solve wants it in the lanes (g, 13)
+    stage0_solve<NP>(w, xinit, lane, __shfl(pv, lane & 48));
     FULLSYNC();
 }
 
 // ------------------------------------------------------------------ forward sweep: dz for all stages
-// du = -T' [hc dw; dx; 1],  ds+ = Mt [du; dx; 1]; the vectors stay in the column-0 lanes (row layout).
+// du = -T' [hc dw; dx; 1],  ds+ = Mt [du; dx; 1]: two chained mat-vec products per stage on the 4x4x4 MFMA (matvec4),
+// the vectors stay in V layout.
 // WITH_Y (corrector pass): also the multipliers of the Newton system  y+_k = P_k ds_k + p_k  (P_k gathered from its
-// packed lower triangle straight into the tile registers, prefetched one stage ahead), written to ynew.
-// Software pipeline, branch-free body: the record of stage k+1 is staged through LDS and its operand tiles are read
-// between the chained MFMAs of stage k; the global prefetch runs two stages ahead.  Two register sets (A/B)
-// alternate, so no tile is ever copied.
+// packed lower triangle straight into the operand registers, prefetched one stage ahead), written to ynew.
+// Software pipeline, branch-free body: the record of stage k+1 is staged through LDS and its operands are gathered
+// while the chained MFMAs of stage k execute; the global prefetch runs two stages ahead.  Two register sets (A/B)
+// alternate, so no operand is ever copied.
 template <int NP, bool WITH_Y>
-__device__ __forceinline__ void forward_step(const WsView &w, int N, int kk, int lane, int g, int c, const int (&tto)[4],
-                                             const int (&mto)[4], const int (&pmo)[4], const d4 &ctt, const d4 &cmt, double chc,
-                                             const d4 &cP, const d4 &cpv, d4 &ntt, d4 &nmt, double &nhc, d4 &nP, d4 &npv,
-                                             double &e0, double &tp, d4 &v)
+__device__ __forceinline__ void forward_step(const WsView &w, int N, int kk, int lane, int idx, const int (&tto)[4],
+                                             const int (&mto)[4], const int (&pmo)[4], int pvo, const d4 &ctt, const d4 &cmt, double chc,
+                                             const d4 &cP, double cpv, d4 &ntt, d4 &nmt, double &nhc, d4 &nP, double &npv,
+                                             double &e0, double &tp, double &v)
 {
-    const d4 zero = {0.0, 0.0, 0.0, 0.0};
-    d4 v1 = v;
-    if (c == 0) {
-        v1[0] = chc * v[0];
-        if (g == 1) v1[3] = 1.0; // row 13 multiplies the kbar column
-    }
-    d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ctt[0], v1[0], zero, 0, 0, 0);
+    const bool q0 = idx < 4 && (lane & 12) == 0; // rows 0..3 (quad 0 of every 16-lane row)
+    const double v1 = q0 ? chc * v : (idx == 13 ? 1.0 : v); // row 13 multiplies the kbar column
+    const double D1 = matvec4(ctt, v1, 0.0);
     // stage the (already fetched) record of the next stage through LDS ...
     WSYNC();
     sm[S_E + lane] = e0; sm[S_T + lane] = tp;
     WSYNC();
-    D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ctt[1], v1[1], D1, 0, 0, 0);
     { // ... prefetch the one after it (clamped: the tail re-reads the last record, unused) ...
         const int kf = (kk + 2 < N) ? kk + 2 : N - 1;
         cgdouble *rp = w.rec + (size_t)kf * REC_STRIDE;
@@ -866,42 +888,25 @@ __device__ __forceinline__ void forward_step(const WsView &w, int N, int kk, int
             const int kn = (kk + 1 < N) ? kk + 1 : N - 1;
             cgdouble *rq = w.rec + (size_t)kn * REC_STRIDE;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                nP[r] = rq[pmo[r]];
-                npv[r] = rq[(c == 0) ? REC_PV + 4 * r + g : REC_ZERO];
-            }
+            for (int r = 0; r < 4; r++) nP[r] = rq[pmo[r]];
+            npv = rq[pvo];
         }
     }
 #pragma unroll
-    for (int s = 0; s < 4; s++) ntt[s] = sm[tto[s]];
-    D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ctt[2], v1[2], D1, 0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < 4; s++) nmt[s] = sm[mto[s]];
+    for (int s = 0; s < 4; s++) { ntt[s] = sm[tto[s]]; nmt[s] = sm[mto[s]]; }
     nhc = sm[S_T + 14];
-    D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ctt[3], v1[3], D1, 0, 0, 0);
-    d4 Y = zero;
-    if (WITH_Y) Y = mm_tn(cP, v, cpv); // y+_k = P_k ds_k + p_k (P symmetric: A operand = the tile itself)
-    const double du = -D1[0];
-    if (c == 0) { // dz rows 17..19 are padding (tile rows 13..15)
+    double Y = 0.0;
+    if (WITH_Y) Y = matvec4(cP, v, cpv); // y+_k = P_k ds_k + p_k
+    const double du = -D1;
+    const double v2 = q0 ? du : (idx == 13 ? 1.0 : v); // row 13 multiplies the d column
+    const double D2 = matvec4(cmt, v2, 0.0);
+    if ((lane & 3) == 0) { // one copy of each row; dz rows 17..19 / ynew rows 13..15 are padding
         double *dzl = dz_area<NP>();
-        dzl[g * NP + kk] = du;
-#pragma unroll
-        for (int r = 0; r < 4; r++) dzl[(4 + 4 * r + g) * NP + kk] = v[r];
+        if (q0) dzl[idx * NP + kk] = du;
+        dzl[(4 + idx) * NP + kk] = v;
+        if (WITH_Y) w.step[idx * NP + kk] = Y;
     }
-    d4 v2 = v;
-    if (c == 0) {
-        v2[0] = du;
-        if (g == 1) v2[3] = 1.0; // row 13 multiplies the d column
-    }
-    const d4 D2 = mm_tn(cmt, v2, zero);
-    if (WITH_Y) {
-        if (c == 0) { // ynew rows 13..15 are padding
-#pragma unroll
-            for (int r = 0; r < 4; r++) w.step[(4 * r + g) * NP + kk] = Y[r];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; r++) v[r] = (c == 0 && 4 * r + g <= 12) ? D2[r] : 0.0;
+    v = D2; // rows 13..15 of Mt are zero
 }
 
 template <int NP, bool WITH_Y>
@@ -909,30 +914,29 @@ __device__ __noinline__ void sweep_forward(WsView w, int N)
 {
     w = uni(w); N = uni(N);
     FULLSYNC(); // phase boundary: T' / kbar of the backward sweep are visible
-    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    const int lane = threadIdx.x;
+    const int idx = 4 * ((lane >> 2) & 3) + (lane >> 4); // V layout: the vector row this lane holds
     int mto[4], tto[4], pmo[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        mto[s] = sm_tab[(TAB_MT + s) * 64 + lane];              // Mt' tile: element [c][4s+g]
-        tto[s] = (c < 4) ? S_T + 16 * c + 4 * s + g : S_ZERO;   // T'' tile: element T'[c][4s+g]
-        pmo[s] = sm_tab[(TAB_PM + s) * 64 + lane];              // symmetric P_k from its packed triangle
+        mto[s] = sm_tab[(TAB4_MT + s) * 64 + lane];
+        tto[s] = sm_tab[(TAB4_TT + s) * 64 + lane];
+        pmo[s] = sm_tab[(TAB4_P + s) * 64 + lane];
     }
+    const int pvo = idx <= 12 ? REC_PV + idx : REC_ZERO;
     init_stage_constants(lane);
-    d4 v;
-#pragma unroll
-    for (int r = 0; r < 4; r++) v[r] = (c == 0 && 4 * r + g <= 12) ? sm[S_DS0 + 4 * r + g] : 0.0;
+    double v = sm[S_DS0 + idx]; // ds_0 (entries 13..15 are zero)
     double e0, tp;
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
-    d4 PA = zero, pvA = zero, PB = zero, pvB = zero;
+    d4 PA = zero, PB = zero;
+    double pvA = 0.0, pvB = 0.0;
     {
         cgdouble *rp = w.rec;
         e0 = rp[lane]; tp = rp[REC_T + lane];
         if (WITH_Y) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                PA[r] = rp[pmo[r]];
-                pvA[r] = rp[(c == 0) ? REC_PV + 4 * r + g : REC_ZERO];
-            }
+            for (int r = 0; r < 4; r++) PA[r] = rp[pmo[r]];
+            pvA = rp[pvo];
         }
     }
     WSYNC();
@@ -949,10 +953,10 @@ __device__ __noinline__ void sweep_forward(WsView w, int N)
     }
     int kk = 0;
     for (; kk + 1 < N; kk += 2) {
-        forward_step<NP, WITH_Y>(w, N, kk, lane, g, c, tto, mto, pmo, ttA, mtA, hcA, PA, pvA, ttB, mtB, hcB, PB, pvB, e0, tp, v);
-        forward_step<NP, WITH_Y>(w, N, kk + 1, lane, g, c, tto, mto, pmo, ttB, mtB, hcB, PB, pvB, ttA, mtA, hcA, PA, pvA, e0, tp, v);
+        forward_step<NP, WITH_Y>(w, N, kk, lane, idx, tto, mto, pmo, pvo, ttA, mtA, hcA, PA, pvA, ttB, mtB, hcB, PB, pvB, e0, tp, v);
+        forward_step<NP, WITH_Y>(w, N, kk + 1, lane, idx, tto, mto, pmo, pvo, ttB, mtB, hcB, PB, pvB, ttA, mtA, hcA, PA, pvA, e0, tp, v);
     }
-    if (kk < N) forward_step<NP, WITH_Y>(w, N, kk, lane, g, c, tto, mto, pmo, ttA, mtA, hcA, PA, pvA, ttB, mtB, hcB, PB, pvB, e0, tp, v);
+    if (kk < N) forward_step<NP, WITH_Y>(w, N, kk, lane, idx, tto, mto, pmo, pvo, ttA, mtA, hcA, PA, pvA, ttB, mtB, hcB, PB, pvB, e0, tp, v);
     WSYNC();
 }
 
