@@ -74,7 +74,8 @@ struct KernelArgs {
     int *exitflag, *iters;
     double *info;
     double *ws;
-    int *counter; // work-queue head (set by the launcher)
+    int *counter;     // work-queue head (set by the launcher)
+    const int *order; // launch order of the problems, or null = index order (set by the launcher)
 };
 
 size_t ws_bytes(int B, int N, int MF);

@@ -470,7 +470,6 @@ __device__ __noinline__ EvalOut phase_eval(WsView w, cgdouble *pbase, int np, cg
 {
     w = uni(w); pbase = uni(pbase); np = uni(np); xinit = uni(xinit); N = uni(N); MF = uni(MF); model = uni(model); hess = uni(hess);
     FULLSYNC(); // phase boundary: other lanes' global writes of the previous phase are visible
-    constexpr int H = 64 / NP;
     const int lane = threadIdx.x;
     double *stg = stage_area<NP>();
     double l_eq = 0, l_in = 0, l_rs = 0, l_rc = 0, l_gap = 0, l_obj = 0;
@@ -1313,13 +1312,20 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 
 #ifdef FRP_PROFILE
     long long tph[6] = {0, 0, 0, 0, 0, 0}, tc0, tc1;
+    const long long t_start = wall_clock64(); // 100 MHz constant clock: start / end of this solve on the launch time line
 #define TICK() tc0 = clock64()
 #define TOCK(i) do { tc1 = clock64(); tph[i] += tc1 - tc0; tc0 = tc1; } while (0)
 #else
 #define TICK()
 #define TOCK(i)
 #endif
+    __builtin_amdgcn_s_setprio(0);
     for (it = 0;; it++) {
+        // Long solves set the duration of a launch (the batch is done when its slowest problem is): a wave that is
+        // past the typical iteration count gets issue priority over the wave it shares the SIMD with.
+        if (it == 7) __builtin_amdgcn_s_setprio(1);
+        else if (it == 10) __builtin_amdgcn_s_setprio(2);
+        else if (it == 14) __builtin_amdgcn_s_setprio(3);
         TICK();
         const EvalOut e = phase_eval<NP>(w, pbase, np, xinit, N, MF, nfk, a.model, hess);
         res_eq = wave_max(e.eq); res_in = wave_max(e.in); rs = wave_max(e.rs); rcomp = wave_max(e.rc);
@@ -1371,6 +1377,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             o[0] = res_eq; o[1] = res_in; o[2] = rs; o[3] = rcomp; o[4] = pobj; o[5] = mu; o[6] = step_cc; o[7] = (double)nfallback;
 #ifdef FRP_PROFILE
             for (int i = 0; i < 6; i++) o[i] = (double)tph[i]; // cycles: eval, factor, forward(affine), affine+step, backvec, forward(corrector, with y)
+            o[6] = (double)t_start; o[7] = (double)wall_clock64();
 #endif
         }
     }
@@ -1390,9 +1397,52 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
         if (threadIdx.x == 0) b = atomicAdd(a.counter, 1);
         b = __builtin_amdgcn_readfirstlane(b);
         if (b >= a.B) break;
+        if (a.order) b = a.order[b]; // longest-expected-first launch order (see order_keys_kernel)
         solve_one<NP>(a, b, slot);
         FULLSYNC();
     }
+}
+
+// ------------------------------------------------------------------ launch order: longest expected solve first
+// The launch ends when its slowest problem does, and a problem that needs 3-5x the typical iteration count should not
+// be the last one to start.  Proxy for the work of a solve: the objective of the caller's initial guess (a plan that
+// starts far from its reference / corridor costs more and takes more interior-point iterations; rank correlation with
+// the iteration count ~0.45 on the BASELINE workloads, and the hardest problems are reliably in the upper half, i.e.
+// in the first wave of resident workgroups).  Only the ORDER in which the persistent workgroups pull problems
+// changes; every problem is solved exactly as before.
+__global__ __launch_bounds__(256) void order_keys_kernel(int B, int N, int np, int model, const double *__restrict__ x0,
+                                                         const double *__restrict__ params, double *__restrict__ keys)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)B * N) return;
+    const int k = (int)(t % N);
+    double zl[NZ], p10[NPRE];
+#pragma unroll
+    for (int i = 0; i < NZ; i++) zl[i] = x0[t * NZ + i];
+#pragma unroll
+    for (int i = 0; i < NPRE; i++) p10[i] = params[t * np + i];
+    const double c = stage_cost(zl, p10, stage_class(k, N), model, nullptr);
+    atomicAdd(&keys[t / N], (c == c && c < 1e300) ? c : 0.0);
+}
+// order[rank(b)] = b with rank = number of problems that come first (larger key, ties by index): a permutation for any
+// input (non-finite keys were mapped to 0 above)
+__global__ __launch_bounds__(256) void order_rank_kernel(int B, const double *__restrict__ keys, int *__restrict__ order)
+{
+    __shared__ double tile[256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const double ki = i < B ? keys[i] : 0.0;
+    int rank = 0;
+    for (int j0 = 0; j0 < B; j0 += 256) {
+        __syncthreads();
+        tile[threadIdx.x] = (j0 + (int)threadIdx.x < B) ? keys[j0 + threadIdx.x] : -1.0;
+        __syncthreads();
+        const int n = B - j0 < 256 ? B - j0 : 256;
+        for (int j = 0; j < n; j++) {
+            const double kj = tile[j];
+            rank += (kj > ki || (kj == ki && j0 + j < i)) ? 1 : 0;
+        }
+    }
+    if (i < B) order[rank] = i;
 }
 
 // ------------------------------------------------------------------ batched model callback
@@ -1477,19 +1527,35 @@ static int resident_slots()
     return slots;
 }
 
-size_t ws_bytes(int B, int N, int MF)
+// workspace = [solver state of min(B, FRP_MAX_SLOTS) slots][work-queue counter, 256 B][keys: B doubles][order: B ints]
+static size_t queue_offset_doubles(int B, int N, int MF)
 {
     const size_t slots = B < FRP_MAX_SLOTS ? B : FRP_MAX_SLOTS;
-    return slots * ws_doubles_per_problem(N, MF) * sizeof(double) + 256; // + the work-queue counter
+    return slots * ws_doubles_per_problem(N, MF);
+}
+size_t ws_bytes(int B, int N, int MF)
+{
+    return (queue_offset_doubles(B, N, MF) + 32 + (size_t)B + ((size_t)B + 1) / 2) * sizeof(double);
 }
 
 hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
 {
     KernelArgs k = a;
     const int slots = a.B < resident_slots() ? a.B : resident_slots();
-    k.counter = reinterpret_cast<int *>(a.ws + (size_t)slots * ws_doubles_per_problem(a.N, a.MF));
-    hipError_t e = hipMemsetAsync(k.counter, 0, sizeof(int), stream);
+    double *q = a.ws + queue_offset_doubles(a.B, a.N, a.MF);
+    k.counter = reinterpret_cast<int *>(q);
+    k.order = nullptr;
+    hipError_t e = hipMemsetAsync(q, 0, 256 + (a.B > slots ? (size_t)a.B * sizeof(double) : 0), stream); // counter (+ keys)
     if (e != hipSuccess) return e;
+    if (a.B > slots) { // more problems than resident workgroups: order the queue, longest expected solve first
+        double *keys = q + 32;
+        int *order = reinterpret_cast<int *>(keys + a.B);
+        k.order = order;
+        const size_t nt = (size_t)a.B * a.N;
+        hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, stream, a.B, a.N, NPRE + 4 * a.M,
+                           a.model, a.x0, a.params, keys);
+        hipLaunchKernelGGL(order_rank_kernel, dim3((unsigned)((a.B + 255) / 256)), dim3(256), 0, stream, a.B, keys, order);
+    }
     switch (padded_stages(a.N)) {
     case 16: hipLaunchKernelGGL(nmpc_ipm_kernel<16>, dim3(slots), dim3(64), 0, stream, k); break;
     case 20: hipLaunchKernelGGL(nmpc_ipm_kernel<20>, dim3(slots), dim3(64), 0, stream, k); break;

@@ -46,14 +46,17 @@ def test_dropin_struct_layouts_match_reference_sizes():
 
 
 def test_workspace_size_formula():
-    """Workspace = (resident slots) x (per-problem solver state) + work-queue counter: grows with the batch only up
-    to the number of slots the library sizes for (4096), with the horizon and with the face count."""
+    """Workspace = (resident slots) x (per-problem solver state) + work queue (counter 256 B, one key and one order
+    entry per problem): the solver state grows with the batch only up to the number of slots the library sizes for
+    (4096), and with the horizon and the face count; the queue is 12 B per problem."""
     lib = solver.lib()
-    b1 = lib.frp_nmpc_workspace_bytes(1, 20, 6); b7 = lib.frp_nmpc_workspace_bytes(7, 20, 6)
-    per = b1 - 256
-    assert per > 20 * 328 * 8 and b7 == 7 * per + 256
-    assert lib.frp_nmpc_workspace_bytes(10 ** 6, 20, 6) == lib.frp_nmpc_workspace_bytes(4096, 20, 6)
-    assert lib.frp_nmpc_workspace_bytes(1, 40, 6) > b1 and lib.frp_nmpc_workspace_bytes(1, 20, 15) > b1
+    ws = lib.frp_nmpc_workspace_bytes
+    queue = lambda B: 8 * (32 + B + (B + 1) // 2)
+    per = ws(1, 20, 6) - queue(1)
+    assert per > 20 * 384 * 8
+    assert ws(7, 20, 6) == 7 * per + queue(7)
+    assert ws(10 ** 6, 20, 6) - queue(10 ** 6) == ws(4096, 20, 6) - queue(4096) == 4096 * per
+    assert ws(1, 40, 6) > ws(1, 20, 6) and ws(1, 20, 15) > ws(1, 20, 6)
 
 
 @pytest.mark.skipif(_has_gpu(), reason="checks the no-device behaviour")
