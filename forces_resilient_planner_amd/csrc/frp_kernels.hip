@@ -39,31 +39,50 @@ namespace frp {
 #define FRP_MAX_SLOTS 4096 // upper bound of resident single-wave workgroups the workspace is sized for
 
 // ------------------------------------------------------------------ wave helpers
-__device__ __forceinline__ double wave_max(double v)
+// Cross-lane reductions on DPP (no LDS round trips): butterflies inside each 16-lane row with quad_perm / row_half_mirror
+// / row_mirror, then the four row results are combined through v_readlane.  Every lane ends up with the result.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+__device__ __forceinline__ double lane_read(double v, int src) // wave-uniform src lane
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)b, src);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+struct OpSum { static __device__ __forceinline__ double f(double a, double b) { return a + b; } };
+struct OpMax { static __device__ __forceinline__ double f(double a, double b) { return fmax(a, b); } };
+struct OpMin { static __device__ __forceinline__ double f(double a, double b) { return fmin(a, b); } };
+template <class Op>
+__device__ __forceinline__ double row16_reduce(double v) // all 16 lanes of a row get the row result
+{
+#ifdef FRP_SHFL_REDUCE // debugging aid: the same butterflies through ds_bpermute
+    for (int o = 1; o < 16; o <<= 1) v = Op::f(v, __shfl_xor(v, o));
+    return v;
+#endif
+    v = Op::f(v, dpp_move<0xB1>(v));  // quad_perm [1,0,3,2]
+    v = Op::f(v, dpp_move<0x4E>(v));  // quad_perm [2,3,0,1]
+    v = Op::f(v, dpp_move<0x141>(v)); // row_half_mirror: quads 0 <-> 1, 2 <-> 3
+    v = Op::f(v, dpp_move<0x140>(v)); // row_mirror: halves of the row
     return v;
 }
-__device__ __forceinline__ double wave_min(double v)
+template <class Op>
+__device__ __forceinline__ double wave_reduce(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
-    return v;
+    v = row16_reduce<Op>(v);
+    return Op::f(Op::f(lane_read(v, 0), lane_read(v, 16)), Op::f(lane_read(v, 32), lane_read(v, 48)));
 }
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ double wave_max(double v) { return wave_reduce<OpMax>(v); }
+__device__ __forceinline__ double wave_min(double v) { return wave_reduce<OpMin>(v); }
+__device__ __forceinline__ double wave_sum(double v) { return wave_reduce<OpSum>(v); }
 // sum over the 16 lanes of one row group (lanes with equal lane >> 4)
-__device__ __forceinline__ double row16_sum(double v)
-{
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ double row16_sum(double v) { return row16_reduce<OpSum>(v); }
 __device__ __forceinline__ double lane_bcast(double v, int src) // wave-uniform src lane
 {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
@@ -465,14 +484,19 @@ __device__ __forceinline__ void eval_rows(cgdouble *__restrict__ ps, cgdouble *_
 // part 1 (lane == stage): model + linearisation -> record, equality residuals, M'y -> LDS
 // part 2 (lane == (row pair, stage), all 64 lanes): corridor rows, then bounds: residual norms,
 //        barrier Hessian / affine rhs -> record
+struct ModelOut {
+    double eq, obj;
+};
+// part 1 (lane == stage): model + linearisation -> record, equality residuals, M'y -> LDS staging.  A function of its
+// own: it needs most of the register file, and the element-wise part that follows has stage-divergent loops.
 template <int NP>
-__device__ __noinline__ EvalOut phase_eval(WsView w, cgdouble *pbase, int np, cgdouble *xinit, int N, int MF, int nfk, int model, int hess)
+__device__ __noinline__ ModelOut phase_model(WsView w, cgdouble *pbase, int np, cgdouble *xinit, int N, int model, int hess)
 {
-    w = uni(w); pbase = uni(pbase); np = uni(np); xinit = uni(xinit); N = uni(N); MF = uni(MF); model = uni(model); hess = uni(hess);
+    w = uni(w); pbase = uni(pbase); np = uni(np); xinit = uni(xinit); N = uni(N); model = uni(model); hess = uni(hess);
     FULLSYNC(); // phase boundary: other lanes' global writes of the previous phase are visible
     const int lane = threadIdx.x;
     double *stg = stage_area<NP>();
-    double l_eq = 0, l_in = 0, l_rs = 0, l_rc = 0, l_gap = 0, l_obj = 0;
+    double l_eq = 0, l_obj = 0;
     if (lane < N) {
         const int k = lane;
         cgdouble *pk = pbase + (size_t)k * np;
@@ -576,8 +600,21 @@ __device__ __noinline__ EvalOut phase_eval(WsView w, cgdouble *pbase, int np, cg
 #pragma unroll
         for (int i = 0; i < NZ; i++) stg[i * NP + k] = gm[i];
     }
-    // ---- part 2: all 64 lanes, lane = (half, stage k); rows handled in pairs
     WSYNC();
+    ModelOut o;
+    o.eq = l_eq; o.obj = l_obj;
+    return o;
+}
+
+// part 2 (lane == (row group, stage), all 64 lanes): corridor rows, then bounds: residual norms, barrier Hessian /
+// affine rhs -> record
+template <int NP>
+__device__ __noinline__ EvalOut phase_eval(WsView w, cgdouble *pbase, int np, int N, int MF, int nfk, int model, double l_eq, double l_obj)
+{
+    w = uni(w); pbase = uni(pbase); np = uni(np); N = uni(N); MF = uni(MF); model = uni(model);
+    WSYNC();
+    double *stg = stage_area<NP>();
+    double l_in = 0, l_rs = 0, l_rc = 0, l_gap = 0;
     eval_rows<NP>(w.s, w.lam, w.z, w.face, w.rec, pbase, np, N, MF, nfk, model, stg, l_in, l_rc, l_gap, l_rs);
     FULLSYNC();
     EvalOut o;
@@ -1202,41 +1239,24 @@ __device__ __noinline__ SlackOut phase_step(WsView w, int N, int MF, int nfk, do
     return o;
 }
 
-// ------------------------------------------------------------------ the solver kernel
-// One problem `b`, using workspace slot `slot` (slots are reused by successive problems of the same workgroup, so
-// the HBM footprint of the solver state is (#resident waves) x (state size), independent of the batch size).
+// ------------------------------------------------------------------ initialisation of one solve (lane == stage)
+// Its own (non-inlined) function like every other phase: the stage-divergent loops below (face counts differ per
+// stage) must not share a register allocation with the long-lived state of the solver loop -- a VGPR spill placed
+// at the exit of such a loop executes with an empty EXEC mask and saves nothing.
+struct InitOut {
+    int nfk, mtot, bad;
+};
 template <int NP>
-__device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, const int slot)
+__device__ __noinline__ InitOut phase_init(WsView w, cgdouble *pk, const int *nfaces, const double *x0, int N, int M, int MF, double mu0)
 {
-    const int lane = threadIdx.x;
-    const int N = a.N, M = a.M, MF = a.MF, np = NPRE + 4 * M;
-    const int mcf = 34 + MF;
-    const bool act = lane < N; // lane == stage in the initialisation
-    const int k = lane;
-
-    WsView w;
-    {
-        gdouble *base = (gdouble *)(a.ws + (size_t)slot * ws_doubles_per_problem(N, MF));
-        w.rec = base;
-        w.z = w.rec + (size_t)N * REC_STRIDE;
-        w.y = w.z + 17 * NP;
-        w.dz = w.y + Y_ROWS * NP;
-        w.s = w.dz + DZ_ROWS * NP;
-        w.lam = w.s + (size_t)mcf * NP;
-        w.corr = w.lam + (size_t)mcf * NP;
-        w.step = w.corr + (size_t)mcf * NP;       // ds | dlam of the corrector step ([2 mcf][NP])
-        w.face = w.step + 2 * (size_t)mcf * NP;
-    }
-    cgdouble *xinit = (cgdouble *)(a.xinit + (size_t)b * 9);
-    cgdouble *pbase = (cgdouble *)(a.params + (size_t)b * N * np);
-    cgdouble *pk = pbase + (size_t)(act ? k : 0) * np;
-
-    // ---------------------------------------------------------------- init (lane == stage)
+    w = uni(w); N = uni(N); M = uni(M); MF = uni(MF); mu0 = uni(mu0);
+    const int lane = threadIdx.x, k = lane;
+    const bool act = lane < N;
     int nf = 0;
     int bad_param = 0;
     double smin = 1e300;
     if (act) {
-        if (a.nfaces) nf = a.nfaces[(size_t)b * N + k];
+        if (nfaces) nf = nfaces[k];
         else { // trailing all-zero rows are padding (forces_normal.cpp:127-135)
             nf = M;
             while (nf > 0) {
@@ -1247,7 +1267,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         }
         if (nf > MF || nf < 0) { bad_param = 1; nf = 0; }
         double zk[NZ];
-        const double *z0 = a.x0 + ((size_t)b * N + k) * NZ;
+        const double *z0 = x0 + (size_t)k * NZ;
 #pragma unroll
         for (int i = 0; i < NZ; i++) {
             zk[i] = z0[i];
@@ -1284,14 +1304,11 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     }
     smin = wave_min(smin);
     const int mtot = (int)wave_sum(act ? (double)(34 + nf) : 0.0);
-    if (wave_max((double)bad_param) > 0.0) {
-        if (lane == 0) { a.exitflag[b] = FRP_EXIT_PARAM_VALUE; a.iters[b] = 0; }
-        if (act) {
-            const double *z0 = a.x0 + ((size_t)b * N + k) * NZ;
-            for (int i = 0; i < NZ; i++) a.z[((size_t)b * N + k) * NZ + i] = z0[i];
-        }
-        return;
-    }
+    InitOut o;
+    o.bad = wave_max((double)bad_param) > 0.0 ? 1 : 0;
+    o.mtot = mtot;
+    o.nfk = 0;
+    if (o.bad) return o;
     {
         // infeasible-start initialisation: uniform slack shift (see oracle/nmpc_ipm.c)
         const double shift = (smin >= S_MIN) ? 0.0 : (S_MIN - smin) + fmax(0.0, -smin);
@@ -1299,11 +1316,54 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             for (int i = 0; i < 34 + nf; i++) {
                 const double s = w.s[i * NP + k] + shift;
                 w.s[i * NP + k] = s;
-                w.lam[i * NP + k] = a.mu0 / s;
+                w.lam[i * NP + k] = mu0 / s;
             }
         }
     }
-    const int nfk = __shfl(nf, lane % NP); // face count of stage k = lane % NP for the (half, stage) lane mapping
+    o.nfk = __shfl(nf, lane % NP); // face count of stage k = lane % NP for the (half, stage) lane mapping
+    return o;
+}
+
+// ------------------------------------------------------------------ the solver kernel
+// One problem `b`, using workspace slot `slot` (slots are reused by successive problems of the same workgroup, so
+// the HBM footprint of the solver state is (#resident waves) x (state size), independent of the batch size).
+template <int NP>
+__device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, const int slot)
+{
+    const int lane = threadIdx.x;
+    const int N = a.N, M = a.M, MF = a.MF, np = NPRE + 4 * M;
+    const int mcf = 34 + MF;
+    const bool act = lane < N; // lane == stage in the initialisation
+    const int k = lane;
+
+    WsView w;
+    {
+        gdouble *base = (gdouble *)(a.ws + (size_t)slot * ws_doubles_per_problem(N, MF));
+        w.rec = base;
+        w.z = w.rec + (size_t)N * REC_STRIDE;
+        w.y = w.z + 17 * NP;
+        w.dz = w.y + Y_ROWS * NP;
+        w.s = w.dz + DZ_ROWS * NP;
+        w.lam = w.s + (size_t)mcf * NP;
+        w.corr = w.lam + (size_t)mcf * NP;
+        w.step = w.corr + (size_t)mcf * NP;       // ds | dlam of the corrector step ([2 mcf][NP])
+        w.face = w.step + 2 * (size_t)mcf * NP;
+    }
+    cgdouble *xinit = (cgdouble *)(a.xinit + (size_t)b * 9);
+    cgdouble *pbase = (cgdouble *)(a.params + (size_t)b * N * np);
+    cgdouble *pk = pbase + (size_t)(act ? k : 0) * np;
+
+    // ---------------------------------------------------------------- init (lane == stage)
+    const InitOut ini = phase_init<NP>(w, pk, a.nfaces ? a.nfaces + (size_t)b * N : nullptr, a.x0 + (size_t)b * N * NZ, N, M, MF, a.mu0);
+    if (ini.bad) { // a stage has more live corridor rows than the workspace was sized for (MF)
+        if (lane == 0) { a.exitflag[b] = FRP_EXIT_PARAM_VALUE; a.iters[b] = 0; }
+        if (act) {
+            const double *z0 = a.x0 + ((size_t)b * N + k) * NZ;
+            for (int i = 0; i < NZ; i++) a.z[((size_t)b * N + k) * NZ + i] = z0[i];
+        }
+        return;
+    }
+    const int nfk = ini.nfk, mtot = ini.mtot;
     const int hess = a.hessian ? 1 : 0;
     FULLSYNC();
 
@@ -1327,7 +1387,8 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         else if (it == 10) __builtin_amdgcn_s_setprio(2);
         else if (it == 14) __builtin_amdgcn_s_setprio(3);
         TICK();
-        const EvalOut e = phase_eval<NP>(w, pbase, np, xinit, N, MF, nfk, a.model, hess);
+        const ModelOut mo_ = phase_model<NP>(w, pbase, np, xinit, N, a.model, hess);
+        const EvalOut e = phase_eval<NP>(w, pbase, np, N, MF, nfk, a.model, mo_.eq, mo_.obj);
         res_eq = wave_max(e.eq); res_in = wave_max(e.in); rs = wave_max(e.rs); rcomp = wave_max(e.rc);
         pobj = wave_sum(e.obj);
         mu = wave_sum(e.gap) / (double)mtot;

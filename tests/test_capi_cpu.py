@@ -162,3 +162,32 @@ def test_workloads_are_seeded_and_well_formed():
             assert np.all(A @ c["ref_pos"][bb, k] < bt)
     d = workloads.config1(4)
     assert d["nfaces"].max() == 0 and np.all(d["params"][:, :, 10:] == 0)
+
+
+def test_stage_divergent_phases_do_not_spill(tmp_path):
+    """Compiler-hazard guard.  The gfx950 backend may place a VGPR spill at the exit of a lane-divergent loop, where the
+    EXEC mask is empty, so the spill saves nothing and the later reload returns whatever the scratch slot held (this
+    crashed a solve through a reloaded zero offset).  Every device function that loops over a per-stage face count
+    must therefore compile without scratch; the long-lived solver state lives in the kernel function, which has no
+    divergent loop."""
+    import re
+    import shutil
+    import subprocess
+    from forces_resilient_planner_amd import build
+    src = os.path.join(build.CSRC, "frp_kernels.hip")
+    out = tmp_path / "k.s"
+    subprocess.check_call([build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                           "-I" + os.path.join(build.ROOT, "include"), src, "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    txt = out.read_text()
+    funcs = re.findall(r"^(_ZN3frp\w+):.*?^; ScratchSize: (\d+)", txt, flags=re.M | re.S)
+    assert len(funcs) > 20
+    scratch = {name: int(sz) for name, sz in funcs}
+    divergent = [n for n in scratch if any(t in n for t in ("phase_init", "phase_eval", "phase_affine", "phase_step"))]
+    assert len(divergent) >= 16  # 4 phases x 4 stage strides
+    assert all(scratch[n] == 0 for n in divergent), {n: scratch[n] for n in divergent if scratch[n]}
+    # the kernels themselves must contain no divergent loop (exec-masked back edge)
+    for np_ in (16, 20, 32, 64):
+        body = txt[txt.index(f"_ZN3frp15nmpc_ipm_kernelILi{np_}EEEvNS_10KernelArgsE:"):]
+        body = body[:body.index("s_endpgm")]
+        assert "s_cbranch_execnz" not in body
