@@ -681,10 +681,10 @@ __device__ __forceinline__ bool factor_step(const WsView &w, int kk, bool last, 
     WSYNC();
     sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1; sm[S_E + 128 + lane] = e2;
     WSYNC();
-    {
-        const int k2 = kk > 1 ? kk - 2 : 0;
-        cgdouble *r2 = w.rec + (size_t)k2 * REC_STRIDE;
-        e0 = r2[lane]; e1 = r2[64 + lane]; e2 = r2[128 + lane];
+    { // this register set is staged again two steps from now: the loads have two full steps to land
+        const int k3 = kk > 2 ? kk - 3 : 0;
+        cgdouble *r3 = w.rec + (size_t)k3 * REC_STRIDE;
+        e0 = r3[lane]; e1 = r3[64 + lane]; e2 = r3[128 + lane];
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -749,12 +749,14 @@ __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, int t
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     d4 P = zero, pv = zero;
     bool ok = true;
-    double e0, e1, e2;
+    double e0, e1, e2, f0, f1, f2; // two prefetch sets: (e*) staged by the odd steps, (f*) by the even ones
     d4 CA, MA, CB = zero, MB = zero;
     double hcA, PhiDwA, phiwA, hcB = 0.0, PhiDwB = 0.0, phiwB = 0.0;
-    { // prologue: tiles of stage N-1 into set A, prefetch of stage N-2
+    { // prologue: tiles of stage N-1 into set A, prefetch of stages N-2 and N-3
         cgdouble *rp = w.rec + (size_t)(N - 1) * REC_STRIDE;
         e0 = rp[lane]; e1 = rp[64 + lane]; e2 = rp[128 + lane];
+        cgdouble *r3 = w.rec + (size_t)(N > 2 ? N - 3 : 0) * REC_STRIDE;
+        f0 = r3[lane]; f1 = r3[64 + lane]; f2 = r3[128 + lane];
         WSYNC();
         sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1; sm[S_E + 128 + lane] = e2;
         WSYNC();
@@ -773,7 +775,7 @@ __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, int t
     for (; kk >= 1 && ok; kk -= 2) {
         ok = factor_step<NP>(w, kk, kk == N - 1, lane, g, c, theta, mo, c1, c2, c3, CA, MA, hcA, PhiDwA, phiwA, CB, MB, hcB, PhiDwB, phiwB, e0, e1, e2, P, pv);
         if (!ok) break;
-        ok = factor_step<NP>(w, kk - 1, false, lane, g, c, theta, mo, c1, c2, c3, CB, MB, hcB, PhiDwB, phiwB, CA, MA, hcA, PhiDwA, phiwA, e0, e1, e2, P, pv);
+        ok = factor_step<NP>(w, kk - 1, false, lane, g, c, theta, mo, c1, c2, c3, CB, MB, hcB, PhiDwB, phiwB, CA, MA, hcA, PhiDwA, phiwA, f0, f1, f2, P, pv);
     }
     if (ok && kk == 0) ok = factor_step<NP>(w, 0, N == 1, lane, g, c, theta, mo, c1, c2, c3, CA, MA, hcA, PhiDwA, phiwA, CB, MB, hcB, PhiDwB, phiwB, e0, e1, e2, P, pv);
     bool fail = !ok;
@@ -808,8 +810,8 @@ __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, int t
 template <int NP>
 __device__ __forceinline__ void backvec_step(const WsView &w, int kk, bool last, int lane, int idx, double smu,
                                              const int (&mo)[4], int pho, int pwo, int pdo,
-                                             const d4 &cM, double cphi, double chc, double cphiw, double ctp, double cpd,
-                                             d4 &nM, double &nphi, double &nhc, double &nphiw, double &ntp, double &npd,
+                                             const d4 &cM, double cphi, double chc, double cphiw, double &ctp, double &cpd,
+                                             d4 &nM, double &nphi, double &nhc, double &nphiw,
                                              double &e0, double &e1, double &e2, double &pv)
 {
     gdouble *rec = w.rec + (size_t)kk * REC_STRIDE;
@@ -820,12 +822,10 @@ __device__ __forceinline__ void backvec_step(const WsView &w, int kk, bool last,
     sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1;
     if (lane < 14) sm[S_E + 128 + lane] = e2;
     WSYNC();
-    {
-        const int k1 = kk > 0 ? kk - 1 : 0, k2 = kk > 1 ? kk - 2 : 0;
-        cgdouble *r1 = w.rec + (size_t)k1 * REC_STRIDE, *r2 = w.rec + (size_t)k2 * REC_STRIDE;
-        ntp = r1[REC_T + lane];
-        npd = r1[pdo];
-        e0 = r2[lane]; e1 = r2[64 + lane]; e2 = r2[128 + (lane < 14 ? lane : 0)];
+    { // staged again two steps from now
+        const int k3 = kk > 2 ? kk - 3 : 0;
+        cgdouble *r3 = w.rec + (size_t)k3 * REC_STRIDE;
+        e0 = r3[lane]; e1 = r3[64 + lane]; e2 = r3[128 + (lane < 14 ? lane : 0)];
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) nM[r] = sm[mo[r]];
@@ -838,6 +838,12 @@ __device__ __forceinline__ void backvec_step(const WsView &w, int kk, bool last,
     const double r1 = quad_rot<1>(q), r2 = quad_rot<2>(q), r3 = quad_rot<3>(q);
     const double qu = qI == 0 ? q : (qI == 1 ? r3 : (qI == 2 ? r2 : r1));
     const double E = mfma4(ctp, qu, 0.0);
+    { // register operands (T', P d) of this set's next stage, two steps from now
+        const int k2 = kk > 1 ? kk - 2 : 0;
+        cgdouble *r2 = w.rec + (size_t)k2 * REC_STRIDE;
+        ctp = r2[REC_T + lane];
+        cpd = r2[pdo];
+    }
     const bool q0 = idx < 4;
     const double pn = q0 ? cphiw - chc * E : (idx <= 12 ? q - E : 0.0);
     if ((lane & 3) == 0) {
@@ -862,10 +868,10 @@ __device__ __noinline__ void sweep_backvec(WsView w, cgdouble *xinit, int N, dou
     const int pdo = idx <= 12 ? REC_PD + idx : REC_ZERO;
     init_stage_constants(lane);
     double pv = 0.0;
-    double e0, e1, e2;
+    double e0, e1, e2, f0, f1, f2; // two prefetch sets: (e*) staged by the odd steps, (f*) by the even ones
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     d4 MA, MB = zero;
-    double phiA, hcA, phiwA, tpA, pdA, phiB = 0.0, hcB = 0.0, phiwB = 0.0, tpB = 0.0, pdB = 0.0;
+    double phiA, hcA, phiwA, tpA, pdA, phiB = 0.0, hcB = 0.0, phiwB = 0.0, tpB, pdB;
     { // prologue: operands of stage N-1 into set A, prefetch of stage N-2
         cgdouble *rp = w.rec + (size_t)(N - 1) * REC_STRIDE;
         e0 = rp[lane]; e1 = rp[64 + lane]; e2 = rp[128 + (lane < 14 ? lane : 0)];
@@ -881,15 +887,17 @@ __device__ __noinline__ void sweep_backvec(WsView w, cgdouble *xinit, int N, dou
         phiA = (idx <= 12) ? phiA : 0.0;
         phiwA = sm[S_E + REC_PHIB + pwo] + smu * sm[S_E + REC_PHIC + pwo];
         hcA = sm[S_E + REC_HC];
-        cgdouble *r2 = w.rec + (size_t)(N > 1 ? N - 2 : 0) * REC_STRIDE;
+        cgdouble *r2 = w.rec + (size_t)(N > 1 ? N - 2 : 0) * REC_STRIDE, *r3 = w.rec + (size_t)(N > 2 ? N - 3 : 0) * REC_STRIDE;
         e0 = r2[lane]; e1 = r2[64 + lane]; e2 = r2[128 + (lane < 14 ? lane : 0)];
+        f0 = r3[lane]; f1 = r3[64 + lane]; f2 = r3[128 + (lane < 14 ? lane : 0)];
+        tpB = r2[REC_T + lane]; pdB = r2[pdo];
     }
     int kk = N - 1;
     for (; kk >= 1; kk -= 2) {
-        backvec_step<NP>(w, kk, kk == N - 1, lane, idx, smu, mo, pho, pwo, pdo, MA, phiA, hcA, phiwA, tpA, pdA, MB, phiB, hcB, phiwB, tpB, pdB, e0, e1, e2, pv);
-        backvec_step<NP>(w, kk - 1, false, lane, idx, smu, mo, pho, pwo, pdo, MB, phiB, hcB, phiwB, tpB, pdB, MA, phiA, hcA, phiwA, tpA, pdA, e0, e1, e2, pv);
+        backvec_step<NP>(w, kk, kk == N - 1, lane, idx, smu, mo, pho, pwo, pdo, MA, phiA, hcA, phiwA, tpA, pdA, MB, phiB, hcB, phiwB, e0, e1, e2, pv);
+        backvec_step<NP>(w, kk - 1, false, lane, idx, smu, mo, pho, pwo, pdo, MB, phiB, hcB, phiwB, tpB, pdB, MA, phiA, hcA, phiwA, f0, f1, f2, pv);
     }
-    if (kk == 0) backvec_step<NP>(w, 0, N == 1, lane, idx, smu, mo, pho, pwo, pdo, MA, phiA, hcA, phiwA, tpA, pdA, MB, phiB, hcB, phiwB, tpB, pdB, e0, e1, e2, pv);
+    if (kk == 0) backvec_step<NP>(w, 0, N == 1, lane, idx, smu, mo, pho, pwo, pdo, MA, phiA, hcA, phiwA, tpA, pdA, MB, phiB, hcB, phiwB, e0, e1, e2, pv);
     // p_w[g] sits in the quad-0 lanes of row g; the stage-0 solve wants it in the lanes (g, 13)
     stage0_solve<NP>(w, xinit, lane, __shfl(pv, lane & 48));
     FULLSYNC();
@@ -917,7 +925,7 @@ __device__ __forceinline__ void forward_step(const WsView &w, int N, int kk, int
     sm[S_E + lane] = e0; sm[S_T + lane] = tp;
     WSYNC();
     { // ... prefetch the one after it (clamped: the tail re-reads the last record, unused) ...
-        const int kf = (kk + 2 < N) ? kk + 2 : N - 1;
+        const int kf = (kk + 3 < N) ? kk + 3 : N - 1; // staged again two steps from now
         cgdouble *rp = w.rec + (size_t)kf * REC_STRIDE;
         e0 = rp[lane]; tp = rp[REC_T + lane];
         if (WITH_Y) { // P and p of the NEXT stage, straight into registers
@@ -983,14 +991,16 @@ __device__ __noinline__ void sweep_forward(WsView w, int N)
 #pragma unroll
     for (int s = 0; s < 4; s++) { ttA[s] = sm[tto[s]]; mtA[s] = sm[mto[s]]; }
     hcA = sm[S_T + 14];
+    double f0, fp; // second prefetch set (staged by the odd steps)
     {
-        cgdouble *rp = w.rec + (size_t)(N > 1 ? 1 : 0) * REC_STRIDE;
+        cgdouble *rp = w.rec + (size_t)(N > 1 ? 1 : 0) * REC_STRIDE, *rq = w.rec + (size_t)(N > 2 ? 2 : N - 1) * REC_STRIDE;
         e0 = rp[lane]; tp = rp[REC_T + lane];
+        f0 = rq[lane]; fp = rq[REC_T + lane];
     }
     int kk = 0;
     for (; kk + 1 < N; kk += 2) {
         forward_step<NP, WITH_Y>(w, N, kk, lane, idx, tto, mto, pmo, pvo, ttA, mtA, hcA, PA, pvA, ttB, mtB, hcB, PB, pvB, e0, tp, v);
-        forward_step<NP, WITH_Y>(w, N, kk + 1, lane, idx, tto, mto, pmo, pvo, ttB, mtB, hcB, PB, pvB, ttA, mtA, hcA, PA, pvA, e0, tp, v);
+        forward_step<NP, WITH_Y>(w, N, kk + 1, lane, idx, tto, mto, pmo, pvo, ttB, mtB, hcB, PB, pvB, ttA, mtA, hcA, PA, pvA, f0, fp, v);
     }
     if (kk < N) forward_step<NP, WITH_Y>(w, N, kk, lane, idx, tto, mto, pmo, pvo, ttA, mtA, hcA, PA, pvA, ttB, mtB, hcB, PB, pvB, e0, tp, v);
     WSYNC();
