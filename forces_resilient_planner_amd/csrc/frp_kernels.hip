@@ -36,6 +36,9 @@ namespace frp {
 #ifndef FRP_WAVES_PER_EU
 #define FRP_WAVES_PER_EU 2
 #endif
+#ifndef FRP_SLOTS_PER_CU
+#define FRP_SLOTS_PER_CU 6
+#endif
 #define FRP_MAX_SLOTS 4096 // upper bound of resident single-wave workgroups the workspace is sized for
 
 // ------------------------------------------------------------------ wave helpers
@@ -1581,21 +1584,27 @@ __global__ __launch_bounds__(256) void stage_eval_kernel(int B, int N, int M, in
 }
 
 // ------------------------------------------------------------------ launchers
-static int resident_slots()
+// Resident single-wave workgroups.  Measured on MI355X (profiles/r01_slots_sweep.txt): 6 per CU (1.5 waves per SIMD)
+// beats the 8 the register budget allows -- the working set of 2048 resident solves (~176 KB each) no longer fits the
+// 256 MB Infinity Cache, and the Riccati sweeps are latency-bound.  For a batch of a few rounds the slots are evened
+// out over the rounds (4096 problems -> 3 rounds of 1366 instead of 1536 + 1536 + 1024).
+static int resident_slots(int B)
 {
-    static int slots = 0;
-    if (slots == 0) {
+    static int cap = 0;
+    if (cap == 0) {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        slots = cus * 4 * FRP_WAVES_PER_EU; // one wave per workgroup, FRP_WAVES_PER_EU waves per SIMD
-        if (const char *e = getenv("FRP_RESIDENT_SLOTS")) { // tuning knob: resident single-wave workgroups
+        cap = cus * FRP_SLOTS_PER_CU;
+        if (const char *e = getenv("FRP_RESIDENT_SLOTS")) { // tuning knob
             const int v = atoi(e);
-            if (v > 0) slots = v;
+            if (v > 0) cap = v;
         }
-        if (slots > FRP_MAX_SLOTS) slots = FRP_MAX_SLOTS;
-        if (slots < 1) slots = 1;
+        if (cap > FRP_MAX_SLOTS) cap = FRP_MAX_SLOTS;
+        if (cap < 1) cap = 1;
     }
-    return slots;
+    if (B <= cap) return B;
+    const int rounds = (B + cap - 1) / cap;
+    return (B + rounds - 1) / rounds;
 }
 
 // workspace = [solver state of min(B, FRP_MAX_SLOTS) slots][work-queue counter, 256 B][keys: B doubles][order: B ints]
@@ -1612,7 +1621,7 @@ size_t ws_bytes(int B, int N, int MF)
 hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
 {
     KernelArgs k = a;
-    const int slots = a.B < resident_slots() ? a.B : resident_slots();
+    const int slots = resident_slots(a.B);
     double *q = a.ws + queue_offset_doubles(a.B, a.N, a.MF);
     k.counter = reinterpret_cast<int *>(q);
     k.order = nullptr;
