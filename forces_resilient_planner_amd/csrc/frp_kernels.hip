@@ -1498,25 +1498,44 @@ __global__ __launch_bounds__(256) void order_keys_kernel(int B, int N, int np, i
     const double c = stage_cost(zl, p10, stage_class(k, N), model, nullptr);
     atomicAdd(&keys[t / N], (c == c && c < 1e300) ? c : 0.0);
 }
-// order[rank(b)] = b with rank = number of problems that come first (larger key, ties by index): a permutation for any
-// input (non-finite keys were mapped to 0 above)
-__global__ __launch_bounds__(256) void order_rank_kernel(int B, const double *__restrict__ keys, int *__restrict__ order)
+// order = the problems sorted by decreasing key, to bucket resolution: one workgroup, a 1024-bin counting sort on the
+// (monotone) bit pattern of the non-negative keys -- i.e. on a log scale -- with the bins spread over the key range of
+// this batch.  The order inside a bin is arbitrary (atomics); order[] is a permutation for any input.
+__global__ __launch_bounds__(1024) void order_bucket_kernel(int B, const double *__restrict__ keys, int *__restrict__ order)
 {
-    __shared__ double tile[256];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const double ki = i < B ? keys[i] : 0.0;
-    int rank = 0;
-    for (int j0 = 0; j0 < B; j0 += 256) {
-        __syncthreads();
-        tile[threadIdx.x] = (j0 + (int)threadIdx.x < B) ? keys[j0 + threadIdx.x] : -1.0;
-        __syncthreads();
-        const int n = B - j0 < 256 ? B - j0 : 256;
-        for (int j = 0; j < n; j++) {
-            const double kj = tile[j];
-            rank += (kj > ki || (kj == ki && j0 + j < i)) ? 1 : 0;
-        }
+    __shared__ unsigned long long s_min, s_max;
+    __shared__ int hist[1024];
+    const int t = threadIdx.x;
+    if (t == 0) { s_min = ~0ull; s_max = 0ull; }
+    hist[t] = 0;
+    __syncthreads();
+    unsigned long long lo = ~0ull, hi = 0ull;
+    for (int i = t; i < B; i += 1024) {
+        const double k = keys[i];
+        const unsigned long long u = (unsigned long long)__double_as_longlong(k > 0.0 ? k : 0.0);
+        lo = u < lo ? u : lo; hi = u > hi ? u : hi;
     }
-    if (i < B) order[rank] = i;
+    atomicMin(&s_min, lo); atomicMax(&s_max, hi);
+    __syncthreads();
+    const unsigned long long base = s_min, span = s_max - s_min;
+    int shift = 0;
+    while ((span >> shift) >= 1024ull) shift++;
+    for (int i = t; i < B; i += 1024) {
+        const double k = keys[i];
+        const unsigned long long u = (unsigned long long)__double_as_longlong(k > 0.0 ? k : 0.0);
+        atomicAdd(&hist[1023 - (int)((u - base) >> shift)], 1); // bin 0 = largest keys
+    }
+    __syncthreads();
+    if (t == 0) { // exclusive prefix sum (1024 adds: negligible next to the solve)
+        int acc = 0;
+        for (int b = 0; b < 1024; b++) { const int h = hist[b]; hist[b] = acc; acc += h; }
+    }
+    __syncthreads();
+    for (int i = t; i < B; i += 1024) {
+        const double k = keys[i];
+        const unsigned long long u = (unsigned long long)__double_as_longlong(k > 0.0 ? k : 0.0);
+        order[atomicAdd(&hist[1023 - (int)((u - base) >> shift)], 1)] = i;
+    }
 }
 
 // ------------------------------------------------------------------ batched model callback
@@ -1634,7 +1653,7 @@ hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
         const size_t nt = (size_t)a.B * a.N;
         hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, stream, a.B, a.N, NPRE + 4 * a.M,
                            a.model, a.x0, a.params, keys);
-        hipLaunchKernelGGL(order_rank_kernel, dim3((unsigned)((a.B + 255) / 256)), dim3(256), 0, stream, a.B, keys, order);
+        hipLaunchKernelGGL(order_bucket_kernel, dim3(1), dim3(1024), 0, stream, a.B, keys, order);
     }
     switch (padded_stages(a.N)) {
     case 16: hipLaunchKernelGGL(nmpc_ipm_kernel<16>, dim3(slots), dim3(64), 0, stream, k); break;
