@@ -78,6 +78,21 @@ def cpu_baseline(w, seconds_target=12.0):
                 converged_frac=conv / solved)
 
 
+def pmc_traffic(batch):
+    """HBM-side bytes per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes of this
+    same command, calibrated on this solver's access width -- tools/collect_profiles.sh, tools/summarize_profiles.py),
+    taken from the newest committed profiles/*_pmc_traffic.json whose batch size matches; None otherwise."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+            if int(t["batch"]) == int(batch):
+                return float(t["bytes_per_launch"]), os.path.basename(f)
+        except Exception:
+            pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,6 +160,7 @@ def main():
         f_solve = mean_it * w["N"] * F_STAGE
         achieved_tf = B * f_solve / (kernel_ms * 1e-3) / 1e12
         achieved_gbs = B * ALG_BYTES_PER_SOLVE / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(B)
         out = {
             "metric": "NMPC solves/sec, batch=4096 horizons N=20", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -156,7 +172,8 @@ def main():
                        "mean_ipm_iterations": mean_it, "p95_ipm_iterations": float(np.percentile(it, 95)),
                        "max_ipm_iterations": int(it.max()), "tolerances": 1e-4},
             "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": "nmpc_ipm_kernel", "kernel_ms": kernel_ms,
                          "flops_per_launch": B * f_solve,
                          "note": "FP64 (vector == matrix peak 78.6 TFLOP/s); flops = SURVEY 8d definition "

@@ -1,27 +1,28 @@
 // frp_kernels.hip -- gfx950 kernels of the batched NMPC solver (hand-written HIP, FP64).
 //
-// nmpc_ipm_kernel: one 64-lane wavefront == one workgroup == one NMPC problem, resident for the whole
-// interior-point solve (no host round trips, per-problem early exit; the hardware dispatcher
-// refills the slot with the next problem).  It replaces the reference's closed NLP solver
+// nmpc_ipm_kernel: one 64-lane wavefront == one workgroup == one NMPC problem at a time, resident for the whole
+// interior-point solve (no host round trips, per-problem early exit).  Persistent workgroups pull the next problem
+// from a device queue that is ordered longest-expected-solve first.  It replaces the reference's closed NLP solver
 //   FORCESNLPsolver_{normal,final}_solve  (FORCESNLPsolver_normal.h:323; forces_normal.cpp:139)
 // and its model callback FORCESNLPsolver_*_casadi2forces (casadi2forces.c:42-245).
 //
 // Iteration (same as the CPU oracle so both can be compared iterate by iterate):
-//   primal-dual interior point, Mehrotra predictor-corrector, stage Hessian = exact cost Hessian +
-//   exact Hessian of the RK2 dynamics (Gauss-Newton fallback when the reduced Hessian is indefinite),
-//   Newton KKT system solved by a Riccati recursion over the stage chain with
+//   primal-dual interior point, Mehrotra predictor-corrector, multiplier safeguard s_i lam_i >= mu / 2,
+//   stage Hessian = exact cost Hessian + exact Hessian of the RK2 dynamics (Gauss-Newton fallback when the reduced
+//   Hessian is indefinite), Newton KKT system solved by a Riccati recursion over the stage chain with
 //   state s = [w; x] (13) and control u (4):   s_{k+1} = [u_k; A_k x_k + B_k u_k] + d_k.
 //
 // Work distribution inside the wavefront
 //   * element-wise phases (residuals, barrier terms, step lengths, updates): all 64 lanes,
-//     lane = (row pair, stage), operands in [row][stage] arrays -> coalesced 64-lane accesses;
+//     lane = (row group, stage), operands in [row][stage] arrays -> coalesced 64-lane accesses;
 //   * model evaluation (RK2 step, Jacobian, exact Hessian): lane == stage;
-//   * the serial Riccati sweeps: every 13x13(+1) block lives in REGISTERS as a 16x16 FP64 tile in the
+//   * factorisation sweep: every 13x13(+1) block lives in REGISTERS as a 16x16 FP64 tile in the
 //     v_mfma_f64_16x16x4_f64 accumulator layout (lane (g,c), register r <-> element [4r+g][c]).  In that
-//     layout D = X'Y is four MFMAs with A := X, B := Y register for register, so the whole recursion
+//     layout D = X'Y is four MFMAs with A := X, B := Y register for register, so
 //       X = P M,  G = M'X + Phi,  T = R G_u,  S = G - G_u' T,  P <- S (+ w blocks)
-//     runs on the matrix pipe with no cross-lane data movement; the right-hand side rides along as
-//     column 13 of the tiles.  Per stage the sweeps stream one 64-lane record row from/to HBM.
+//     runs on the matrix pipe with no cross-lane data movement; the right-hand side rides along as column 13;
+//   * vector sweeps (forward, corrector backward): chained mat-vec products on v_mfma_f64_4x4x4_4b_f64 (matvec4).
+//   Per stage the sweeps stream 64-lane record rows from/to HBM, prefetched two steps ahead.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "frp_model.hpp"
@@ -223,8 +224,8 @@ __device__ __forceinline__ WsView uni(WsView w)
 }
 
 __shared__ double sm[L_TOTAL];
-// Newton step dz = [du(4); ds(13); 3 pad rows][NP]: written by the forward sweep, read by the step phases and the
-// costate sweep -- kept in LDS so that the sweeps carry no global stores for it (a store in the loop makes the
+// Newton step dz = [du(4); ds(13); 3 pad rows][NP]: written by the forward sweep, read by the step phases
+// -- kept in LDS so that the sweeps carry no global stores for it (a store in the loop makes the
 // staging write of the next stage wait for vmcnt(0))
 __shared__ double sm_dz16[DZ_ROWS * 16];
 __shared__ double sm_dz20[DZ_ROWS * 20];
