@@ -114,7 +114,7 @@ __device__ __forceinline__ double lane_bcast(double v, int src) // wave-uniform 
 constexpr int S_E = 0;                    // E part of the stage record (192 used)
 constexpr int S_ZERO = 248, S_ONE = 249, S_DTC = 250;
 constexpr int S_T = 256;                  // T' (64)
-constexpr int S_R = 320;                  // 4x4 inverse handed from uniform registers to lanes (16)
+constexpr int S_MI = 320, S_DI = 328;      // pivot block handed from uniform registers to lanes: m = L^-1 (6), D^-1 (4)
 constexpr int S_STAGING = 23 * 32;        // 736
 constexpr int S_RW = S_STAGING;           // stage-0 solve: Pww^-1 (16)
 constexpr int S_PWX = S_RW + 16;          // stage-0 solve: Pwx (4 x 9)
@@ -133,27 +133,25 @@ __device__ __forceinline__ double fast_rcp(double x)
     return fma(r, e, r);
 }
 
-// symmetric positive definite 4x4 inverse via LDL'; returns false if a pivot is not positive
-__device__ __forceinline__ bool spd4_inverse(const double *a /*row-major 4x4, lower part used*/, double *r /*16*/)
+// symmetric positive definite 4x4 inverse via LDL'; returns false if a pivot is not positive (results then undefined)
+// (optionally also the factors: m = L^-1 (unit lower triangular, row-major 4x4) and dinv = diag(D)^-1, R = m' D^-1 m)
+__device__ __forceinline__ bool spd4_inverse(const double *a /*row-major 4x4, lower part used*/, double *r /*16*/,
+                                             double *mout = nullptr /*16*/, double *dinv = nullptr /*4*/)
 {
     const double a00 = a[0], a10 = a[4], a11 = a[5], a20 = a[8], a21 = a[9], a22 = a[10];
     const double a30 = a[12], a31 = a[13], a32 = a[14], a33 = a[15];
     const double d0 = a00;
-    if (!(d0 > 0.0)) return false;
     const double i0 = fast_rcp(d0);
     const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
     const double d1 = a11 - l10 * a10;
-    if (!(d1 > 0.0)) return false;
     const double i1 = fast_rcp(d1);
     const double t21 = a21 - l20 * a10, t31 = a31 - l30 * a10;
     const double l21 = t21 * i1, l31 = t31 * i1;
     const double d2 = a22 - l20 * a20 - l21 * t21;
-    if (!(d2 > 0.0)) return false;
     const double i2 = fast_rcp(d2);
     const double t32 = a32 - l30 * a20 - l31 * t21;
     const double l32 = t32 * i2;
     const double d3 = a33 - l30 * a30 - l31 * t31 - l32 * t32;
-    if (!(d3 > 0.0)) return false;
     const double i3 = fast_rcp(d3);
     // inverse of unit lower L: m = L^-1
     const double m10 = -l10, m21 = -l21, m32 = -l32;
@@ -173,7 +171,44 @@ __device__ __forceinline__ bool spd4_inverse(const double *a /*row-major 4x4, lo
     r[4] = r10; r[5] = r11; r[6] = r21; r[7] = r31;
     r[8] = r20; r[9] = r21; r[10] = r22; r[11] = r32;
     r[12] = r30; r[13] = r31; r[14] = r32; r[15] = r33;
-    return true;
+    if (mout) {
+        mout[0] = 1.0; mout[1] = 0.0; mout[2] = 0.0; mout[3] = 0.0;
+        mout[4] = m10; mout[5] = 1.0; mout[6] = 0.0; mout[7] = 0.0;
+        mout[8] = m20; mout[9] = m21; mout[10] = 1.0; mout[11] = 0.0;
+        mout[12] = m30; mout[13] = m31; mout[14] = m32; mout[15] = 1.0;
+        dinv[0] = i0; dinv[1] = i1; dinv[2] = i2; dinv[3] = i3;
+    }
+    // branch-free: a non-positive (or NaN) pivot poisons the results, which the caller discards
+    return (d0 > 0.0) && (d1 > 0.0) && (d2 > 0.0) && (d3 > 0.0);
+}
+
+// LDL' factors of a symmetric positive definite 4x4 block (lower part of row-major a): m6 = the strictly lower
+// triangle of m = L^-1 in the order (1,0) (2,0) (2,1) (3,0) (3,1) (3,2), dinv = 1 / diag(D).  Branch-free; returns
+// false if a pivot is not positive (results then undefined).
+__device__ __forceinline__ bool ldl4(const double *a, double *m6, double *dinv)
+{
+    const double a00 = a[0], a10 = a[4], a11 = a[5], a20 = a[8], a21 = a[9], a22 = a[10];
+    const double a30 = a[12], a31 = a[13], a32 = a[14], a33 = a[15];
+    const double d0 = a00;
+    const double i0 = fast_rcp(d0);
+    const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+    const double d1 = a11 - l10 * a10;
+    const double i1 = fast_rcp(d1);
+    const double t21 = a21 - l20 * a10, t31 = a31 - l30 * a10;
+    const double l21 = t21 * i1, l31 = t31 * i1;
+    const double d2 = a22 - l20 * a20 - l21 * t21;
+    const double i2 = fast_rcp(d2);
+    const double t32 = a32 - l30 * a20 - l31 * t21;
+    const double l32 = t32 * i2;
+    const double d3 = a33 - l30 * a30 - l31 * t31 - l32 * t32;
+    const double i3 = fast_rcp(d3);
+    const double m10 = -l10, m21 = -l21, m32 = -l32;
+    const double m20 = -l20 - l21 * m10;
+    const double m31 = -l31 - l32 * m21;
+    const double m30 = -l30 - l31 * m10 - l32 * m20;
+    m6[0] = m10; m6[1] = m20; m6[2] = m21; m6[3] = m30; m6[4] = m31; m6[5] = m32;
+    dinv[0] = i0; dinv[1] = i1; dinv[2] = i2; dinv[3] = i3;
+    return (d0 > 0.0) && (d1 > 0.0) && (d2 > 0.0) && (d3 > 0.0);
 }
 
 // Explicit global address space: inside non-inlined device functions a plain double* is a GENERIC
@@ -661,7 +696,7 @@ __device__ __forceinline__ void stage0_solve(const WsView &w, cgdouble *xinit, i
 // (prefetched) record of stage k-1 through LDS and assembles its tiles into the alternate register set, and issues
 // the global prefetch of stage k-2.
 template <int NP>
-__device__ __forceinline__ bool factor_step(const WsView &w, int kk, bool last, int lane, int g, int c, double theta,
+__device__ __forceinline__ bool factor_step(const WsView &w, int kk, bool last, int lane, int g, int c, double theta, int mgo, int mco,
                                             const int (&mo)[4], const int (&c1)[4], const int (&c2)[4], const int (&c3)[4],
                                             const d4 &cC, const d4 &cM, double chc, double cPhiDw, double cphiw,
                                             d4 &nC, d4 &nM, double &nhc, double &nPhiDw, double &nphiw,
@@ -698,21 +733,40 @@ __device__ __forceinline__ bool factor_step(const WsView &w, int kk, bool last, 
     nhc = sm[S_E + REC_HC];
     nPhiDw = sm[S_E + REC_PHID + 4 + g];
     nphiw = sm[S_E + REC_PHI + 4 + g];
-    // ---- R = Guu^-1 (4 x 4): gather the lower triangle to uniform registers, invert redundantly
-    double q[16], R[16];
+    // ---- pivot block Guu = L D L' (4 x 4): gather the lower triangle to uniform registers, factor redundantly
+    double q[16], Mi[6], Di[4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j <= i; j++) q[i * 4 + j] = lane_bcast(G[0], 16 * i + j);
-    if (!spd4_inverse(q, R)) return false;
+#ifdef FRP_DEBUG_FACTOR
+    if (lane == 0) printf("gpu stage %2d theta %.3g Guu %.9e %.9e %.9e %.9e | %.6e %.6e %.6e %.6e %.6e %.6e\n", kk, theta, q[0], q[5], q[10], q[15], q[4], q[8], q[9], q[12], q[13], q[14]);
+#endif
+    if (!ldl4(q, Mi, Di)) return false;
+    if (lane == 0) { // uniform values: one lane hands them to the others
 #pragma unroll
-    for (int t = 0; t < 16; t++) sm[S_R + t] = R[t];
+        for (int t = 0; t < 6; t++) sm[S_MI + t] = Mi[t];
+#pragma unroll
+        for (int t = 0; t < 4; t++) sm[S_DI + t] = Di[t];
+    }
     WSYNC();
-    const double rt = (c < 4) ? sm[S_R + g * 4 + c] : 0.0;
+    // m = L^-1.  The elimination is carried out in factored form,
+    //     K = m G_u,   R = m' D^-1 m,   T = m' D^-1 K (= R G_u),   TT = K' D^-1 m (= G_u' R),   S = G - K' D^-1 K,
+    // not as G - G_u'(R G_u): when a state bound far down the horizon is active, B'PB puts a rank-one term of 1e10 on
+    // Guu and G_u; the explicit-inverse form then cancels O(1e10) quantities against an R that is only accurate to
+    // cond(Guu) eps and S comes out with O(100) errors (seen as a spurious indefinite pivot), whereas the factored form
+    // subtracts a symmetric product and is as accurate as a Cholesky-based elimination.
+    const double m_gc = sm[mgo], m_cg = sm[mco]; // m[g][c], m[c][g] (unit diagonal / zeros from the constant slots)
+    const double dg = sm[S_DI + g];
     const double hc = chc;
-    const d4 T = mm_tn4(rt, G[0], zero);
-    const d4 TT = mm_tn4(G[0], rt, zero);
-    const d4 S = mm_tn4(-G[0], T[0], G);
+    const double md = dg * m_gc;
+    const d4 K = mm_tn4(m_cg, G[0], zero);
+    const d4 Rt = mm_tn4(m_gc, md, zero);
+    const double rt = Rt[0]; // R[g][c] in the lanes c < 4 (zero elsewhere)
+    const double Kd = dg * K[0];
+    const d4 T = mm_tn4(m_gc, Kd, zero);
+    const d4 TT = mm_tn4(K[0], md, zero);
+    const d4 S = mm_tn4(-Kd, K[0], G);
     rec[REC_T + lane] = (c < 4) ? rt : (c <= 13 ? T[0] : (lane == 14 ? hc : 0.0));
     d4 Pn, pn;
     Pn[0] = (c < 4) ? ((g == c ? cPhiDw : 0.0) - hc * hc * rt) : (c <= 12 ? -hc * T[0] : 0.0);
@@ -735,12 +789,11 @@ __device__ __forceinline__ bool factor_step(const WsView &w, int kk, bool last, 
 }
 
 template <int NP>
-__device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, int theta_i)
+__device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, double theta)
 {
-    w = uni(w); xinit = uni(xinit); N = uni(N); theta_i = uni(theta_i);
+    w = uni(w); xinit = uni(xinit); N = uni(N); theta = uni(theta);
     FULLSYNC(); // phase boundary: the evaluation phase's record writes are visible
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-    const double theta = theta_i ? 1.0 : 0.0;
     int mo[4], c1[4], c2[4], c3[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -750,6 +803,9 @@ __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, int t
         c3[r] = sm_tab[(TAB_C3 + r) * 64 + lane];
     }
     init_stage_constants(lane); // the element-wise phases reuse this part of LDS as staging
+    // LDS slot of m[g][c] / m[c][g] for this lane (m = L^-1 of the pivot block, strictly lower part in S_MI)
+    const int mgo = c < 4 ? (c < g ? S_MI + g * (g - 1) / 2 + c : (c == g ? S_ONE : S_ZERO)) : S_ZERO;
+    const int mco = c < 4 ? (g < c ? S_MI + c * (c - 1) / 2 + g : (c == g ? S_ONE : S_ZERO)) : S_ZERO;
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     d4 P = zero, pv = zero;
     bool ok = true;
@@ -777,11 +833,11 @@ __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, int t
     }
     int kk = N - 1;
     for (; kk >= 1 && ok; kk -= 2) {
-        ok = factor_step<NP>(w, kk, kk == N - 1, lane, g, c, theta, mo, c1, c2, c3, CA, MA, hcA, PhiDwA, phiwA, CB, MB, hcB, PhiDwB, phiwB, e0, e1, e2, P, pv);
+        ok = factor_step<NP>(w, kk, kk == N - 1, lane, g, c, theta, mgo, mco, mo, c1, c2, c3, CA, MA, hcA, PhiDwA, phiwA, CB, MB, hcB, PhiDwB, phiwB, e0, e1, e2, P, pv);
         if (!ok) break;
-        ok = factor_step<NP>(w, kk - 1, false, lane, g, c, theta, mo, c1, c2, c3, CB, MB, hcB, PhiDwB, phiwB, CA, MA, hcA, PhiDwA, phiwA, f0, f1, f2, P, pv);
+        ok = factor_step<NP>(w, kk - 1, false, lane, g, c, theta, mgo, mco, mo, c1, c2, c3, CB, MB, hcB, PhiDwB, phiwB, CA, MA, hcA, PhiDwA, phiwA, f0, f1, f2, P, pv);
     }
-    if (ok && kk == 0) ok = factor_step<NP>(w, 0, N == 1, lane, g, c, theta, mo, c1, c2, c3, CA, MA, hcA, PhiDwA, phiwA, CB, MB, hcB, PhiDwB, phiwB, e0, e1, e2, P, pv);
+    if (ok && kk == 0) ok = factor_step<NP>(w, 0, N == 1, lane, g, c, theta, mgo, mco, mo, c1, c2, c3, CA, MA, hcA, PhiDwA, phiwA, CB, MB, hcB, PhiDwB, phiwB, e0, e1, e2, P, pv);
     bool fail = !ok;
     if (!fail) {
         // stage 0: keep Pww^-1 and Pwx for the corrector pass, then solve for ds_0
@@ -1382,6 +1438,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     FULLSYNC();
 
     int flag = FRP_EXIT_MAXIT, it = 0, nfallback = 0;
+    double theta_h = hess ? 1.0 : 0.0; // weight of the dynamics Hessian
     double res_eq = 0, res_in = 0, rs = 0, rcomp = 0, pobj = 0, mu = 0, sigma = 0, step_cc = 0;
 
 #ifdef FRP_PROFILE
@@ -1412,13 +1469,17 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         if (mu > DIVERGE_MU * fmax(1.0, a.mu0) || rs > DIVERGE_RS) { flag = FRP_EXIT_NOPROGRESS; break; }
         TOCK(0);
 
-        // predictor (affine) solve; exact Hessian first, Gauss-Newton if the reduced Hessian is indefinite
-        int theta = hess;
-        int fr = sweep_factor<NP>(w, xinit, N, theta);
-        if (fr && theta) {
-            theta = 0;
+        // predictor (affine) solve with the Hessian  H_GN + theta_h H_dyn.  theta_h = 1 is the exact Hessian; when a
+        // Riccati pivot block is indefinite the iteration is redone with the Gauss-Newton Hessian (theta 0), theta_h is
+        // quartered and then recovers by 0.1 per successful iteration: alternating between the two Hessians at full
+        // weight can cycle for 100+ iterations on a locally non-convex problem.
+        int fr = sweep_factor<NP>(w, xinit, N, theta_h);
+        if (fr && theta_h > 0.0) {
             nfallback++;
-            fr = sweep_factor<NP>(w, xinit, N, 0);
+            theta_h *= THETA_DOWN;
+            fr = sweep_factor<NP>(w, xinit, N, 0.0);
+        } else if (hess) {
+            theta_h = fmin(1.0, theta_h + THETA_UP);
         }
         if (fr) { flag = FRP_EXIT_FACTORIZATION; break; }
         TOCK(1);

@@ -21,6 +21,9 @@
 #include <omp.h>
 #endif
 #include "nmpc_oracle.h"
+#ifdef ORC_TRACE
+#include <stdio.h>
+#endif
 
 void orc_rk2(const double *x, const double *u, const double *fext, double *xn, double *Ax, double *Bx);
 void orc_cost_quadratic(const double *p, int stage_class, int model, double *hd, double *hc, double *q, double *cst);
@@ -30,6 +33,8 @@ void orc_rk2_hess(const double *x, const double *u, const double *fext, const do
 #define HU_OFF 1e-5 /* hu = 1e-5, mpc_generator_normal.m:14 */
 #define S_MIN 1e-2
 #define MU_FLOOR_FRAC 0.1
+#define THETA_DOWN 0.25
+#define THETA_UP 0.1
 #define KAPPA_LAM 2.0      /* multiplier safeguard: s_i lam_i >= mu / KAPPA_LAM after every step */
 #define DIVERGE_MU 1e6
 #define DIVERGE_RS 1e12
@@ -57,6 +62,7 @@ typedef struct {
     double PhiD[17], PhiPos[9];    /* barrier-augmented Hessian: diagonal + pos 3x3 block           */
     double Hd[100];                /* exact Hessian of y'c(z) over (rates, T, v, e), see orc_rk2_hess  */
     int useH;
+    double thetaH; /* weight of the dynamics Hessian */
 } stage_ws;
 
 static int stage_class_of(int k, int N) { return k == 0 ? ORC_STAGE_FIRST : (k == N - 1 ? ORC_STAGE_LAST : ORC_STAGE_MID); }
@@ -98,7 +104,7 @@ static int riccati_step(stage_ws *w, const double *Pn, const double *pn, int ful
         if (w->useH) {
             static const int zi[10] = {0, 1, 2, 3, 11, 12, 13, 14, 15, 16};
             for (int i = 0; i < 10; i++)
-                for (int j = 0; j < 10; j++) Q[zi[i] * 17 + zi[j]] += w->Hd[i * 10 + j];
+                for (int j = 0; j < 10; j++) Q[zi[i] * 17 + zi[j]] += w->thetaH * w->Hd[i * 10 + j];
         }
         if (Pn) {
             /* M = [I4 0 0; Bx 0 Ax] (rows [w;x] of stage k+1, cols [u w x] of stage k) */
@@ -140,6 +146,9 @@ static int riccati_step(stage_ws *w, const double *Pn, const double *pn, int ful
                     Q[(8 + i) * 17 + 8 + j] += a;
                 }
         }
+#ifdef ORC_TRACE
+        fprintf(stderr, "orc Quu %.9e %.9e %.9e %.9e | %.6e %.6e %.6e %.6e %.6e %.6e\n", Q[0], Q[18], Q[36], Q[54], Q[17], Q[34], Q[35], Q[51], Q[52], Q[53]);
+#endif
         /* Cholesky of Quu */
         double *L = w->L;
         memset(L, 0, 16 * sizeof(double));
@@ -313,7 +322,6 @@ static int kkt_solve(solver_ws *W, const double *xinit, int full)
 }
 
 #ifdef ORC_TRACE
-#include <stdio.h>
 static int trace_kp, trace_ip, trace_kd, trace_id;
 #endif
 /* ds, dlam from dz; returns max feasible step fractions (unscaled) through *ap, *ad */
@@ -433,6 +441,10 @@ int orc_solve(int N, int M, int model, const double *xinit, const double *z0,
     }
 
     int flag = ORC_MAXIT, it = 0, nfallback = 0;
+    /* weight of the dynamics Hessian: 1 = exact Hessian.  An indefinite Riccati pivot block redoes the iteration with
+     * the Gauss-Newton Hessian, quarters the weight, and it recovers by 0.1 per successful iteration (alternating
+     * between the two Hessians at full weight can cycle for 100+ iterations on a locally non-convex problem). */
+    double theta_h = 1.0;
     orc_info inf;
     memset(&inf, 0, sizeof inf);
     for (it = 0;; it++) {
@@ -525,6 +537,7 @@ int orc_solve(int N, int M, int model, const double *xinit, const double *z0,
                 const double *zk = W.z + 17 * k, *yn = W.y + NS * (k + 1);
                 orc_rk2_hess(zk + 8, zk, params + (size_t)k * np + 3, yn + 4, yn + 7, w->Hd);
                 w->useH = 1;
+                w->thetaH = theta_h;
             }
         }
         /* ---- predictor ---- */
@@ -535,6 +548,9 @@ int orc_solve(int N, int M, int model, const double *xinit, const double *z0,
             for (int k = 0; k < N; k++) W.st[k].useH = 0;
             frc = kkt_solve(&W, xinit, 1);
             nfallback++;
+            theta_h *= THETA_DOWN;
+        } else if (want_exact) {
+            theta_h = fmin(1.0, theta_h + THETA_UP);
         }
         if (frc) { flag = ORC_FACTORIZATION_ERROR; break; }
         slack_steps(&W, params, 0.0, 0, &ap, &ad);
