@@ -3,7 +3,9 @@
 
 A "step" = one pass of the hot path over one batch: solve B = 4096 independent N = 20 NMPC problems
 (BASELINE.json configs[2]: constant f_ext, 6-face tightened corridor per stage, cold start) with the
-HIP solver, inputs already resident in HBM, outputs left in HBM.  N GPUs -> each rank solves its own
+HIP solver, inputs already resident in HBM, outputs left in HBM.  Steps are issued round-robin on 2 HIP streams
+(own workspace / outputs each) so that the few long solves at the end of one launch overlap the next launch;
+config.single_stream_solves_per_s is the same measurement with strictly serial launches.  N GPUs -> each rank solves its own
 4096-problem shard (different seed), no data-path collective ("weak").
 
   python bench.py --gpus 1 --steps 20 --warmup 3
@@ -100,6 +102,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the steps are issued round-robin on (each with its own workspace and outputs); "
+                         "1 = strictly back-to-back launches.  Default 2: the tail of one launch (a few long solves) overlaps "
+                         "the head of the next; the strictly serial rate is measured as well and reported in config")
     args = ap.parse_args()
 
     import torch
@@ -124,6 +130,12 @@ def main():
     ds = solver.DeviceSolver(B, w["N"], w["M"], 6, w["model"], f"cuda:{local_rank}")
     ds.upload(w)
     stream = torch.cuda.current_stream(dev)
+    lanes = [(ds, stream)]
+    for _ in range(1, max(1, args.streams)):  # further streams: own solver state / outputs, same resident inputs
+        d2 = solver.DeviceSolver(B, w["N"], w["M"], 6, w["model"], f"cuda:{local_rank}")
+        d2.xinit, d2.x0, d2.params, d2.nfaces = ds.xinit, ds.x0, ds.params, ds.nfaces
+        lanes.append((d2, torch.cuda.Stream(dev)))
+    torch.cuda.synchronize(dev)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -131,18 +143,24 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        ds.solve(stream)
+    for i in range(args.warmup):
+        lanes[i % len(lanes)][0].solve(lanes[i % len(lanes)][1])
     barrier()
     t0 = time.perf_counter()
+    for i in range(args.steps):
+        lanes[i % len(lanes)][0].solve(lanes[i % len(lanes)][1])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # the same K steps strictly back to back on ONE stream (no overlap between launches), for reference
+    t1 = time.perf_counter()
     for _ in range(args.steps):
         ds.solve(stream)
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_serial = time.perf_counter() - t1
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, elapsed_serial], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, elapsed_serial = float(t[0].item()), float(t[1].item())
 
     fl = ds.exitflag.cpu().numpy(); it = ds.iters.cpu().numpy()
     stats = torch.tensor([float((fl == 1).sum()), float(it.sum()), float(B)], dtype=torch.float64, device=dev)
@@ -169,7 +187,9 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: batch=4096 per GPU, N=20, constant f_ext~U[-3,3]^3, "
                                    "6-face tightened corridor per stage, cold start, reference 30-row parameter layout",
                        "batch_per_gpu": B, "horizon": int(w["N"]), "converged_frac": conv_frac,
-                       "mean_ipm_iterations": mean_it, "p95_ipm_iterations": float(np.percentile(it, 95)),
+                       "mean_ipm_iterations": mean_it, "streams": len(lanes),
+                       "single_stream_solves_per_s": world * B * args.steps / elapsed_serial,
+                       "single_stream_ms_per_step": elapsed_serial / args.steps * 1e3, "p95_ipm_iterations": float(np.percentile(it, 95)),
                        "max_ipm_iterations": int(it.max()), "tolerances": 1e-4},
             "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
