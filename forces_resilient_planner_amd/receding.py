@@ -50,3 +50,51 @@ def run(w0, ticks, solve_fn):
         last_ok = ok
         flags.append(fl.copy()); iters.append(it.copy())
     return np.array(flags), np.array(iters), mpc
+
+
+def run_device(w0, ticks, device="cuda:0", collect=True):
+    """The same loop with every per-tick step on the GPU: device-side packing, solve, device-side
+    result bookkeeping; only the (shared) nominal reference / corridor of configs[4] is produced on the host, one
+    problem's worth per tick, and broadcast on the device.  Returns (flags [ticks,B], iters [ticks,B], final plan,
+    seconds of GPU time for all ticks)."""
+    import torch
+    from . import solver
+    from .workloads import _bbox_faces, _weights
+    B, N, M, model = w0["B"], w0["N"], w0["M"], w0["model"]
+    fleet = solver.DeviceFleet(B, N, M, 6, model, _weights(model), device)
+    dev = fleet.solver.device
+    fleet.mpc_output.copy_(fleet.to_device(w0["mpc_output"]))
+    fleet.ellipsoid.copy_(fleet.to_device(w0["E"]))
+    fleet.poly_nfaces.fill_(6)
+    f_ext = fleet.to_device(w0["f_ext"])
+    ref_long = w0["ref_long"]; yaw = float(w0["heading"][0])
+    ref_yaw = torch.full((B, N), yaw, dtype=torch.float64, device=dev)
+    flags = torch.zeros((ticks, B), dtype=torch.int32, device=dev)
+    iters = torch.zeros((ticks, B), dtype=torch.int32, device=dev)
+    # per-tick shared reference and corridor (one problem's worth), prepared up front
+    refs, As, bs = [], [], []
+    for t in range(ticks):
+        r1 = ref_long[:, t:t + N]
+        A1, b1 = _bbox_faces(r1, np.full((1, N), yaw))
+        refs.append(fleet.to_device(r1)); As.append(fleet.to_device(A1)); bs.append(fleet.to_device(b1))
+    cold_thrust = 7.3
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for t in range(ticks):
+        ref_pos = refs[t].expand(B, N, 3).contiguous()
+        fleet.poly_A.copy_(As[t].expand(B, N, 6, 3))
+        fleet.poly_b.copy_(bs[t].expand(B, N, 6))
+        if t > 0:  # cold start for planners whose last solve failed (nmpc_solver.cpp:363-364)
+            bad = fleet.solver.exitflag != 1
+            if bool(bad.any()):
+                st = fleet.mpc_output[bad][:, 1, 8:17]
+                row = torch.zeros((st.shape[0], 17), dtype=torch.float64, device=dev)
+                row[:, 3] = cold_thrust; row[:, 7] = cold_thrust; row[:, 8:] = st
+                fleet.mpc_output[bad] = row[:, None, :].expand(-1, N + 1, -1)
+        fleet.tick(f_ext, ref_pos, ref_yaw)
+        if collect:
+            flags[t] = fleet.solver.exitflag; iters[t] = fleet.solver.iters
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    return flags.cpu().numpy(), iters.cpu().numpy(), fleet.mpc_output.cpu().numpy(), ev0.elapsed_time(ev1) * 1e-3

@@ -34,6 +34,16 @@ class Batch(ctypes.Structure):
                 ("iters", ctypes.c_void_p), ("info", ctypes.c_void_p)]
 
 
+class Pack(ctypes.Structure):  # frp_nmpc_pack (include/frp_nmpc.h)
+    _fields_ = [("B", ctypes.c_int), ("N", ctypes.c_int), ("M", ctypes.c_int), ("NPOLY", ctypes.c_int), ("F", ctypes.c_int),
+                ("external_acc_per_stage", ctypes.c_int), ("mpc_output", ctypes.c_void_p), ("external_acc", ctypes.c_void_p), ("ref_pos", ctypes.c_void_p),
+                ("ref_yaw", ctypes.c_void_p), ("ellipsoid", ctypes.c_void_p), ("poly_A", ctypes.c_void_p),
+                ("poly_b", ctypes.c_void_p), ("poly_nfaces", ctypes.c_void_p), ("poly_index", ctypes.c_void_p),
+                ("w_stage_wp", ctypes.c_double), ("w_stage_input", ctypes.c_double), ("w_input_rate", ctypes.c_double),
+                ("w_terminal_wp", ctypes.c_double), ("w_terminal_input", ctypes.c_double),
+                ("xinit", ctypes.c_void_p), ("x0", ctypes.c_void_p), ("params", ctypes.c_void_p), ("nfaces", ctypes.c_void_p)]
+
+
 class ForcesParams(ctypes.Structure):
     _fields_ = [("xinit", ctypes.c_double * 9), ("x0", ctypes.c_double * 340),
                 ("all_parameters", ctypes.c_double * 2600), ("num_of_threads", ctypes.c_uint)]
@@ -56,7 +66,7 @@ EXTFUNC = ctypes.CFUNCTYPE(None, c_double_p, c_double_p, c_double_p, c_double_p,
 EXPORTS = ["frp_nmpc_default_options", "frp_nmpc_workspace_bytes", "frp_nmpc_solve_batch",
            "frp_nmpc_solve_batch_host", "frp_nmpc_stage_eval", "frp_nmpc_stage_eval_host", "frp_nmpc_time_solve",
            "frp_nmpc_version", "frp_nmpc_device_count", "FORCESNLPsolver_normal_solve",
-           "FORCESNLPsolver_final_solve"]
+           "FORCESNLPsolver_final_solve", "frp_nmpc_pack_batch", "frp_nmpc_update_batch"]
 
 _lib = None
 
@@ -67,6 +77,15 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        # PyTorch ships its own HIP runtime; the library links the system one.  Both coexist in one process as long
+        # as torch's is initialised first (the reverse order leaves torch with "No HIP GPUs are available"), and
+        # DeviceSolver / DeviceFleet hand torch-owned HBM to the library, so initialise torch here if it has a GPU.
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         l = ctypes.CDLL(LIB_PATH)
         l.frp_nmpc_workspace_bytes.restype = ctypes.c_size_t
         l.frp_nmpc_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -76,6 +95,9 @@ def lib():
         l.frp_nmpc_time_solve.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(Options), ctypes.c_void_p,
                                           ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         l.frp_nmpc_solve_batch_host.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(Options)]
+        l.frp_nmpc_pack_batch.argtypes = [ctypes.POINTER(Pack), ctypes.c_void_p]
+        l.frp_nmpc_update_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p]
         _lib = l
     return _lib
 
@@ -173,3 +195,56 @@ class DeviceSolver:
         _check(lib().frp_nmpc_time_solve(ctypes.byref(b), ctypes.byref(self.opt), self.ws.data_ptr(), self.ws_bytes,
                                          ctypes.c_void_p(s.cuda_stream), reps, ctypes.byref(ms)), "frp_nmpc_time_solve")
         return ms.value
+
+
+class DeviceFleet:
+    """B planners whose receding-horizon loop lives in HBM: per tick
+        pack (forces_normal.cpp:55-136 on the device)  ->  solve  ->  update (forces_normal.cpp:142-168,
+        nmpc_solver.cpp:524-543 on the device).
+    Host data is uploaded once (plans, polytopes, tube matrices); references / external forces per tick are device
+    tensors handed to tick()."""
+
+    def __init__(self, B, N, M, F, model, weights, device="cuda:0", npoly=None):
+        import torch
+        self.torch = torch
+        self.B, self.N, self.M, self.F, self.model = B, N, M, F, model
+        self.NPOLY = N if npoly is None else npoly
+        self.weights = tuple(float(x) for x in weights)  # (w_stage_wp, w_stage_input, w_input_rate, w_terminal_wp, w_terminal_input)
+        self.solver = DeviceSolver(B, N, M, min(M, F), model, device)
+        dev = self.solver.device
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.mpc_output = torch.zeros((B, N + 1, L.NZ), **f64)
+        self.ellipsoid = torch.zeros((B, N, 3, 3), **f64)
+        self.poly_A = torch.zeros((B, self.NPOLY, F, 3), **f64)
+        self.poly_b = torch.zeros((B, self.NPOLY, F), **f64)
+        self.poly_nfaces = torch.zeros((B, self.NPOLY), dtype=torch.int32, device=dev)
+        self.poly_index = None
+
+    def to_device(self, a, dtype=None):
+        t = self.torch
+        return t.from_numpy(np.ascontiguousarray(a)).to(self.solver.device, dtype=dtype)
+
+    def pack(self, external_acc, ref_pos, ref_yaw, stream=None):
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.solver.device)
+        ds = self.solver
+        pk = Pack(self.B, self.N, self.M, self.NPOLY, self.F, 1 if external_acc.dim() == 3 else 0,
+                  self.mpc_output.data_ptr(), external_acc.data_ptr(),
+                  ref_pos.data_ptr(), ref_yaw.data_ptr(), self.ellipsoid.data_ptr(), self.poly_A.data_ptr(),
+                  self.poly_b.data_ptr(), self.poly_nfaces.data_ptr(),
+                  self.poly_index.data_ptr() if self.poly_index is not None else None, *self.weights,
+                  ds.xinit.data_ptr(), ds.x0.data_ptr(), ds.params.data_ptr(), ds.nfaces.data_ptr())
+        _check(lib().frp_nmpc_pack_batch(ctypes.byref(pk), ctypes.c_void_p(s.cuda_stream)), "frp_nmpc_pack_batch")
+
+    def update(self, stream=None, keep_failed=True):
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.solver.device)
+        ds = self.solver
+        _check(lib().frp_nmpc_update_batch(self.B, self.N, ctypes.c_void_p(ds.z.data_ptr()),
+                                           ctypes.c_void_p(ds.exitflag.data_ptr()) if keep_failed else None,
+                                           ctypes.c_void_p(self.mpc_output.data_ptr()), ctypes.c_void_p(s.cuda_stream)),
+               "frp_nmpc_update_batch")
+
+    def tick(self, external_acc, ref_pos, ref_yaw, stream=None):
+        """One receding-horizon tick of all B planners, asynchronous on `stream`."""
+        self.pack(external_acc, ref_pos, ref_yaw, stream)
+        self.solver.solve(stream)
+        self.update(stream)

@@ -119,6 +119,41 @@ int frp_nmpc_stage_eval_host(int B, int N, int M, int model, const double *z, co
 int frp_nmpc_time_solve(const frp_nmpc_batch *batch, const frp_nmpc_options *opt, void *workspace,
                         size_t workspace_bytes, void *stream, int reps, float *avg_ms);
 
+/* ---- (3) SURVEY 8f row f-1: the adapter's packing / result bookkeeping on the device (all pointers DEVICE) ---- */
+typedef struct frp_nmpc_pack {
+    int B, N, M;   /* problems, horizon, corridor rows of the parameter layout (num_const, nmpc_utils.h:50)      */
+    int NPOLY;     /* polytopes stored per problem (= N when poly_index is NULL)                                 */
+    int F;         /* rows stored per polytope (>= any nfaces; rows beyond M are dropped, forces_normal.cpp:114) */
+    int external_acc_per_stage;
+    /* inputs: the arguments of FORCESNormal::solveNormal (plan_manage/src/forces_normal.cpp:55-60)              */
+    const double *mpc_output;   /* [B][N+1][17]  plan deque (row 0 = applied stage)                              */
+    const double *external_acc; /* [B][3], or [B][N][3] when external_acc_per_stage != 0 (the per-stage parameter
+                                   layout allows it, matlab_code/setup.m:62; the reference passes one vector)       */
+    const double *ref_pos;      /* [B][N][3]     ref_total_pos                                                   */
+    const double *ref_yaw;      /* [B][N]        ref_total_yaw                                                   */
+    const double *ellipsoid;    /* [B][N][3][3]  ellipsoid_matrices E_i (row-major)                              */
+    const double *poly_A;       /* [B][NPOLY][F][3]  poly_constraints[.].A_                                      */
+    const double *poly_b;       /* [B][NPOLY][F]     poly_constraints[.].b_                                      */
+    const int *poly_nfaces;     /* [B][NPOLY]    live rows of each polytope                                      */
+    const int *poly_index;      /* [B][N]        poly_indices(i), or NULL: stage i uses polytope i               */
+    /* the weights of setParasNormal / setParasFinal (forces_normal.cpp:36-52)                                   */
+    double w_stage_wp, w_stage_input, w_input_rate, w_terminal_wp, w_terminal_input;
+    /* outputs: the solver inputs of frp_nmpc_batch                                                              */
+    double *xinit;  /* [B][9]        */
+    double *x0;     /* [B][N][17]    */
+    double *params; /* [B][N][10+4M] */
+    int *nfaces;    /* [B][N]        */
+} frp_nmpc_pack;
+
+/* forces_normal.cpp:36-136 for B planners: weights, xinit / shifted x0, per-stage parameters with the robust
+ * tightening b_j - ||E_i a_j||_2 and zero padding.  Asynchronous on `stream`. */
+int frp_nmpc_pack_batch(const frp_nmpc_pack *p, void *stream);
+
+/* updateNormal (forces_normal.cpp:142-168) + NMPCSolver::updateFORCESResults (nmpc_solver.cpp:524-543) for B
+ * planners: plan rows 0..N-1 <- z, yaw wrapped into [-pi, pi], row N <- row N-1.  With exitflag != NULL a planner
+ * whose solve did not return 1 keeps its previous plan (nmpc_solver.cpp:397-424). */
+int frp_nmpc_update_batch(int B, int N, const double *z, const int *exitflag, double *mpc_output, void *stream);
+
 const char *frp_nmpc_version(void);
 int frp_nmpc_device_count(void);
 

@@ -237,3 +237,52 @@ def test_horizon_lengths_cover_every_lane_mapping(N):
     same = ok & (it == np.array([i.it for i in io]))
     assert same.sum() >= 0.9 * ok.sum() and np.max(np.abs(z[same] - zo[same])) < 1e-6
     assert np.max(np.abs(z[ok] - zo[ok])) < 1e-3
+
+
+def test_device_packing_matches_the_adapter():
+    """frp_nmpc_pack_batch / frp_nmpc_update_batch against the host adapter (adapter.py, itself
+    checked against the C++ mirror of forces_normal.cpp): copies bit-exact, the tightened offsets b - ||E a|| to 2 ulp
+    (sum order / FMA contraction), identical zero padding and face counts."""
+    import torch
+    from forces_resilient_planner_amd.adapter import ForcesAdapter, update_forces_results
+    w = workloads.config3(64)                       # N = 30, 6..15 faces per stage, per-stage tube matrices
+    B, N, M = w["B"], w["N"], w["M"]
+    F = w["poly_A"].shape[2]
+    wts = workloads._weights(w["model"])
+    fleet = solver.DeviceFleet(B, N, M, F, w["model"], wts)
+    fleet.mpc_output.copy_(fleet.to_device(w["mpc_output"]))
+    fleet.ellipsoid.copy_(fleet.to_device(w["E"]))
+    fleet.poly_A.copy_(fleet.to_device(w["poly_A"])); fleet.poly_b.copy_(fleet.to_device(w["poly_b"]))
+    fleet.poly_nfaces.copy_(fleet.to_device(w["nfaces"], dtype=torch.int32))
+    fleet.pack(fleet.to_device(w["f_ext"]), fleet.to_device(w["ref_pos"]), fleet.to_device(w["ref_yaw"]))
+    torch.cuda.synchronize()
+    ds = fleet.solver
+    assert np.array_equal(ds.xinit.cpu().numpy(), w["xinit"])
+    assert np.array_equal(ds.x0.cpu().numpy(), w["x0"])
+    assert np.array_equal(ds.nfaces.cpu().numpy(), w["nfaces"])
+    p = ds.params.cpu().numpy()
+    assert np.array_equal(p[:, :, :10 + 3 * M], w["params"][:, :, :10 + 3 * M])
+    assert np.array_equal(p == 0.0, w["params"] == 0.0)
+    assert np.max(np.abs(p - w["params"])) <= 4 * np.finfo(float).eps * (1 + np.abs(w["params"]).max())
+    # solve from the device-packed inputs, then the device-side bookkeeping against the host one
+    ds.solve(); fleet.update()
+    torch.cuda.synchronize()
+    z = ds.z.cpu().numpy(); fl = ds.exitflag.cpu().numpy()
+    ref = w["mpc_output"].copy()
+    upd = ref.copy(); upd[:, :N] = z; upd = update_forces_results(upd)
+    ref[fl == 1] = upd[fl == 1]
+    assert (fl == 1).mean() > 0.8
+    assert np.array_equal(fleet.mpc_output.cpu().numpy(), ref)
+    yaw = fleet.mpc_output[:, :N, 16].cpu().numpy()
+    assert np.all(np.abs(yaw) <= np.pi + 1e-12)
+
+
+def test_receding_horizon_on_device_matches_host_loop():
+    """configs[4] in miniature with the whole tick on the GPU (pack -> solve -> update) against the host-driven loop."""
+    from forces_resilient_planner_amd import receding
+    w0 = workloads.config4_nominal(B=32, ticks=5)
+    fg, ig, mg = receding.run(w0, 5, lambda w: solver.solve_batch_host(w)[:3])
+    fd, idv, md, secs = receding.run_device(w0, 5)
+    assert np.array_equal(fd, fg)
+    assert (idv == ig).mean() >= 0.95
+    assert np.max(np.abs(md - mg)) < 1e-6
