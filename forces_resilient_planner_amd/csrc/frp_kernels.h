@@ -60,7 +60,7 @@ constexpr int DZ_ROWS = 20;     // dz rows: du(4) + ds(13) + 3 pad rows (tile ro
 constexpr int Y_ROWS = 16;      // y rows: 13 + 3 pad rows
 
 constexpr double S_MIN = 1e-2;          // smallest initial slack (infeasible start shift)
-constexpr double MU_FLOOR_FRAC = 0.1;   // centring target floor = 0.1 * tol_comp
+constexpr double MU_FLOOR_FRAC = 0.3;   // centring target floor = 0.3 * tol_comp
 constexpr double THETA_DOWN = 0.25;     // dynamics-Hessian weight after an indefinite pivot block ...
 constexpr double THETA_UP = 0.1;        // ... and its recovery per successful iteration
 constexpr double KAPPA_LAM = 2.0;       // multiplier safeguard: s_i lam_i >= mu / KAPPA_LAM after every step

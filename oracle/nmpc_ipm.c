@@ -32,7 +32,7 @@ void orc_rk2_hess(const double *x, const double *u, const double *fext, const do
 #define NS 13
 #define HU_OFF 1e-5 /* hu = 1e-5, mpc_generator_normal.m:14 */
 #define S_MIN 1e-2
-#define MU_FLOOR_FRAC 0.1
+#define MU_FLOOR_FRAC 0.3
 #define THETA_DOWN 0.25
 #define THETA_UP 0.1
 #define KAPPA_LAM 2.0      /* multiplier safeguard: s_i lam_i >= mu / KAPPA_LAM after every step */
