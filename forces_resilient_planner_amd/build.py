@@ -39,6 +39,22 @@ def build_native(force=False, verbose=True):
     return LIB
 
 
+def build_ubench(verbose=True):
+    """Micro-benchmarks / probes behind the numbers in DESIGN.md (tools/ubench/*.hip -> binaries next to the sources):
+    MFMA layout and latency probes, the mat-vec building block, the FETCH_SIZE / WRITE_SIZE calibration kernel."""
+    d = os.path.join(ROOT, "tools", "ubench")
+    for f in sorted(os.listdir(d)):
+        if not f.endswith(".hip"):
+            continue
+        src, exe = os.path.join(d, f), os.path.join(d, f[:-4])
+        if os.path.exists(exe) and os.path.getmtime(exe) >= os.path.getmtime(src):
+            continue
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-Wno-unused-value", src, "-o", exe]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+
 def build_oracle(verbose=True):
     """Test infrastructure: oracle/liboracle.so and, when /root/reference is present, oracle/_ref."""
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "all"],
@@ -47,4 +63,5 @@ def build_oracle(verbose=True):
 
 if __name__ == "__main__":
     build_native(force=True)
+    build_ubench()
     build_oracle()
