@@ -286,3 +286,38 @@ def test_receding_horizon_on_device_matches_host_loop():
     assert np.array_equal(fd, fg)
     assert (idv == ig).mean() >= 0.95
     assert np.max(np.abs(md - mg)) < 1e-6
+
+
+def test_maximum_sizes_horizon_64_all_30_corridor_rows_live():
+    """Edge of the supported range: N = 64 stages (one stage per lane), every one of the 30 corridor rows of the
+    reference layout live (each random polytope row repeated: redundant faces, non-unique multipliers), batch 6;
+    plus a batch of ONE and an N = 2 horizon."""
+    w = workloads.config3(6, N=64, M=30)
+    p = w["params"].copy(); nf = w["nfaces"].copy()
+    for b in range(6):
+        for k in range(64):
+            n = nf[b, k]
+            A = p[b, k, 10:10 + 3 * 30].reshape(30, 3); bb = p[b, k, 100:130]
+            for j in range(n, 30):  # repeat the live rows, pushed out by 1 cm .. 16 cm so that they stay inactive-ish
+                A[j] = A[j % n]; bb[j] = bb[j % n] + 0.01 * (1 + j // n)
+            nf[b, k] = 30
+    w2 = dict(w, params=p, nfaces=nf)
+    z, fl, it, info = solver.solve_batch_host(w2)
+    zo, flo, io = OL.solve_batch(w2)
+    assert np.array_equal(fl, flo)
+    ok = fl == 1
+    assert ok.sum() >= 3
+    assert np.max(np.abs(z[ok] - zo[ok])) < 1e-5
+    # the redundant rows do not move the solution of the 6..15-row problem
+    z1, fl1, _, _ = solver.solve_batch_host(w)
+    both = ok & (fl1 == 1)
+    assert np.max(np.abs(z[both] - z1[both])) < 5e-3
+    # batch of one
+    w1 = {k: (v[:1] if isinstance(v, np.ndarray) and v.shape[:1] == (6,) else v) for k, v in w2.items()}
+    za, fla, _, _ = solver.solve_batch_host(w1)
+    assert fla[0] == fl[0] and np.max(np.abs(za[0] - z[0])) < 1e-9
+    # shortest horizon the API accepts
+    ws = workloads.config3(8, N=2, M=15)
+    zs, fls, its, _ = solver.solve_batch_host(ws)
+    zso, flso, _ = OL.solve_batch(ws)
+    assert np.array_equal(fls, flso) and np.max(np.abs(zs[fls == 1] - zso[fls == 1])) < 1e-6
