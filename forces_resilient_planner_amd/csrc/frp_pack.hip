@@ -10,8 +10,8 @@
 //                   (plan_manage/src/nmpc_solver.cpp:524-543): rows 0..N-1 <- solver output, yaw wrapped into
 //                   [-pi, pi], row N <- row N-1.
 //
-// Pure HBM-bound byte/FP64 work: one wavefront per (problem, stage) row, lanes over the row's columns, so every
-// store is a coalesced 512-byte run.  Algorithmic bytes per problem (N = 20, M = 30, F stored faces per stage):
+// Pure HBM-bound byte/FP64 work: one 256-thread workgroup per problem, threads over the problem's flattened output
+// elements, so every store instruction of a wave is a coalesced 512-byte run.  Algorithmic bytes per problem (N = 20, M = 30, F stored faces per stage):
 //   pack   read  8 (21*17 + 3 + 20*3 + 20 + 20*9 + 20*F*4) + 4*20    write 8 (9 + 340 + 2600) + 4*20
 //   update read  8*340                                                 write 8*357
 #include <hip/hip_runtime.h>
@@ -22,27 +22,34 @@ namespace frp {
 
 constexpr int PK_NZ = 17, PK_NPRE = 10;
 
-__global__ __launch_bounds__(64) void pack_kernel(frp_nmpc_pack p)
+// One workgroup per problem: its 2600 + 340 + 9 output doubles are written as contiguous 2 KB runs.
+__global__ __launch_bounds__(256) void pack_kernel(frp_nmpc_pack p)
 {
-    const int row = blockIdx.x;            // (problem, stage)
-    const int b = row / p.N, i = row % p.N;
-    const int lane = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const int np = PK_NPRE + 4 * p.M;
     const double *mo = p.mpc_output + (size_t)b * (p.N + 1) * PK_NZ;
-    // x0 row i = plan row i + 1 (forces_normal.cpp:74-97); xinit = state part of plan row 1 (:62-72)
-    if (lane < PK_NZ) p.x0[((size_t)b * p.N + i) * PK_NZ + lane] = mo[(i + 1) * PK_NZ + lane];
-    if (i == 0 && lane < 9) p.xinit[(size_t)b * 9 + lane] = mo[PK_NZ + 8 + lane];
-    // this stage's polytope (poly_constraints[poly_indices(i)], forces_normal.cpp:112) and tube matrix E_i
-    const int pi = p.poly_index ? p.poly_index[(size_t)b * p.N + i] : i;
-    const size_t pbase = (size_t)b * p.NPOLY + pi;
-    const double *A = p.poly_A + pbase * p.F * 3, *bb = p.poly_b + pbase * p.F;
-    int nf = p.poly_nfaces[pbase];
-    nf = nf < p.M ? nf : p.M;              // faces beyond num_const are dropped (:114)
-    nf = nf < p.F ? nf : p.F;
-    const double *E = p.ellipsoid + ((size_t)b * p.N + i) * 9;
-    double *out = p.params + ((size_t)b * p.N + i) * np;
-    const bool last = i == p.N - 1;
-    for (int c = lane; c < np; c += 64) {
+    // x0 rows 0..N-1 = plan rows 1..N (forces_normal.cpp:74-97): one contiguous copy; xinit = state of plan row 1 (:62-72)
+    for (int e = tid; e < p.N * PK_NZ; e += 256) p.x0[(size_t)b * p.N * PK_NZ + e] = mo[PK_NZ + e];
+    if (tid < 9) p.xinit[(size_t)b * 9 + tid] = mo[PK_NZ + 8 + tid];
+    // per stage: its polytope (poly_constraints[poly_indices(i)], forces_normal.cpp:112) and live face count
+    __shared__ int s_pi[64], s_nf[64];
+    if (tid < p.N) {
+        const int pi = p.poly_index ? p.poly_index[(size_t)b * p.N + tid] : tid;
+        int nf = p.poly_nfaces[(size_t)b * p.NPOLY + pi];
+        nf = nf < p.M ? nf : p.M;              // faces beyond num_const are dropped (:114)
+        nf = nf < p.F ? nf : p.F;
+        s_pi[tid] = pi; s_nf[tid] = nf;
+        p.nfaces[(size_t)b * p.N + tid] = nf;
+    }
+    __syncthreads();
+    const float inv_np = 1.0f / (float)np;
+    auto element = [&](int e) -> double {
+        int i = (int)(((float)e + 0.5f) * inv_np); // stage (exact: e < 2^16)
+        i = i * np > e ? i - 1 : ((i + 1) * np <= e ? i + 1 : i);
+        const int c = e - i * np;
+        const size_t pbase = (size_t)b * p.NPOLY + s_pi[i];
+        const int nf = s_nf[i];
+        const bool last = i == p.N - 1;
         double v = 0.0;
         if (c < 3) v = p.ref_pos[((size_t)b * p.N + i) * 3 + c];                         // :99-102
         else if (c < 6) v = p.external_acc[(p.external_acc_per_stage ? (size_t)b * p.N + i : (size_t)b) * 3 + c - 3]; // :103-106
@@ -52,10 +59,11 @@ __global__ __launch_bounds__(64) void pack_kernel(frp_nmpc_pack p)
         else if (c == 9) v = p.ref_yaw[(size_t)b * p.N + i];                             // :107-108
         else if (c < PK_NPRE + 3 * p.M) {                                                // A row-major (:116-123)
             const int j = (c - PK_NPRE) / 3;
-            v = j < nf ? A[c - PK_NPRE] : 0.0;
+            if (j < nf) v = p.poly_A[pbase * p.F * 3 + c - PK_NPRE];
         } else {                                                                         // b_j - ||E a_j||_2 (:124-125)
             const int j = c - PK_NPRE - 3 * p.M;
             if (j < nf) {
+                const double *A = p.poly_A + pbase * p.F * 3, *E = p.ellipsoid + ((size_t)b * p.N + i) * 9;
                 const double a0 = A[3 * j], a1 = A[3 * j + 1], a2 = A[3 * j + 2];
                 double n2 = 0.0;
 #pragma unroll
@@ -63,48 +71,50 @@ __global__ __launch_bounds__(64) void pack_kernel(frp_nmpc_pack p)
                     const double t = E[3 * r] * a0 + E[3 * r + 1] * a1 + E[3 * r + 2] * a2;
                     n2 += t * t;
                 }
-                v = bb[j] - sqrt(n2);
+                v = p.poly_b[pbase * p.F + j] - sqrt(n2);
             }
         }
-        out[c] = v;
-    }
-    if (lane == 0) p.nfaces[(size_t)b * p.N + i] = nf;
+        return v;
+    };
+    double *out = p.params + (size_t)b * p.N * np;
+    for (int e = tid; e < p.N * np; e += 256) out[e] = element(e);
 }
 
-__global__ __launch_bounds__(64) void update_kernel(int B, int N, const double *__restrict__ z, const int *__restrict__ exitflag,
-                                                    double *__restrict__ mpc_output)
+__global__ __launch_bounds__(256) void update_kernel(int B, int N, const double *__restrict__ z, const int *__restrict__ exitflag,
+                                                     double *__restrict__ mpc_output)
 {
-    const int row = blockIdx.x;            // (problem, plan row 0..N)
-    const int b = row / (N + 1), i = row % (N + 1);
-    const int lane = threadIdx.x;
-    if (lane >= PK_NZ) return;
-    if (exitflag && exitflag[b] != FRP_EXIT_OPTIMAL) return; // the reference keeps the old plan when the solver fails (nmpc_solver.cpp:392-420)
-    const int src = i < N ? i : N - 1;     // row N duplicates row N-1 (nmpc_solver.cpp:543)
-    double v = z[((size_t)b * N + src) * PK_NZ + lane];
-    if (lane == 16) {                      // yaw wrap (nmpc_solver.cpp:527-541)
-        const double PI = 3.14159265358979323846;
-        if (v < -PI) v += 2 * PI;
-        else if (v > PI) v -= 2 * PI;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (exitflag && exitflag[b] != FRP_EXIT_OPTIMAL) return; // the reference keeps the old plan when the solver fails (nmpc_solver.cpp:397-424)
+    const double PI = 3.14159265358979323846;
+    for (int e = tid; e < (N + 1) * PK_NZ; e += 256) {
+        const int i = e / PK_NZ, c = e - i * PK_NZ;
+        const int src = i < N ? i : N - 1;    // row N duplicates row N-1 (nmpc_solver.cpp:543)
+        double v = z[((size_t)b * N + src) * PK_NZ + c];
+        if (c == 16) {                        // yaw wrap (nmpc_solver.cpp:527-541)
+            if (v < -PI) v += 2 * PI;
+            else if (v > PI) v -= 2 * PI;
+        }
+        mpc_output[(size_t)b * (N + 1) * PK_NZ + e] = v;
     }
-    mpc_output[((size_t)b * (N + 1) + i) * PK_NZ + lane] = v;
 }
 
 } // namespace frp
 
 extern "C" int frp_nmpc_pack_batch(const frp_nmpc_pack *p, void *stream)
 {
-    if (!p || p->B <= 0 || p->N < 2 || p->M < 0 || p->F <= 0 || p->NPOLY <= 0 || !p->mpc_output || !p->external_acc || !p->ref_pos ||
+    if (!p || p->B <= 0 || p->N < 2 || p->N > 64 || p->M < 0 || p->F <= 0 || p->NPOLY <= 0 || !p->mpc_output || !p->external_acc || !p->ref_pos ||
         !p->ref_yaw || !p->ellipsoid || !p->poly_A || !p->poly_b || !p->poly_nfaces || !p->xinit || !p->x0 || !p->params || !p->nfaces)
         return FRP_ERR_ARG;
     if (!p->poly_index && p->NPOLY != p->N) return FRP_ERR_ARG;
-    hipLaunchKernelGGL(frp::pack_kernel, dim3((unsigned)((size_t)p->B * p->N)), dim3(64), 0, static_cast<hipStream_t>(stream), *p);
+    if ((long long)p->N * (10 + 4 * p->M) >= 65536) return FRP_ERR_ARG; // N * np must stay below 2^16 (float index split in pack_kernel)
+    hipLaunchKernelGGL(frp::pack_kernel, dim3((unsigned)p->B), dim3(256), 0, static_cast<hipStream_t>(stream), *p);
     return hipGetLastError() == hipSuccess ? FRP_OK : FRP_ERR_HIP;
 }
 
 extern "C" int frp_nmpc_update_batch(int B, int N, const double *z, const int *exitflag, double *mpc_output, void *stream)
 {
     if (B <= 0 || N < 2 || !z || !mpc_output) return FRP_ERR_ARG;
-    hipLaunchKernelGGL(frp::update_kernel, dim3((unsigned)((size_t)B * (N + 1))), dim3(64), 0, static_cast<hipStream_t>(stream), B, N, z,
+    hipLaunchKernelGGL(frp::update_kernel, dim3((unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), B, N, z,
                        exitflag, mpc_output);
     return hipGetLastError() == hipSuccess ? FRP_OK : FRP_ERR_HIP;
 }
