@@ -69,6 +69,21 @@ def cpu_baseline(w, seconds_target=12.0):
         dt = time.perf_counter() - t0
         if dt >= seconds_target or reps >= 2000:
             break
+    # the one piece of the reference's own hot path that runs without the ForcesPro licence: its CasADi model callback
+    # (oracle/_ref, built from the reference sources in place), timed per stage call next to the port's stage evaluation
+    anchor = None
+    try:
+        import ctypes
+        so = os.path.join(OL.ORC_DIR, "_ref", "libref_model_normal.so")
+        if os.path.exists(so):
+            ref = ctypes.CDLL(so)
+            fn = ctypes.cast(ref.FORCESNLPsolver_normal_casadi2forces, ctypes.c_void_p)
+            a, b = ctypes.c_double(0), ctypes.c_double(0)
+            OL.lib().orc_time_callback(fn, 0, 300000, ctypes.byref(a), ctypes.byref(b))
+            anchor = {"reference_callback_ns_per_stage_call": a.value, "port_stage_eval_ns_per_call": b.value,
+                      "what": "FORCESNLPsolver_normal_casadi2forces (reference, casadi2forces.c:42-245) vs orc_stage_eval, 1 thread"}
+    except Exception as e:  # the anchor is optional evidence, never a reason to lose the bench line
+        anchor = {"error": str(e)}
     n1 = min(B, 512)
     sub = {k: (v[:n1] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in w.items()}
     t1 = time.perf_counter(); OL.solve_batch(sub, nthreads=1); dt1 = time.perf_counter() - t1
@@ -77,7 +92,7 @@ def cpu_baseline(w, seconds_target=12.0):
                        f"same interior-point method, not ForcesPro: its binary is licence-locked), OpenMP over problems on "
                        f"{cores} threads (os.cpu_count()={os.cpu_count()}, affinity/cgroup-limited to {cores}), {dt:.1f} s; "
                        f"single-thread {n1 / dt1:.0f} solves/s",
-                converged_frac=conv / solved)
+                converged_frac=conv / solved, reference_anchor=anchor)
 
 
 def pmc_traffic(batch):

@@ -346,3 +346,35 @@ void orc_bounds(double *lb, double *ub)
     memcpy(lb, l, sizeof l);
     memcpy(ub, u, sizeof u);
 }
+
+
+/* ---- timing anchor: the reference's OWN model callback (oracle/_ref, FORCESNLPsolver_*_casadi2forces,
+ * casadi2forces.c:42-245 -- the only piece of the reference's hot path that can run without the ForcesPro licence)
+ * against this file's restatement of the same stage evaluation, both called `reps` times on one thread.
+ * fn = the callback's address (extfunc signature, FORCESNLPsolver_normal.h:321).  Returns ns per call. */
+#include <time.h>
+typedef void (*orc_extfunc)(double *x, double *y, double *lambda, double *params, double *pobj, double *g, double *c,
+                            double *Jeq, double *h, double *Jineq, double *H, int stage, int iterations, int threadID);
+static double now_ns(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 1e9 * (double)t.tv_sec + (double)t.tv_nsec; }
+void orc_time_callback(void *fn, int model, int reps, double *ns_reference, double *ns_port)
+{
+    double z[17], p[130], y[13] = {0}, lam[64] = {0}, f, gf[17], c[13], Jc[221], h[30], Jh[510];
+    for (int i = 0; i < 17; i++) z[i] = 0.1 * (i + 1) - 0.8;
+    z[3] = 7.0; z[7] = 7.2;
+    for (int i = 0; i < 130; i++) p[i] = 0.0;
+    p[0] = 1.0; p[1] = 2.0; p[2] = 1.5; p[3] = 0.5; p[4] = -0.3; p[5] = 0.2; p[6] = 7.0; p[7] = 1.0; p[8] = 80.0; p[9] = 0.3;
+    for (int j = 0; j < 6; j++) { p[10 + 3 * j + j % 3] = (j & 1) ? -1.0 : 1.0; p[100 + j] = 2.0; }
+    volatile double sink = 0.0;
+    if (fn && ns_reference) {
+        orc_extfunc cb = (orc_extfunc)fn;
+        const double t0 = now_ns();
+        for (int r = 0; r < reps; r++) { z[0] += 1e-9; cb(z, y, lam, p, &f, gf, c, Jc, h, Jh, 0, 3, 0, 0); sink += f + c[5] + Jc[40]; }
+        *ns_reference = (now_ns() - t0) / reps;
+    }
+    if (ns_port) {
+        const double t0 = now_ns();
+        for (int r = 0; r < reps; r++) { z[0] += 1e-9; orc_stage_eval(z, p, 30, 1, model, &f, gf, c, Jc, h, Jh); sink += f + c[5] + Jc[40]; }
+        *ns_port = (now_ns() - t0) / reps;
+    }
+    (void)sink;
+}
