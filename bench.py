@@ -134,7 +134,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("FRP_BENCH_FORCE_DIST"):  # (the env knob lets a 1-GPU box exercise the RCCL path)
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
