@@ -1549,22 +1549,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
 __global__ __launch_bounds__(256) void order_keys_kernel(int B, int N, int np, int model, const double *__restrict__ x0,
                                                          const double *__restrict__ params, double *__restrict__ keys)
 {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)B * N) return;
-    const int k = (int)(t % N);
-    double zl[NZ], p10[NPRE];
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), k = threadIdx.x & 63; // one wavefront per problem, lane = stage
+    if (b >= B) return;
+    double c = 0.0;
+    if (k < N) {
+        const size_t t = (size_t)b * N + k;
+        double zl[NZ], p10[NPRE];
 #pragma unroll
-    for (int i = 0; i < NZ; i++) zl[i] = x0[t * NZ + i];
+        for (int i = 0; i < NZ; i++) zl[i] = x0[t * NZ + i];
 #pragma unroll
-    for (int i = 0; i < NPRE; i++) p10[i] = params[t * np + i];
-    const double c = stage_cost(zl, p10, stage_class(k, N), model, nullptr);
-    atomicAdd(&keys[t / N], (c == c && c < 1e300) ? c : 0.0);
+        for (int i = 0; i < NPRE; i++) p10[i] = params[t * np + i];
+        c = stage_cost(zl, p10, stage_class(k, N), model, nullptr);
+    }
+    c = wave_sum(c);
+    if (k == 0) keys[b] = (c == c && c < 1e300) ? c : 0.0;
 }
-// order = the problems sorted by decreasing key, to bucket resolution: one workgroup, a 1024-bin counting sort on the
+// order = the problems sorted by decreasing key, to bucket resolution (also zeroes the work-queue head): one workgroup, a 1024-bin counting sort on the
 // (monotone) bit pattern of the non-negative keys -- i.e. on a log scale -- with the bins spread over the key range of
 // this batch.  The order inside a bin is arbitrary (atomics); order[] is a permutation for any input.
-__global__ __launch_bounds__(1024) void order_bucket_kernel(int B, const double *__restrict__ keys, int *__restrict__ order)
+__global__ __launch_bounds__(1024) void order_bucket_kernel(int B, const double *__restrict__ keys, int *__restrict__ order, int *__restrict__ counter)
 {
+    if (threadIdx.x == 0) *counter = 0; // queue head of the solve that follows on this stream
     __shared__ unsigned long long s_min, s_max;
     __shared__ int hist[1024];
     const int t = threadIdx.x;
@@ -1588,9 +1593,17 @@ __global__ __launch_bounds__(1024) void order_bucket_kernel(int B, const double 
         atomicAdd(&hist[1023 - (int)((u - base) >> shift)], 1); // bin 0 = largest keys
     }
     __syncthreads();
-    if (t == 0) { // exclusive prefix sum (1024 adds: negligible next to the solve)
-        int acc = 0;
-        for (int b = 0; b < 1024; b++) { const int h = hist[b]; hist[b] = acc; acc += h; }
+    { // exclusive prefix sum over the 1024 bins (Hillis-Steele, 10 steps)
+        const int own = hist[t];
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int add = t >= off ? hist[t - off] : 0;
+            __syncthreads();
+            hist[t] += add;
+            __syncthreads();
+        }
+        const int incl = hist[t];
+        __syncthreads();
+        hist[t] = incl - own;
     }
     __syncthreads();
     for (int i = t; i < B; i += 1024) {
@@ -1706,16 +1719,16 @@ hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
     double *q = a.ws + queue_offset_doubles(a.B, a.N, a.MF);
     k.counter = reinterpret_cast<int *>(q);
     k.order = nullptr;
-    hipError_t e = hipMemsetAsync(q, 0, 256 + (a.B > slots ? (size_t)a.B * sizeof(double) : 0), stream); // counter (+ keys)
-    if (e != hipSuccess) return e;
     if (a.B > slots) { // more problems than resident workgroups: order the queue, longest expected solve first
         double *keys = q + 32;
         int *order = reinterpret_cast<int *>(keys + a.B);
         k.order = order;
-        const size_t nt = (size_t)a.B * a.N;
-        hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, stream, a.B, a.N, NPRE + 4 * a.M,
-                           a.model, a.x0, a.params, keys);
-        hipLaunchKernelGGL(order_bucket_kernel, dim3(1), dim3(1024), 0, stream, a.B, keys, order);
+        hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, stream, a.B, a.N, NPRE + 4 * a.M, a.model,
+                           a.x0, a.params, keys);
+        hipLaunchKernelGGL(order_bucket_kernel, dim3(1), dim3(1024), 0, stream, a.B, keys, order, k.counter);
+    } else {
+        const hipError_t e = hipMemsetAsync(k.counter, 0, sizeof(int), stream);
+        if (e != hipSuccess) return e;
     }
     switch (padded_stages(a.N)) {
     case 16: hipLaunchKernelGGL(nmpc_ipm_kernel<16>, dim3(slots), dim3(64), 0, stream, k); break;

@@ -5,7 +5,7 @@
 set -x
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof; rm -rf $OUT; mkdir -p $OUT
-BENCH="python $PWD/bench.py --steps 20 --warmup 3 --no-cpu"
+BENCH="python $PWD/bench.py --steps 20 --warmup 3 --no-cpu --streams 1"   # one stream: launches do not overlap, so per-kernel durations are those of an isolated launch
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $BENCH > $OUT/bench_stats.json 2> $OUT/stats.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o bench -- $BENCH > /dev/null 2> $OUT/fetch.log
