@@ -115,6 +115,7 @@ constexpr int S_E = 0;                    // E part of the stage record (192 use
 constexpr int S_ZERO = 248, S_ONE = 249, S_DTC = 250;
 constexpr int S_T = 256;                  // T' (64)
 constexpr int S_MI = 320, S_DI = 328;      // pivot block handed from uniform registers to lanes: m = L^-1 (6), D^-1 (4)
+constexpr int S_PRAW = 336;               // forward sweep: staged copy of the next stage's p (16) + packed P (96)
 constexpr int S_STAGING = 23 * 32;        // 736
 constexpr int S_RW = S_STAGING;           // stage-0 solve: Pww^-1 (16)
 constexpr int S_PWX = S_RW + 16;          // stage-0 solve: Pwx (4 x 9)
@@ -975,7 +976,7 @@ template <int NP, bool WITH_Y>
 __device__ __forceinline__ void forward_step(const WsView &w, int N, int kk, int lane, int idx, const int (&tto)[4],
                                              const int (&mto)[4], const int (&pmo)[4], int pvo, const d4 &ctt, const d4 &cmt, double chc,
                                              const d4 &cP, double cpv, d4 &ntt, d4 &nmt, double &nhc, d4 &nP, double &npv,
-                                             double &e0, double &tp, double &v)
+                                             double &e0, double &tp, double &pr0, double &pr1, double &v)
 {
     const bool q0 = idx < 4 && (lane & 12) == 0; // rows 0..3 (quad 0 of every 16-lane row)
     const double v1 = q0 ? chc * v : (idx == 13 ? 1.0 : v); // row 13 multiplies the kbar column
@@ -983,22 +984,22 @@ __device__ __forceinline__ void forward_step(const WsView &w, int N, int kk, int
     // stage the (already fetched) record of the next stage through LDS ...
     WSYNC();
     sm[S_E + lane] = e0; sm[S_T + lane] = tp;
+    if (WITH_Y) { sm[S_PRAW + lane] = pr0; if (lane < 48) sm[S_PRAW + 64 + lane] = pr1; }
     WSYNC();
     { // ... prefetch the one after it (clamped: the tail re-reads the last record, unused) ...
         const int kf = (kk + 3 < N) ? kk + 3 : N - 1; // staged again two steps from now
         cgdouble *rp = w.rec + (size_t)kf * REC_STRIDE;
         e0 = rp[lane]; tp = rp[REC_T + lane];
-        if (WITH_Y) { // P and p of the NEXT stage, straight into registers
-            const int kn = (kk + 1 < N) ? kk + 1 : N - 1;
-            cgdouble *rq = w.rec + (size_t)kn * REC_STRIDE;
-#pragma unroll
-            for (int r = 0; r < 4; r++) nP[r] = rq[pmo[r]];
-            npv = rq[pvo];
-        }
+        if (WITH_Y) { pr0 = rp[REC_PV + lane]; pr1 = rp[REC_PV + 64 + (lane < 48 ? lane : 0)]; } // p (16) and packed P (96)
     }
 #pragma unroll
     for (int s = 0; s < 4; s++) { ntt[s] = sm[tto[s]]; nmt[s] = sm[mto[s]]; }
     nhc = sm[S_T + 14];
+    if (WITH_Y) { // P and p of the next stage, gathered from the staged (coalesced) copy of its packed block
+#pragma unroll
+        for (int r = 0; r < 4; r++) nP[r] = sm[pmo[r]];
+        npv = sm[pvo];
+    }
     double Y = 0.0;
     if (WITH_Y) Y = matvec4(cP, v, cpv); // y+_k = P_k ds_k + p_k
     const double du = -D1;
@@ -1025,44 +1026,51 @@ __device__ __noinline__ void sweep_forward(WsView w, int N)
     for (int s = 0; s < 4; s++) {
         mto[s] = sm_tab[(TAB4_MT + s) * 64 + lane];
         tto[s] = sm_tab[(TAB4_TT + s) * 64 + lane];
-        pmo[s] = sm_tab[(TAB4_P + s) * 64 + lane];
+        const int po = sm_tab[(TAB4_P + s) * 64 + lane]; // record slot of P[row][col] (or REC_ZERO) -> slot of its staged copy
+        pmo[s] = po == REC_ZERO ? S_ZERO : S_PRAW + (po - REC_PV);
     }
-    const int pvo = idx <= 12 ? REC_PV + idx : REC_ZERO;
+    const int pvo = idx <= 12 ? S_PRAW + idx : S_ZERO;
     init_stage_constants(lane);
     double v = sm[S_DS0 + idx]; // ds_0 (entries 13..15 are zero)
-    double e0, tp;
+    double e0, tp, pr0 = 0.0, pr1 = 0.0;
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     d4 PA = zero, PB = zero;
     double pvA = 0.0, pvB = 0.0;
     {
         cgdouble *rp = w.rec;
         e0 = rp[lane]; tp = rp[REC_T + lane];
-        if (WITH_Y) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) PA[r] = rp[pmo[r]];
-            pvA = rp[pvo];
-        }
+        if (WITH_Y) { pr0 = rp[REC_PV + lane]; pr1 = rp[REC_PV + 64 + (lane < 48 ? lane : 0)]; }
     }
     WSYNC();
     sm[S_E + lane] = e0; sm[S_T + lane] = tp;
+    if (WITH_Y) { sm[S_PRAW + lane] = pr0; if (lane < 48) sm[S_PRAW + 64 + lane] = pr1; }
     WSYNC();
     d4 ttA, mtA, ttB, mtB;
     double hcA, hcB = 0.0;
 #pragma unroll
     for (int s = 0; s < 4; s++) { ttA[s] = sm[tto[s]]; mtA[s] = sm[mto[s]]; }
     hcA = sm[S_T + 14];
-    double f0, fp; // second prefetch set (staged by the odd steps)
+    if (WITH_Y) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) PA[r] = sm[pmo[r]];
+        pvA = sm[pvo];
+    }
+    double f0, fp, fr0 = 0.0, fr1 = 0.0; // second prefetch set (staged by the odd steps)
     {
         cgdouble *rp = w.rec + (size_t)(N > 1 ? 1 : 0) * REC_STRIDE, *rq = w.rec + (size_t)(N > 2 ? 2 : N - 1) * REC_STRIDE;
         e0 = rp[lane]; tp = rp[REC_T + lane];
         f0 = rq[lane]; fp = rq[REC_T + lane];
+        if (WITH_Y) {
+            pr0 = rp[REC_PV + lane]; pr1 = rp[REC_PV + 64 + (lane < 48 ? lane : 0)];
+            fr0 = rq[REC_PV + lane]; fr1 = rq[REC_PV + 64 + (lane < 48 ? lane : 0)];
+        }
     }
     int kk = 0;
     for (; kk + 1 < N; kk += 2) {
-        forward_step<NP, WITH_Y>(w, N, kk, lane, idx, tto, mto, pmo, pvo, ttA, mtA, hcA, PA, pvA, ttB, mtB, hcB, PB, pvB, e0, tp, v);
-        forward_step<NP, WITH_Y>(w, N, kk + 1, lane, idx, tto, mto, pmo, pvo, ttB, mtB, hcB, PB, pvB, ttA, mtA, hcA, PA, pvA, f0, fp, v);
+        forward_step<NP, WITH_Y>(w, N, kk, lane, idx, tto, mto, pmo, pvo, ttA, mtA, hcA, PA, pvA, ttB, mtB, hcB, PB, pvB, e0, tp, pr0, pr1, v);
+        forward_step<NP, WITH_Y>(w, N, kk + 1, lane, idx, tto, mto, pmo, pvo, ttB, mtB, hcB, PB, pvB, ttA, mtA, hcA, PA, pvA, f0, fp, fr0, fr1, v);
     }
-    if (kk < N) forward_step<NP, WITH_Y>(w, N, kk, lane, idx, tto, mto, pmo, pvo, ttA, mtA, hcA, PA, pvA, ttB, mtB, hcB, PB, pvB, e0, tp, v);
+    if (kk < N) forward_step<NP, WITH_Y>(w, N, kk, lane, idx, tto, mto, pmo, pvo, ttA, mtA, hcA, PA, pvA, ttB, mtB, hcB, PB, pvB, e0, tp, pr0, pr1, v);
     WSYNC();
 }
 

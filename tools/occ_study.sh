@@ -1,6 +1,5 @@
 #!/bin/bash
-run() { python bench.py --steps 10 --warmup 2 --no-cpu --batch $1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  B=$1 slots=${FRP_RESIDENT_SLOTS:-default}: solves/s %.0f kernel_ms %.3f' % (d['value'], d['roofline']['kernel_ms']))"; }
-cp forces_resilient_planner_amd/lib_main.so forces_resilient_planner_amd/libfrp_nmpc_amd.so
-for B in 1024 2048 4096 8192 16384 32768; do run $B; done
-for S in 1280 1792; do FRP_RESIDENT_SLOTS=$S run 32768; done
-for S in 1024 1152 1280 1408; do FRP_RESIDENT_SLOTS=$S run 4096; done
+# resident-slot sweep, serial (1 stream) and pipelined (2 streams) launches
+run() { python bench.py --steps 20 --warmup 3 --no-cpu --batch $1 --streams $2 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  B=$1 streams=$2 slots=${FRP_RESIDENT_SLOTS:-default}: %.0f solves/s (serial %.0f)' % (d['value'], d['config']['single_stream_solves_per_s']))"; }
+for S in 768 1024 1280 1536 2048; do FRP_RESIDENT_SLOTS=$S run 4096 2; done
+for S in 1024 1536; do FRP_RESIDENT_SLOTS=$S run 16384 2; done
