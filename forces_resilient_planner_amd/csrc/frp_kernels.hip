@@ -267,6 +267,15 @@ __shared__ double sm_dz16[DZ_ROWS * 16];
 __shared__ double sm_dz20[DZ_ROWS * 20];
 __shared__ double sm_dz32[DZ_ROWS * 32];
 __shared__ double sm_dz64[DZ_ROWS * 64];
+// Transposition buffer [stage][RB_LD] for record rows that are PRODUCED lane == stage (or lane == (row, stage)) but live
+// in per-stage records: written to LDS first, then flushed with one coalesced 64-lane store per stage instead of one
+// 8-byte store per lane into 20+ different cache lines (NP = 64 keeps the direct stores: its LDS budget is spent).
+constexpr int RB_LD = 65; // odd leading dimension: conflict-free both ways
+__shared__ double sm_rb16[16 * RB_LD];
+__shared__ double sm_rb20[20 * RB_LD];
+__shared__ double sm_rb32[32 * RB_LD];
+template <int NP>
+__device__ __forceinline__ double *rb_area() { return NP == 16 ? sm_rb16 : (NP == 20 ? sm_rb20 : sm_rb32); }
 template <int NP>
 __device__ __forceinline__ double *dz_area() { return NP == 16 ? sm_dz16 : (NP == 20 ? sm_dz20 : (NP == 32 ? sm_dz32 : sm_dz64)); }
 
@@ -537,6 +546,12 @@ __device__ __noinline__ ModelOut phase_model(WsView w, cgdouble *pbase, int np, 
     const int lane = threadIdx.x;
     double *stg = stage_area<NP>();
     double l_eq = 0, l_obj = 0;
+    constexpr bool BUF = NP <= 32; // record rows go through the LDS transposition buffer (see rb_area)
+    double *rb = rb_area<NP>();
+    // kept for the Hessian pass that follows the flush of the linearisation
+    AccJac J1;
+    Trig tg1 = {0, 0, 0, 0, 0, 0}, tg2 = {0, 0, 0, 0, 0, 0};
+    double vt[3] = {0, 0, 0}, vk[3] = {0, 0, 0}, ypv[6] = {0, 0, 0, 0, 0, 0}, Tk = 0.0;
     if (lane < N) {
         const int k = lane;
         cgdouble *pk = pbase + (size_t)k * np;
@@ -549,6 +564,8 @@ __device__ __noinline__ ModelOut phase_model(WsView w, cgdouble *pbase, int np, 
         for (int i = 0; i < NZ; i++) zk[i] = w.z[i * NP + k];
         l_obj = stage_cost(zk, p10, sc_k, model, nullptr);
         gdouble *rec = w.rec + (size_t)k * REC_STRIDE;
+        double *rbk = rb + k * RB_LD;
+        auto put = [&](int slot, double val) { if (BUF) rbk[slot] = val; else rec[slot] = val; };
         if (k == 0) {
 #pragma unroll
             for (int i = 0; i < 9; i++) l_eq = fmax(l_eq, fabs(xinit[i] - zk[8 + i]));
@@ -565,21 +582,24 @@ __device__ __noinline__ ModelOut phase_model(WsView w, cgdouble *pbase, int np, 
             for (int i = 0; i < NS; i++) yn[i] = w.y[i * NP + k + 1];
             const double *yw = yn, *yp = yn + 4, *yv = yn + 7, *ye = yn + 10;
             // one Heun step with its linearisation streamed out entry by entry (record + M'y)
-            AccJac J1, J2;
-            double a1[3], a2[3], vt[3], et[3];
-            const Trig tg1 = make_trig(zk + 14);
+            AccJac J2;
+            double a1[3], a2[3], et[3];
+            tg1 = make_trig(zk + 14);
             accel_t<true>(zk + 11, tg1, zk[3], p10 + 3, a1, &J1);
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 vt[i] = zk[11 + i] + DT * a1[i];
                 et[i] = zk[14 + i] + DT * zk[i];
             }
-            const Trig tg2 = make_trig(et);
+            tg2 = make_trig(et);
             accel_t<true>(vt, tg2, zk[3], p10 + 3, a2, &J2);
+#pragma unroll
+            for (int i = 0; i < 3; i++) { vk[i] = zk[11 + i]; ypv[i] = yp[i]; ypv[3 + i] = yv[i]; }
+            Tk = zk[3];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const double d = zk[i] - w.z[(4 + i) * NP + k + 1];
-                rec[REC_D + i] = d;
+                put(REC_D + i, d);
                 l_eq = fmax(l_eq, fabs(d));
                 gm[i] += yw[i];
             }
@@ -590,7 +610,7 @@ __device__ __noinline__ ModelOut phase_model(WsView w, cgdouble *pbase, int np, 
                 const double dp = xp - w.z[(8 + i) * NP + k + 1];
                 const double dv = xv - w.z[(11 + i) * NP + k + 1];
                 const double de = et[i] - w.z[(14 + i) * NP + k + 1];
-                rec[REC_D + 4 + i] = dp; rec[REC_D + 7 + i] = dv; rec[REC_D + 10 + i] = de;
+                put(REC_D + 4 + i, dp); put(REC_D + 7 + i, dv); put(REC_D + 10 + i, de);
                 l_eq = fmax(l_eq, fmax(fabs(dp), fmax(fabs(dv), fabs(de))));
                 gm[i] += DT * ye[i];
                 gm[8 + i] += yp[i];
@@ -613,11 +633,11 @@ __device__ __noinline__ ModelOut phase_model(WsView w, cgdouble *pbase, int np, 
                     const double avv = (i == j ? 1.0 : 0.0) + 0.5 * DT * (J1.Fvv[i * 3 + j] + sv);
                     const double ave = 0.5 * DT * (J1.Fve[i * 3 + j] + se);
                     const double bvw = 0.5 * DT * DT * J2.Fve[i * 3 + j];
-                    rec[REC_LIN + i * 3 + j] = apv;
-                    rec[REC_LIN + 9 + i * 3 + j] = ape;
-                    rec[REC_LIN + 18 + i * 3 + j] = avv;
-                    rec[REC_LIN + 27 + i * 3 + j] = ave;
-                    rec[REC_LIN + 42 + i * 3 + j] = bvw;
+                    put(REC_LIN + i * 3 + j, apv);
+                    put(REC_LIN + 9 + i * 3 + j, ape);
+                    put(REC_LIN + 18 + i * 3 + j, avv);
+                    put(REC_LIN + 27 + i * 3 + j, ave);
+                    put(REC_LIN + 42 + i * 3 + j, bvw);
                     gm[j] += bvw * yv[i];
                     gm[11 + j] += apv * yp[i] + avv * yv[i];
                     gm[14 + j] += ape * yp[i] + ave * yv[i];
@@ -625,20 +645,34 @@ __device__ __noinline__ ModelOut phase_model(WsView w, cgdouble *pbase, int np, 
                 }
                 const double bpt = 0.5 * DT * DT * J1.gT[i];
                 const double bvt = 0.5 * DT * (J1.gT[i] + sT);
-                rec[REC_LIN + 36 + i] = bpt;
-                rec[REC_LIN + 39 + i] = bvt;
+                put(REC_LIN + 36 + i, bpt);
+                put(REC_LIN + 39 + i, bvt);
                 gT += bpt * yp[i] + bvt * yv[i];
             }
             gm[3] += gT;
-            if (hess) {
-                // exact Hessian of y_{k+1}' c(z_k): only the pos / vel rows of the RK2 step are non-linear
-                rk2_hessian_core(zk + 11, zk[3], J1, vt, tg1, tg2, yp, yv, [&](int i, int j, double val) {
-                    if (hd_index(i, j) >= 0) rec[REC_HD + hd_index(i, j)] = val;
-                });
-            }
         }
 #pragma unroll
         for (int i = 0; i < NZ; i++) stg[i * NP + k] = gm[i];
+    }
+    WSYNC();
+    if (BUF) { // flush the linearisation rows (record slots 0..63) of the stages that have dynamics: one 512-byte store each
+        for (int k = 0; k < N - 1; k++) w.rec[(size_t)k * REC_STRIDE + lane] = rb[k * RB_LD + lane];
+        WSYNC();
+    }
+    if (hess) {
+        if (lane < N - 1) {
+            // exact Hessian of y_{k+1}' c(z_k): only the pos / vel rows of the RK2 step are non-linear
+            gdouble *rec = w.rec + (size_t)lane * REC_STRIDE;
+            double *rbk = rb + lane * RB_LD;
+            rk2_hessian_core(vk, Tk, J1, vt, tg1, tg2, ypv, ypv + 3, [&](int i, int j, double val) {
+                if (hd_index(i, j) >= 0) { if (BUF) rbk[hd_index(i, j)] = val; else rec[REC_HD + hd_index(i, j)] = val; }
+            });
+        }
+        if (BUF) {
+            WSYNC();
+            const int slot = lane < REC_HD_SIZE ? REC_HD + lane : REC_E_SIZE - 1; // other lanes: the pad slot (all lanes stay active)
+            for (int k = 0; k < N - 1; k++) w.rec[(size_t)k * REC_STRIDE + slot] = rb[k * RB_LD + lane];
+        }
     }
     WSYNC();
     ModelOut o;
