@@ -1407,12 +1407,17 @@ __device__ __noinline__ InitOut phase_init(WsView w, cgdouble *pk, const int *nf
         for (int i = 0; i < NS; i++) w.y[i * NP + k] = 0.0;
         gdouble *rec = w.rec + (size_t)k * REC_STRIDE;
         rec[REC_HC] = -2.0 * pk[8]; // (u_i, w_i) cost coupling of this stage (constant)
-        for (int i = REC_ZERO; i < REC_E_SIZE; i++) rec[i] = 0.0; // zero slot, Hd (stays zero in Gauss-Newton mode / last stage), pad
-        for (int i = 0; i < 64; i++) rec[i] = 0.0;                // linearisation of the last stage is never written
         for (int i = 0; i < 3; i++) { // padding rows (tile rows 13..15) of dz and y
             dz_area<NP>()[(17 + i) * NP + k] = 0.0;
             w.y[(13 + i) * NP + k] = 0.0;
         }
+    }
+    // record slots that are read before (or without ever) being written: the linearisation of the last stage (0..63), the
+    // zero slot, the dynamics Hessian (stays zero in Gauss-Newton mode / last stage) and the pad (128..191 covers them;
+    // PHIC in 128..141 is rewritten every iteration) -- coalesced, all lanes
+    for (int kk = 0; kk < N; kk++) {
+        w.rec[(size_t)kk * REC_STRIDE + lane] = 0.0;
+        w.rec[(size_t)kk * REC_STRIDE + 128 + lane] = 0.0;
     }
     smin = wave_min(smin);
     const int mtot = (int)wave_sum(act ? (double)(34 + nf) : 0.0);
