@@ -109,7 +109,7 @@ __device__ __forceinline__ double lane_bcast(double v, int src) // wave-uniform 
 
 // ------------------------------------------------------------------ LDS layout (doubles)
 // [0, 736): staging.  Element-wise phases: gm[17][NP] + corridor sums[6][NP] (NP = 32).
-//           Riccati sweeps: the E part of the current stage record + constants + T' + R.
+//           Riccati sweeps: the E part of the current stage record + constants + T' + pivot factors + packed P.
 // [736, ...): fields that live across phases of one iteration.
 constexpr int S_E = 0;                    // E part of the stage record (192 used)
 constexpr int S_ZERO = 248, S_ONE = 249, S_DTC = 250;
@@ -531,7 +531,7 @@ __device__ __forceinline__ void eval_rows(cgdouble *__restrict__ ps, cgdouble *_
 
 // ------------------------------------------------------------------ E: evaluate
 // part 1 (lane == stage): model + linearisation -> record, equality residuals, M'y -> LDS
-// part 2 (lane == (row pair, stage), all 64 lanes): corridor rows, then bounds: residual norms,
+// part 2 (lane == (row group, stage), all 64 lanes): corridor rows, then bounds: residual norms,
 //        barrier Hessian / affine rhs -> record
 struct ModelOut {
     double eq, obj;
