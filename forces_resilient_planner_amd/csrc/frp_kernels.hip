@@ -49,8 +49,8 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v)
 {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)b, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 __device__ __forceinline__ double lane_read(double v, int src) // wave-uniform src lane
@@ -319,8 +319,8 @@ template <int M>
 __device__ __forceinline__ double quad_rot(double v) // result in quad q <- quad (q + M) & 3 of the same 16-lane row
 {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x120 + (16 - 4 * M), 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x120 + (16 - 4 * M), 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)b, 0x120 + (16 - 4 * M), 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), 0x120 + (16 - 4 * M), 0xF, 0xF, true);
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 __device__ __forceinline__ double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
