@@ -321,3 +321,25 @@ def test_maximum_sizes_horizon_64_all_30_corridor_rows_live():
     zs, fls, its, _ = solver.solve_batch_host(ws)
     zso, flso, _ = OL.solve_batch(ws)
     assert np.array_equal(fls, flso) and np.max(np.abs(zs[fls == 1] - zso[fls == 1])) < 1e-6
+
+
+def test_launch_order_is_a_permutation_for_hostile_keys():
+    """More problems than resident workgroups -> the queue is ordered by the objective of the initial guess.  Keys that are
+    NaN, infinite, equal or astronomically large must still give every problem exactly one solve: the clean problems come
+    out as in a batch without the hostile ones, the poisoned ones report a failure flag."""
+    B = 3000
+    w = workloads.config2(B, seed=77)
+    x0 = w["x0"].copy()
+    bad_nan, bad_inf, bad_big, dup = np.arange(0, 40), np.arange(40, 60), np.arange(60, 80), np.arange(80, 400)
+    x0[bad_nan, 3, 9] = np.nan
+    x0[bad_inf, 5, 8] = np.inf
+    x0[bad_big, :, 8] = 1e150        # objective ~1e300+: overflows the key
+    x0[dup] = x0[80]                 # identical keys
+    z, fl, it, info = solver.solve_batch_host(w, x0=x0)
+    assert np.all(fl[bad_nan] == L.BADFUNCEVAL) and np.all(fl[bad_inf] != 1)
+    clean = np.ones(B, dtype=bool); clean[:80] = False
+    zc, flc, itc, _ = solver.solve_batch_host(w)   # same problems, original initial guesses
+    keep = clean.copy(); keep[dup] = False          # (the dup block was given another initial guess)
+    assert np.array_equal(fl[keep], flc[keep]) and np.array_equal(it[keep], itc[keep])
+    assert np.max(np.abs(z[keep] - zc[keep])) == 0.0
+    assert np.all(np.isfinite(z[clean]))
