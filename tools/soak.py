@@ -1,0 +1,29 @@
+"""Soak test (GPU box): many launches with random batch sizes / configs / horizons, exit flags and iteration counts against
+the oracle on every launch.   python tools/soak.py [seconds=90]"""
+import sys, time
+import numpy as np
+sys.path.insert(0, '.')
+from forces_resilient_planner_amd import solver, workloads
+import tests.oracle_lib as OL
+T = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
+rng = np.random.default_rng(2026)
+t0 = time.time(); n = 0; solved = 0; worst = 0.0
+while time.time() - t0 < T:
+    kind = int(rng.integers(0, 4)); B = int(rng.integers(1, 5000)); seed = int(rng.integers(0, 1 << 30))
+    if kind == 0: w = workloads.config1(B, seed=seed)
+    elif kind == 1: w = workloads.config2(B, seed=seed, model=int(rng.integers(0, 2)))
+    elif kind == 2: w = workloads.config3(min(B, 1500), seed=seed, N=int(rng.integers(2, 41)), M=15)
+    else: w = workloads.config3(min(B, 800), seed=seed, N=int(rng.integers(41, 65)), M=int(rng.integers(15, 31)))
+    z, fl, it, info = solver.solve_batch_host(w)
+    zo, flo, io = OL.solve_batch(w, nthreads=16)
+    ito = np.array([i.it for i in io])
+    ok = (fl == 1) & (flo == 1)
+    mism = int((fl != flo).sum())
+    same = ok & (it == ito)
+    dz = float(np.max(np.abs(z[same] - zo[same]))) if same.any() else 0.0
+    worst = max(worst, dz)
+    assert mism <= max(1, len(fl) // 500), (kind, B, seed, mism)
+    assert np.all(np.isfinite(z[fl == 1]))
+    assert (it[ok] == ito[ok]).mean() > 0.97 if ok.any() else True
+    n += 1; solved += len(fl)
+print(f"soak: {n} launches, {solved} problems, {time.time() - t0:.0f} s, worst |dz| at equal iteration counts {worst:.2e}: OK")
