@@ -37,6 +37,17 @@ namespace {
         }                                                                                    \
     } while (0)
 
+// device allocation that is released on every exit path of the *_host helpers
+struct DevMem {
+    void *p = nullptr;
+    DevMem() = default;
+    DevMem(const DevMem &) = delete;
+    DevMem &operator=(const DevMem &) = delete;
+    ~DevMem() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
 bool fill_args(const frp_nmpc_batch *b, const frp_nmpc_options *opt_in, void *ws, size_t ws_bytes, frp::KernelArgs *a)
 {
     if (!b || b->B <= 0 || b->N < 2 || b->N > 64 || b->M < 0 || b->MF < 0 || b->MF > b->M) return false;
@@ -260,38 +271,34 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FRP_ERR_NO_DEVICE;
     const size_t B = h->B, N = h->N, np = FRP_NPAR(h->M);
-    double *d_xinit = nullptr, *d_x0 = nullptr, *d_par = nullptr, *d_z = nullptr, *d_info = nullptr;
-    int *d_nf = nullptr, *d_flag = nullptr, *d_it = nullptr;
-    void *d_ws = nullptr;
+    DevMem xinit, x0, par, z, info, nf, flag, it, ws;
     const size_t wsb = frp::ws_bytes(h->B, h->N, h->MF);
-    FRP_HIP(hipMalloc(&d_xinit, B * 9 * sizeof(double)));
-    FRP_HIP(hipMalloc(&d_x0, B * N * 17 * sizeof(double)));
-    FRP_HIP(hipMalloc(&d_par, B * N * np * sizeof(double)));
-    FRP_HIP(hipMalloc(&d_z, B * N * 17 * sizeof(double)));
-    FRP_HIP(hipMalloc(&d_info, B * FRP_INFO_STRIDE * sizeof(double)));
-    FRP_HIP(hipMalloc(&d_flag, B * sizeof(int)));
-    FRP_HIP(hipMalloc(&d_it, B * sizeof(int)));
-    FRP_HIP(hipMalloc(&d_ws, wsb));
-    FRP_HIP(hipMemcpy(d_xinit, h->xinit, B * 9 * sizeof(double), hipMemcpyHostToDevice));
-    FRP_HIP(hipMemcpy(d_x0, h->x0, B * N * 17 * sizeof(double), hipMemcpyHostToDevice));
-    FRP_HIP(hipMemcpy(d_par, h->params, B * N * np * sizeof(double), hipMemcpyHostToDevice));
+    FRP_HIP(xinit.alloc(B * 9 * sizeof(double)));
+    FRP_HIP(x0.alloc(B * N * 17 * sizeof(double)));
+    FRP_HIP(par.alloc(B * N * np * sizeof(double)));
+    FRP_HIP(z.alloc(B * N * 17 * sizeof(double)));
+    FRP_HIP(info.alloc(B * FRP_INFO_STRIDE * sizeof(double)));
+    FRP_HIP(flag.alloc(B * sizeof(int)));
+    FRP_HIP(it.alloc(B * sizeof(int)));
+    FRP_HIP(ws.alloc(wsb));
+    FRP_HIP(hipMemcpy(xinit.p, h->xinit, B * 9 * sizeof(double), hipMemcpyHostToDevice));
+    FRP_HIP(hipMemcpy(x0.p, h->x0, B * N * 17 * sizeof(double), hipMemcpyHostToDevice));
+    FRP_HIP(hipMemcpy(par.p, h->params, B * N * np * sizeof(double), hipMemcpyHostToDevice));
     if (h->nfaces) {
-        FRP_HIP(hipMalloc(&d_nf, B * N * sizeof(int)));
-        FRP_HIP(hipMemcpy(d_nf, h->nfaces, B * N * sizeof(int), hipMemcpyHostToDevice));
+        FRP_HIP(nf.alloc(B * N * sizeof(int)));
+        FRP_HIP(hipMemcpy(nf.p, h->nfaces, B * N * sizeof(int), hipMemcpyHostToDevice));
     }
     frp_nmpc_batch d = *h;
-    d.xinit = d_xinit; d.x0 = d_x0; d.params = d_par; d.nfaces = d_nf; d.z = d_z; d.exitflag = d_flag; d.iters = d_it; d.info = d_info;
-    int rc = frp_nmpc_solve_batch(&d, opt, d_ws, wsb, nullptr);
-    if (rc == FRP_OK) {
-        FRP_HIP(hipDeviceSynchronize());
-        FRP_HIP(hipMemcpy(h->z, d_z, B * N * 17 * sizeof(double), hipMemcpyDeviceToHost));
-        FRP_HIP(hipMemcpy(h->exitflag, d_flag, B * sizeof(int), hipMemcpyDeviceToHost));
-        FRP_HIP(hipMemcpy(h->iters, d_it, B * sizeof(int), hipMemcpyDeviceToHost));
-        if (h->info) FRP_HIP(hipMemcpy(h->info, d_info, B * FRP_INFO_STRIDE * sizeof(double), hipMemcpyDeviceToHost));
-    }
-    (void)hipFree(d_xinit); (void)hipFree(d_x0); (void)hipFree(d_par); (void)hipFree(d_z); (void)hipFree(d_info); (void)hipFree(d_flag); (void)hipFree(d_it);
-    (void)hipFree(d_ws); if (d_nf) (void)hipFree(d_nf);
-    return rc;
+    d.xinit = xinit.as<double>(); d.x0 = x0.as<double>(); d.params = par.as<double>(); d.nfaces = h->nfaces ? nf.as<int>() : nullptr;
+    d.z = z.as<double>(); d.exitflag = flag.as<int>(); d.iters = it.as<int>(); d.info = info.as<double>();
+    const int rc = frp_nmpc_solve_batch(&d, opt, ws.p, wsb, nullptr);
+    if (rc != FRP_OK) return rc;
+    FRP_HIP(hipDeviceSynchronize());
+    FRP_HIP(hipMemcpy(h->z, z.p, B * N * 17 * sizeof(double), hipMemcpyDeviceToHost));
+    FRP_HIP(hipMemcpy(h->exitflag, flag.p, B * sizeof(int), hipMemcpyDeviceToHost));
+    FRP_HIP(hipMemcpy(h->iters, it.p, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (h->info) FRP_HIP(hipMemcpy(h->info, info.p, B * FRP_INFO_STRIDE * sizeof(double), hipMemcpyDeviceToHost));
+    return FRP_OK;
 }
 
 int frp_nmpc_stage_eval(int B, int N, int M, int model, const double *z, const double *params, double *f,
@@ -309,27 +316,26 @@ int frp_nmpc_stage_eval_host(int B, int N, int M, int model, const double *z, co
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FRP_ERR_NO_DEVICE;
     const size_t T = (size_t)B * N, np = FRP_NPAR(M);
-    double *d_z, *d_p, *d_f = nullptr, *d_g = nullptr, *d_c = nullptr, *d_J = nullptr, *d_h = nullptr;
-    FRP_HIP(hipMalloc(&d_z, T * 17 * sizeof(double)));
-    FRP_HIP(hipMalloc(&d_p, T * np * sizeof(double)));
-    FRP_HIP(hipMemcpy(d_z, z, T * 17 * sizeof(double), hipMemcpyHostToDevice));
-    FRP_HIP(hipMemcpy(d_p, params, T * np * sizeof(double), hipMemcpyHostToDevice));
-    if (f) FRP_HIP(hipMalloc(&d_f, T * sizeof(double)));
-    if (grad_f) FRP_HIP(hipMalloc(&d_g, T * 17 * sizeof(double)));
-    if (c) FRP_HIP(hipMalloc(&d_c, T * 13 * sizeof(double)));
-    if (jac_c) FRP_HIP(hipMalloc(&d_J, T * 221 * sizeof(double)));
-    if (h && M > 0) FRP_HIP(hipMalloc(&d_h, T * M * sizeof(double)));
-    int rc = frp_nmpc_stage_eval(B, N, M, model, d_z, d_p, d_f, d_g, d_c, d_J, d_h, nullptr);
-    if (rc == FRP_OK) {
-        FRP_HIP(hipDeviceSynchronize());
-        if (f) FRP_HIP(hipMemcpy(f, d_f, T * sizeof(double), hipMemcpyDeviceToHost));
-        if (grad_f) FRP_HIP(hipMemcpy(grad_f, d_g, T * 17 * sizeof(double), hipMemcpyDeviceToHost));
-        if (c) FRP_HIP(hipMemcpy(c, d_c, T * 13 * sizeof(double), hipMemcpyDeviceToHost));
-        if (jac_c) FRP_HIP(hipMemcpy(jac_c, d_J, T * 221 * sizeof(double), hipMemcpyDeviceToHost));
-        if (d_h) FRP_HIP(hipMemcpy(h, d_h, T * M * sizeof(double), hipMemcpyDeviceToHost));
-    }
-    (void)hipFree(d_z); (void)hipFree(d_p); (void)hipFree(d_f); (void)hipFree(d_g); (void)hipFree(d_c); (void)hipFree(d_J); (void)hipFree(d_h);
-    return rc;
+    DevMem dz, dp, df, dg, dc, dJ, dh;
+    FRP_HIP(dz.alloc(T * 17 * sizeof(double)));
+    FRP_HIP(dp.alloc(T * np * sizeof(double)));
+    FRP_HIP(hipMemcpy(dz.p, z, T * 17 * sizeof(double), hipMemcpyHostToDevice));
+    FRP_HIP(hipMemcpy(dp.p, params, T * np * sizeof(double), hipMemcpyHostToDevice));
+    if (f) FRP_HIP(df.alloc(T * sizeof(double)));
+    if (grad_f) FRP_HIP(dg.alloc(T * 17 * sizeof(double)));
+    if (c) FRP_HIP(dc.alloc(T * 13 * sizeof(double)));
+    if (jac_c) FRP_HIP(dJ.alloc(T * 221 * sizeof(double)));
+    if (h && M > 0) FRP_HIP(dh.alloc(T * M * sizeof(double)));
+    const int rc = frp_nmpc_stage_eval(B, N, M, model, dz.as<double>(), dp.as<double>(), df.as<double>(), dg.as<double>(),
+                                       dc.as<double>(), dJ.as<double>(), dh.as<double>(), nullptr);
+    if (rc != FRP_OK) return rc;
+    FRP_HIP(hipDeviceSynchronize());
+    if (f) FRP_HIP(hipMemcpy(f, df.p, T * sizeof(double), hipMemcpyDeviceToHost));
+    if (grad_f) FRP_HIP(hipMemcpy(grad_f, dg.p, T * 17 * sizeof(double), hipMemcpyDeviceToHost));
+    if (c) FRP_HIP(hipMemcpy(c, dc.p, T * 13 * sizeof(double), hipMemcpyDeviceToHost));
+    if (jac_c) FRP_HIP(hipMemcpy(jac_c, dJ.p, T * 221 * sizeof(double), hipMemcpyDeviceToHost));
+    if (dh.p) FRP_HIP(hipMemcpy(h, dh.p, T * M * sizeof(double), hipMemcpyDeviceToHost));
+    return FRP_OK;
 }
 
 int FORCESNLPsolver_normal_solve(frp_forces_params *params, frp_forces_output *output, frp_forces_info *info,
