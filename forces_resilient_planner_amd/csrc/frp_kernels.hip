@@ -37,6 +37,9 @@ namespace frp {
 #ifndef FRP_WAVES_PER_EU
 #define FRP_WAVES_PER_EU 2
 #endif
+#ifndef FRP_RB_MAX_NP
+#define FRP_RB_MAX_NP 32 // largest stage stride whose model phase goes through the LDS transposition buffer
+#endif
 #ifndef FRP_SLOTS_PER_CU
 #define FRP_SLOTS_PER_CU 6
 #endif
@@ -546,7 +549,7 @@ __device__ __noinline__ ModelOut phase_model(WsView w, cgdouble *pbase, int np, 
     const int lane = threadIdx.x;
     double *stg = stage_area<NP>();
     double l_eq = 0, l_obj = 0;
-    constexpr bool BUF = NP <= 32; // record rows go through the LDS transposition buffer (see rb_area)
+    constexpr bool BUF = NP <= FRP_RB_MAX_NP; // record rows go through the LDS transposition buffer (see rb_area)
     double *rb = rb_area<NP>();
     // kept for the Hessian pass that follows the flush of the linearisation
     AccJac J1;
