@@ -37,6 +37,11 @@ namespace frp {
 #ifndef FRP_WAVES_PER_EU
 #define FRP_WAVES_PER_EU 2
 #endif
+#ifndef FRP_PRIO_IT1 // iteration counts at which a long solve raises its wave priority
+#define FRP_PRIO_IT1 7
+#define FRP_PRIO_IT2 10
+#define FRP_PRIO_IT3 14
+#endif
 #ifndef FRP_RB_MAX_NP
 #define FRP_RB_MAX_NP 32 // largest stage stride whose model phase goes through the LDS transposition buffer
 #endif
@@ -1504,9 +1509,9 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     for (it = 0;; it++) {
         // Long solves set the duration of a launch (the batch is done when its slowest problem is): a wave that is
         // past the typical iteration count gets issue priority over the wave it shares the SIMD with.
-        if (it == 7) __builtin_amdgcn_s_setprio(1);
-        else if (it == 10) __builtin_amdgcn_s_setprio(2);
-        else if (it == 14) __builtin_amdgcn_s_setprio(3);
+        if (it == FRP_PRIO_IT1) __builtin_amdgcn_s_setprio(1);
+        else if (it == FRP_PRIO_IT2) __builtin_amdgcn_s_setprio(2);
+        else if (it == FRP_PRIO_IT3) __builtin_amdgcn_s_setprio(3);
         TICK();
         const ModelOut mo_ = phase_model<NP>(w, pbase, np, xinit, N, a.model, hess);
         const EvalOut e = phase_eval<NP>(w, pbase, np, N, MF, nfk, a.model, mo_.eq, mo_.obj);
