@@ -23,9 +23,9 @@ constexpr int REC_HD_SIZE = 45;
 constexpr int REC_E_SIZE = 192; // 188..191 pad
 //   F part (written by the factorisation sweep):
 constexpr int REC_T = 192;      // T' = [R | Kbar_x | kbar | hc] as tile register 0 (64): lane (g,c) <-> T'[g][c]
-constexpr int REC_PD = 256;     // P_{k+1} d (16, s-order rows)
-constexpr int REC_PV = 272;     // p_k of the corrector solve (16, s-order rows)
-constexpr int REC_P = 288;      // P_k, packed lower triangle: (row, col <= row) -> row (row + 1) / 2 + col  (91, padded 96)
+constexpr int REC_PD = 256;     // P_{k+1} d (16, s-order rows)                                   } written as one contiguous
+constexpr int REC_P = 272;      // P_k, packed lower triangle: (row, col <= row) -> row (row + 1) / 2 + col  (91, padded 96) } 112-double run
+constexpr int REC_PV = 368;     // p_k of the corrector solve (16, s-order rows): [P | p] is read as one 112-double run
 constexpr int REC_STRIDE = 384;
 
 // Packed index of entry (i, j) of the 10 x 10 dynamics Hessian over (rates 0..2, T 3, v 4..6, e 7..9), or -1 where

@@ -123,7 +123,8 @@ constexpr int S_E = 0;                    // E part of the stage record (192 use
 constexpr int S_ZERO = 248, S_ONE = 249, S_DTC = 250;
 constexpr int S_T = 256;                  // T' (64)
 constexpr int S_MI = 320, S_DI = 328;      // pivot block handed from uniform registers to lanes: m = L^-1 (6), D^-1 (4)
-constexpr int S_PRAW = 336;               // forward sweep: staged copy of the next stage's p (16) + packed P (96)
+constexpr int S_PRAW = 336;               // forward sweep: staged copy of the next stage's packed P (96) + p (16)
+constexpr int S_FOUT = 448;               // factorisation sweep: P d (16) + packed P (96) of the current stage before they are stored
 constexpr int S_STAGING = 23 * 32;        // 736
 constexpr int S_RW = S_STAGING;           // stage-0 solve: Pww^-1 (16)
 constexpr int S_PWX = S_RW + 16;          // stage-0 solve: Pwx (4 x 9)
@@ -753,7 +754,7 @@ __device__ __forceinline__ bool factor_step(const WsView &w, int kk, bool last, 
         if (c == 13) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                rec[REC_PD + 4 * r + g] = X[r];
+                sm[S_FOUT + 4 * r + g] = X[r]; // P d, flushed with the packed P at the end of the step
                 X[r] += pv[r];
             }
         }
@@ -826,8 +827,12 @@ __device__ __forceinline__ bool factor_step(const WsView &w, int kk, bool last, 
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 4 * r + g;
-        if (row <= 12 && c <= row) rec[REC_P + row * (row + 1) / 2 + c] = Pn[r];
+        if (row <= 12 && c <= row) sm[S_FOUT + 16 + row * (row + 1) / 2 + c] = Pn[r];
     }
+    // [P d | packed P] leave as two coalesced stores (the record keeps them adjacent)
+    WSYNC();
+    rec[REC_PD + lane] = sm[S_FOUT + lane];
+    if (lane < 48) rec[REC_PD + 64 + lane] = sm[S_FOUT + 64 + lane];
     return true;
 }
 
@@ -1032,7 +1037,7 @@ __device__ __forceinline__ void forward_step(const WsView &w, int N, int kk, int
         const int kf = (kk + 3 < N) ? kk + 3 : N - 1; // staged again two steps from now
         cgdouble *rp = w.rec + (size_t)kf * REC_STRIDE;
         e0 = rp[lane]; tp = rp[REC_T + lane];
-        if (WITH_Y) { pr0 = rp[REC_PV + lane]; pr1 = rp[REC_PV + 64 + (lane < 48 ? lane : 0)]; } // p (16) and packed P (96)
+        if (WITH_Y) { pr0 = rp[REC_P + lane]; pr1 = rp[REC_P + 64 + (lane < 48 ? lane : 0)]; } // packed P (96) and p (16)
     }
 #pragma unroll
     for (int s = 0; s < 4; s++) { ntt[s] = sm[tto[s]]; nmt[s] = sm[mto[s]]; }
@@ -1069,9 +1074,9 @@ __device__ __noinline__ void sweep_forward(WsView w, int N)
         mto[s] = sm_tab[(TAB4_MT + s) * 64 + lane];
         tto[s] = sm_tab[(TAB4_TT + s) * 64 + lane];
         const int po = sm_tab[(TAB4_P + s) * 64 + lane]; // record slot of P[row][col] (or REC_ZERO) -> slot of its staged copy
-        pmo[s] = po == REC_ZERO ? S_ZERO : S_PRAW + (po - REC_PV);
+        pmo[s] = po == REC_ZERO ? S_ZERO : S_PRAW + (po - REC_P);
     }
-    const int pvo = idx <= 12 ? S_PRAW + idx : S_ZERO;
+    const int pvo = idx <= 12 ? S_PRAW + (REC_PV - REC_P) + idx : S_ZERO;
     init_stage_constants(lane);
     double v = sm[S_DS0 + idx]; // ds_0 (entries 13..15 are zero)
     double e0, tp, pr0 = 0.0, pr1 = 0.0;
@@ -1081,7 +1086,7 @@ __device__ __noinline__ void sweep_forward(WsView w, int N)
     {
         cgdouble *rp = w.rec;
         e0 = rp[lane]; tp = rp[REC_T + lane];
-        if (WITH_Y) { pr0 = rp[REC_PV + lane]; pr1 = rp[REC_PV + 64 + (lane < 48 ? lane : 0)]; }
+        if (WITH_Y) { pr0 = rp[REC_P + lane]; pr1 = rp[REC_P + 64 + (lane < 48 ? lane : 0)]; }
     }
     WSYNC();
     sm[S_E + lane] = e0; sm[S_T + lane] = tp;
@@ -1103,8 +1108,8 @@ __device__ __noinline__ void sweep_forward(WsView w, int N)
         e0 = rp[lane]; tp = rp[REC_T + lane];
         f0 = rq[lane]; fp = rq[REC_T + lane];
         if (WITH_Y) {
-            pr0 = rp[REC_PV + lane]; pr1 = rp[REC_PV + 64 + (lane < 48 ? lane : 0)];
-            fr0 = rq[REC_PV + lane]; fr1 = rq[REC_PV + 64 + (lane < 48 ? lane : 0)];
+            pr0 = rp[REC_P + lane]; pr1 = rp[REC_P + 64 + (lane < 48 ? lane : 0)];
+            fr0 = rq[REC_P + lane]; fr1 = rq[REC_P + 64 + (lane < 48 ? lane : 0)];
         }
     }
     int kk = 0;
