@@ -228,7 +228,7 @@ typedef __attribute__((address_space(1))) double gdouble;
 typedef __attribute__((address_space(1))) const double cgdouble;
 
 struct WsView {
-    gdouble *rec, *z, *y, *dz, *s, *lam, *corr, *face, *step;
+    gdouble *rec, *z, *y, *pre, *s, *lam, *corr, *face, *step; // pre: the 10 leading stage parameters, [row][stage]
 };
 
 // stage stride NP of the [row][stage] arrays = lanes per row group of the element-wise phases (H = 64 / NP groups)
@@ -263,7 +263,7 @@ __device__ __forceinline__ double uni(double v)
 }
 __device__ __forceinline__ WsView uni(WsView w)
 {
-    w.rec = uni(w.rec); w.z = uni(w.z); w.y = uni(w.y); w.dz = uni(w.dz);
+    w.rec = uni(w.rec); w.z = uni(w.z); w.y = uni(w.y); w.pre = uni(w.pre);
     w.s = uni(w.s); w.lam = uni(w.lam); w.corr = uni(w.corr); w.face = uni(w.face); w.step = uni(w.step);
     return w;
 }
@@ -454,8 +454,8 @@ __device__ __forceinline__ double xsub_sum(double v)
 // several row rounds can be batched across the record stores
 template <int NP>
 __device__ __forceinline__ void eval_rows(cgdouble *__restrict__ ps, cgdouble *__restrict__ pl, cgdouble *__restrict__ pz,
-                                          cgdouble *__restrict__ pface, gdouble *__restrict__ prec, cgdouble *__restrict__ pbase,
-                                          int np, int N, int MF, int nfk, int model, double *stg,
+                                          cgdouble *__restrict__ pface, gdouble *__restrict__ prec, cgdouble *__restrict__ ppre,
+                                          int N, int MF, int nfk, int model, double *stg,
                                           double &l_in, double &l_rc, double &l_gap, double &l_rs)
 {
     constexpr int H = 64 / NP;
@@ -501,9 +501,9 @@ __device__ __forceinline__ void eval_rows(cgdouble *__restrict__ ps, cgdouble *_
     WSYNC();
     // bounds: residuals, barrier Hessian / gradient, finished entry by entry
     if (kact) {
-        cgdouble *pk = pbase + (size_t)k * np;
-        double pc[NPRE];
-        pc[0] = pk[0]; pc[1] = pk[1]; pc[2] = pk[2]; pc[6] = pk[6]; pc[7] = pk[7]; pc[8] = pk[8]; pc[9] = pk[9];
+        double pc[NPRE]; // ref(3), weights(3), yaw_ref from the transposed copy (coalesced; the parameter rows are 1 KB apart)
+        pc[0] = ppre[0 * NP + k]; pc[1] = ppre[1 * NP + k]; pc[2] = ppre[2 * NP + k];
+        pc[6] = ppre[6 * NP + k]; pc[7] = ppre[7 * NP + k]; pc[8] = ppre[8 * NP + k]; pc[9] = ppre[9 * NP + k];
         const CostQ cq = make_cost(pc, stage_class(k, N), model);
         gdouble *rec = prec + (size_t)k * REC_STRIDE;
         constexpr int R = (NZ + H - 1) / H;
@@ -548,9 +548,9 @@ struct ModelOut {
 // part 1 (lane == stage): model + linearisation -> record, equality residuals, M'y -> LDS staging.  A function of its
 // own: it needs most of the register file, and the element-wise part that follows has stage-divergent loops.
 template <int NP>
-__device__ __noinline__ ModelOut phase_model(WsView w, cgdouble *pbase, int np, cgdouble *xinit, int N, int model, int hess)
+__device__ __noinline__ ModelOut phase_model(WsView w, cgdouble *xinit, int N, int model, int hess)
 {
-    w = uni(w); pbase = uni(pbase); np = uni(np); xinit = uni(xinit); N = uni(N); model = uni(model); hess = uni(hess);
+    w = uni(w); xinit = uni(xinit); N = uni(N); model = uni(model); hess = uni(hess);
     FULLSYNC(); // phase boundary: other lanes' global writes of the previous phase are visible
     const int lane = threadIdx.x;
     double *stg = stage_area<NP>();
@@ -563,10 +563,9 @@ __device__ __noinline__ ModelOut phase_model(WsView w, cgdouble *pbase, int np, 
     double vt[3] = {0, 0, 0}, vk[3] = {0, 0, 0}, ypv[6] = {0, 0, 0, 0, 0, 0}, Tk = 0.0;
     if (lane < N) {
         const int k = lane;
-        cgdouble *pk = pbase + (size_t)k * np;
         double p10[NPRE];
 #pragma unroll
-        for (int i = 0; i < NPRE; i++) p10[i] = pk[i];
+        for (int i = 0; i < NPRE; i++) p10[i] = w.pre[i * NP + k];
         const int sc_k = stage_class(k, N);
         double zk[NZ];
 #pragma unroll
@@ -692,13 +691,13 @@ __device__ __noinline__ ModelOut phase_model(WsView w, cgdouble *pbase, int np, 
 // part 2 (lane == (row group, stage), all 64 lanes): corridor rows, then bounds: residual norms, barrier Hessian /
 // affine rhs -> record
 template <int NP>
-__device__ __noinline__ EvalOut phase_eval(WsView w, cgdouble *pbase, int np, int N, int MF, int nfk, int model, double l_eq, double l_obj)
+__device__ __noinline__ EvalOut phase_eval(WsView w, int N, int MF, int nfk, int model, double l_eq, double l_obj)
 {
-    w = uni(w); pbase = uni(pbase); np = uni(np); N = uni(N); MF = uni(MF); model = uni(model);
+    w = uni(w); N = uni(N); MF = uni(MF); model = uni(model);
     WSYNC();
     double *stg = stage_area<NP>();
     double l_in = 0, l_rs = 0, l_rc = 0, l_gap = 0;
-    eval_rows<NP>(w.s, w.lam, w.z, w.face, w.rec, pbase, np, N, MF, nfk, model, stg, l_in, l_rc, l_gap, l_rs);
+    eval_rows<NP>(w.s, w.lam, w.z, w.face, w.rec, w.pre, N, MF, nfk, model, stg, l_in, l_rc, l_gap, l_rs);
     FULLSYNC();
     EvalOut o;
     o.eq = l_eq; o.in = l_in; o.rs = l_rs; o.rc = l_rc; o.gap = l_gap; o.obj = l_obj;
@@ -1139,7 +1138,7 @@ struct SlackOut {
 template <int NP>
 __device__ __forceinline__ void affine_body(cgdouble *__restrict__ ps, cgdouble *__restrict__ pl, gdouble *__restrict__ pcorr,
                                             cgdouble *__restrict__ pz, const double *__restrict__ pdz, cgdouble *__restrict__ pface,
-                                            gdouble *__restrict__ prec, cgdouble *__restrict__ pbase, int np, int N, int MF, int nfk,
+                                            gdouble *__restrict__ prec, cgdouble *__restrict__ ppre, int N, int MF, int nfk,
                                             int model, double &m_p, double &m_d, double &s_sdl, double &s_lds, double &s_dsdl)
 {
     constexpr int H = 64 / NP;
@@ -1191,9 +1190,9 @@ __device__ __forceinline__ void affine_body(cgdouble *__restrict__ ps, cgdouble 
     }
     WSYNC();
     if (kact) {
-        cgdouble *pk = pbase + (size_t)k * np;
-        double pc[NPRE];
-        pc[0] = pk[0]; pc[1] = pk[1]; pc[2] = pk[2]; pc[6] = pk[6]; pc[7] = pk[7]; pc[8] = pk[8]; pc[9] = pk[9];
+        double pc[NPRE]; // ref(3), weights(3), yaw_ref from the transposed copy (coalesced; the parameter rows are 1 KB apart)
+        pc[0] = ppre[0 * NP + k]; pc[1] = ppre[1 * NP + k]; pc[2] = ppre[2 * NP + k];
+        pc[6] = ppre[6 * NP + k]; pc[7] = ppre[7 * NP + k]; pc[8] = ppre[8 * NP + k]; pc[9] = ppre[9 * NP + k];
         const CostQ cq = make_cost(pc, stage_class(k, N), model);
         gdouble *rec = prec + (size_t)k * REC_STRIDE;
 #pragma unroll
@@ -1222,16 +1221,16 @@ __device__ __forceinline__ void affine_body(cgdouble *__restrict__ ps, cgdouble 
 }
 
 template <int NP>
-__device__ __noinline__ SlackOut phase_affine(WsView w, cgdouble *pbase, int np, int N, int MF, int nfk, int model,
+__device__ __noinline__ SlackOut phase_affine(WsView w, int N, int MF, int nfk, int model,
                                               double mu, int mtot, double tol_comp)
 {
-    w = uni(w); pbase = uni(pbase); np = uni(np); N = uni(N); MF = uni(MF); model = uni(model);
+    w = uni(w); N = uni(N); MF = uni(MF); model = uni(model);
     mu = uni(mu); mtot = uni(mtot); tol_comp = uni(tol_comp);
     PROF_BEGIN();
     FULLSYNC(); // phase boundary: dz of the forward sweep is visible
     PROF_SEG(0);
     double m_p = 0.0, m_d = 0.0, s_sdl = 0.0, s_lds = 0.0, s_dsdl = 0.0;
-    affine_body<NP>(w.s, w.lam, w.corr, w.z, dz_area<NP>(), w.face, w.rec, pbase, np, N, MF, nfk, model, m_p, m_d, s_sdl, s_lds, s_dsdl);
+    affine_body<NP>(w.s, w.lam, w.corr, w.z, dz_area<NP>(), w.face, w.rec, w.pre, N, MF, nfk, model, m_p, m_d, s_sdl, s_lds, s_dsdl);
     PROF_SEG(2);
     m_p = wave_max(m_p); m_d = wave_max(m_d);
     const double ap = (m_p > 1.0) ? 1.0 / m_p : 1.0;
@@ -1420,6 +1419,8 @@ __device__ __noinline__ InitOut phase_init(WsView w, cgdouble *pk, const int *nf
         for (int i = 0; i < NS; i++) w.y[i * NP + k] = 0.0;
         gdouble *rec = w.rec + (size_t)k * REC_STRIDE;
         rec[REC_HC] = -2.0 * pk[8]; // (u_i, w_i) cost coupling of this stage (constant)
+#pragma unroll
+        for (int i = 0; i < NPRE; i++) w.pre[i * NP + k] = pk[i]; // transposed copy of the leading parameters for the per-iteration phases
         for (int i = 0; i < 3; i++) { // padding rows (tile rows 13..15) of dz and y
             dz_area<NP>()[(17 + i) * NP + k] = 0.0;
             w.y[(13 + i) * NP + k] = 0.0;
@@ -1472,8 +1473,8 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         w.rec = base;
         w.z = w.rec + (size_t)N * REC_STRIDE;
         w.y = w.z + 17 * NP;
-        w.dz = w.y + Y_ROWS * NP;
-        w.s = w.dz + DZ_ROWS * NP;
+        w.pre = w.y + Y_ROWS * NP;   // [NPRE][NP] (the block keeps its historical size of DZ_ROWS rows)
+        w.s = w.pre + DZ_ROWS * NP;
         w.lam = w.s + (size_t)mcf * NP;
         w.corr = w.lam + (size_t)mcf * NP;
         w.step = w.corr + (size_t)mcf * NP;       // ds | dlam of the corrector step ([2 mcf][NP])
@@ -1518,8 +1519,8 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         else if (it == FRP_PRIO_IT2) __builtin_amdgcn_s_setprio(2);
         else if (it == FRP_PRIO_IT3) __builtin_amdgcn_s_setprio(3);
         TICK();
-        const ModelOut mo_ = phase_model<NP>(w, pbase, np, xinit, N, a.model, hess);
-        const EvalOut e = phase_eval<NP>(w, pbase, np, N, MF, nfk, a.model, mo_.eq, mo_.obj);
+        const ModelOut mo_ = phase_model<NP>(w, xinit, N, a.model, hess);
+        const EvalOut e = phase_eval<NP>(w, N, MF, nfk, a.model, mo_.eq, mo_.obj);
         res_eq = wave_max(e.eq); res_in = wave_max(e.in); rs = wave_max(e.rs); rcomp = wave_max(e.rc);
         pobj = wave_sum(e.obj);
         mu = wave_sum(e.gap) / (double)mtot;
@@ -1545,7 +1546,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         TOCK(1);
         sweep_forward<NP, false>(w, N);
         TOCK(2);
-        const SlackOut s0 = phase_affine<NP>(w, pbase, np, N, MF, nfk, a.model, mu, mtot, a.tol_comp);
+        const SlackOut s0 = phase_affine<NP>(w, N, MF, nfk, a.model, mu, mtot, a.tol_comp);
         sigma = s0.sigma;
         TOCK(3);
         // corrector solve (same factorisation, new rhs)
