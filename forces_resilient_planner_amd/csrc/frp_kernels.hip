@@ -1055,7 +1055,10 @@ __device__ __forceinline__ void forward_step(const WsView &w, int N, int kk, int
         double *dzl = dz_area<NP>();
         if (q0) dzl[idx * NP + kk] = du;
         dzl[(4 + idx) * NP + kk] = v;
-        if (WITH_Y) w.step[idx * NP + kk] = Y;
+        if (WITH_Y) { // y+ of the Newton system: kept in LDS (the model phase's transposition buffer is idle here)
+            if (NP <= FRP_RB_MAX_NP) rb_area<NP>()[idx * NP + kk] = Y;
+            else w.step[idx * NP + kk] = Y;
+        }
     }
     v = D2; // rows 13..15 of Mt are zero
 }
@@ -1258,7 +1261,7 @@ __device__ __noinline__ SlackOut phase_affine(WsView w, int N, int MF, int nfk, 
 template <int NP>
 __device__ __forceinline__ void step_body(gdouble *__restrict__ ps, gdouble *__restrict__ pl, cgdouble *__restrict__ pcorr,
                                           gdouble *__restrict__ pz, const double *__restrict__ pdz, cgdouble *__restrict__ pface,
-                                          gdouble *__restrict__ py, cgdouble *__restrict__ pynew,
+                                          gdouble *__restrict__ py, const double *__restrict__ pynew,
                                           int N, int MF, int nfk, double smu, double ftb, double gap, double inv_mtot_kappa, double &ap_out, double &ad_out)
 {
     constexpr int H = 64 / NP;
@@ -1353,7 +1356,8 @@ __device__ __noinline__ SlackOut phase_step(WsView w, int N, int MF, int nfk, do
     FULLSYNC(); // phase boundary: dz of the forward sweep is visible
     PROF_SEG(6);
     double ap, ad;
-    step_body<NP>(w.s, w.lam, w.corr, w.z, dz_area<NP>(), w.face, w.y, w.step, N, MF, nfk, smu, ftb, gap, inv_mtot_kappa, ap, ad);
+    const double *ynew = NP <= FRP_RB_MAX_NP ? (const double *)rb_area<NP>() : (const double *)w.step;
+    step_body<NP>(w.s, w.lam, w.corr, w.z, dz_area<NP>(), w.face, w.y, ynew, N, MF, nfk, smu, ftb, gap, inv_mtot_kappa, ap, ad);
     PROF_SEG(7);
     FULLSYNC();
     PROF_SEG(8);
