@@ -392,7 +392,9 @@ constexpr int TAB4_MT = 16;  // 4x4x4 A-operand layout: Mt[row][col]            
 constexpr int TAB4_MTT = 20; //                         Mt[col][row]            (vector backward sweep, q~ = phi~ + Mt' x)
 constexpr int TAB4_TT = 24;  //                         T'[row][col], row < 4   (forward sweep, du = -T' [hc dw; dx; 1])
 constexpr int TAB4_P = 28;   //                         P_k[row][col] from its packed lower triangle (record offset)
-constexpr int TAB_ROWS = 32;
+constexpr int TAB_PP = 32;   // LDS slot (S_FOUT) of packed P_k element (4r+g, c), or its dump slot: the writes are unconditional
+constexpr int TAB_PD = 36;   // LDS slot (S_FOUT) of (P d)[4r+g] for the lanes of column 13, dump slot elsewhere
+constexpr int TAB_ROWS = 40;
 __shared__ unsigned short sm_tab[TAB_ROWS * 64];
 __device__ __noinline__ void init_lane_tables()
 {
@@ -411,6 +413,9 @@ __device__ __noinline__ void init_lane_tables()
         sm_tab[(TAB4_TT + r) * 64 + lane] = (unsigned short)(row < 4 ? S_T + 16 * row + col : S_ZERO);
         const int hi = row > col ? row : col, lo = row > col ? col : row;
         sm_tab[(TAB4_P + r) * 64 + lane] = (unsigned short)((row <= 12 && col <= 12) ? REC_P + hi * (hi + 1) / 2 + lo : REC_ZERO);
+        const int trow = 4 * r + g; // 16x16 tile element (trow, c)
+        sm_tab[(TAB_PP + r) * 64 + lane] = (unsigned short)(S_FOUT + 16 + ((trow <= 12 && c <= trow) ? trow * (trow + 1) / 2 + c : 95));
+        sm_tab[(TAB_PD + r) * 64 + lane] = (unsigned short)(S_FOUT + ((c == 13 && trow <= 12) ? trow : 16 + 94));
     }
     __syncthreads();
 }
@@ -740,6 +745,7 @@ __device__ __forceinline__ void stage0_solve(const WsView &w, cgdouble *xinit, i
 // the global prefetch of stage k-2.
 template <int NP>
 __device__ __forceinline__ bool factor_step(const WsView &w, int kk, bool last, int lane, int g, int c, double theta, int mgo, int mco,
+                                            const int (&ppo)[4], const int (&pdo)[4],
                                             const int (&mo)[4], const int (&c1)[4], const int (&c2)[4], const int (&c3)[4],
                                             const d4 &cC, const d4 &cM, double chc, double cPhiDw, double cphiw,
                                             d4 &nC, d4 &nM, double &nhc, double &nPhiDw, double &nphiw,
@@ -750,12 +756,10 @@ __device__ __forceinline__ bool factor_step(const WsView &w, int kk, bool last, 
     d4 G = cC;
     if (!last) {
         d4 X = mm_tn(P, cM, zero);
-        if (c == 13) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                sm[S_FOUT + 4 * r + g] = X[r]; // P d, flushed with the packed P at the end of the step
-                X[r] += pv[r];
-            }
+        for (int r = 0; r < 4; r++) {
+            sm[pdo[r]] = X[r]; // P d (column 13; every other lane writes the dump slot), flushed with the packed P below
+            X[r] += pv[r];     // pv is zero outside column 13
         }
         G = mm_tn(cM, X, cC);
     }
@@ -824,10 +828,7 @@ __device__ __forceinline__ bool factor_step(const WsView &w, int kk, bool last, 
     pv = pn;
     // P_k (packed lower triangle) for the multiplier recovery y_k = P_k ds_k + p_k in the forward sweep
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int row = 4 * r + g;
-        if (row <= 12 && c <= row) sm[S_FOUT + 16 + row * (row + 1) / 2 + c] = Pn[r];
-    }
+    for (int r = 0; r < 4; r++) sm[ppo[r]] = Pn[r]; // lanes outside the lower triangle write the dump slot
     // [P d | packed P] leave as two coalesced stores (the record keeps them adjacent)
     WSYNC();
     rec[REC_PD + lane] = sm[S_FOUT + lane];
@@ -841,13 +842,15 @@ __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, doubl
     w = uni(w); xinit = uni(xinit); N = uni(N); theta = uni(theta);
     FULLSYNC(); // phase boundary: the evaluation phase's record writes are visible
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-    int mo[4], c1[4], c2[4], c3[4];
+    int mo[4], c1[4], c2[4], c3[4], ppo[4], pdo[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         mo[r] = sm_tab[(TAB_M + r) * 64 + lane];
         c1[r] = sm_tab[(TAB_C1 + r) * 64 + lane];
         c2[r] = sm_tab[(TAB_C2 + r) * 64 + lane];
         c3[r] = sm_tab[(TAB_C3 + r) * 64 + lane];
+        ppo[r] = sm_tab[(TAB_PP + r) * 64 + lane];
+        pdo[r] = sm_tab[(TAB_PD + r) * 64 + lane];
     }
     init_stage_constants(lane); // the element-wise phases reuse this part of LDS as staging
     // LDS slot of m[g][c] / m[c][g] for this lane (m = L^-1 of the pivot block, strictly lower part in S_MI)
@@ -880,11 +883,11 @@ __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, doubl
     }
     int kk = N - 1;
     for (; kk >= 1 && ok; kk -= 2) {
-        ok = factor_step<NP>(w, kk, kk == N - 1, lane, g, c, theta, mgo, mco, mo, c1, c2, c3, CA, MA, hcA, PhiDwA, phiwA, CB, MB, hcB, PhiDwB, phiwB, e0, e1, e2, P, pv);
+        ok = factor_step<NP>(w, kk, kk == N - 1, lane, g, c, theta, mgo, mco, ppo, pdo, mo, c1, c2, c3, CA, MA, hcA, PhiDwA, phiwA, CB, MB, hcB, PhiDwB, phiwB, e0, e1, e2, P, pv);
         if (!ok) break;
-        ok = factor_step<NP>(w, kk - 1, false, lane, g, c, theta, mgo, mco, mo, c1, c2, c3, CB, MB, hcB, PhiDwB, phiwB, CA, MA, hcA, PhiDwA, phiwA, f0, f1, f2, P, pv);
+        ok = factor_step<NP>(w, kk - 1, false, lane, g, c, theta, mgo, mco, ppo, pdo, mo, c1, c2, c3, CB, MB, hcB, PhiDwB, phiwB, CA, MA, hcA, PhiDwA, phiwA, f0, f1, f2, P, pv);
     }
-    if (ok && kk == 0) ok = factor_step<NP>(w, 0, N == 1, lane, g, c, theta, mgo, mco, mo, c1, c2, c3, CA, MA, hcA, PhiDwA, phiwA, CB, MB, hcB, PhiDwB, phiwB, e0, e1, e2, P, pv);
+    if (ok && kk == 0) ok = factor_step<NP>(w, 0, N == 1, lane, g, c, theta, mgo, mco, ppo, pdo, mo, c1, c2, c3, CA, MA, hcA, PhiDwA, phiwA, CB, MB, hcB, PhiDwB, phiwB, e0, e1, e2, P, pv);
     bool fail = !ok;
     if (!fail) {
         // stage 0: keep Pww^-1 and Pwx for the corrector pass, then solve for ds_0
