@@ -790,12 +790,11 @@ __device__ __forceinline__ bool factor_step(const WsView &w, int kk, bool last, 
     if (lane == 0) printf("gpu stage %2d theta %.3g Guu %.9e %.9e %.9e %.9e | %.6e %.6e %.6e %.6e %.6e %.6e\n", kk, theta, q[0], q[5], q[10], q[15], q[4], q[8], q[9], q[12], q[13], q[14]);
 #endif
     if (!ldl4(q, Mi, Di)) return false;
-    if (lane == 0) { // uniform values: one lane hands them to the others
+    // uniform values handed to the lanes through LDS (every lane writes the same value to the same slot: no branch)
 #pragma unroll
-        for (int t = 0; t < 6; t++) sm[S_MI + t] = Mi[t];
+    for (int t = 0; t < 6; t++) sm[S_MI + t] = Mi[t];
 #pragma unroll
-        for (int t = 0; t < 4; t++) sm[S_DI + t] = Di[t];
-    }
+    for (int t = 0; t < 4; t++) sm[S_DI + t] = Di[t];
     WSYNC();
     // m = L^-1.  The elimination is carried out in factored form,
     //     K = m G_u,   R = m' D^-1 m,   T = m' D^-1 K (= R G_u),   TT = K' D^-1 m (= G_u' R),   S = G - K' D^-1 K,
@@ -1054,13 +1053,14 @@ __device__ __forceinline__ void forward_step(const WsView &w, int N, int kk, int
     const double du = -D1;
     const double v2 = q0 ? du : (idx == 13 ? 1.0 : v); // row 13 multiplies the d column
     const double D2 = matvec4(cmt, v2, 0.0);
-    if ((lane & 3) == 0) { // one copy of each row; dz rows 17..19 / ynew rows 13..15 are padding
+    { // branch-free LDS writes: the four replicas of a row (lane & 3) write the same value to the same slot, du goes to
+      // the padding row 19 from the lanes that do not hold it; dz rows 17..19 / ynew rows 13..15 are padding
         double *dzl = dz_area<NP>();
-        if (q0) dzl[idx * NP + kk] = du;
-        dzl[(4 + idx) * NP + kk] = v;
+        dzl[(q0 ? idx : DZ_ROWS - 1) * NP + kk] = du;
+        dzl[(4 + idx) * NP + kk] = v; // (row 19 = padding: whichever write lands there is never read)
         if (WITH_Y) { // y+ of the Newton system: kept in LDS (the model phase's transposition buffer is idle here)
             if (NP <= FRP_RB_MAX_NP) rb_area<NP>()[idx * NP + kk] = Y;
-            else w.step[idx * NP + kk] = Y;
+            else if ((lane & 3) == 0) w.step[idx * NP + kk] = Y;
         }
     }
     v = D2; // rows 13..15 of Mt are zero
