@@ -124,6 +124,8 @@ constexpr int S_ZERO = 248, S_ONE = 249, S_DTC = 250;
 constexpr int S_T = 256;                  // T' (64)
 constexpr int S_MI = 320, S_DI = 328;      // pivot block handed from uniform registers to lanes: m = L^-1 (6), D^-1 (4)
 constexpr int S_PRAW = 336;               // forward sweep: staged copy of the next stage's packed P (96) + p (16)
+constexpr int S_M = 560;                  // staged M row of the next stage: record slots 0..63 (LIN | d) + the constants 0, 1, dt (67)
+constexpr int MS_ZERO = 64, MS_ONE = 65, MS_DT = 66; // row-space slots of the constants
 constexpr int S_FOUT = 448;               // factorisation sweep: P d (16) + packed P (96) of the current stage before they are stored
 constexpr int S_STAGING = 23 * 32;        // 736
 constexpr int S_RW = S_STAGING;           // stage-0 solve: Pww^-1 (16)
@@ -285,6 +287,9 @@ __shared__ double sm_rb20[20 * RB_LD];
 __shared__ double sm_rb32[32 * RB_LD];
 template <int NP>
 __device__ __forceinline__ double *rb_area() { return NP == 16 ? sm_rb16 : (NP == 20 ? sm_rb20 : sm_rb32); }
+// M row (record slots 0..63 + constants) of stage ks as the sweeps gather it: the staged copy in `sm` (stage-independent)
+template <int NP>
+__device__ __forceinline__ const double *m_row(int ks) { (void)ks; return sm + S_M; }
 template <int NP>
 __device__ __forceinline__ double *dz_area() { return NP == 16 ? sm_dz16 : (NP == 20 ? sm_dz20 : (NP == 32 ? sm_dz32 : sm_dz64)); }
 
@@ -342,25 +347,26 @@ __device__ __forceinline__ double matvec4(const d4 &A, double x, double c)
     return mfma4(A[3], x3, d);
 }
 
-// LDS offset (within the staged E record) of Mt[row][col], the augmented transition matrix
+// Row-space slot of Mt[row][col], the augmented transition matrix: a slot of the stage's M row = record slots 0..63
+// (compact linearisation | d) followed by the constants 0, 1, dt
 //   rows: s+ = [w+(0..3); x+(4..12)],  cols: [u(0..3); x(4..12); 13 = d]
 //   w+ = u + d_w,  x+ = A x + B u + d_x
 __device__ __forceinline__ int m_src(int row, int col)
 {
-    if (row > 12 || col > 13) return S_ZERO;
-    if (col == 13) return S_E + REC_D + row;
-    if (row < 4) return (col == row) ? S_ONE : S_ZERO;
+    if (row > 12 || col > 13) return MS_ZERO;
+    if (col == 13) return REC_D + row;
+    if (row < 4) return (col == row) ? MS_ONE : MS_ZERO;
     const int i = row - 4, bi = i / 3, ii = i % 3;
     if (col < 4) { // B[i][col]
-        if (col == 3) return bi == 0 ? S_E + REC_LIN + 36 + ii : (bi == 1 ? S_E + REC_LIN + 39 + ii : S_ZERO);
-        if (bi == 1) return S_E + REC_LIN + 42 + ii * 3 + col;
-        if (bi == 2) return ii == col ? S_DTC : S_ZERO;
-        return S_ZERO;
+        if (col == 3) return bi == 0 ? REC_LIN + 36 + ii : (bi == 1 ? REC_LIN + 39 + ii : MS_ZERO);
+        if (bi == 1) return REC_LIN + 42 + ii * 3 + col;
+        if (bi == 2) return ii == col ? MS_DT : MS_ZERO;
+        return MS_ZERO;
     }
     const int j = col - 4, bj = j / 3, jj = j % 3;
-    if (bi == 0) return bj == 0 ? (ii == jj ? S_ONE : S_ZERO) : S_E + REC_LIN + (bj == 1 ? 0 : 9) + ii * 3 + jj;
-    if (bi == 1) return bj == 0 ? S_ZERO : S_E + REC_LIN + (bj == 1 ? 18 : 27) + ii * 3 + jj;
-    return (bj == 2 && ii == jj) ? S_ONE : S_ZERO;
+    if (bi == 0) return bj == 0 ? (ii == jj ? MS_ONE : MS_ZERO) : REC_LIN + (bj == 1 ? 0 : 9) + ii * 3 + jj;
+    if (bi == 1) return bj == 0 ? MS_ZERO : REC_LIN + (bj == 1 ? 18 : 27) + ii * 3 + jj;
+    return (bj == 2 && ii == jj) ? MS_ONE : MS_ZERO;
 }
 // z index of tile index a over (u, x):  u -> 0..3, x -> 8..16
 __device__ __forceinline__ int zi_of(int a) { return a < 4 ? a : a + 4; }
@@ -381,7 +387,10 @@ __device__ __forceinline__ void c_src(int row, int col, int &o1, int &o2, int &o
 
 __device__ __forceinline__ void init_stage_constants(int lane)
 {
-    if (lane == 0) { sm[S_ZERO] = 0.0; sm[S_ONE] = 1.0; sm[S_DTC] = DT; }
+    if (lane == 0) {
+        sm[S_ZERO] = 0.0; sm[S_ONE] = 1.0; sm[S_DTC] = DT;
+        sm[S_M + MS_ZERO] = 0.0; sm[S_M + MS_ONE] = 1.0; sm[S_M + MS_DT] = DT;
+    }
 }
 
 // Per-lane gather offsets of the register tiles (which LDS / record slot feeds tile element (4r+g, c)): they depend
@@ -765,17 +774,18 @@ __device__ __forceinline__ bool factor_step(const WsView &w, int kk, bool last, 
     }
     // ---- between / behind the MFMAs: tiles of stage kk-1 (clamped at 0: the tail re-stages stage 0, unused)
     WSYNC();
-    sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1; sm[S_E + 128 + lane] = e2;
+    sm[S_M + lane] = e0; sm[S_E + 64 + lane] = e1; sm[S_E + 128 + lane] = e2;
     WSYNC();
     { // this register set is staged again two steps from now: the loads have two full steps to land
         const int k3 = kk > 2 ? kk - 3 : 0;
         cgdouble *r3 = w.rec + (size_t)k3 * REC_STRIDE;
         e0 = r3[lane]; e1 = r3[64 + lane]; e2 = r3[128 + lane];
     }
+    const int ks = kk > 0 ? kk - 1 : 0; // the stage whose tiles are assembled now
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         nC[r] = sm[c1[r]] + sm[c2[r]] + theta * sm[c3[r]];
-        nM[r] = sm[mo[r]];
+        nM[r] = m_row<NP>(ks)[mo[r]];
     }
     nhc = sm[S_E + REC_HC];
     nPhiDw = sm[S_E + REC_PHID + 4 + g];
@@ -867,12 +877,12 @@ __device__ __noinline__ int sweep_factor(WsView w, cgdouble *xinit, int N, doubl
         cgdouble *r3 = w.rec + (size_t)(N > 2 ? N - 3 : 0) * REC_STRIDE;
         f0 = r3[lane]; f1 = r3[64 + lane]; f2 = r3[128 + lane];
         WSYNC();
-        sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1; sm[S_E + 128 + lane] = e2;
+        sm[S_M + lane] = e0; sm[S_E + 64 + lane] = e1; sm[S_E + 128 + lane] = e2;
         WSYNC();
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             CA[r] = sm[c1[r]] + sm[c2[r]] + theta * sm[c3[r]];
-            MA[r] = sm[mo[r]];
+            MA[r] = m_row<NP>(N - 1)[mo[r]];
         }
         hcA = sm[S_E + REC_HC];
         PhiDwA = sm[S_E + REC_PHID + 4 + g];
@@ -928,7 +938,7 @@ __device__ __forceinline__ void backvec_step(const WsView &w, int kk, bool last,
     if (!last) q = matvec4(cM, cpd + pv, cphi);
     // ---- while the MFMAs execute: operands of stage kk-1 (clamped at 0: the tail re-stages stage 0, unused)
     WSYNC();
-    sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1;
+    sm[S_M + lane] = e0; sm[S_E + 64 + lane] = e1;
     if (lane < 14) sm[S_E + 128 + lane] = e2;
     WSYNC();
     { // staged again two steps from now
@@ -937,7 +947,7 @@ __device__ __forceinline__ void backvec_step(const WsView &w, int kk, bool last,
         e0 = r3[lane]; e1 = r3[64 + lane]; e2 = r3[128 + (lane < 14 ? lane : 0)];
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) nM[r] = sm[mo[r]];
+    for (int r = 0; r < 4; r++) nM[r] = m_row<NP>(kk > 0 ? kk - 1 : 0)[mo[r]];
     nphi = sm[S_E + REC_PHIB + pho] + smu * sm[S_E + REC_PHIC + pho];
     nphi = (idx <= 12) ? nphi : 0.0;
     nphiw = sm[S_E + REC_PHIB + pwo] + smu * sm[S_E + REC_PHIC + pwo];
@@ -987,11 +997,11 @@ __device__ __noinline__ void sweep_backvec(WsView w, cgdouble *xinit, int N, dou
         tpA = rp[REC_T + lane];
         pdA = rp[pdo];
         WSYNC();
-        sm[S_E + lane] = e0; sm[S_E + 64 + lane] = e1;
+        sm[S_M + lane] = e0; sm[S_E + 64 + lane] = e1;
         if (lane < 14) sm[S_E + 128 + lane] = e2;
         WSYNC();
 #pragma unroll
-        for (int r = 0; r < 4; r++) MA[r] = sm[mo[r]];
+        for (int r = 0; r < 4; r++) MA[r] = m_row<NP>(N - 1)[mo[r]];
         phiA = sm[S_E + REC_PHIB + pho] + smu * sm[S_E + REC_PHIC + pho];
         phiA = (idx <= 12) ? phiA : 0.0;
         phiwA = sm[S_E + REC_PHIB + pwo] + smu * sm[S_E + REC_PHIC + pwo];
@@ -1031,7 +1041,7 @@ __device__ __forceinline__ void forward_step(const WsView &w, int N, int kk, int
     const double D1 = matvec4(ctt, v1, 0.0);
     // stage the (already fetched) record of the next stage through LDS ...
     WSYNC();
-    sm[S_E + lane] = e0; sm[S_T + lane] = tp;
+    sm[S_M + lane] = e0; sm[S_T + lane] = tp;
     if (WITH_Y) { sm[S_PRAW + lane] = pr0; if (lane < 48) sm[S_PRAW + 64 + lane] = pr1; }
     WSYNC();
     { // ... prefetch the one after it (clamped: the tail re-reads the last record, unused) ...
@@ -1041,7 +1051,7 @@ __device__ __forceinline__ void forward_step(const WsView &w, int N, int kk, int
         if (WITH_Y) { pr0 = rp[REC_P + lane]; pr1 = rp[REC_P + 64 + (lane < 48 ? lane : 0)]; } // packed P (96) and p (16)
     }
 #pragma unroll
-    for (int s = 0; s < 4; s++) { ntt[s] = sm[tto[s]]; nmt[s] = sm[mto[s]]; }
+    for (int s = 0; s < 4; s++) { ntt[s] = sm[tto[s]]; nmt[s] = m_row<NP>(kk + 1 < N ? kk + 1 : N - 1)[mto[s]]; }
     nhc = sm[S_T + 14];
     if (WITH_Y) { // P and p of the next stage, gathered from the staged (coalesced) copy of its packed block
 #pragma unroll
@@ -1094,13 +1104,13 @@ __device__ __noinline__ void sweep_forward(WsView w, int N)
         if (WITH_Y) { pr0 = rp[REC_P + lane]; pr1 = rp[REC_P + 64 + (lane < 48 ? lane : 0)]; }
     }
     WSYNC();
-    sm[S_E + lane] = e0; sm[S_T + lane] = tp;
+    sm[S_M + lane] = e0; sm[S_T + lane] = tp;
     if (WITH_Y) { sm[S_PRAW + lane] = pr0; if (lane < 48) sm[S_PRAW + 64 + lane] = pr1; }
     WSYNC();
     d4 ttA, mtA, ttB, mtB;
     double hcA, hcB = 0.0;
 #pragma unroll
-    for (int s = 0; s < 4; s++) { ttA[s] = sm[tto[s]]; mtA[s] = sm[mto[s]]; }
+    for (int s = 0; s < 4; s++) { ttA[s] = sm[tto[s]]; mtA[s] = m_row<NP>(0)[mto[s]]; }
     hcA = sm[S_T + 14];
     if (WITH_Y) {
 #pragma unroll
