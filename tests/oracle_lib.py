@@ -78,3 +78,40 @@ def solve_one(xinit, x0, params, nfaces, N, M, model, opt=None):
 
 def ref_model_available():
     return os.path.exists(os.path.join(ORC_DIR, "_ref", "libref_model_normal.so"))
+
+
+def reference_kkt(z, xinit, params, nfaces, N, M, model, active=1e-3):
+    """KKT residuals of a returned plan z [N,17] for the REFERENCE NLP, measured with the reference's own
+    CasADi callbacks (oracle/_ref, FORCESNLPsolver_*_casadi2forces.c:42-245) -- no oracle arithmetic.
+
+    The reference's output struct carries no multipliers (FORCESNLPsolver_normal.h:129-190), so they are
+    recovered here: least squares over (y free, lambda >= 0 on the constraints within `active` of their
+    bound) of |grad f + A'y - C'lambda|.  Returns dict(stat, eq, ineq, bound) of infinity norms.
+    """
+    import sys
+    from scipy.optimize import lsq_linear
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_golden as G
+    nlp = G.RefNLP(N, M, model, np.asarray(xinit, float), np.asarray(params, float), np.asarray(nfaces))
+    Z = np.ascontiguousarray(z, dtype=np.float64).ravel()
+    _, g = nlp.fun(Z)
+    A = nlp.eq_jac(Z)
+    cols = [A.T]
+    lo = [-np.inf] * A.shape[0]
+    c = nlp.ineq(Z)
+    if c.size:
+        act = np.nonzero(c < active)[0]
+        cols.append(-nlp.ineq_jac(Z)[act].T)
+        lo += [0.0] * len(act)
+    lb, ub = np.tile(nlp.lb, N), np.tile(nlp.ub, N)
+    n = Z.size
+    for i in np.nonzero(Z - lb < active)[0]:
+        e = np.zeros((n, 1)); e[i] = -1.0; cols.append(e); lo.append(0.0)
+    for i in np.nonzero(ub - Z < active)[0]:
+        e = np.zeros((n, 1)); e[i] = 1.0; cols.append(e); lo.append(0.0)
+    Bm = np.concatenate(cols, axis=1)
+    res = lsq_linear(Bm, -g, bounds=(np.array(lo), np.full(len(lo), np.inf)), tol=1e-14, max_iter=200)
+    r = g + Bm @ res.x
+    return dict(stat=float(np.max(np.abs(r))), eq=float(np.max(np.abs(nlp.eq(Z)))),
+                ineq=float(max(0.0, -c.min())) if c.size else 0.0,
+                bound=float(max(0.0, (lb - Z).max(), (Z - ub).max())))

@@ -343,3 +343,19 @@ def test_launch_order_is_a_permutation_for_hostile_keys():
     assert np.array_equal(fl[keep], flc[keep]) and np.array_equal(it[keep], itc[keep])
     assert np.max(np.abs(z[keep] - zc[keep])) == 0.0
     assert np.all(np.isfinite(z[clean]))
+
+
+@pytest.mark.skipif(not OL.ref_model_available(), reason="oracle/_ref not built (reference tree absent)")
+def test_gpu_plans_satisfy_reference_kkt_measured_with_reference_callbacks():
+    """The HIP path's plans are KKT points of the REFERENCE NLP as measured with the reference's own CasADi
+    callbacks (oracle/_ref travels to the GPU box as a built .so; nothing under /root/reference is read).
+    No oracle arithmetic is involved: OL.reference_kkt recovers multipliers by bounded least squares."""
+    for w in (workloads.config0(), workloads.config2(6), workloads.config3(3)):
+        for tol, stat_max, eq_max in ((1e-4, 5e-3, 1e-4), (1e-8, 1e-6, 1e-8)):
+            opt = solver.default_options()
+            opt.tol_stat = opt.tol_eq = opt.tol_ineq = opt.tol_comp = tol
+            z, fl, _, _ = solver.solve_batch_host(w, opt)
+            assert np.all(fl == 1)
+            for b in range(z.shape[0]):
+                k = OL.reference_kkt(z[b], w["xinit"][b], w["params"][b], w["nfaces"][b], w["N"], w["M"], w["model"])
+                assert k["stat"] < stat_max and k["eq"] < eq_max and k["ineq"] < eq_max and k["bound"] < eq_max, (tol, b, k)

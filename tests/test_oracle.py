@@ -117,3 +117,18 @@ def test_infeasible_problem_reports_failure_not_nan():
     z, fl, info = OL.solve_batch(w)
     assert np.all(fl != 1)
     assert np.all(np.isfinite(z))
+
+
+@pytest.mark.skipif(not OL.ref_model_available(), reason="oracle/_ref not built (reference tree absent)")
+def test_plans_satisfy_reference_kkt_measured_with_reference_callbacks():
+    """the returned plan is a KKT point of the REFERENCE NLP.  Gradient, dynamics, corridor rows
+    and their Jacobians come from the reference's CasADi callbacks only (OL.reference_kkt); solved to 1e-8
+    so that the multipliers of inactive constraints (<= tol/slack) drop below the check."""
+    for w in (workloads.config0(), workloads.config2(4), workloads.config3(2)):
+        for tol, stat_max, eq_max in ((1e-4, 5e-3, 1e-4), (1e-8, 1e-6, 1e-8)):
+            opt = OL.default_options(tol_stat=tol, tol_eq=tol, tol_ineq=tol, tol_comp=tol)
+            z, fl, _ = OL.solve_batch(w, opt)
+            assert np.all(fl == 1)
+            for b in range(z.shape[0]):
+                k = OL.reference_kkt(z[b], w["xinit"][b], w["params"][b], w["nfaces"][b], w["N"], w["M"], w["model"])
+                assert k["stat"] < stat_max and k["eq"] < eq_max and k["ineq"] < eq_max and k["bound"] < eq_max, (tol, b, k)
