@@ -44,6 +44,17 @@ class Pack(ctypes.Structure):  # frp_nmpc_pack (include/frp_nmpc.h)
                 ("xinit", ctypes.c_void_p), ("x0", ctypes.c_void_p), ("params", ctypes.c_void_p), ("nfaces", ctypes.c_void_p)]
 
 
+class Tube(ctypes.Structure):  # frp_nmpc_tube (include/frp_nmpc.h)
+    _fields_ = [("B", ctypes.c_int), ("N", ctypes.c_int), ("mpc_output", ctypes.c_void_p),
+                ("mass", ctypes.c_double), ("drag", ctypes.c_double), ("ego_r", ctypes.c_double), ("ego_h", ctypes.c_double),
+                ("noise", ctypes.c_double * 3), ("epsilon", ctypes.c_double), ("Ts", ctypes.c_double),
+                ("ellipsoid", ctypes.c_void_p)]
+
+
+# ROS parameter defaults of the tube model (nmpc_solver.cpp:68-74, nmpc_utils.h:188-189)
+TUBE_DEFAULTS = dict(mass=0.74, drag=0.33, ego_r=0.27, ego_h=0.0425, noise=(0.5, 0.5, 0.5), epsilon=0.06, Ts=0.05)
+
+
 class ForcesParams(ctypes.Structure):
     _fields_ = [("xinit", ctypes.c_double * 9), ("x0", ctypes.c_double * 340),
                 ("all_parameters", ctypes.c_double * 2600), ("num_of_threads", ctypes.c_uint)]
@@ -66,7 +77,7 @@ EXTFUNC = ctypes.CFUNCTYPE(None, c_double_p, c_double_p, c_double_p, c_double_p,
 EXPORTS = ["frp_nmpc_default_options", "frp_nmpc_workspace_bytes", "frp_nmpc_solve_batch",
            "frp_nmpc_solve_batch_host", "frp_nmpc_stage_eval", "frp_nmpc_stage_eval_host", "frp_nmpc_time_solve",
            "frp_nmpc_version", "frp_nmpc_device_count", "FORCESNLPsolver_normal_solve",
-           "FORCESNLPsolver_final_solve", "frp_nmpc_pack_batch", "frp_nmpc_update_batch"]
+           "FORCESNLPsolver_final_solve", "frp_nmpc_pack_batch", "frp_nmpc_update_batch", "frp_nmpc_tube_batch"]
 
 _lib = None
 
@@ -98,6 +109,7 @@ def lib():
         l.frp_nmpc_pack_batch.argtypes = [ctypes.POINTER(Pack), ctypes.c_void_p]
         l.frp_nmpc_update_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_void_p]
+        l.frp_nmpc_tube_batch.argtypes = [ctypes.POINTER(Tube), ctypes.c_void_p]
         _lib = l
     return _lib
 
@@ -197,6 +209,34 @@ class DeviceSolver:
         return ms.value
 
 
+def tube_batch_device(mpc_output, ellipsoid, consts=None, stream=None):
+    """frp_nmpc_tube_batch on device tensors: mpc_output [B,N+1,17] f64 -> ellipsoid [B,N,3,3] f64 (in place)."""
+    import torch
+    c = dict(TUBE_DEFAULTS)
+    c.update(consts or {})
+    B, rows, nz = mpc_output.shape
+    assert nz == L.NZ and mpc_output.is_contiguous() and ellipsoid.is_contiguous() and mpc_output.dtype == torch.float64
+    assert tuple(ellipsoid.shape) == (B, rows - 1, 3, 3) and ellipsoid.dtype == torch.float64
+    s = stream if stream is not None else torch.cuda.current_stream(mpc_output.device)
+    tb = Tube(B, rows - 1, mpc_output.data_ptr(), c["mass"], c["drag"], c["ego_r"], c["ego_h"],
+              (ctypes.c_double * 3)(*c["noise"]), c["epsilon"], c["Ts"], ellipsoid.data_ptr())
+    _check(lib().frp_nmpc_tube_batch(ctypes.byref(tb), ctypes.c_void_p(s.cuda_stream)), "frp_nmpc_tube_batch")
+
+
+def tube_batch_host(plans, consts=None, device="cuda:0"):
+    """Host convenience: plans [B,N,17] (rows 0..N-1 of the plan deque) -> E [B,N,3,3]."""
+    import torch
+    lib()
+    plans = np.ascontiguousarray(plans, dtype=np.float64)
+    B, N, _ = plans.shape
+    mo = torch.zeros((B, N + 1, L.NZ), dtype=torch.float64, device=device)
+    mo[:, :N] = torch.from_numpy(plans).to(device)
+    E = torch.empty((B, N, 3, 3), dtype=torch.float64, device=device)
+    tube_batch_device(mo, E, consts)
+    torch.cuda.synchronize(device)
+    return E.cpu().numpy()
+
+
 class DeviceFleet:
     """B planners whose receding-horizon loop lives in HBM: per tick
         pack (forces_normal.cpp:55-136 on the device)  ->  solve  ->  update (forces_normal.cpp:142-168,
@@ -243,8 +283,17 @@ class DeviceFleet:
                                            ctypes.c_void_p(self.mpc_output.data_ptr()), ctypes.c_void_p(s.cuda_stream)),
                "frp_nmpc_update_batch")
 
-    def tick(self, external_acc, ref_pos, ref_yaw, stream=None):
-        """One receding-horizon tick of all B planners, asynchronous on `stream`."""
+    def tube(self, consts=None, stream=None):
+        """ellipsoid_matrices_ of all B planners from their current plans
+        (NMPCSolver::setFORCESParams, nmpc_solver.cpp:484-521) -> self.ellipsoid, on the device."""
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.solver.device)
+        tube_batch_device(self.mpc_output, self.ellipsoid, consts, s)
+
+    def tick(self, external_acc, ref_pos, ref_yaw, stream=None, tube_consts=None, propagate_tube=False):
+        """One receding-horizon tick of all B planners, asynchronous on `stream`.  With propagate_tube the
+        tube matrices are recomputed from the current plans first, as the reference does every tick."""
+        if propagate_tube:
+            self.tube(tube_consts, stream)
         self.pack(external_acc, ref_pos, ref_yaw, stream)
         self.solver.solve(stream)
         self.update(stream)

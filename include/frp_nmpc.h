@@ -154,6 +154,22 @@ int frp_nmpc_pack_batch(const frp_nmpc_pack *p, void *stream);
  * whose solve did not return 1 keeps its previous plan (nmpc_solver.cpp:397-424). */
 int frp_nmpc_update_batch(int B, int N, const double *z, const int *exitflag, double *mpc_output, void *stream);
 
+/* ---- (4) SURVEY 8f row f-2: tube (ego + disturbance ellipsoid) propagation on the device ---- */
+typedef struct frp_nmpc_tube {
+    int B, N;                 /* planners, horizon (planning_horizon_, <= 64)                                      */
+    const double *mpc_output; /* [B][N+1][17]  plan deque; rows 0..N-1 are linearised (nmpc_solver.cpp:498-501)    */
+    double mass, drag;        /* nmpc/mass, nmpc/drag_coefficient (nmpc_solver.cpp:72-73)                          */
+    double ego_r, ego_h;      /* nmpc/ego_r, nmpc/ego_h: ego_size_ = diag(r^2, r^2, h^2) (:69-70, :90-92)          */
+    double noise[3];          /* w_: nmpc/ext_noise_bound per channel (:74, :99)                                   */
+    double epsilon, Ts;       /* nmpc_utils.h:188-189                                                              */
+    double *ellipsoid;        /* [B][N][3][3] out: ellipsoid_matrices_ E_i (row-major) = frp_nmpc_pack.ellipsoid   */
+} frp_nmpc_tube;
+
+/* NMPCSolver::setFORCESParams' tube part (nmpc_solver.cpp:484-521) with updateMatrix (:615-699) and
+ * getDistrEllipsoid (:567-611) for B planners.  The feedback gain K is the reference's constant (:28-31).
+ * Asynchronous on `stream`. */
+int frp_nmpc_tube_batch(const frp_nmpc_tube *p, void *stream);
+
 const char *frp_nmpc_version(void);
 int frp_nmpc_device_count(void);
 

@@ -359,3 +359,67 @@ def test_gpu_plans_satisfy_reference_kkt_measured_with_reference_callbacks():
             for b in range(z.shape[0]):
                 k = OL.reference_kkt(z[b], w["xinit"][b], w["params"][b], w["nfaces"][b], w["N"], w["M"], w["model"])
                 assert k["stat"] < stat_max and k["eq"] < eq_max and k["ineq"] < eq_max and k["bound"] < eq_max, (tol, b, k)
+
+
+# ---- tube propagation (oracle/tube_oracle.py is the numpy/scipy restatement; parity with the
+# reference itself is unpinned -- Eigen is absent -- so the tolerance is the agreement of two FP64 methods) ----
+def _tube_oracle():
+    import sys
+    sys.path.insert(0, OL.ROOT)
+    from oracle import tube_oracle
+    return tube_oracle
+
+
+def _tube_plans(B, N, seed=5):
+    """Plans with the reference's state ranges: solved horizons plus large attitude / speed / thrust excursions."""
+    rng = np.random.default_rng(seed)
+    lb, ub = L.bounds()
+    z = lb + (ub - lb) * rng.random((B, N, 17))
+    z[..., 8:11] = rng.uniform(-20, 20, (B, N, 3))
+    z[..., 11:14] = rng.uniform(-6, 6, (B, N, 3))
+    z[..., 16] = rng.uniform(-np.pi, np.pi, (B, N))
+    return z
+
+
+@pytest.mark.parametrize("N", [20, 1, 21, 22, 43, 64])
+def test_tube_matches_oracle(N):
+    T = _tube_oracle()
+    B = 6 if N <= 22 else 2
+    z = _tube_plans(B, N, seed=N)
+    z[0] = workloads.config2(1)["x0"][0][np.arange(N) % 20]  # a real warm-start plan
+    E = solver.tube_batch_host(z)
+    Eo = T.tube_batch(z)
+    assert np.max(np.abs(E - Eo) / (1e-3 + np.abs(Eo))) < 1e-9
+    assert np.max(np.abs(E - np.swapaxes(E, -1, -2))) < 1e-14  # symmetric principal root
+
+
+def test_tube_nondefault_constants_and_properties():
+    T = _tube_oracle()
+    c = dict(mass=1.3, drag=0.1, ego_r=0.4, ego_h=0.15, noise=(0.2, 0.7, 1.1), epsilon=0.1, Ts=0.08)
+    z = _tube_plans(4, 20, seed=99)
+    E = solver.tube_batch_host(z, c)
+    assert np.max(np.abs(E - T.tube_batch(z, c)) / (1e-3 + np.abs(T.tube_batch(z, c)))) < 1e-9
+    # properties at full batch size: positive definite, and the tube grows along the horizon (Minkowski sums)
+    zb = _tube_plans(4096, 20, seed=3)
+    Eb = solver.tube_batch_host(zb)
+    ev = np.linalg.eigvalsh(Eb)
+    assert np.isfinite(Eb).all() and ev.min() > 0
+    tr = np.trace(Eb @ Eb, axis1=-2, axis2=-1)
+    assert np.all(np.diff(tr, axis=1)[:, 1:] > 0)
+    # stage 0 is the bare ego ellipsoid: E0^2 = R diag(r^2, r^2, h^2) R' has the ego's eigenvalues
+    assert np.max(np.abs(np.linalg.eigvalsh(Eb[:, 0]) - np.array([0.0425, 0.27, 0.27]))) < 1e-12
+
+
+def test_tube_feeds_the_packer_on_device():
+    """plan -> tube -> pack on the device equals the adapter fed with the oracle's E."""
+    import torch
+    T = _tube_oracle()
+    w = workloads.config2(8)
+    B, N, M = 8, w["N"], w["M"]
+    fleet = solver.DeviceFleet(B, N, M, M, w["model"], (15.0, 3.0, 80.0, 15.0, 0.0))
+    plan = np.concatenate([w["x0"], w["x0"][:, -1:]], axis=1)
+    fleet.mpc_output.copy_(fleet.to_device(plan))
+    fleet.tube()
+    torch.cuda.synchronize()
+    Eo = T.tube_batch(plan[:, :N])
+    assert np.max(np.abs(fleet.ellipsoid.cpu().numpy() - Eo)) < 1e-10
