@@ -11,9 +11,10 @@
 // four Pade matrix exponentials, a general 3x3 eigendecomposition -- is restated for a GPU lane through the
 // quantities those calls define:
 //   * the Sylvester solution of  Phi X + X Phi' = N - e^{-Phi t} N e^{-Phi' t},  N = t w^2 d d',  is the Gramian
-//     X = t w^2 int_0^t (e^{-Phi s} d)(e^{-Phi s} d)' ds  (differentiate the integrand; unique because Phi is
-//     Hurwitz).  The integrand is entire and ||Phi|| t < 2, so 8-point Gauss-Legendre is exact to rounding; the
-//     vectors e^{-Phi s_j} d are stepped node to node with a 14-term Taylor series (||Phi|| ds < 0.4);
+//     X = t w^2 int_0^t (e^{-Phi s} d)(e^{-Phi s} d)' ds  (differentiate the integrand; the Gramian always solves
+//     the equation, and the solution is unique unless two eigenvalues of Phi sum to zero).  The integrand is
+//     entire and ||Phi|| t < 2, so 8-point Gauss-Legendre is exact to rounding; the vectors e^{-Phi s_j} d are
+//     stepped node to node with a 14-term Taylor series (||Phi|| ds < 0.4);
 //   * only rows 0..2 of e^{Phi t} are used (the position block): three Taylor-stepped vectors e^{Phi' t} e_j;
 //   * Phi is never formed densely: rows 0..2 are [0 I 0], rows 6..8 are the constant gain rows, so a product with
 //     Phi or Phi' is 21 variable + 15 constant multiply-adds;

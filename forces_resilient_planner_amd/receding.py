@@ -15,8 +15,10 @@ from . import layout as L
 from .adapter import ForcesAdapter, init_mpc_output, update_forces_results
 
 
-def run(w0, ticks, solve_fn):
+def run(w0, ticks, solve_fn, tube_fn=None):
     """w0: workloads.config4_nominal(...) dict; solve_fn(workload_dict) -> (z [B,N,17], exitflag [B], iters [B]).
+    tube_fn(plans [B,N,17]) -> E [B,N,3,3], when given, recomputes the tube from the current plans every tick as
+    NMPCSolver::setFORCESParams does (nmpc_solver.cpp:484-521); otherwise the generator's fixed E is used.
     Returns per-tick exit flags / iteration counts and the final plan deque."""
     B, N, M, model = w0["B"], w0["N"], w0["M"], w0["model"]
     ad = ForcesAdapter(B, model, N, M)
@@ -38,7 +40,8 @@ def run(w0, ticks, solve_fn):
         if not last_ok.all():
             bad = ~last_ok
             mpc[bad] = init_mpc_output(mpc[bad][:, 1, 8:17], N)
-        xinit, x0, params, nf = ad.pack(mpc, w0["f_ext"], ref_pos, ref_yaw, w0["E"], A, b, np.full((B, N), 6, np.int32))
+        E = w0["E"] if tube_fn is None else tube_fn(mpc[:, :N])
+        xinit, x0, params, nf = ad.pack(mpc, w0["f_ext"], ref_pos, ref_yaw, E, A, b, np.full((B, N), 6, np.int32))
         w = dict(xinit=xinit, x0=x0, params=params, nfaces=nf, N=N, M=M, model=model, B=B)
         z, fl, it = solve_fn(w)
         ok = fl == 1
@@ -52,9 +55,9 @@ def run(w0, ticks, solve_fn):
     return np.array(flags), np.array(iters), mpc
 
 
-def run_device(w0, ticks, device="cuda:0", collect=True):
+def run_device(w0, ticks, device="cuda:0", collect=True, propagate_tube=False):
     """The same loop with every per-tick step on the GPU: device-side packing, solve, device-side
-    result bookkeeping; only the (shared) nominal reference / corridor of configs[4] is produced on the host, one
+    result bookkeeping, and with propagate_tube also the tube propagation (row f-2); only the (shared) nominal reference / corridor of configs[4] is produced on the host, one
     problem's worth per tick, and broadcast on the device.  Returns (flags [ticks,B], iters [ticks,B], final plan,
     seconds of GPU time for all ticks)."""
     import torch
@@ -92,7 +95,7 @@ def run_device(w0, ticks, device="cuda:0", collect=True):
                 row = torch.zeros((st.shape[0], 17), dtype=torch.float64, device=dev)
                 row[:, 3] = cold_thrust; row[:, 7] = cold_thrust; row[:, 8:] = st
                 fleet.mpc_output[bad] = row[:, None, :].expand(-1, N + 1, -1)
-        fleet.tick(f_ext, ref_pos, ref_yaw)
+        fleet.tick(f_ext, ref_pos, ref_yaw, propagate_tube=propagate_tube)
         if collect:
             flags[t] = fleet.solver.exitflag; iters[t] = fleet.solver.iters
     ev1.record()

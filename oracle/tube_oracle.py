@@ -20,8 +20,9 @@ Bartels-Stewart via scipy.linalg.solve_sylvester, Pade expm, general eigendecomp
 
 PARITY UNPINNED: Eigen (and its unsupported MatrixFunctions module) is not in this image and nmpc_solver.cpp
 needs ROS, so the reference cannot be run here and its tests hold no vectors for this function.  The pin that IS
-available: every step is a mathematically defined quantity (unique Sylvester solution because Phi is Hurwitz,
-principal square root), so any FP64 method must agree to rounding; tests check the GPU kernel -- which uses a
+available: every step is a mathematically defined quantity (the Sylvester solution is unique whenever no two eigenvalues of Phi
+sum to zero -- Phi is Hurwitz near zero yaw, where the reference's gain was designed -- and the square root is the
+principal one), so any FP64 method must agree to rounding; tests check the GPU kernel -- which uses a
 different method (Gauss-Legendre quadrature of the Gramian integral, Jacobi eigen-solver) -- against this
 restatement at 1e-9 relative.
 

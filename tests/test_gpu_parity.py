@@ -423,3 +423,16 @@ def test_tube_feeds_the_packer_on_device():
     torch.cuda.synchronize()
     Eo = T.tube_batch(plan[:, :N])
     assert np.max(np.abs(fleet.ellipsoid.cpu().numpy() - Eo)) < 1e-10
+
+
+def test_receding_horizon_with_tube_propagation_on_device():
+    """configs[4] in miniature, the reference's full tick: tube from the current plan (f-2) -> pack (f-1) -> solve ->
+    update, all on the device, against the host loop that takes its tube from the numpy/scipy oracle."""
+    from forces_resilient_planner_amd import receding
+    T = _tube_oracle()
+    w0 = workloads.config4_nominal(B=8, ticks=4)
+    fg, ig, mg = receding.run(w0, 4, lambda w: solver.solve_batch_host(w)[:3], tube_fn=T.tube_batch)
+    fd, idv, md, secs = receding.run_device(w0, 4, propagate_tube=True)
+    assert np.array_equal(fd, fg) and (fd == 1).all()
+    assert (idv == ig).mean() >= 0.95
+    assert np.max(np.abs(md - mg)) < 1e-6

@@ -132,3 +132,41 @@ def test_plans_satisfy_reference_kkt_measured_with_reference_callbacks():
             for b in range(z.shape[0]):
                 k = OL.reference_kkt(z[b], w["xinit"][b], w["params"][b], w["nfaces"][b], w["N"], w["M"], w["model"])
                 assert k["stat"] < stat_max and k["eq"] < eq_max and k["ineq"] < eq_max and k["bound"] < eq_max, (tol, b, k)
+
+
+def test_tube_oracle_is_self_consistent():
+    """Row f-2's oracle (oracle/tube_oracle.py) cannot be pinned against the reference (Eigen absent).  What can be
+    checked on the CPU: its Sylvester solutions satisfy the reference's equation (nmpc_solver.cpp:592-596), they
+    equal the Gramian integral the GPU kernel evaluates (computed here with scipy.integrate) whenever the Sylvester
+    operator is nonsingular (no two eigenvalues of Phi summing to zero -- Phi is Hurwitz near zero yaw, where the
+    reference's gain was designed, and merely nonsingular elsewhere), and sqrtm3 is the principal root."""
+    import sys
+    import scipy.integrate as si
+    import scipy.linalg as sl
+    sys.path.insert(0, OL.ROOT)
+    from oracle import tube_oracle as T
+    c = T.default_consts()
+    rng = np.random.default_rng(11)
+    lb, ub = L.bounds()
+    for _ in range(6):
+        z = lb + (ub - lb) * rng.random(17)
+        z[11:14] = rng.uniform(-6, 6, 3)
+        Phi, R = T.update_matrix(z[14:17], z[11:14], z[3], c)
+        lam = np.linalg.eigvals(Phi)
+        assert np.min(np.abs(lam[:, None] + lam[None, :])) > 1e-2
+        assert np.max(np.abs(R @ R.T - np.eye(3))) < 1e-14
+        t = c["Ts"]
+        d = np.zeros(9); d[4] = 1.0
+        Nt = t * 0.25 * np.outer(d, d)
+        Em = sl.expm(-Phi * t)
+        W = Nt - Em @ Nt @ Em.T
+        X = sl.solve_sylvester(Phi, Phi.T, W)
+        assert np.max(np.abs(Phi @ X + X @ Phi.T - W)) < 1e-14
+        G, _ = si.quad_vec(lambda s: np.outer(sl.expm(-Phi * s) @ d, sl.expm(-Phi * s) @ d), 0, t, epsabs=1e-16, epsrel=1e-13)
+        assert np.max(np.abs(X - t * 0.25 * G)) < 1e-13 * np.abs(X).max() + 1e-18
+    Phi0, _ = T.update_matrix(np.array([0.05, -0.03, 0.1]), np.array([1.0, 0.5, -0.2]), c["mass"] * 9.81, c)
+    assert np.linalg.eigvals(Phi0).real.max() < 0
+    E = T.tube_one(workloads.config2(1)["x0"][0])
+    assert np.linalg.eigvalsh(E).min() > 0 and np.max(np.abs(E - np.swapaxes(E, -1, -2))) < 1e-13
+    # stage 0 is the bare ego ellipsoid (nmpc_solver.cpp:503-506)
+    assert np.max(np.abs(np.linalg.eigvalsh(E[0]) - np.array([c["ego_h"], c["ego_r"], c["ego_r"]]))) < 1e-13
