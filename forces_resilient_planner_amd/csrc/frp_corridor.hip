@@ -1,0 +1,504 @@
+// frp_corridor.hip -- SURVEY 8f row f-3: corridor generation and selection (NMPCSolver::getSikangConst over the
+// horizon, nmpc_solver.cpp:288-332, on top of DecompROS' EllipsoidDecomp3D::dilate) batched on the device.  Inputs
+// are the stage references (row f-4 / the caller), the tube matrices of frp_nmpc_tube_batch (f-2) and the obstacle
+// cloud; outputs are exactly the polytope inputs of frp_nmpc_pack_batch (f-1): poly_A, poly_b, poly_nfaces,
+// poly_index.
+//
+// Reference (src/ThirdParty/DecompROS/decomp_ros_utils/include/ unless noted):
+//   getSikangConst                   plan_manage/src/nmpc_solver.cpp:288-332
+//   EllipsoidDecomp3D::dilate / get_constraints   decomp_util/ellipsoid_decomp.h:47-90
+//   DecompBase::set_obs / find_polyhedron         decomp_util/decomp_base.h:33-38, 63-83
+//   LineSegment::dilate / add_local_bbox / find_ellipsoid (3D)   decomp_util/line_segment.h:31-35, 47-85, 136-211
+//   Ellipsoid::dist / closest_point / closest_hyperplane         decomp_geometry/ellipsoid.h:19-58
+//   Polyhedron::inside, LinearConstraint(p0, planes)             decomp_geometry/polyhedron.h:51-58, 98-118
+//   vec3_to_rotation                 decomp_geometry/geometric_utils.h:27-35;  epsilon_  decomp_basis/data_type.h:129
+//
+// Mapping.  One 256-thread workgroup per planner walks the stages in order (a stage reuses the polytope made for an
+// earlier stage while its inflated tube ellipsoid fits, so the stage loop is sequential by definition).  A
+// decomposition is a sequence of scans over the cloud -- "keep the points that ..., and find the one closest to the
+// ellipsoid centre in the ellipsoid's metric" -- where the reference rebuilds std::vectors:
+//   * the point lists are bit masks in LDS, one 64-bit word per 64 consecutive points, produced by wave ballots, so a
+//     scan reads the cloud with coalesced loads, skips words that are already empty, and preserves the reference's
+//     list order; word g is always read and written by the same wave, so the masks need no barrier;
+//   * "filter with the new ellipsoid, then take the closest of what is left" uses the same distances, so both happen
+//     in ONE scan; the minimum is reduced with (distance, index) ordering = the reference's first-minimum rule;
+//   * the 3x3 algebra of an ellipsoid / hyperplane update is done redundantly by every lane (wave-uniform values).
+// HBM/L2-bound: 24 bytes per live point per scan; the cloud is shared by the planners of a fleet and stays in L2.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "../../include/frp_nmpc.h"
+
+namespace frp {
+
+constexpr int CR_THREADS = 256, CR_WAVES = 4, CR_UNROLL = 8, CR_BATCH = 4;
+constexpr double CR_EPS = 1e-10; // epsilon_, data_type.h:129
+
+struct M3 { double m[9]; };
+
+__device__ __forceinline__ M3 mul(const M3 &a, const M3 &b)
+{
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
+    return r;
+}
+__device__ __forceinline__ M3 transpose(const M3 &a)
+{
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r.m[3 * i + j] = a.m[3 * j + i];
+    return r;
+}
+__device__ __forceinline__ M3 inverse(const M3 &a) // cofactors / determinant
+{
+    const double *m = a.m;
+    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    const double inv = 1.0 / (m[0] * c00 + m[1] * c01 + m[2] * c02);
+    M3 r;
+    r.m[0] = c00 * inv; r.m[1] = (m[2] * m[7] - m[1] * m[8]) * inv; r.m[2] = (m[1] * m[5] - m[2] * m[4]) * inv;
+    r.m[3] = c01 * inv; r.m[4] = (m[0] * m[8] - m[2] * m[6]) * inv; r.m[5] = (m[2] * m[3] - m[0] * m[5]) * inv;
+    r.m[6] = c02 * inv; r.m[7] = (m[1] * m[6] - m[0] * m[7]) * inv; r.m[8] = (m[0] * m[4] - m[1] * m[3]) * inv;
+    return r;
+}
+__device__ __forceinline__ M3 quat_to_rot(double w, double x, double y, double z)
+{
+    M3 r;
+    r.m[0] = 1 - 2 * (y * y + z * z); r.m[1] = 2 * (x * y - w * z);     r.m[2] = 2 * (x * z + w * y);
+    r.m[3] = 2 * (x * y + w * z);     r.m[4] = 1 - 2 * (x * x + z * z); r.m[5] = 2 * (y * z - w * x);
+    r.m[6] = 2 * (x * z - w * y);     r.m[7] = 2 * (y * z + w * x);     r.m[8] = 1 - 2 * (x * x + y * y);
+    return r;
+}
+__device__ __forceinline__ M3 rot_diag_rot(const M3 &R, double a0, double a1, double a2) // R diag(a) R'
+{
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            r.m[3 * i + j] = R.m[3 * i] * a0 * R.m[3 * j] + R.m[3 * i + 1] * a1 * R.m[3 * j + 1] + R.m[3 * i + 2] * a2 * R.m[3 * j + 2];
+    return r;
+}
+__device__ __forceinline__ void tmul(const M3 &R, const double v[3], double o[3]) // o = R' v
+{
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o[j] = R.m[j] * v[0] + R.m[3 + j] * v[1] + R.m[6 + j] * v[2];
+}
+// Ellipsoid::dist (ellipsoid.h:19-21) with C^-1 precomputed
+__device__ __forceinline__ double ell_dist(const M3 &Ci, const double d[3], double x, double y, double z)
+{
+    const double u = x - d[0], v = y - d[1], w = z - d[2];
+    const double a = Ci.m[0] * u + Ci.m[1] * v + Ci.m[2] * w, b = Ci.m[3] * u + Ci.m[4] * v + Ci.m[5] * w,
+                 c = Ci.m[6] * u + Ci.m[7] * v + Ci.m[8] * w;
+    return sqrt(a * a + b * b + c * c);
+}
+
+struct Best { double dist; int idx; double x, y, z; }; // candidate closest point: metric distance, cloud index, coordinates
+
+__device__ __forceinline__ bool before(double da, int ia, double db, int ib) { return da < db || (da == db && ia < ib); }
+
+// minimum over the workgroup in (distance, index) order; idx = INT_MAX when no point was alive.  The winner's
+// coordinates travel with it, so nobody has to fetch the point again.  s_red is double-buffered by `phase`: one barrier.
+__device__ Best block_min(const Best &mine, Best *s_red, int &phase)
+{
+    double d = mine.dist;
+    int i = mine.idx;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double od = __shfl_xor(d, off);
+        const int oi = __shfl_xor(i, off);
+        if (before(od, oi, d, i)) { d = od; i = oi; }
+    }
+    Best *buf = s_red + phase * CR_WAVES;
+    phase ^= 1;
+    const int lane = threadIdx.x & 63;
+    if (i == 0x7fffffff ? lane == 0 : mine.idx == i) buf[threadIdx.x >> 6] = mine; // the lane that owns the wave's minimum
+    __syncthreads();
+    Best r = buf[0];
+#pragma unroll
+    for (int w = 1; w < CR_WAVES; ++w)
+        if (before(buf[w].dist, buf[w].idx, r.dist, r.idx)) r = buf[w];
+    return r;
+}
+
+struct Scan {             // what a scan iterates over
+    const double *pts;    // the planner's cloud [.][3]
+    const uint32_t *list; // nullptr: positions are cloud indices; else positions index this list of cloud indices
+    int Pn, W;            // positions, 64-position words
+};
+
+constexpr int CR_LIST = 8192; // capacity of the in-box index list (LDS); larger boxes fall back to cloud positions
+
+// Wave-uniform state of the running decomposition.  It lives in LDS and is advanced by thread 0 only, so the 3x3
+// algebra costs no registers in the scanning waves: a scan loads just the 9 + 3 (+ 6) doubles it needs.
+struct Uni {
+    double Ri[9], Rf[9], Ci[9], CC[9]; // initial / final ellipsoid frame, C^-1, C^-1 C^-T
+    double mid[3], ax[3];              // ellipsoid centre (p1 + p2) / 2, semi-axes
+    double q[3], n[3];                 // the hyperplane being applied
+    double box[12][3];                 // local box: points 0..5, outward normals 6..11
+    double frame[3][3], p1[3], len;    // the same box as a frame at p1: axes dir_h, dir, dir_v; segment length
+    int rows, overflow, count;         // rows emitted, > F rows seen, in-box points appended to the list
+};
+
+__device__ __forceinline__ M3 ld3(const double *p) { M3 r; for (int k = 0; k < 9; ++k) r.m[k] = p[k]; return r; }
+__device__ __forceinline__ void st3(double *p, const M3 &a) { for (int k = 0; k < 9; ++k) p[k] = a.m[k]; }
+
+enum { KEEP_OUTSIDE = 0, KEEP_INSIDE = 1, KEEP_ALL = 2, KEEP_BEHIND_PLANE = 3 };
+
+// One pass: out = { points of `in` that satisfy MODE }, returns the kept point closest to the centre in the metric
+// of u.Ci (first minimum in list order).  Word g of a mask is always handled by wave g % CR_WAVES.
+template <int MODE>
+__device__ __forceinline__ Best scan(const Scan &s, const uint64_t *in, uint64_t *out, const Uni &u, Best *s_red, int &phase)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const M3 Ci = ld3(u.Ci);
+    const double d[3] = {u.mid[0], u.mid[1], u.mid[2]};
+    double q[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+    if (MODE == KEEP_BEHIND_PLANE) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { q[k] = u.q[k]; n[k] = u.n[k]; }
+    }
+    Best best{1.7976931348623157e308, 0x7fffffff, 0.0, 0.0, 0.0};
+    // Most words of a list are empty.  Each lane fetches one of the wave's next 64 words, a ballot tells which are
+    // not, and only those are visited -- one LDS round trip per 4096 points instead of one per 64.
+    for (int base = wave; base < s.W; base += CR_WAVES * 64) {
+        const int gm = base + lane * CR_WAVES;
+        const uint64_t wm = gm < s.W ? in[gm] : 0;
+        if (out != in && gm < s.W && wm == 0) out[gm] = 0;
+        uint64_t nz = __ballot(wm != 0);
+        while (nz) { // up to CR_BATCH non-empty words at a time, their loads issued together
+            int gs[CR_BATCH], id[CR_BATCH];
+            bool al[CR_BATCH];
+            double x[CR_BATCH], y[CR_BATCH], z[CR_BATCH];
+#pragma unroll
+            for (int k = 0; k < CR_BATCH; ++k) {
+                gs[k] = -1; id[k] = 0; al[k] = false; x[k] = y[k] = z[k] = 0.0;
+                if (nz) {
+                    const int l = __builtin_ctzll(nz);
+                    nz &= nz - 1;
+                    gs[k] = base + l * CR_WAVES;
+                    const uint64_t word = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(wm >> 32), l) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wm, l);
+                    const int pos = gs[k] * 64 + lane;
+                    al[k] = ((word >> lane) & 1) && pos < s.Pn;
+                    if (al[k]) {
+                        id[k] = s.list ? (int)(s.list[pos] & 0x7fffffffu) : pos;
+                        x[k] = s.pts[3 * (size_t)id[k]]; y[k] = s.pts[3 * (size_t)id[k] + 1]; z[k] = s.pts[3 * (size_t)id[k] + 2];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < CR_BATCH; ++k) {
+                if (gs[k] < 0) break;
+                bool alive = al[k];
+                if (alive) {
+                    const double dist = ell_dist(Ci, d, x[k], y[k], z[k]);
+                    if (MODE == KEEP_OUTSIDE) alive = 1 - dist > CR_EPS;
+                    if (MODE == KEEP_INSIDE) alive = dist <= 1;
+                    if (MODE == KEEP_BEHIND_PLANE) alive = n[0] * (x[k] - q[0]) + n[1] * (y[k] - q[1]) + n[2] * (z[k] - q[2]) < 0;
+                    if (alive && before(dist, id[k], best.dist, best.idx)) best = Best{dist, id[k], x[k], y[k], z[k]};
+                }
+                const uint64_t o = __ballot(alive);
+                if (lane == 0) out[gs[k]] = o;
+            }
+        }
+    }
+    return block_min(best, s_red, phase);
+}
+
+// first scan of a decomposition: obs_ = cloud points inside the local box (decomp_base.h:33-38) -> m0, obs = those
+// inside the seed ellipsoid -> m1 and m2.  Every point is read here, so the loads of CR_UNROLL word groups are
+// issued before any of them is used.
+__device__ __forceinline__ Best scan_cloud(const Scan &s, uint64_t *m0, uint64_t *m1, uint64_t *m2, uint32_t *list, Uni &u, bool has_box, const double *bbox, Best *s_red, int &phase)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const M3 Ci = ld3(u.Ci);
+    const double d[3] = {u.mid[0], u.mid[1], u.mid[2]};
+    // The six planes of add_local_bbox have unit normals +-dir_h, +-dir, +-dir_v, so signed_dist(x) > epsilon_ for
+    // any of them is a bound on the coordinates of x - p1 in that frame (12 + 4 registers instead of 36).
+    double fr[3][3], o[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = u.p1[k];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) fr[k][j] = u.frame[k][j];
+    }
+    const double bh = bbox[1] + CR_EPS, bd_lo = -bbox[0] - CR_EPS, bd_hi = u.len + bbox[0] + CR_EPS, bv = bbox[2] + CR_EPS;
+    Best best{1.7976931348623157e308, 0x7fffffff, 0.0, 0.0, 0.0};
+    for (int g0 = wave; g0 < s.W; g0 += CR_WAVES * CR_UNROLL) {
+        double x[CR_UNROLL], y[CR_UNROLL], z[CR_UNROLL];
+#pragma unroll
+        for (int k = 0; k < CR_UNROLL; ++k) {
+            const int idx = (g0 + k * CR_WAVES) * 64 + lane;
+            const size_t o3 = 3 * (size_t)(idx < s.Pn ? idx : 0);
+            x[k] = s.Pn ? s.pts[o3] : 0.0; y[k] = s.Pn ? s.pts[o3 + 1] : 0.0; z[k] = s.Pn ? s.pts[o3 + 2] : 0.0;
+        }
+        uint64_t w0[CR_UNROLL];
+        bool i1[CR_UNROLL];
+        int total = 0;
+#pragma unroll
+        for (int k = 0; k < CR_UNROLL; ++k) {
+            const int g = g0 + k * CR_WAVES, idx = g * 64 + lane;
+            bool in0 = g < s.W && idx < s.Pn;
+            i1[k] = false;
+            if (has_box) { // Polyhedron::inside: rejected if signed_dist > epsilon_ (polyhedron.h:51-58)
+                const double ex = x[k] - o[0], ey = y[k] - o[1], ez = z[k] - o[2];
+                const double h = fr[0][0] * ex + fr[0][1] * ey + fr[0][2] * ez, t = fr[1][0] * ex + fr[1][1] * ey + fr[1][2] * ez,
+                             v = fr[2][0] * ex + fr[2][1] * ey + fr[2][2] * ez;
+                in0 = in0 && !(h > bh) && !(-h > bh) && !(t > bd_hi) && !(t < bd_lo) && !(v > bv) && !(-v > bv);
+            }
+            if (in0) {
+                const double dist = ell_dist(Ci, d, x[k], y[k], z[k]);
+                i1[k] = dist <= 1;
+                if (i1[k] && dist < best.dist) best = Best{dist, idx, x[k], y[k], z[k]};
+            }
+            w0[k] = __ballot(in0);
+            const uint64_t w1 = __ballot(i1[k]);
+            if (lane == 0 && g < s.W) { m0[g] = w0[k]; m1[g] = w1; m2[g] = w1; }
+            total += (int)__popcll(w0[k]);
+        }
+        if (total) { // append the in-box points to the dense list (any order: minima are tie-broken by cloud index);
+                     // one LDS atomic per CR_UNROLL words
+            int at = 0;
+            if (lane == 0) at = atomicAdd(&u.count, total);
+            at = __builtin_amdgcn_readfirstlane(at);
+#pragma unroll
+            for (int k = 0; k < CR_UNROLL; ++k) {
+                const int mine = at + (int)__popcll(w0[k] & ((1ull << lane) - 1));
+                if (((w0[k] >> lane) & 1) && mine < CR_LIST)
+                    list[mine] = (uint32_t)((g0 + k * CR_WAVES) * 64 + lane) | (i1[k] ? 0x80000000u : 0u);
+                at += (int)__popcll(w0[k]);
+            }
+        }
+    }
+    return block_min(best, s_red, phase);
+}
+
+// LinearConstraint row of hyperplane (q, n) seen from the seed centre (polyhedron.h:98-118); thread 0 only
+__device__ void emit_row(Uni &u, const double q[3], const double n_[3], int F, double *s_A, double *s_b, double *gA, double *gb)
+{
+    double n[3] = {n_[0], n_[1], n_[2]};
+    double cc = q[0] * n[0] + q[1] * n[1] + q[2] * n[2];
+    if (n[0] * u.mid[0] + n[1] * u.mid[1] + n[2] * u.mid[2] - cc > 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; cc = -cc; }
+    const int r = u.rows;
+    if (r < F) {
+        s_A[3 * r] = n[0]; s_A[3 * r + 1] = n[1]; s_A[3 * r + 2] = n[2]; s_b[r] = cc;
+        gA[3 * r] = n[0]; gA[3 * r + 1] = n[1]; gA[3 * r + 2] = n[2]; gb[r] = cc;
+    } else
+        u.overflow = 1;
+    u.rows = r + 1;
+}
+
+#ifdef FRP_CORRIDOR_PROFILE
+#define CR_T0 long long t0_ = wall_clock64();
+#define CR_ACC(v) { long long t1_ = wall_clock64(); v += t1_ - t0_; t0_ = t1_; }
+#define CR_CNT(v) ++v;
+#else
+#define CR_CNT(v)
+#define CR_T0
+#define CR_ACC(v)
+#endif
+
+__global__ __launch_bounds__(CR_THREADS) void corridor_kernel(frp_nmpc_corridor c)
+{
+#ifdef FRP_CORRIDOR_PROFILE
+    long long tp_check = 0, tp_init = 0, tp_cloud = 0, tp_lead = 0, tp_scan = 0, tp_emit = 0, tp_begin = wall_clock64();
+    int np_scan = 0;
+#endif
+    extern __shared__ uint64_t s_mask[];
+    __shared__ double s_A[FRP_CORRIDOR_MAX_F * 3], s_b[FRP_CORRIDOR_MAX_F];
+    __shared__ Best s_red[2 * CR_WAVES];
+    int phase = 0;
+    __shared__ Uni u;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    Scan sc;
+    sc.Pn = c.cloud_count ? c.cloud_count[c.cloud_per_planner ? b : 0] : c.P;
+    sc.Pn = sc.Pn < c.P ? sc.Pn : c.P;
+    sc.W = (c.P + 63) / 64;
+    sc.pts = c.cloud + (c.cloud_per_planner ? (size_t)b * c.P * 3 : 0);
+    const int W_cloud = sc.W, P_cloud = sc.Pn;
+    uint64_t *m0 = s_mask, *m1 = s_mask + sc.W, *m2 = s_mask + 2 * sc.W; // obs_, obs, working list
+    uint32_t *list = reinterpret_cast<uint32_t *>(s_mask + 3 * sc.W);
+    const double *ref = c.ref_pos + (size_t)b * c.N * 3, *yaw = c.ref_yaw + (size_t)b * c.N, *Eb = c.ellipsoid + (size_t)b * c.N * 9;
+    const bool has_box = c.bbox[0] != 0.0 || c.bbox[1] != 0.0 || c.bbox[2] != 0.0;
+    int npoly = 0, rows = 0; // rows = stored rows of the last polytope (s_A / s_b)
+    if (tid == 0) u.overflow = 0;
+
+    for (int i = 0; i < c.N; ++i) {
+        CR_T0
+        // ---- does the stage's inflated tube ellipsoid fit the last polytope? (nmpc_solver.cpp:291-313) ----------
+        if (npoly > 0) {
+            int viol = 0;
+            if (tid < rows) {
+                const double a0 = s_A[3 * tid], a1 = s_A[3 * tid + 1], a2 = s_A[3 * tid + 2];
+                const double *E = Eb + 9 * i;
+                const double e0 = E[0] * a0 + E[1] * a1 + E[2] * a2, e1 = E[3] * a0 + E[4] * a1 + E[5] * a2, e2 = E[6] * a0 + E[7] * a1 + E[8] * a2;
+                const double add = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+                viol = (a0 * ref[3 * i] + a1 * ref[3 * i + 1] + a2 * ref[3 * i + 2] - (s_b[tid] - c.inflation * add)) > 0;
+            }
+            if (!__syncthreads_or(viol)) {
+                if (tid == 0) c.poly_index[(size_t)b * c.N + i] = npoly - 1;
+                CR_ACC(tp_check)
+                continue;
+            }
+        }
+        CR_ACC(tp_check)
+        // ---- new decomposition around the seed segment (nmpc_solver.cpp:315-329) -------------------------------
+        if (tid == 0) {
+            double sy, cy;
+            sincos(yaw[i], &sy, &cy);
+            const double p1[3] = {ref[3 * i], ref[3 * i + 1], ref[3 * i + 2]};
+            const double p2[3] = {p1[0] + c.seed_len * cy, p1[1] + c.seed_len * sy, p1[2]};
+            const double dv[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+            const double len = sqrt(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) u.mid[k] = (p1[k] + p2[k]) / 2;
+            u.len = len;
+            if (has_box) { // local box planes (line_segment.h:47-85)
+                const double dir[3] = {dv[0] / len, dv[1] / len, dv[2] / len};
+                double dh[3] = {dir[1], -dir[0], 0.0};
+                double hn = sqrt(dh[0] * dh[0] + dh[1] * dh[1]);
+                if (hn == 0.0) { dh[0] = -1.0; dh[1] = 0.0; hn = 1.0; }
+                dh[0] /= hn; dh[1] /= hn;
+                const double dvv[3] = {dir[1] * dh[2] - dir[2] * dh[1], dir[2] * dh[0] - dir[0] * dh[2], dir[0] * dh[1] - dir[1] * dh[0]};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    u.frame[0][k] = dh[k]; u.frame[1][k] = dir[k]; u.frame[2][k] = dvv[k]; u.p1[k] = p1[k];
+                    u.box[0][k] = p1[k] + dh[k] * c.bbox[1];  u.box[6][k] = dh[k];
+                    u.box[1][k] = p1[k] - dh[k] * c.bbox[1];  u.box[7][k] = -dh[k];
+                    u.box[2][k] = p2[k] + dir[k] * c.bbox[0]; u.box[8][k] = dir[k];
+                    u.box[3][k] = p1[k] - dir[k] * c.bbox[0]; u.box[9][k] = -dir[k];
+                    u.box[4][k] = p1[k] + dvv[k] * c.bbox[2]; u.box[10][k] = dvv[k];
+                    u.box[5][k] = p1[k] - dvv[k] * c.bbox[2]; u.box[11][k] = -dvv[k];
+                }
+            }
+            // seed ellipsoid (line_segment.h:139-154)
+            const double f = len / 2;
+            double ax0 = f + c.offset_x, ax1 = f, ax2 = f, c00 = f + c.offset_x, cdd = f;
+            if (ax0 > 0) { const double ratio = ax1 / ax0; ax0 *= ratio; ax1 *= ratio; ax2 *= ratio; c00 *= ratio; cdd *= ratio; }
+            u.ax[0] = ax0; u.ax[1] = ax1; u.ax[2] = ax2;
+            const double pitch = atan2(-dv[2], sqrt(dv[0] * dv[0] + dv[1] * dv[1])), yw = atan2(dv[1], dv[0]);
+            const M3 Ri = mul(quat_to_rot(cos(yw / 2), 0, 0, sin(yw / 2)), quat_to_rot(cos(pitch / 2), 0, sin(pitch / 2), 0));
+            u.count = 0;
+            st3(u.Ri, Ri); st3(u.Rf, Ri);
+            st3(u.Ci, inverse(rot_diag_rot(Ri, c00, cdd, cdd)));
+        }
+        __syncthreads();
+        CR_ACC(tp_init)
+        sc.list = nullptr; sc.W = W_cloud; sc.Pn = P_cloud;
+        Best cp = scan_cloud(sc, m0, m1, m2, list, u, has_box, c.bbox, s_red, phase);
+        if (u.count <= CR_LIST) { // the usual case: from here on a position is an entry of the dense list
+            sc.list = list; sc.Pn = u.count; sc.W = (u.count + 63) / 64;
+            for (int g = tid >> 6; g < sc.W; g += CR_WAVES) {
+                const int pos = g * 64 + (tid & 63);
+                const bool valid = pos < sc.Pn;
+                const uint64_t w0 = __ballot(valid), w1 = __ballot(valid && (list[valid ? pos : 0] >> 31));
+                if ((tid & 63) == 0) { m0[g] = w0; m1[g] = w1; m2[g] = w1; }
+            }
+        }
+        CR_ACC(tp_cloud)
+        // shrink the second axis until no obstacle is inside (line_segment.h:156-181)
+        while (cp.idx != 0x7fffffff) {
+            if (tid == 0) {
+                const double pw[3] = {cp.x - u.mid[0], cp.y - u.mid[1], cp.z - u.mid[2]};
+                const M3 Ri = ld3(u.Ri);
+                double p[3];
+                tmul(Ri, pw, p);
+                const double roll = atan2(p[2], p[1]);
+                const M3 Rf = mul(Ri, quat_to_rot(cos(roll / 2), sin(roll / 2), 0, 0));
+                tmul(Rf, pw, p);
+                if (p[0] < u.ax[0]) u.ax[1] = fabs(p[1]) / sqrt(1 - (p[0] / u.ax[0]) * (p[0] / u.ax[0]));
+                st3(u.Rf, Rf);
+                st3(u.Ci, inverse(rot_diag_rot(Rf, u.ax[0], u.ax[1], u.ax[1])));
+            }
+            __syncthreads();
+            CR_ACC(tp_lead)
+            cp = scan<KEEP_OUTSIDE>(sc, m2, m2, u, s_red, phase);
+            CR_ACC(tp_scan) CR_CNT(np_scan)
+        }
+        // third axis (line_segment.h:183-208)
+        if (tid == 0) st3(u.Ci, inverse(rot_diag_rot(ld3(u.Rf), u.ax[0], u.ax[1], u.ax[2])));
+        __syncthreads();
+        CR_ACC(tp_lead)
+        cp = scan<KEEP_INSIDE>(sc, m1, m2, u, s_red, phase);
+        CR_ACC(tp_scan) CR_CNT(np_scan)
+        while (cp.idx != 0x7fffffff) {
+            if (tid == 0) {
+                const double pw[3] = {cp.x - u.mid[0], cp.y - u.mid[1], cp.z - u.mid[2]};
+                const M3 Rf = ld3(u.Rf);
+                double p[3];
+                tmul(Rf, pw, p);
+                const double dd = 1 - (p[0] / u.ax[0]) * (p[0] / u.ax[0]) - (p[1] / u.ax[1]) * (p[1] / u.ax[1]);
+                if (dd > CR_EPS) u.ax[2] = fabs(p[2]) / sqrt(dd);
+                st3(u.Ci, inverse(rot_diag_rot(Rf, u.ax[0], u.ax[1], u.ax[2])));
+            }
+            __syncthreads();
+            CR_ACC(tp_lead)
+            cp = scan<KEEP_OUTSIDE>(sc, m2, m2, u, s_red, phase);
+            CR_ACC(tp_scan) CR_CNT(np_scan)
+        }
+        // hyperplanes (decomp_base.h:63-83) + LinearConstraint rows (polyhedron.h:98-118)
+        double *gA = c.poly_A + (((size_t)b * c.N + npoly) * c.F) * 3, *gb = c.poly_b + ((size_t)b * c.N + npoly) * c.F;
+        if (tid == 0) {
+            const M3 Ci = ld3(u.Ci);
+            st3(u.CC, mul(Ci, transpose(Ci))); // C^-1 C^-T (ellipsoid.h:53-58)
+            u.rows = 0;
+        }
+        CR_ACC(tp_lead)
+        cp = scan<KEEP_ALL>(sc, m0, m2, u, s_red, phase); // Ci is unchanged since the last barrier
+        CR_ACC(tp_scan) CR_CNT(np_scan)
+        while (cp.idx != 0x7fffffff) {
+            if (tid == 0) {
+                const double q[3] = {cp.x, cp.y, cp.z};
+                const double w[3] = {q[0] - u.mid[0], q[1] - u.mid[1], q[2] - u.mid[2]};
+                double n[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) n[k] = u.CC[3 * k] * w[0] + u.CC[3 * k + 1] * w[1] + u.CC[3 * k + 2] * w[2];
+                const double nl = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { n[k] /= nl; u.n[k] = n[k]; u.q[k] = q[k]; }
+                emit_row(u, q, n, c.F, s_A, s_b, gA, gb);
+            }
+            __syncthreads();
+            CR_ACC(tp_lead)
+            cp = scan<KEEP_BEHIND_PLANE>(sc, m2, m2, u, s_red, phase);
+            CR_ACC(tp_scan) CR_CNT(np_scan)
+        }
+        if (tid == 0) {
+            if (has_box)
+                for (int k = 0; k < 6; ++k) emit_row(u, u.box[k], u.box[6 + k], c.F, s_A, s_b, gA, gb);
+            c.poly_nfaces[(size_t)b * c.N + npoly] = u.rows;
+            c.poly_index[(size_t)b * c.N + i] = npoly;
+        }
+        __syncthreads(); // rows of the new polytope visible to the containment check of the next stage
+        CR_ACC(tp_emit)
+        rows = u.rows < c.F ? u.rows : c.F;
+        ++npoly;
+    }
+#ifdef FRP_CORRIDOR_PROFILE
+    if (tid == 0 && (b == 0 || b == 1000))
+        printf("corridor wg %d: total %lld check %lld init %lld cloud %lld lead %lld scan %lld (%d scans) emit %lld [100 MHz ticks], %d polytopes\n", b,
+               wall_clock64() - tp_begin, tp_check, tp_init, tp_cloud, tp_lead, tp_scan, np_scan, tp_emit, npoly);
+#endif
+    if (tid == 0) {
+        for (int k = npoly; k < c.N; ++k) c.poly_nfaces[(size_t)b * c.N + k] = 0;
+        if (c.poly_count) c.poly_count[b] = u.overflow ? -npoly : npoly;
+    }
+}
+
+} // namespace frp
+
+extern "C" int frp_nmpc_corridor_batch(const frp_nmpc_corridor *p, void *stream)
+{
+    if (!p || p->B <= 0 || p->N < 1 || p->N > 64 || p->F < 6 || p->F > FRP_CORRIDOR_MAX_F || p->P < 0 || p->P > FRP_CORRIDOR_MAX_POINTS ||
+        (p->P > 0 && !p->cloud) || !p->ref_pos || !p->ref_yaw || !p->ellipsoid || !p->poly_A || !p->poly_b || !p->poly_nfaces || !p->poly_index)
+        return FRP_ERR_ARG;
+    if (!(p->seed_len > 0.0) || !(p->inflation >= 0.0)) return FRP_ERR_ARG;
+    const size_t lds = (size_t)3 * ((p->P + 63) / 64) * sizeof(uint64_t) + frp::CR_LIST * sizeof(uint32_t);
+    hipLaunchKernelGGL(frp::corridor_kernel, dim3((unsigned)p->B), dim3(frp::CR_THREADS), lds, static_cast<hipStream_t>(stream), *p);
+    return hipGetLastError() == hipSuccess ? FRP_OK : FRP_ERR_HIP;
+}

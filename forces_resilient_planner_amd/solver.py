@@ -51,6 +51,20 @@ class Tube(ctypes.Structure):  # frp_nmpc_tube (include/frp_nmpc.h)
                 ("ellipsoid", ctypes.c_void_p)]
 
 
+class Corridor(ctypes.Structure):  # frp_nmpc_corridor (include/frp_nmpc.h)
+    _fields_ = [("B", ctypes.c_int), ("N", ctypes.c_int), ("F", ctypes.c_int), ("P", ctypes.c_int),
+                ("cloud", ctypes.c_void_p), ("cloud_per_planner", ctypes.c_int), ("cloud_count", ctypes.c_void_p),
+                ("ref_pos", ctypes.c_void_p), ("ref_yaw", ctypes.c_void_p), ("ellipsoid", ctypes.c_void_p),
+                ("bbox", ctypes.c_double * 3), ("seed_len", ctypes.c_double), ("inflation", ctypes.c_double),
+                ("offset_x", ctypes.c_double),
+                ("poly_A", ctypes.c_void_p), ("poly_b", ctypes.c_void_p), ("poly_nfaces", ctypes.c_void_p),
+                ("poly_index", ctypes.c_void_p), ("poly_count", ctypes.c_void_p)]
+
+
+# getSikangConst's constants (nmpc_solver.cpp:302, :318, :323)
+CORRIDOR_DEFAULTS = dict(bbox=(2.0, 2.0, 1.0), seed_len=0.1, inflation=1.1, offset_x=0.0)
+CORRIDOR_MAX_F = 64
+
 # ROS parameter defaults of the tube model (nmpc_solver.cpp:68-74, nmpc_utils.h:188-189)
 TUBE_DEFAULTS = dict(mass=0.74, drag=0.33, ego_r=0.27, ego_h=0.0425, noise=(0.5, 0.5, 0.5), epsilon=0.06, Ts=0.05)
 
@@ -77,7 +91,8 @@ EXTFUNC = ctypes.CFUNCTYPE(None, c_double_p, c_double_p, c_double_p, c_double_p,
 EXPORTS = ["frp_nmpc_default_options", "frp_nmpc_workspace_bytes", "frp_nmpc_solve_batch",
            "frp_nmpc_solve_batch_host", "frp_nmpc_stage_eval", "frp_nmpc_stage_eval_host", "frp_nmpc_time_solve",
            "frp_nmpc_version", "frp_nmpc_device_count", "FORCESNLPsolver_normal_solve",
-           "FORCESNLPsolver_final_solve", "frp_nmpc_pack_batch", "frp_nmpc_update_batch", "frp_nmpc_tube_batch"]
+           "FORCESNLPsolver_final_solve", "frp_nmpc_pack_batch", "frp_nmpc_update_batch", "frp_nmpc_tube_batch",
+           "frp_nmpc_corridor_batch"]
 
 _lib = None
 
@@ -110,6 +125,7 @@ def lib():
         l.frp_nmpc_update_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_void_p]
         l.frp_nmpc_tube_batch.argtypes = [ctypes.POINTER(Tube), ctypes.c_void_p]
+        l.frp_nmpc_corridor_batch.argtypes = [ctypes.POINTER(Corridor), ctypes.c_void_p]
         _lib = l
     return _lib
 
@@ -223,6 +239,42 @@ def tube_batch_device(mpc_output, ellipsoid, consts=None, stream=None):
     _check(lib().frp_nmpc_tube_batch(ctypes.byref(tb), ctypes.c_void_p(s.cuda_stream)), "frp_nmpc_tube_batch")
 
 
+def corridor_batch_device(cloud, ref_pos, ref_yaw, ellipsoid, poly_A, poly_b, poly_nfaces, poly_index, poly_count=None,
+                          cloud_count=None, consts=None, stream=None):
+    """frp_nmpc_corridor_batch on device tensors.  cloud [P,3] (shared) or [B,P,3]; ref_pos [B,N,3]; ref_yaw [B,N];
+    ellipsoid [B,N,3,3]; outputs poly_A [B,N,F,3], poly_b [B,N,F], poly_nfaces / poly_index [B,N] int32."""
+    import torch
+    c = dict(CORRIDOR_DEFAULTS)
+    c.update(consts or {})
+    B, N, F, _ = poly_A.shape
+    per = 1 if cloud.dim() == 3 else 0
+    P = cloud.shape[-2]
+    for t in (cloud, ref_pos, ref_yaw, ellipsoid, poly_A, poly_b):
+        assert t.is_contiguous() and t.dtype == torch.float64
+    assert tuple(ref_pos.shape) == (B, N, 3) and tuple(ellipsoid.shape) == (B, N, 3, 3) and tuple(poly_b.shape) == (B, N, F)
+    assert poly_nfaces.dtype == torch.int32 and poly_index.dtype == torch.int32
+    s = stream if stream is not None else torch.cuda.current_stream(ref_pos.device)
+    cr = Corridor(B, N, F, P, cloud.data_ptr() if P else None, per, cloud_count.data_ptr() if cloud_count is not None else None,
+                  ref_pos.data_ptr(), ref_yaw.data_ptr(), ellipsoid.data_ptr(), (ctypes.c_double * 3)(*c["bbox"]),
+                  c["seed_len"], c["inflation"], c["offset_x"], poly_A.data_ptr(), poly_b.data_ptr(),
+                  poly_nfaces.data_ptr(), poly_index.data_ptr(), poly_count.data_ptr() if poly_count is not None else None)
+    _check(lib().frp_nmpc_corridor_batch(ctypes.byref(cr), ctypes.c_void_p(s.cuda_stream)), "frp_nmpc_corridor_batch")
+
+
+def corridor_batch_host(cloud, ref_pos, ref_yaw, ellipsoid, F=CORRIDOR_MAX_F, consts=None, device="cuda:0"):
+    """Host convenience: numpy in, (poly_index [B,N], poly_A [B,N,F,3], poly_b [B,N,F], poly_nfaces [B,N], poly_count [B]) out."""
+    import torch
+    lib()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)
+    B, N, _ = ref_pos.shape
+    A = torch.zeros((B, N, F, 3), dtype=torch.float64, device=device); b = torch.zeros((B, N, F), dtype=torch.float64, device=device)
+    nf = torch.zeros((B, N), dtype=torch.int32, device=device); pi = torch.zeros((B, N), dtype=torch.int32, device=device)
+    cnt = torch.zeros((B,), dtype=torch.int32, device=device)
+    corridor_batch_device(dev(cloud), dev(ref_pos), dev(ref_yaw), dev(ellipsoid), A, b, nf, pi, cnt, consts=consts)
+    torch.cuda.synchronize(device)
+    return pi.cpu().numpy(), A.cpu().numpy(), b.cpu().numpy(), nf.cpu().numpy(), cnt.cpu().numpy()
+
+
 def tube_batch_host(plans, consts=None, device="cuda:0"):
     """Host convenience: plans [B,N,17] (rows 0..N-1 of the plan deque) -> E [B,N,3,3]."""
     import torch
@@ -288,6 +340,16 @@ class DeviceFleet:
         (NMPCSolver::setFORCESParams, nmpc_solver.cpp:484-521) -> self.ellipsoid, on the device."""
         s = stream if stream is not None else self.torch.cuda.current_stream(self.solver.device)
         tube_batch_device(self.mpc_output, self.ellipsoid, consts, s)
+
+    def corridor(self, cloud, ref_pos, ref_yaw, consts=None, stream=None, cloud_count=None):
+        """polytopes and poly_indices of all B planners from the obstacle cloud, the stage
+        references and the current tube (getSikangConst, nmpc_solver.cpp:288-332) -> self.poly_*, on the device."""
+        t = self.torch
+        assert self.NPOLY == self.N
+        if self.poly_index is None:
+            self.poly_index = t.zeros((self.B, self.N), dtype=t.int32, device=self.solver.device)
+        corridor_batch_device(cloud, ref_pos, ref_yaw, self.ellipsoid, self.poly_A, self.poly_b, self.poly_nfaces,
+                              self.poly_index, None, cloud_count, consts, stream)
 
     def tick(self, external_acc, ref_pos, ref_yaw, stream=None, tube_consts=None, propagate_tube=False):
         """One receding-horizon tick of all B planners, asynchronous on `stream`.  With propagate_tube the

@@ -170,6 +170,37 @@ typedef struct frp_nmpc_tube {
  * Asynchronous on `stream`. */
 int frp_nmpc_tube_batch(const frp_nmpc_tube *p, void *stream);
 
+/* ---- (5) SURVEY 8f row f-3: corridor generation / selection on the device ---- */
+#define FRP_CORRIDOR_MAX_F 64           /* rows kept per polytope                                   */
+#define FRP_CORRIDOR_MAX_POINTS 65536   /* cloud points per planner (3 x P/8 bytes of LDS masks)    */
+typedef struct frp_nmpc_corridor {
+    int B, N;               /* planners, horizon                                                                    */
+    int F;                  /* rows stored per polytope, 6 <= F <= FRP_CORRIDOR_MAX_F (= frp_nmpc_pack.F)            */
+    int P;                  /* points stored per cloud                                                              */
+    const double *cloud;    /* [P][3] shared by all planners, or [B][P][3] when cloud_per_planner != 0: vec_obs_    */
+    int cloud_per_planner;
+    const int *cloud_count; /* live points (<= P) per cloud, [1] or [B]; NULL: P                                    */
+    const double *ref_pos;  /* [B][N][3]     ref_pos_ of stage i (nmpc_solver.cpp:117-122)                          */
+    const double *ref_yaw;  /* [B][N]        ref_yaw_ of stage i (:861)                                             */
+    const double *ellipsoid;/* [B][N][3][3]  E_i (frp_nmpc_tube.ellipsoid)                                          */
+    double bbox[3];         /* set_local_bbox(Vec3f(2, 2, 1)) (:323)                                                */
+    double seed_len;        /* 0.1: second seed point ahead along the yaw (:318)                                    */
+    double inflation;       /* 1.1: "with little inflation" (:302)                                                  */
+    double offset_x;        /* 0: dilate()'s offset on the long semi-axis (ellipsoid_decomp.h:67)                   */
+    /* outputs = the polytope inputs of frp_nmpc_pack (NPOLY = N)                                                   */
+    double *poly_A;         /* [B][N][F][3]  LinearConstraint3D::A_ of polytope k (rows beyond F are not stored)    */
+    double *poly_b;         /* [B][N][F]                                                                            */
+    int *poly_nfaces;       /* [B][N]        rows of polytope k (may exceed F), 0 for unused polytopes              */
+    int *poly_index;        /* [B][N]        poly_indices(i)                                                        */
+    int *poly_count;        /* [B] or NULL   polytopes made; negated when one had more than F rows, in which case the
+                                             containment test of later stages saw only its first F rows              */
+} frp_nmpc_corridor;
+
+/* For every planner, the getSikangConst calls of NMPCSolver::setFORCESParams (nmpc_solver.cpp:288-332, :515):
+ * stage i keeps the latest polytope while its tube ellipsoid, inflated, fits; otherwise DecompROS'
+ * EllipsoidDecomp3D::dilate is run on the seed segment (decomp_util/line_segment.h:31-35).  Asynchronous on `stream`. */
+int frp_nmpc_corridor_batch(const frp_nmpc_corridor *p, void *stream);
+
 const char *frp_nmpc_version(void);
 int frp_nmpc_device_count(void);
 

@@ -436,3 +436,82 @@ def test_receding_horizon_with_tube_propagation_on_device():
     assert np.array_equal(fd, fg) and (fd == 1).all()
     assert (idv == ig).mean() >= 0.95
     assert np.max(np.abs(md - mg)) < 1e-6
+
+
+# ---- corridor generation / selection (oracle/corridor_oracle.py restates DecompROS in numpy;
+# parity with the reference itself is unpinned -- Eigen is absent) ----
+def _corridor_oracle():
+    import sys
+    sys.path.insert(0, OL.ROOT)
+    from oracle import corridor_oracle
+    return corridor_oracle
+
+
+def _corridor_world(seed, P=6000, B=4, N=20, tunnel=0.6, grid=None):
+    """A cluttered box with a free tunnel along a gently curved path; per-planner references jittered inside it."""
+    rng = np.random.default_rng(seed)
+    cloud = np.c_[rng.uniform(-3, 9, P), rng.uniform(-4, 4, P), rng.uniform(-0.5, 3, P)]
+    if grid:
+        cloud = np.round(cloud / grid) * grid  # voxel-map-like cloud: many coplanar / equidistant points
+    s = np.linspace(0, 5, N)
+    centre = np.c_[s, 0.4 * np.sin(0.8 * s), 1.0 + 0.1 * np.cos(s)]
+    cx = np.interp(cloud[:, 0], centre[:, 0], centre[:, 1]); cz = np.interp(cloud[:, 0], centre[:, 0], centre[:, 2])
+    cloud = cloud[np.hypot(cloud[:, 1] - cx, cloud[:, 2] - cz) > tunnel]
+    ref = centre[None] + rng.normal(0, 0.03, (B, N, 3))
+    yaw = np.arctan2(np.gradient(centre[:, 1]), np.gradient(centre[:, 0]))[None] + rng.normal(0, 0.05, (B, N))
+    T = _tube_oracle()
+    z = np.zeros((B, N, 17)); z[..., 3] = 7.3; z[..., 8:11] = ref; z[..., 16] = yaw
+    z[..., 11:14] = rng.normal(0, 0.5, (B, N, 3)); z[..., 14:16] = rng.normal(0, 0.1, (B, N, 2))
+    E = T.tube_batch(z)
+    return cloud, ref, yaw, E
+
+
+def _check_corridor(cloud, ref, yaw, E, consts=None, F=64, ordered=True):
+    """ordered=False: rows are matched as a set.  After find_ellipsoid has shrunk the seed ellipsoid onto obstacle
+    points, those points all sit at distance 1 +- 1 ulp, and which of them find_polyhedron visits first is decided
+    by rounding (in the reference as much as here); the set of hyperplanes is the same."""
+    C = _corridor_oracle()
+    pi, A, b, nf, cnt = solver.corridor_batch_host(cloud, ref, yaw, E, F=F, consts=consts)
+    kw = consts or {}
+    for p in range(ref.shape[0]):
+        idx, polys = C.corridor_one(ref[p], yaw[p], E[p], cloud, **kw)
+        assert np.array_equal(pi[p], idx), (p, pi[p], idx)
+        assert cnt[p] == len(polys)
+        for k, (Ao, bo) in enumerate(polys):
+            assert nf[p, k] == len(bo), (p, k, nf[p, k], len(bo))
+            G = np.c_[A[p, k, :len(bo)], b[p, k, :len(bo)]]; O = np.c_[Ao, bo]
+            if not ordered:
+                D = np.abs(G[:, None, :] - O[None, :, :]).max(axis=2)
+                match = D.argmin(axis=0)
+                assert sorted(match) == list(range(len(bo))), (p, k, match)
+                G = G[match]
+            assert np.max(np.abs(G - O)) < 1e-9, (p, k)
+        assert np.all(nf[p, len(polys):] == 0)
+    return pi, A, b, nf
+
+
+@pytest.mark.parametrize("seed,P,grid", [(1, 6000, None), (2, 20000, None), (3, 6000, 0.1), (4, 300, None)])
+def test_corridor_matches_oracle(seed, P, grid):
+    cloud, ref, yaw, E = _corridor_world(seed, P=P, grid=grid)
+    pi, A, b, nf = _check_corridor(cloud, ref, yaw, E)
+    assert pi.max() >= 1  # the path leaves the first polytope: reuse AND re-decomposition are exercised
+    # property: no cloud point lies strictly inside any polytope, every reference point lies inside its own
+    for p in range(ref.shape[0]):
+        for k in range(pi[p].max() + 1):
+            m = nf[p, k]
+            assert not np.any(np.all(cloud @ A[p, k, :m].T - b[p, k, :m] < -1e-9, axis=1))
+        for i in range(ref.shape[1]):
+            m = nf[p, pi[p, i]]
+            assert np.all(A[p, pi[p, i], :m] @ ref[p, i] - b[p, pi[p, i], :m] <= 0)
+
+
+def test_corridor_obstacles_inside_the_seed_ellipsoid_and_edge_cases():
+    """Exercises both shrink loops of find_ellipsoid (line_segment.h:156-208) -- only reached when an obstacle lies
+    inside the seed ellipsoid, i.e. with a long seed segment -- plus the empty cloud and a one-stage horizon."""
+    cloud, ref, yaw, E = _corridor_world(7, P=8000, B=3, tunnel=0.25)
+    _check_corridor(cloud, ref, yaw, E, consts=dict(seed_len=1.5, bbox=(2.0, 2.0, 1.0), inflation=1.1), ordered=False)
+    _check_corridor(cloud, ref, yaw, E, consts=dict(seed_len=0.8, bbox=(1.0, 1.5, 0.7), inflation=1.0), ordered=False)
+    # empty cloud: the polytope is the local box, reused for as long as the tube fits
+    pi, A, b, nf = _check_corridor(np.zeros((0, 3)), ref, yaw, E)
+    assert np.all(nf[:, 0] == 6)
+    _check_corridor(cloud, ref[:, :1], yaw[:, :1], E[:, :1])
