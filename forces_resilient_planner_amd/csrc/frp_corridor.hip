@@ -15,15 +15,23 @@
 //
 // Mapping.  One 256-thread workgroup per planner walks the stages in order (a stage reuses the polytope made for an
 // earlier stage while its inflated tube ellipsoid fits, so the stage loop is sequential by definition).  A
-// decomposition is a sequence of scans over the cloud -- "keep the points that ..., and find the one closest to the
-// ellipsoid centre in the ellipsoid's metric" -- where the reference rebuilds std::vectors:
-//   * the point lists are bit masks in LDS, one 64-bit word per 64 consecutive points, produced by wave ballots, so a
-//     scan reads the cloud with coalesced loads, skips words that are already empty, and preserves the reference's
-//     list order; word g is always read and written by the same wave, so the masks need no barrier;
+// decomposition is a sequence of scans -- "keep the points that ..., and find the one closest to the ellipsoid
+// centre in the ellipsoid's metric" -- where the reference rebuilds std::vectors:
+//   * the first scan reads the whole cloud once (CR_UNROLL 64-point words in flight per wave), tests the local box
+//     in the box's own frame, and appends the indices of the in-box points to a dense list in LDS (one LDS atomic
+//     per CR_UNROLL words; the order of the list is irrelevant because minima are tie-broken by cloud index, which
+//     is the reference's first-minimum rule on its order-preserving lists);
+//   * every later scan runs over that list (typically 10 % of the cloud) with all lanes busy; point lists are bit
+//     masks over list positions, one 64-bit word per 64 positions, produced by wave ballots; word g is always read
+//     and written by the same wave, empty words are skipped 64 at a time with a ballot.  Boxes holding more than
+//     CR_LIST points fall back to masks over the cloud itself;
 //   * "filter with the new ellipsoid, then take the closest of what is left" uses the same distances, so both happen
-//     in ONE scan; the minimum is reduced with (distance, index) ordering = the reference's first-minimum rule;
-//   * the 3x3 algebra of an ellipsoid / hyperplane update is done redundantly by every lane (wave-uniform values).
-// HBM/L2-bound: 24 bytes per live point per scan; the cloud is shared by the planners of a fleet and stays in L2.
+//     in ONE scan; the workgroup minimum carries the winner's coordinates (one barrier, double-buffered);
+//   * the 3x3 algebra of an ellipsoid / hyperplane update is wave-uniform: thread 0 does it and publishes the
+//     result through LDS (struct Uni), so it costs the scanning waves no registers.
+// Memory-side work: 24 bytes per cloud point per decomposition, then 24-byte gathers of in-box points from L2 (the
+// cloud is shared by the planners of a fleet).  Measured (profiles/r01_corridor_bench.json): a list scan is ~3 us
+// of latency (leader algebra, LDS, one L2 round trip, one reduction), and a decomposition makes ~20-30 of them.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
