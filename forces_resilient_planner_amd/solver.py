@@ -61,6 +61,15 @@ class Corridor(ctypes.Structure):  # frp_nmpc_corridor (include/frp_nmpc.h)
                 ("poly_index", ctypes.c_void_p), ("poly_count", ctypes.c_void_p)]
 
 
+class Reference(ctypes.Structure):  # frp_nmpc_reference (include/frp_nmpc.h)
+    _fields_ = [("B", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("kino_path", ctypes.c_void_p),
+                ("path_per_planner", ctypes.c_int), ("kino_size", ctypes.c_void_p), ("time_offset", ctypes.c_void_p),
+                ("mpc_output", ctypes.c_void_p), ("Ts", ctypes.c_double), ("pi", ctypes.c_double),
+                ("ref_pos", ctypes.c_void_p), ("ref_yaw", ctypes.c_void_p), ("replan", ctypes.c_void_p)]
+
+
+REFERENCE_PI = 3.1415926  # nmpc_solver.cpp:3
+
 # getSikangConst's constants (nmpc_solver.cpp:302, :318, :323)
 CORRIDOR_DEFAULTS = dict(bbox=(2.0, 2.0, 1.0), seed_len=0.1, inflation=1.1, offset_x=0.0)
 CORRIDOR_MAX_F = 64
@@ -92,7 +101,7 @@ EXPORTS = ["frp_nmpc_default_options", "frp_nmpc_workspace_bytes", "frp_nmpc_sol
            "frp_nmpc_solve_batch_host", "frp_nmpc_stage_eval", "frp_nmpc_stage_eval_host", "frp_nmpc_time_solve",
            "frp_nmpc_version", "frp_nmpc_device_count", "FORCESNLPsolver_normal_solve",
            "FORCESNLPsolver_final_solve", "frp_nmpc_pack_batch", "frp_nmpc_update_batch", "frp_nmpc_tube_batch",
-           "frp_nmpc_corridor_batch"]
+           "frp_nmpc_corridor_batch", "frp_nmpc_reference_batch"]
 
 _lib = None
 
@@ -126,6 +135,7 @@ def lib():
                                             ctypes.c_void_p]
         l.frp_nmpc_tube_batch.argtypes = [ctypes.POINTER(Tube), ctypes.c_void_p]
         l.frp_nmpc_corridor_batch.argtypes = [ctypes.POINTER(Corridor), ctypes.c_void_p]
+        l.frp_nmpc_reference_batch.argtypes = [ctypes.POINTER(Reference), ctypes.c_void_p]
         _lib = l
     return _lib
 
@@ -239,6 +249,39 @@ def tube_batch_device(mpc_output, ellipsoid, consts=None, stream=None):
     _check(lib().frp_nmpc_tube_batch(ctypes.byref(tb), ctypes.c_void_p(s.cuda_stream)), "frp_nmpc_tube_batch")
 
 
+def reference_batch_device(kino_path, time_offset, mpc_output, ref_pos, ref_yaw, replan=None, kino_size=None, Ts=0.05,
+                           stream=None):
+    """frp_nmpc_reference_batch on device tensors: kino_path [K,3] (shared) or [B,K,3]; time_offset [B];
+    mpc_output [B,N+1,17] -> ref_pos [B,N,3], ref_yaw [B,N], replan [B] int32."""
+    import torch
+    B, N, _ = ref_pos.shape
+    per = 1 if kino_path.dim() == 3 else 0
+    K = kino_path.shape[-2]
+    for t in (kino_path, time_offset, mpc_output, ref_pos, ref_yaw):
+        assert t.is_contiguous() and t.dtype == torch.float64
+    assert tuple(mpc_output.shape) == (B, N + 1, L.NZ) and tuple(ref_yaw.shape) == (B, N) and tuple(time_offset.shape) == (B,)
+    s = stream if stream is not None else torch.cuda.current_stream(ref_pos.device)
+    rf = Reference(B, N, K, kino_path.data_ptr(), per, kino_size.data_ptr() if kino_size is not None else None,
+                   time_offset.data_ptr(), mpc_output.data_ptr(), Ts, REFERENCE_PI, ref_pos.data_ptr(), ref_yaw.data_ptr(),
+                   replan.data_ptr() if replan is not None else None)
+    _check(lib().frp_nmpc_reference_batch(ctypes.byref(rf), ctypes.c_void_p(s.cuda_stream)), "frp_nmpc_reference_batch")
+
+
+def reference_batch_host(kino_path, time_offset, mpc_output, kino_size=None, Ts=0.05, device="cuda:0"):
+    """Host convenience: numpy in, (ref_pos [B,N,3], ref_yaw [B,N], replan [B]) out."""
+    import torch
+    lib()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)
+    B, rows, _ = mpc_output.shape
+    N = rows - 1
+    rp = torch.zeros((B, N, 3), dtype=torch.float64, device=device); ry = torch.zeros((B, N), dtype=torch.float64, device=device)
+    fl = torch.zeros((B,), dtype=torch.int32, device=device)
+    ks = None if kino_size is None else torch.from_numpy(np.ascontiguousarray(kino_size, dtype=np.int32)).to(device)
+    reference_batch_device(dev(kino_path), dev(time_offset), dev(mpc_output), rp, ry, fl, ks, Ts)
+    torch.cuda.synchronize(device)
+    return rp.cpu().numpy(), ry.cpu().numpy(), fl.cpu().numpy()
+
+
 def corridor_batch_device(cloud, ref_pos, ref_yaw, ellipsoid, poly_A, poly_b, poly_nfaces, poly_index, poly_count=None,
                           cloud_count=None, consts=None, stream=None):
     """frp_nmpc_corridor_batch on device tensors.  cloud [P,3] (shared) or [B,P,3]; ref_pos [B,N,3]; ref_yaw [B,N];
@@ -350,6 +393,24 @@ class DeviceFleet:
             self.poly_index = t.zeros((self.B, self.N), dtype=t.int32, device=self.solver.device)
         corridor_batch_device(cloud, ref_pos, ref_yaw, self.ellipsoid, self.poly_A, self.poly_b, self.poly_nfaces,
                               self.poly_index, None, cloud_count, consts, stream)
+
+    def references(self, kino_path, time_offset, ref_pos, ref_yaw, replan=None, kino_size=None, Ts=0.05, stream=None):
+        """SURVEY 8f row f-4 (first half): ref_total_pos_ / ref_total_yaw_ of all B planners from the kinodynamic
+        path (getCurTraj + calculate_yaw, nmpc_solver.cpp:109-142, 834-862), on the device."""
+        reference_batch_device(kino_path, time_offset, self.mpc_output, ref_pos, ref_yaw, replan, kino_size, Ts, stream)
+
+    def full_tick(self, external_acc, kino_path, time_offset, cloud, ref_pos, ref_yaw, stream=None, replan=None,
+                  kino_size=None, tube_consts=None, corridor_consts=None, Ts=0.05):
+        """The reference's whole per-tick computation downstream of the A* (NMPCSolver::solveNMPC,
+        nmpc_solver.cpp:351-482) for B planners, asynchronous on `stream`, nothing touching the host:
+        stage references (f-4) -> tube (f-2) -> corridor (f-3) -> parameter packing (f-1) -> NLP solve -> result
+        bookkeeping.  ref_pos [B,N,3] / ref_yaw [B,N] are caller-owned scratch that receives the references."""
+        self.references(kino_path, time_offset, ref_pos, ref_yaw, replan, kino_size, Ts, stream)
+        self.tube(tube_consts, stream)
+        self.corridor(cloud, ref_pos, ref_yaw, corridor_consts, stream)
+        self.pack(external_acc, ref_pos, ref_yaw, stream)
+        self.solver.solve(stream)
+        self.update(stream)
 
     def tick(self, external_acc, ref_pos, ref_yaw, stream=None, tube_consts=None, propagate_tube=False):
         """One receding-horizon tick of all B planners, asynchronous on `stream`.  With propagate_tube the

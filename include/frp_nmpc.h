@@ -201,6 +201,26 @@ typedef struct frp_nmpc_corridor {
  * EllipsoidDecomp3D::dilate is run on the seed segment (decomp_util/line_segment.h:31-35).  Asynchronous on `stream`. */
 int frp_nmpc_corridor_batch(const frp_nmpc_corridor *p, void *stream);
 
+/* ---- (6) SURVEY 8f row f-4 (first half): stage references from the kinodynamic path, on the device ---- */
+typedef struct frp_nmpc_reference {
+    int B, N, K;               /* planners, horizon, samples stored per path                                        */
+    const double *kino_path;   /* [K][3] shared, or [B][K][3] when path_per_planner != 0: kino_path_ =
+                                  KinodynamicAstar::getKinoTraj(Ts_) (nmpc_solver.cpp:215)                           */
+    int path_per_planner;
+    const int *kino_size;      /* kino_size_ (<= K) per path, [1] or [B]; NULL: K                                   */
+    const double *time_offset; /* [B] (mpc_start_time_ - kino_start_time_).toSec() (:111)                           */
+    const double *mpc_output;  /* [B][N+1][17] plan deque: row 1 seeds last_yaw_ (:486) and the replan test (:136)  */
+    double Ts;                 /* nmpc_utils.h:189                                                                  */
+    double pi;                 /* the file's own constant, 3.1415926 (nmpc_solver.cpp:3)                            */
+    double *ref_pos;           /* [B][N][3] out: ref_total_pos_                                                     */
+    double *ref_yaw;           /* [B][N]    out: ref_total_yaw_                                                     */
+    int *replan;               /* [B] out or NULL: kino_replan_ raised by stage 0 (:136-140)                        */
+} frp_nmpc_reference;
+
+/* NMPCSolver::getCurTraj (nmpc_solver.cpp:109-142) + calculate_yaw (:834-862) for all stages of B planners.
+ * Asynchronous on `stream`. */
+int frp_nmpc_reference_batch(const frp_nmpc_reference *p, void *stream);
+
 const char *frp_nmpc_version(void);
 int frp_nmpc_device_count(void);
 

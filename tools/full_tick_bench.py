@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""The reference's whole per-tick computation downstream of the A* for a fleet, on one GPU, nothing on the host:
+stage references (f-4) -> tube (f-2) -> corridor (f-3) -> packing (f-1) -> NLP solve -> bookkeeping
+(DeviceFleet.full_tick).  Prints ms per step of the chain (HIP events on the launch stream) and planner-ticks/s.
+   python tools/full_tick_bench.py [B=4096] [ticks=10] [P=20000]"""
+import json
+import sys
+import numpy as np
+sys.path.insert(0, '.')
+import torch
+from forces_resilient_planner_amd import layout as L
+from forces_resilient_planner_amd import solver
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+TICKS = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+P = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
+N, M, F, K = 20, 30, 64, 120
+rng = np.random.default_rng(0)
+s = np.arange(K) * 0.05 * 1.6
+path = np.c_[s, 0.4 * np.sin(0.8 * s), 1.0 + 0.1 * np.cos(s)]
+cloud = np.c_[rng.uniform(-3, 12, P), rng.uniform(-4, 4, P), rng.uniform(-0.5, 3, P)]
+cx = np.interp(cloud[:, 0], path[:, 0], path[:, 1]); cz = np.interp(cloud[:, 0], path[:, 0], path[:, 2])
+cloud = cloud[np.hypot(cloud[:, 1] - cx, cloud[:, 2] - cz) > 0.9]
+plan = np.zeros((B, N + 1, 17)); plan[..., 3] = 7.3; plan[..., 7] = 7.3
+plan[..., 8:11] = path[0] + rng.normal(0, 0.02, (B, 1, 3)); plan[..., 16] = 0.2
+fleet = solver.DeviceFleet(B, N, M, F, L.MODEL_NORMAL, (15.0, 3.0, 80.0, 15.0, 0.0))
+fleet.mpc_output.copy_(fleet.to_device(plan))
+d_path, d_cloud = fleet.to_device(path), fleet.to_device(cloud)
+d_f = fleet.to_device(rng.normal(0, 0.5, (B, 3)))
+rp = torch.zeros((B, N, 3), dtype=torch.float64, device="cuda:0"); ry = torch.zeros((B, N), dtype=torch.float64, device="cuda:0")
+offs = [fleet.to_device(np.full(B, 0.05 * t) + rng.uniform(0, 0.01, B)) for t in range(TICKS + 1)]
+steps = [("reference", lambda t: fleet.references(d_path, offs[t], rp, ry)), ("tube", lambda t: fleet.tube()),
+         ("corridor", lambda t: fleet.corridor(d_cloud, rp, ry)), ("pack", lambda t: fleet.pack(d_f, rp, ry)),
+         ("solve", lambda t: fleet.solver.solve()), ("update", lambda t: fleet.update())]
+for _, fn in steps:  # warm-up tick
+    fn(0)
+torch.cuda.synchronize()
+ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(steps) + 1)] for _ in range(TICKS)]
+flags, iters = [], []
+for t in range(TICKS):
+    ev[t][0].record()
+    for k, (_, fn) in enumerate(steps):
+        fn(t + 1)
+        ev[t][k + 1].record()
+    flags.append(fleet.solver.exitflag.clone()); iters.append(fleet.solver.iters.clone())
+torch.cuda.synchronize()
+ms = {name: float(np.mean([ev[t][k].elapsed_time(ev[t][k + 1]) for t in range(TICKS)])) for k, (name, _) in enumerate(steps)}
+total = float(np.mean([ev[t][0].elapsed_time(ev[t][-1]) for t in range(TICKS)]))
+fl = torch.stack(flags).cpu().numpy(); it = torch.stack(iters).cpu().numpy()
+print(json.dumps({"workload": f"{B} planners x {TICKS} ticks, N=20, shared cloud of {len(cloud)} points, shared kinodynamic path",
+                  "ms_per_tick": total, "planner_ticks_per_s": B / total * 1e3, "ms_per_step": ms,
+                  "converged_frac": float((fl == 1).mean()), "mean_iters": float(it.mean()),
+                  "polytopes_per_planner": float((fleet.poly_nfaces > 0).sum().item() / B)}))
