@@ -170,3 +170,57 @@ def test_tube_oracle_is_self_consistent():
     assert np.linalg.eigvalsh(E).min() > 0 and np.max(np.abs(E - np.swapaxes(E, -1, -2))) < 1e-13
     # stage 0 is the bare ego ellipsoid (nmpc_solver.cpp:503-506)
     assert np.max(np.abs(np.linalg.eigvalsh(E[0]) - np.array([c["ego_h"], c["ego_r"], c["ego_r"]]))) < 1e-13
+
+
+def test_corridor_oracle_properties():
+    """Row f-3's oracle (oracle/corridor_oracle.py, parity unpinned): what the reference's algorithm guarantees by
+    construction must hold -- no obstacle strictly inside a polytope, the seed inside, the local box always present,
+    a polytope reused exactly while the inflated tube ellipsoid fits (nmpc_solver.cpp:291-313)."""
+    import sys
+    sys.path.insert(0, OL.ROOT)
+    from oracle import corridor_oracle as C
+    rng = np.random.default_rng(3)
+    cloud = np.c_[rng.uniform(-3, 8, 3000), rng.uniform(-4, 4, 3000), rng.uniform(-0.5, 3, 3000)]
+    cloud = cloud[np.hypot(cloud[:, 1], cloud[:, 2] - 1.0) > 0.6]
+    N = 20
+    ref = np.c_[np.linspace(0, 4, N), 0.1 * np.sin(np.linspace(0, 3, N)), np.ones(N)]
+    yaw = np.full(N, 0.1)
+    E = np.tile(np.diag([0.27, 0.27, 0.05]), (N, 1, 1))
+    idx, polys = C.corridor_one(ref, yaw, E, cloud)
+    assert idx[0] == 0 and np.all(np.diff(idx) >= 0) and np.all(np.diff(idx) <= 1) and idx[-1] == len(polys) - 1 >= 1
+    for k, (A, b) in enumerate(polys):
+        assert not np.any(np.all(cloud @ A.T - b < -1e-9, axis=1))
+        assert np.max(np.abs(np.linalg.norm(A, axis=1) - 1)) < 1e-12
+        first = int(np.argmax(idx == k))
+        assert np.all(A @ ref[first] - b < 0)                     # the seed point is inside
+        assert len(b) >= 6                                        # six local-box rows close every polytope
+    for i in range(1, N):
+        A, b = polys[idx[i - 1]] if idx[i] == idx[i - 1] else polys[idx[i] - 1]
+        fits = np.all(A @ ref[i] - (b - 1.1 * np.linalg.norm(A @ E[i].T, axis=1)) <= 0)
+        assert fits == (idx[i] == idx[i - 1])
+    # an obstacle inside the seed ellipsoid shrinks it: the ellipsoid ends up touching, not containing, the obstacle
+    p1, p2 = np.array([0.0, 0, 1]), np.array([1.5, 0, 1])
+    obs = np.array([[0.7, 0.3, 1.1], [0.9, -0.2, 0.8], [0.2, 0.1, 1.4]])
+    Cm, d = C.find_ellipsoid(p1, p2, obs)
+    dist = np.linalg.norm((obs - d) @ np.linalg.inv(Cm).T, axis=1)
+    assert dist.min() > 1 - 1e-9 and np.isclose(dist, 1, atol=1e-9).any()
+
+
+def test_reference_oracle_known_answers():
+    """Row f-4's oracle: straight path along +y sampled at the stage times; the yaw filter converges geometrically
+    (0.2 / 0.8 weights, nmpc_solver.cpp:858) from the plan's stage-1 yaw towards pi/2; stage 0 raises the replan flag
+    only when it is more than 1 m from the plan (:136)."""
+    import sys
+    sys.path.insert(0, OL.ROOT)
+    from oracle import reference_oracle as R
+    K, N = 60, 20
+    path = np.c_[np.zeros(K), 0.1 * np.arange(K), np.ones(K)]
+    plan = np.zeros((N + 1, 17)); plan[1, 8:11] = [0.0, 0.3, 1.0]; plan[1, 16] = 0.0
+    pos, yaw, replan = R.references_one(path, K, 0.125, plan, N)
+    assert np.allclose(pos[:, 1], 0.1 * (0.125 / 0.05 + np.arange(N)), atol=1e-12) and not replan
+    assert np.allclose(yaw, np.arctan2(1, 0) * (1 - 0.2 ** np.arange(1, N + 1)), atol=1e-12)
+    plan[1, 8:11] = [1.5, 0.3, 1.0]
+    assert R.references_one(path, K, 0.125, plan, N)[2]
+    # past the end of the path: last sample, direction shorter than 0.1 m -> the yaw is held by the filter
+    pos, yaw, _ = R.references_one(path, K, 0.05 * (K + 3), plan, N)
+    assert np.all(pos == path[-1]) and np.allclose(yaw, 0.0)
