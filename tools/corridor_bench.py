@@ -7,7 +7,8 @@ import json
 import sys
 import time
 import numpy as np
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from forces_resilient_planner_amd import solver
 from oracle import corridor_oracle as C, tube_oracle as T   # CPU-baseline leg only

@@ -6,7 +6,8 @@ import json
 import sys
 import time
 import numpy as np
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from forces_resilient_planner_amd import layout as L
 from forces_resilient_planner_amd import solver
