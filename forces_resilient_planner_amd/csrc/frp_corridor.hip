@@ -30,8 +30,8 @@
 //   * the 3x3 algebra of an ellipsoid / hyperplane update is wave-uniform: thread 0 does it and publishes the
 //     result through LDS (struct Uni), so it costs the scanning waves no registers.
 // Memory-side work: 24 bytes per cloud point per decomposition, then 24-byte gathers of in-box points from L2 (the
-// cloud is shared by the planners of a fleet).  Measured (profiles/r01_corridor_bench.json): a list scan is ~3 us
-// of latency (leader algebra, LDS, one L2 round trip, one reduction), and a decomposition makes ~20-30 of them.
+// cloud is shared by the planners of a fleet); lists of up to CR_TILE * 256 points live in registers (scan_tile).
+// Measured (profiles/r01_corridor_bench.json): full-cloud scan 32 us, then ~20-30 scans of ~1.9 us per decomposition.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -39,7 +39,7 @@
 
 namespace frp {
 
-constexpr int CR_THREADS = 256, CR_WAVES = 4, CR_UNROLL = 8, CR_BATCH = 4;
+constexpr int CR_THREADS = 256, CR_WAVES = 4, CR_UNROLL = 4, CR_BATCH = 2;
 constexpr double CR_EPS = 1e-10; // epsilon_, data_type.h:129
 
 struct M3 { double m[9]; };
@@ -96,31 +96,55 @@ __device__ __forceinline__ void tmul(const M3 &R, const double v[3], double o[3]
 #pragma unroll
     for (int j = 0; j < 3; ++j) o[j] = R.m[j] * v[0] + R.m[3 + j] * v[1] + R.m[6 + j] * v[2];
 }
-// Ellipsoid::dist (ellipsoid.h:19-21) with C^-1 precomputed
-__device__ __forceinline__ double ell_dist(const M3 &Ci, const double d[3], double x, double y, double z)
+// Ellipsoid::dist (ellipsoid.h:19-21), squared, with C^-1 precomputed.  The scans are FP64-VALU-bound and a square
+// root is half of their arithmetic, so it is taken only where the reference's threshold needs it (1 - dist >
+// epsilon_); "dist <= 1" and the ordering of distances are the same on the squares.
+__device__ __forceinline__ double ell_dist2(const M3 &Ci, const double d[3], double x, double y, double z)
 {
     const double u = x - d[0], v = y - d[1], w = z - d[2];
     const double a = Ci.m[0] * u + Ci.m[1] * v + Ci.m[2] * w, b = Ci.m[3] * u + Ci.m[4] * v + Ci.m[5] * w,
                  c = Ci.m[6] * u + Ci.m[7] * v + Ci.m[8] * w;
-    return sqrt(a * a + b * b + c * c);
+    return a * a + b * b + c * c;
 }
 
-struct Best { double dist; int idx; double x, y, z; }; // candidate closest point: metric distance, cloud index, coordinates
+struct Best { double dist; int idx; double x, y, z; }; // candidate closest point: SQUARED metric distance, cloud index, coordinates
 
 __device__ __forceinline__ bool before(double da, int ia, double db, int ib) { return da < db || (da == db && ia < ib); }
+
+// Wave minima on the DPP network (quad_perm, row_half_mirror, row_mirror, then v_readlane across the four rows):
+// a ds_bpermute butterfly costs an LDS round trip per step, and this reduction runs once per scan.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const int lo = dpp_i32<CTRL>((int)(unsigned)b), hi = dpp_i32<CTRL>((int)(unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+    v = fmin(v, dpp_f64<0xB1>(v)); v = fmin(v, dpp_f64<0x4E>(v)); v = fmin(v, dpp_f64<0x141>(v)); v = fmin(v, dpp_f64<0x140>(v));
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    double r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        r[k] = __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 16 * k) << 32) |
+                                                (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 16 * k)));
+    return fmin(fmin(r[0], r[1]), fmin(r[2], r[3]));
+}
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+    v = min(v, dpp_i32<0xB1>(v)); v = min(v, dpp_i32<0x4E>(v)); v = min(v, dpp_i32<0x141>(v)); v = min(v, dpp_i32<0x140>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
 
 // minimum over the workgroup in (distance, index) order; idx = INT_MAX when no point was alive.  The winner's
 // coordinates travel with it, so nobody has to fetch the point again.  s_red is double-buffered by `phase`: one barrier.
 __device__ Best block_min(const Best &mine, Best *s_red, int &phase)
 {
-    double d = mine.dist;
-    int i = mine.idx;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double od = __shfl_xor(d, off);
-        const int oi = __shfl_xor(i, off);
-        if (before(od, oi, d, i)) { d = od; i = oi; }
-    }
+    const double d = wave_min_f64(mine.dist);
+    const int i = wave_min_i32(mine.dist == d ? mine.idx : 0x7fffffff);
     Best *buf = s_red + phase * CR_WAVES;
     phase ^= 1;
     const int lane = threadIdx.x & 63;
@@ -139,6 +163,7 @@ struct Scan {             // what a scan iterates over
     int Pn, W;            // positions, 64-position words
 };
 
+constexpr int CR_TILE = 8;    // 64-position words per wave held in registers (CR_TILE * CR_THREADS points per planner)
 constexpr int CR_LIST = 8192; // capacity of the in-box index list (LDS); larger boxes fall back to cloud positions
 
 // Wave-uniform state of the running decomposition.  It lives in LDS and is advanced by thread 0 only, so the 3x3
@@ -155,6 +180,10 @@ struct Uni {
 __device__ __forceinline__ M3 ld3(const double *p) { M3 r; for (int k = 0; k < 9; ++k) r.m[k] = p[k]; return r; }
 __device__ __forceinline__ void st3(double *p, const M3 &a) { for (int k = 0; k < 9; ++k) p[k] = a.m[k]; }
 
+#ifdef FRP_CORRIDOR_PROFILE
+__device__ long long g_prof[2];
+#endif
+
 enum { KEEP_OUTSIDE = 0, KEEP_INSIDE = 1, KEEP_ALL = 2, KEEP_BEHIND_PLANE = 3 };
 
 // One pass: out = { points of `in` that satisfy MODE }, returns the kept point closest to the centre in the metric
@@ -163,6 +192,9 @@ template <int MODE>
 __device__ __forceinline__ Best scan(const Scan &s, const uint64_t *in, uint64_t *out, const Uni &u, Best *s_red, int &phase)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef FRP_CORRIDOR_PROFILE
+    long long ts0 = wall_clock64();
+#endif
     const M3 Ci = ld3(u.Ci);
     const double d[3] = {u.mid[0], u.mid[1], u.mid[2]};
     double q[3] = {0, 0, 0}, n[3] = {0, 0, 0};
@@ -204,8 +236,8 @@ __device__ __forceinline__ Best scan(const Scan &s, const uint64_t *in, uint64_t
                 if (gs[k] < 0) break;
                 bool alive = al[k];
                 if (alive) {
-                    const double dist = ell_dist(Ci, d, x[k], y[k], z[k]);
-                    if (MODE == KEEP_OUTSIDE) alive = 1 - dist > CR_EPS;
+                    const double dist = ell_dist2(Ci, d, x[k], y[k], z[k]); // squared: same order, same "<= 1"
+                    if (MODE == KEEP_OUTSIDE) alive = 1 - sqrt(dist) > CR_EPS;
                     if (MODE == KEEP_INSIDE) alive = dist <= 1;
                     if (MODE == KEEP_BEHIND_PLANE) alive = n[0] * (x[k] - q[0]) + n[1] * (y[k] - q[1]) + n[2] * (z[k] - q[2]) < 0;
                     if (alive && before(dist, id[k], best.dist, best.idx)) best = Best{dist, id[k], x[k], y[k], z[k]};
@@ -214,6 +246,52 @@ __device__ __forceinline__ Best scan(const Scan &s, const uint64_t *in, uint64_t
                 if (lane == 0) out[gs[k]] = o;
             }
         }
+    }
+#ifdef FRP_CORRIDOR_PROFILE
+    long long ts1 = wall_clock64();
+    Best r_ = block_min(best, s_red, phase);
+    if (threadIdx.x == 0) { g_prof[0] += ts1 - ts0; g_prof[1] += wall_clock64() - ts1; }
+    return r_;
+#else
+    return block_min(best, s_red, phase);
+#endif
+}
+
+// The same pass when the whole list fits the wave's REGISTER TILE: up to CR_TILE words per wave (CR_TILE * 256 points
+// per workgroup), whose coordinates and cloud indices were loaded once after the first scan and stay in VGPRs for
+// the 20-30 scans of the decomposition -- no memory traffic at all besides the mask words.
+struct Tile { double x[CR_TILE], y[CR_TILE], z[CR_TILE]; int id[CR_TILE]; };
+
+template <int MODE>
+__device__ __forceinline__ Best scan_tile(const Tile &t, int W, const uint64_t *in, uint64_t *out, const Uni &u, Best *s_red, int &phase)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const M3 Ci = ld3(u.Ci);
+    const double d[3] = {u.mid[0], u.mid[1], u.mid[2]};
+    double q[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+    if (MODE == KEEP_BEHIND_PLANE) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { q[k] = u.q[k]; n[k] = u.n[k]; }
+    }
+    uint64_t w[CR_TILE];
+#pragma unroll
+    for (int j = 0; j < CR_TILE; ++j) { const int g = wave + j * CR_WAVES; w[j] = g < W ? in[g] : 0; }
+    Best best{1.7976931348623157e308, 0x7fffffff, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < CR_TILE; ++j) {
+        const int g = wave + j * CR_WAVES;
+        if (g >= W) break;
+        if (w[j] == 0) { if (out != in && lane == 0) out[g] = 0; continue; }
+        bool alive = (w[j] >> lane) & 1;
+        if (alive) {
+            const double dist = ell_dist2(Ci, d, t.x[j], t.y[j], t.z[j]);
+            if (MODE == KEEP_OUTSIDE) alive = 1 - sqrt(dist) > CR_EPS;
+            if (MODE == KEEP_INSIDE) alive = dist <= 1;
+            if (MODE == KEEP_BEHIND_PLANE) alive = n[0] * (t.x[j] - q[0]) + n[1] * (t.y[j] - q[1]) + n[2] * (t.z[j] - q[2]) < 0;
+            if (alive && before(dist, t.id[j], best.dist, best.idx)) best = Best{dist, t.id[j], t.x[j], t.y[j], t.z[j]};
+        }
+        const uint64_t o = __ballot(alive);
+        if (lane == 0) out[g] = o;
     }
     return block_min(best, s_red, phase);
 }
@@ -260,7 +338,7 @@ __device__ __forceinline__ Best scan_cloud(const Scan &s, uint64_t *m0, uint64_t
                 in0 = in0 && !(h > bh) && !(-h > bh) && !(t > bd_hi) && !(t < bd_lo) && !(v > bv) && !(-v > bv);
             }
             if (in0) {
-                const double dist = ell_dist(Ci, d, x[k], y[k], z[k]);
+                const double dist = ell_dist2(Ci, d, x[k], y[k], z[k]);
                 i1[k] = dist <= 1;
                 if (i1[k] && dist < best.dist) best = Best{dist, idx, x[k], y[k], z[k]};
             }
@@ -408,6 +486,17 @@ __global__ __launch_bounds__(CR_THREADS) void corridor_kernel(frp_nmpc_corridor 
                 if ((tid & 63) == 0) { m0[g] = w0; m1[g] = w1; m2[g] = w1; }
             }
         }
+        const bool tiled = u.count <= CR_TILE * CR_THREADS;
+        Tile tile;
+#pragma unroll
+        for (int j = 0; j < CR_TILE; ++j) {
+            const int pos = ((tid >> 6) + j * CR_WAVES) * 64 + (tid & 63);
+            const bool valid = tiled && pos < sc.Pn;
+            tile.id[j] = valid ? (int)(list[pos] & 0x7fffffffu) : 0;
+            tile.x[j] = valid ? sc.pts[3 * (size_t)tile.id[j]] : 0.0;
+            tile.y[j] = valid ? sc.pts[3 * (size_t)tile.id[j] + 1] : 0.0;
+            tile.z[j] = valid ? sc.pts[3 * (size_t)tile.id[j] + 2] : 0.0;
+        }
         CR_ACC(tp_cloud)
         // shrink the second axis until no obstacle is inside (line_segment.h:156-181)
         while (cp.idx != 0x7fffffff) {
@@ -425,14 +514,14 @@ __global__ __launch_bounds__(CR_THREADS) void corridor_kernel(frp_nmpc_corridor 
             }
             __syncthreads();
             CR_ACC(tp_lead)
-            cp = scan<KEEP_OUTSIDE>(sc, m2, m2, u, s_red, phase);
+            cp = tiled ? scan_tile<KEEP_OUTSIDE>(tile, sc.W, m2, m2, u, s_red, phase) : scan<KEEP_OUTSIDE>(sc, m2, m2, u, s_red, phase);
             CR_ACC(tp_scan) CR_CNT(np_scan)
         }
         // third axis (line_segment.h:183-208)
         if (tid == 0) st3(u.Ci, inverse(rot_diag_rot(ld3(u.Rf), u.ax[0], u.ax[1], u.ax[2])));
         __syncthreads();
         CR_ACC(tp_lead)
-        cp = scan<KEEP_INSIDE>(sc, m1, m2, u, s_red, phase);
+        cp = tiled ? scan_tile<KEEP_INSIDE>(tile, sc.W, m1, m2, u, s_red, phase) : scan<KEEP_INSIDE>(sc, m1, m2, u, s_red, phase);
         CR_ACC(tp_scan) CR_CNT(np_scan)
         while (cp.idx != 0x7fffffff) {
             if (tid == 0) {
@@ -446,7 +535,7 @@ __global__ __launch_bounds__(CR_THREADS) void corridor_kernel(frp_nmpc_corridor 
             }
             __syncthreads();
             CR_ACC(tp_lead)
-            cp = scan<KEEP_OUTSIDE>(sc, m2, m2, u, s_red, phase);
+            cp = tiled ? scan_tile<KEEP_OUTSIDE>(tile, sc.W, m2, m2, u, s_red, phase) : scan<KEEP_OUTSIDE>(sc, m2, m2, u, s_red, phase);
             CR_ACC(tp_scan) CR_CNT(np_scan)
         }
         // hyperplanes (decomp_base.h:63-83) + LinearConstraint rows (polyhedron.h:98-118)
@@ -457,7 +546,7 @@ __global__ __launch_bounds__(CR_THREADS) void corridor_kernel(frp_nmpc_corridor 
             u.rows = 0;
         }
         CR_ACC(tp_lead)
-        cp = scan<KEEP_ALL>(sc, m0, m2, u, s_red, phase); // Ci is unchanged since the last barrier
+        cp = tiled ? scan_tile<KEEP_ALL>(tile, sc.W, m0, m2, u, s_red, phase) : scan<KEEP_ALL>(sc, m0, m2, u, s_red, phase); // Ci is unchanged since the last barrier
         CR_ACC(tp_scan) CR_CNT(np_scan)
         while (cp.idx != 0x7fffffff) {
             if (tid == 0) {
@@ -473,7 +562,7 @@ __global__ __launch_bounds__(CR_THREADS) void corridor_kernel(frp_nmpc_corridor 
             }
             __syncthreads();
             CR_ACC(tp_lead)
-            cp = scan<KEEP_BEHIND_PLANE>(sc, m2, m2, u, s_red, phase);
+            cp = tiled ? scan_tile<KEEP_BEHIND_PLANE>(tile, sc.W, m2, m2, u, s_red, phase) : scan<KEEP_BEHIND_PLANE>(sc, m2, m2, u, s_red, phase);
             CR_ACC(tp_scan) CR_CNT(np_scan)
         }
         if (tid == 0) {
@@ -488,9 +577,11 @@ __global__ __launch_bounds__(CR_THREADS) void corridor_kernel(frp_nmpc_corridor 
         ++npoly;
     }
 #ifdef FRP_CORRIDOR_PROFILE
-    if (tid == 0 && (b == 0 || b == 1000))
+    if (tid == 0 && (b == 0 || b == 1000)) {
+        printf("scan body %lld reduce %lld (all WGs thread 0)\n", g_prof[0], g_prof[1]);
         printf("corridor wg %d: total %lld check %lld init %lld cloud %lld lead %lld scan %lld (%d scans) emit %lld [100 MHz ticks], %d polytopes\n", b,
                wall_clock64() - tp_begin, tp_check, tp_init, tp_cloud, tp_lead, tp_scan, np_scan, tp_emit, npoly);
+    }
 #endif
     if (tid == 0) {
         for (int k = npoly; k < c.N; ++k) c.poly_nfaces[(size_t)b * c.N + k] = 0;
