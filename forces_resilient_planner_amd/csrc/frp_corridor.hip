@@ -412,6 +412,9 @@ __global__ __launch_bounds__(CR_THREADS) void corridor_kernel(frp_nmpc_corridor 
     const double *ref = c.ref_pos + (size_t)b * c.N * 3, *yaw = c.ref_yaw + (size_t)b * c.N, *Eb = c.ellipsoid + (size_t)b * c.N * 9;
     const bool has_box = c.bbox[0] != 0.0 || c.bbox[1] != 0.0 || c.bbox[2] != 0.0;
     int npoly = 0, rows = 0; // rows = stored rows of the last polytope (s_A / s_b)
+    // Every round of the reference's while-loops removes at least the closest point, so a list is exhausted after at
+    // most Pn rounds; the bound only matters for non-finite input, where the reference would spin forever.
+    const int max_rounds = sc.Pn + 8;
     if (tid == 0) u.overflow = 0;
 
     for (int i = 0; i < c.N; ++i) {
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(CR_THREADS) void corridor_kernel(frp_nmpc_corridor 
         }
         CR_ACC(tp_cloud)
         // shrink the second axis until no obstacle is inside (line_segment.h:156-181)
-        while (cp.idx != 0x7fffffff) {
+        for (int guard = 0; cp.idx != 0x7fffffff && guard < max_rounds; ++guard) {
             if (tid == 0) {
                 const double pw[3] = {cp.x - u.mid[0], cp.y - u.mid[1], cp.z - u.mid[2]};
                 const M3 Ri = ld3(u.Ri);
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(CR_THREADS) void corridor_kernel(frp_nmpc_corridor 
         CR_ACC(tp_lead)
         cp = tiled ? scan_tile<KEEP_INSIDE>(tile, sc.W, m1, m2, u, s_red, phase) : scan<KEEP_INSIDE>(sc, m1, m2, u, s_red, phase);
         CR_ACC(tp_scan) CR_CNT(np_scan)
-        while (cp.idx != 0x7fffffff) {
+        for (int guard = 0; cp.idx != 0x7fffffff && guard < max_rounds; ++guard) {
             if (tid == 0) {
                 const double pw[3] = {cp.x - u.mid[0], cp.y - u.mid[1], cp.z - u.mid[2]};
                 const M3 Rf = ld3(u.Rf);
@@ -548,7 +551,7 @@ __global__ __launch_bounds__(CR_THREADS) void corridor_kernel(frp_nmpc_corridor 
         CR_ACC(tp_lead)
         cp = tiled ? scan_tile<KEEP_ALL>(tile, sc.W, m0, m2, u, s_red, phase) : scan<KEEP_ALL>(sc, m0, m2, u, s_red, phase); // Ci is unchanged since the last barrier
         CR_ACC(tp_scan) CR_CNT(np_scan)
-        while (cp.idx != 0x7fffffff) {
+        for (int guard = 0; cp.idx != 0x7fffffff && guard < max_rounds; ++guard) {
             if (tid == 0) {
                 const double q[3] = {cp.x, cp.y, cp.z};
                 const double w[3] = {q[0] - u.mid[0], q[1] - u.mid[1], q[2] - u.mid[2]};

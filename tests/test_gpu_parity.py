@@ -612,3 +612,20 @@ def test_full_tick_on_device_matches_the_chain_of_oracles():
         upd = plan.copy(); ad.update(upd); plan = update_forces_results(upd)
         assert np.max(np.abs(fleet.mpc_output.cpu().numpy() - plan)) < 1e-6
         plan = fleet.mpc_output.cpu().numpy().copy()
+
+
+def test_corridor_terminates_on_non_finite_and_degenerate_input():
+    """NaN / inf coordinates, an obstacle exactly at the seed centre and a NaN reference must not hang the kernel
+    (the reference's while-loops would spin on such input); finite planners in the same launch are unaffected."""
+    cloud, ref, yaw, E = _corridor_world(11, P=500, B=4)
+    good = solver.corridor_batch_host(cloud, ref, yaw, E)
+    bad_cloud = cloud.copy()
+    bad_cloud[3] = np.nan; bad_cloud[7] = np.inf
+    bad_cloud[11] = ref[0, 0] + np.array([0.05 * np.cos(yaw[0, 0]), 0.05 * np.sin(yaw[0, 0]), 0.0])  # the seed centre itself
+    ref2 = ref.copy(); ref2[1, 5] = np.nan
+    pi, A, b, nf, cnt = solver.corridor_batch_host(bad_cloud, ref2, yaw, E)
+    assert pi.shape == good[0].shape and np.all(np.abs(cnt) >= 1)
+    # planners 2 and 3 never see the poisoned points' effects differently from the oracle's rules: still valid polytopes
+    for p in (2, 3):
+        for k in range(abs(int(cnt[p]))):
+            assert nf[p, k] >= 6
