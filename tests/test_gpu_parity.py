@@ -447,7 +447,7 @@ def _corridor_oracle():
     return corridor_oracle
 
 
-def _corridor_world(seed, P=6000, B=4, N=20, tunnel=0.6, grid=None):
+def _corridor_world(seed, P=6000, B=4, N=20, tunnel=0.6, grid=None, gpu_tube=False):
     """A cluttered box with a free tunnel along a gently curved path; per-planner references jittered inside it."""
     rng = np.random.default_rng(seed)
     cloud = np.c_[rng.uniform(-3, 9, P), rng.uniform(-4, 4, P), rng.uniform(-0.5, 3, P)]
@@ -462,7 +462,7 @@ def _corridor_world(seed, P=6000, B=4, N=20, tunnel=0.6, grid=None):
     T = _tube_oracle()
     z = np.zeros((B, N, 17)); z[..., 3] = 7.3; z[..., 8:11] = ref; z[..., 16] = yaw
     z[..., 11:14] = rng.normal(0, 0.5, (B, N, 3)); z[..., 14:16] = rng.normal(0, 0.1, (B, N, 2))
-    E = T.tube_batch(z)
+    E = solver.tube_batch_host(z) if gpu_tube else T.tube_batch(z)
     return cloud, ref, yaw, E
 
 
@@ -629,3 +629,36 @@ def test_corridor_terminates_on_non_finite_and_degenerate_input():
     for p in (2, 3):
         for k in range(abs(int(cnt[p]))):
             assert nf[p, k] >= 6
+
+
+def test_corridor_full_size_properties():
+    """B = 4096 planners on a 20 k-point cloud (the fleet size of BASELINE configs[2]/[4]): size-independent
+    properties of every polytope, checked on the device with torch -- no obstacle strictly inside, unit normals,
+    every stage's reference inside the polytope it was assigned, indices non-decreasing by at most one."""
+    import torch
+    cloud, ref, yaw, E = _corridor_world(5, P=20000, B=4096, gpu_tube=True)
+    dev = "cuda:0"
+    t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
+    B, N, F = ref.shape[0], ref.shape[1], 64
+    A = torch.zeros((B, N, F, 3), dtype=torch.float64, device=dev); b = torch.zeros((B, N, F), dtype=torch.float64, device=dev)
+    nf = torch.zeros((B, N), dtype=torch.int32, device=dev); pi = torch.zeros((B, N), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+    d_cloud, d_ref = t(cloud), t(ref)
+    solver.corridor_batch_device(d_cloud, d_ref, t(yaw), t(E), A, b, nf, pi, cnt)
+    torch.cuda.synchronize()
+    assert int((cnt <= 0).sum()) == 0 and int(nf.max()) <= F
+    live = torch.arange(F, device=dev)[None, None, :] < nf[:, :, None]
+    assert float(((A.norm(dim=-1) - 1).abs() * live).max()) < 1e-12
+    d = torch.diff(pi, dim=1)
+    assert int(pi[:, 0].abs().max()) == 0 and int(d.min()) >= 0 and int(d.max()) <= 1 and torch.equal(pi[:, -1] + 1, cnt)
+    # reference of stage i inside polytope pi[i]
+    Ai = torch.gather(A, 1, pi.long()[:, :, None, None].expand(-1, -1, F, 3)); bi = torch.gather(b, 1, pi.long()[:, :, None].expand(-1, -1, F))
+    li = torch.gather(live, 1, pi.long()[:, :, None].expand(-1, -1, F))
+    viol = (torch.einsum("bnfk,bnk->bnf", Ai, d_ref) - bi > 0) & li
+    assert int(viol.sum()) == 0
+    # no cloud point strictly inside any polytope (a sample of planners, all their polytopes)
+    for p0 in range(0, B, 256):
+        Ap, bp, lp = A[p0], b[p0], live[p0]                                  # [N,F,3], [N,F], [N,F]
+        sd = torch.einsum("nfk,pk->npf", Ap, d_cloud) - bp[:, None, :]       # [N,P,F]
+        inside = ((sd < -1e-9) | ~lp[:, None, :]).all(dim=-1) & (nf[p0] > 0)[:, None]
+        assert int(inside.sum()) == 0, p0
