@@ -662,3 +662,27 @@ def test_corridor_full_size_properties():
         sd = torch.einsum("nfk,pk->npf", Ap, d_cloud) - bp[:, None, :]       # [N,P,F]
         inside = ((sd < -1e-9) | ~lp[:, None, :]).all(dim=-1) & (nf[p0] > 0)[:, None]
         assert int(inside.sum()) == 0, p0
+
+
+@pytest.mark.parametrize("P,mode", [(9000, "list"), (40000, "cloud")])
+def test_corridor_dense_boxes_use_the_list_and_cloud_paths(P, mode):
+    """The kernel keeps a decomposition's in-box points in registers (<= 2048), in an LDS index list (<= 8192) or, beyond
+    that, addresses the cloud directly; the other corridor tests stay in the first regime.  A dense cloud packed into a
+    region little larger than one local box forces the other two, against the same oracle."""
+    rng = np.random.default_rng(P)
+    cloud = np.c_[rng.uniform(-1.5, 4.5, P), rng.uniform(-2.2, 2.2, P), rng.uniform(0.0, 2.0, P)]
+    N, B = 6, 2
+    s = np.linspace(0.5, 2.5, N)
+    centre = np.c_[s, 0.2 * np.sin(s), np.full(N, 1.0)]
+    cx = np.interp(cloud[:, 0], centre[:, 0], centre[:, 1])
+    cloud = cloud[np.hypot(cloud[:, 1] - cx, cloud[:, 2] - 1.0) > 0.45]
+    ref = centre[None] + rng.normal(0, 0.02, (B, N, 3))
+    yaw = rng.normal(0.1, 0.05, (B, N))
+    E = np.tile(np.diag([0.2, 0.2, 0.05]), (B, N, 1, 1))
+    C = _corridor_oracle()
+    box = C.local_bbox_planes(ref[0, 0], ref[0, 0] + 0.1 * np.array([np.cos(yaw[0, 0]), np.sin(yaw[0, 0]), 0]), np.array([2.0, 2.0, 1.0]))
+    inbox = np.ones(len(cloud), bool)
+    for pp, n in box:
+        inbox &= (cloud - pp) @ n <= 1e-10
+    assert (2048 < inbox.sum() <= 8192) if mode == "list" else inbox.sum() > 8192
+    _check_corridor(cloud, ref, yaw, E)
