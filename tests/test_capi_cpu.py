@@ -191,3 +191,15 @@ def test_stage_divergent_phases_do_not_spill(tmp_path):
         body = txt[txt.index(f"_ZN3frp15nmpc_ipm_kernelILi{np_}EEEvNS_10KernelArgsE:"):]
         body = body[:body.index("s_endpgm")]
         assert "s_cbranch_execnz" not in body
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The boundary is a C ABI: include/frp_nmpc.h must compile as strict C99 on its own (no C++, no torch types)."""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "frp_nmpc.h"\n'
+                   'int main(void) { frp_nmpc_batch b; frp_nmpc_pack p; frp_nmpc_tube t; frp_nmpc_corridor c; frp_nmpc_reference r;\n'
+                   '  frp_forces_params fp; (void)b; (void)p; (void)t; (void)c; (void)r; (void)fp;\n'
+                   '  return sizeof(frp_forces_params) == 23600 ? 0 : 1; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
