@@ -1790,6 +1790,8 @@ size_t ws_bytes(int B, int N, int MF)
     return (queue_offset_doubles(B, N, MF) + 32 + (size_t)B + ((size_t)B + 1) / 2) * sizeof(double);
 }
 
+__global__ void reset_counter_kernel(int *counter) { *counter = 0; }
+
 hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
 {
     KernelArgs k = a;
@@ -1805,8 +1807,14 @@ hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
                            a.x0, a.params, keys);
         hipLaunchKernelGGL(order_bucket_kernel, dim3(1), dim3(1024), 0, stream, a.B, keys, order, k.counter);
     } else {
-        const hipError_t e = hipMemsetAsync(k.counter, 0, sizeof(int), stream);
-        if (e != hipSuccess) return e;
+        // a one-thread kernel rather than hipMemsetAsync: as a node of a captured hipGraph the 4-byte memset was not
+        // ordered before the solve on the graph's first launch (ROCm 7.2; tools/graph_tick.py), which left the queue
+        // exhausted and the previous outputs in place
+#ifdef FRP_COUNTER_MEMSET
+        if (hipMemsetAsync(k.counter, 0, sizeof(int), stream) != hipSuccess) return hipErrorUnknown;
+#else
+        hipLaunchKernelGGL(reset_counter_kernel, dim3(1), dim3(1), 0, stream, k.counter);
+#endif
     }
     switch (padded_stages(a.N)) {
     case 16: hipLaunchKernelGGL(nmpc_ipm_kernel<16>, dim3(slots), dim3(64), 0, stream, k); break;

@@ -686,3 +686,48 @@ def test_corridor_dense_boxes_use_the_list_and_cloud_paths(P, mode):
         inbox &= (cloud - pp) @ n <= 1e-10
     assert (2048 < inbox.sum() <= 8192) if mode == "list" else inbox.sum() > 8192
     _check_corridor(cloud, ref, yaw, E)
+
+
+def test_full_tick_replayed_from_a_hipgraph_equals_eager_launches():
+    """Every entry point is asynchronous on the caller's stream and allocates nothing, so a tick can be captured into a
+    hipGraph (the launch-bound case: small fleets).  Outputs are poisoned before each run: a solve that silently does
+    nothing -- what a captured hipMemsetAsync of the queue counter produced on ROCm 7.2 -- cannot pass."""
+    import torch
+    B, N, M, F, K = 16, 20, 30, 64, 200
+    rng = np.random.default_rng(8)
+    s = np.arange(K) * 0.05 * 0.4
+    path = np.c_[s, 0.4 * np.sin(0.8 * s), 1.0 + 0.1 * np.cos(s)]
+    cloud = np.c_[rng.uniform(-3, 12, 3000), rng.uniform(-4, 4, 3000), rng.uniform(-0.5, 3, 3000)]
+    cx = np.interp(cloud[:, 0], path[:, 0], path[:, 1]); cz = np.interp(cloud[:, 0], path[:, 0], path[:, 2])
+    cloud = cloud[np.hypot(cloud[:, 1] - cx, cloud[:, 2] - cz) > 0.9]
+    plan = np.zeros((B, N + 1, 17)); plan[..., 3] = 7.3; plan[..., 7] = 7.3
+    plan[..., 8:11] = path[0] + rng.normal(0, 0.02, (B, 1, 3)); plan[..., 16] = 0.2
+    fleet = solver.DeviceFleet(B, N, M, F, L.MODEL_NORMAL, (15.0, 3.0, 80.0, 15.0, 0.0))
+    fleet.poly_index = torch.zeros((B, N), dtype=torch.int32, device="cuda:0")
+    d_path, d_cloud, d_f = fleet.to_device(path), fleet.to_device(cloud), fleet.to_device(rng.normal(0, 0.5, (B, 3)))
+    rp = torch.zeros((B, N, 3), dtype=torch.float64, device="cuda:0"); ry = torch.zeros((B, N), dtype=torch.float64, device="cuda:0")
+    toff = torch.zeros((B,), dtype=torch.float64, device="cuda:0")
+
+    def run(ticks, fn):
+        fleet.mpc_output.copy_(fleet.to_device(plan)); toff.zero_()
+        fleet.solver.z.fill_(float("nan")); fleet.solver.exitflag.fill_(-99)
+        out = []
+        for _ in range(ticks):
+            fn(); toff.add_(0.05)
+            out.append(fleet.mpc_output.clone())
+        torch.cuda.synchronize()
+        return torch.stack(out), fleet.solver.exitflag.clone()
+
+    eager = lambda: fleet.full_tick(d_f, d_path, toff, d_cloud, rp, ry)
+    ref_plans, ref_flags = run(5, eager)
+    assert bool((ref_flags == 1).all()) and bool(torch.isfinite(ref_plans).all())
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        fleet.full_tick(d_f, d_path, toff, d_cloud, rp, ry, stream=side)
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        fleet.full_tick(d_f, d_path, toff, d_cloud, rp, ry, stream=torch.cuda.current_stream())
+    for _ in range(2):  # the first replay after capture included
+        plans, flags = run(5, g.replay)
+        assert torch.equal(plans, ref_plans) and torch.equal(flags, ref_flags)
