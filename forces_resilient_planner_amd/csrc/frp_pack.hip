@@ -98,6 +98,23 @@ __global__ __launch_bounds__(256) void update_kernel(int B, int N, const double 
     }
 }
 
+// NMPCSolver::initMPCOutput (nmpc_solver.cpp:265-286) as solveNMPC applies it (:363-364): a planner whose last solve did
+// not return 1 restarts from the constant plan [0 0 0 T | 0 0 0 T | state].  One workgroup per planner, coalesced rows.
+__global__ __launch_bounds__(256) void coldstart_kernel(int B, int N, const double *state, const int *exitflag, double thrust, double *mpc_output)
+{
+    const int b = blockIdx.x;
+    if (exitflag && exitflag[b] == 1) return;
+    double *mo = mpc_output + (size_t)b * (N + 1) * PK_NZ;
+    const double *st = state ? state + (size_t)b * 9 : nullptr;
+    __shared__ double row[PK_NZ];
+    if (threadIdx.x < PK_NZ) {
+        const int j = threadIdx.x;
+        row[j] = j >= 8 ? (st ? st[j - 8] : mo[PK_NZ + j]) : ((j == 3 || j == 7) ? thrust : 0.0); // state == NULL: the plan's own stage-1 state
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < (N + 1) * PK_NZ; e += 256) mo[e] = row[e % PK_NZ];
+}
+
 } // namespace frp
 
 extern "C" int frp_nmpc_pack_batch(const frp_nmpc_pack *p, void *stream)
@@ -108,6 +125,13 @@ extern "C" int frp_nmpc_pack_batch(const frp_nmpc_pack *p, void *stream)
     if (!p->poly_index && p->NPOLY != p->N) return FRP_ERR_ARG;
     if ((long long)p->N * (10 + 4 * p->M) >= 65536) return FRP_ERR_ARG; // N * np must stay below 2^16 (float index split in pack_kernel)
     hipLaunchKernelGGL(frp::pack_kernel, dim3((unsigned)p->B), dim3(256), 0, static_cast<hipStream_t>(stream), *p);
+    return hipGetLastError() == hipSuccess ? FRP_OK : FRP_ERR_HIP;
+}
+
+extern "C" int frp_nmpc_coldstart_batch(int B, int N, const double *state, const int *exitflag, double thrust, double *mpc_output, void *stream)
+{
+    if (B <= 0 || N < 1 || !mpc_output) return FRP_ERR_ARG;
+    hipLaunchKernelGGL(frp::coldstart_kernel, dim3((unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), B, N, state, exitflag, thrust, mpc_output);
     return hipGetLastError() == hipSuccess ? FRP_OK : FRP_ERR_HIP;
 }
 

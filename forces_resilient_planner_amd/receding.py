@@ -88,13 +88,8 @@ def run_device(w0, ticks, device="cuda:0", collect=True, propagate_tube=False):
         ref_pos = refs[t].expand(B, N, 3).contiguous()
         fleet.poly_A.copy_(As[t].expand(B, N, 6, 3))
         fleet.poly_b.copy_(bs[t].expand(B, N, 6))
-        if t > 0:  # cold start for planners whose last solve failed (nmpc_solver.cpp:363-364)
-            bad = fleet.solver.exitflag != 1
-            if bool(bad.any()):
-                st = fleet.mpc_output[bad][:, 1, 8:17]
-                row = torch.zeros((st.shape[0], 17), dtype=torch.float64, device=dev)
-                row[:, 3] = cold_thrust; row[:, 7] = cold_thrust; row[:, 8:] = st
-                fleet.mpc_output[bad] = row[:, None, :].expand(-1, N + 1, -1)
+        if t > 0:  # cold start for planners whose last solve failed (nmpc_solver.cpp:363-364), on the device
+            fleet.coldstart(thrust=cold_thrust)
         fleet.tick(f_ext, ref_pos, ref_yaw, propagate_tube=propagate_tube)
         if collect:
             flags[t] = fleet.solver.exitflag; iters[t] = fleet.solver.iters

@@ -101,7 +101,8 @@ EXPORTS = ["frp_nmpc_default_options", "frp_nmpc_workspace_bytes", "frp_nmpc_sol
            "frp_nmpc_solve_batch_host", "frp_nmpc_stage_eval", "frp_nmpc_stage_eval_host", "frp_nmpc_time_solve",
            "frp_nmpc_version", "frp_nmpc_device_count", "FORCESNLPsolver_normal_solve",
            "FORCESNLPsolver_final_solve", "frp_nmpc_pack_batch", "frp_nmpc_update_batch", "frp_nmpc_tube_batch",
-           "frp_nmpc_corridor_batch", "frp_nmpc_reference_batch"]
+           "frp_nmpc_corridor_batch", "frp_nmpc_reference_batch",
+           "frp_nmpc_coldstart_batch"]
 
 _lib = None
 
@@ -136,6 +137,8 @@ def lib():
         l.frp_nmpc_tube_batch.argtypes = [ctypes.POINTER(Tube), ctypes.c_void_p]
         l.frp_nmpc_corridor_batch.argtypes = [ctypes.POINTER(Corridor), ctypes.c_void_p]
         l.frp_nmpc_reference_batch.argtypes = [ctypes.POINTER(Reference), ctypes.c_void_p]
+        l.frp_nmpc_coldstart_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
+                                               ctypes.c_void_p, ctypes.c_void_p]
         _lib = l
     return _lib
 
@@ -394,17 +397,29 @@ class DeviceFleet:
         corridor_batch_device(cloud, ref_pos, ref_yaw, self.ellipsoid, self.poly_A, self.poly_b, self.poly_nfaces,
                               self.poly_index, None, cloud_count, consts, stream)
 
+    def coldstart(self, state=None, only_failed=True, thrust=7.3, stream=None):
+        """initMPCOutput for the planners whose last solve failed (nmpc_solver.cpp:363-364, :265-286), on the device.
+        state [B,9] = stateMpc_ (odometry), or None: each planner restarts from its plan's stage-1 state."""
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.solver.device)
+        _check(lib().frp_nmpc_coldstart_batch(self.B, self.N, ctypes.c_void_p(state.data_ptr()) if state is not None else None,
+                                              ctypes.c_void_p(self.solver.exitflag.data_ptr()) if only_failed else None,
+                                              float(thrust), ctypes.c_void_p(self.mpc_output.data_ptr()),
+                                              ctypes.c_void_p(s.cuda_stream)), "frp_nmpc_coldstart_batch")
+
     def references(self, kino_path, time_offset, ref_pos, ref_yaw, replan=None, kino_size=None, Ts=0.05, stream=None):
         """SURVEY 8f row f-4 (first half): ref_total_pos_ / ref_total_yaw_ of all B planners from the kinodynamic
         path (getCurTraj + calculate_yaw, nmpc_solver.cpp:109-142, 834-862), on the device."""
         reference_batch_device(kino_path, time_offset, self.mpc_output, ref_pos, ref_yaw, replan, kino_size, Ts, stream)
 
     def full_tick(self, external_acc, kino_path, time_offset, cloud, ref_pos, ref_yaw, stream=None, replan=None,
-                  kino_size=None, tube_consts=None, corridor_consts=None, Ts=0.05):
+                  kino_size=None, tube_consts=None, corridor_consts=None, Ts=0.05, coldstart=True, state=None):
         """The reference's whole per-tick computation downstream of the A* (NMPCSolver::solveNMPC,
         nmpc_solver.cpp:351-482) for B planners, asynchronous on `stream`, nothing touching the host:
         stage references (f-4) -> tube (f-2) -> corridor (f-3) -> parameter packing (f-1) -> NLP solve -> result
-        bookkeeping.  ref_pos [B,N,3] / ref_yaw [B,N] are caller-owned scratch that receives the references."""
+        bookkeeping.  ref_pos [B,N,3] / ref_yaw [B,N] are caller-owned scratch that receives the references.
+        With coldstart (default) planners whose previous solve failed first restart from the constant plan (:363-364)."""
+        if coldstart:
+            self.coldstart(state, True, stream=stream)
         self.references(kino_path, time_offset, ref_pos, ref_yaw, replan, kino_size, Ts, stream)
         self.tube(tube_consts, stream)
         self.corridor(cloud, ref_pos, ref_yaw, corridor_consts, stream)

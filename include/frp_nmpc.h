@@ -221,6 +221,13 @@ typedef struct frp_nmpc_reference {
  * Asynchronous on `stream`. */
 int frp_nmpc_reference_batch(const frp_nmpc_reference *p, void *stream);
 
+/* NMPCSolver::initMPCOutput (nmpc_solver.cpp:265-286) as applied at the start of solveNMPC (:363-364) for B planners:
+ * every planner whose exitflag != 1 (all of them when exitflag is NULL) gets the constant cold-start plan
+ * [0 0 0 T | 0 0 0 T | state] in all N+1 rows; T = real_thrust_c_ (nmpc_utils.h:191).  state [B][9] = stateMpc_, or NULL
+ * to restart from the plan's own stage-1 state.  Asynchronous on `stream`. */
+int frp_nmpc_coldstart_batch(int B, int N, const double *state, const int *exitflag, double thrust, double *mpc_output,
+                             void *stream);
+
 const char *frp_nmpc_version(void);
 int frp_nmpc_device_count(void);
 

@@ -731,3 +731,25 @@ def test_full_tick_replayed_from_a_hipgraph_equals_eager_launches():
     for _ in range(2):  # the first replay after capture included
         plans, flags = run(5, g.replay)
         assert torch.equal(plans, ref_plans) and torch.equal(flags, ref_flags)
+
+
+def test_coldstart_on_device_matches_init_mpc_output():
+    import torch
+    from forces_resilient_planner_amd.adapter import init_mpc_output
+    B, N = 37, 20
+    rng = np.random.default_rng(4)
+    fleet = solver.DeviceFleet(B, N, 30, 6, L.MODEL_NORMAL, (15.0, 3.0, 80.0, 15.0, 0.0))
+    plan = rng.normal(size=(B, N + 1, 17))
+    state = rng.normal(size=(B, 9))
+    flags = rng.choice([1, 0, -7, -6], size=B).astype(np.int32)
+    fleet.solver.exitflag.copy_(torch.from_numpy(flags).to("cuda:0"))
+    for st in (state, None):
+        fleet.mpc_output.copy_(fleet.to_device(plan))
+        fleet.coldstart(fleet.to_device(st) if st is not None else None)
+        torch.cuda.synchronize()
+        want = plan.copy()
+        bad = flags != 1
+        want[bad] = init_mpc_output(st[bad] if st is not None else plan[bad][:, 1, 8:17], N)
+        assert np.array_equal(fleet.mpc_output.cpu().numpy(), want)
+    fleet.mpc_output.copy_(fleet.to_device(plan)); fleet.coldstart(fleet.to_device(state), only_failed=False)
+    assert np.array_equal(fleet.mpc_output.cpu().numpy(), init_mpc_output(state, N))
