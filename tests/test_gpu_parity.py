@@ -753,3 +753,50 @@ def test_coldstart_on_device_matches_init_mpc_output():
         assert np.array_equal(fleet.mpc_output.cpu().numpy(), want)
     fleet.mpc_output.copy_(fleet.to_device(plan)); fleet.coldstart(fleet.to_device(state), only_failed=False)
     assert np.array_equal(fleet.mpc_output.cpu().numpy(), init_mpc_output(state, N))
+
+
+def test_plain_c_program_drives_the_whole_tick_through_the_c_abi(tmp_path):
+    """tests/cpp/tick_harness.c: C99 + HIP runtime + include/frp_nmpc.h only (no torch, no C++).  Three ticks of
+    coldstart -> reference -> tube -> corridor -> pack -> solve -> update; same bits as the Python DeviceFleet."""
+    import subprocess
+    import torch
+    root = OL.ROOT
+    exe = os.path.join(root, "tests", "cpp", "tick_harness")
+    src = exe + ".c"
+    libdir = os.path.dirname(solver.LIB_PATH)
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(solver.LIB_PATH)):
+        subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-I" + os.path.join(root, "include"), "-I/opt/rocm/include", src, "-o", exe,
+                               "-L" + libdir, "-lfrp_nmpc_amd", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    B, N, K, T = 12, 20, 80, 3
+    rng = np.random.default_rng(31)
+    s = np.arange(K) * 0.05 * 1.2
+    path = np.c_[s, 0.4 * np.sin(0.8 * s), 1.0 + 0.1 * np.cos(s)]
+    cloud = np.c_[rng.uniform(-3, 9, 4000), rng.uniform(-4, 4, 4000), rng.uniform(-0.5, 3, 4000)]
+    cx = np.interp(cloud[:, 0], path[:, 0], path[:, 1]); cz = np.interp(cloud[:, 0], path[:, 0], path[:, 2])
+    cloud = cloud[np.hypot(cloud[:, 1] - cx, cloud[:, 2] - cz) > 0.9]
+    plan = np.zeros((B, N + 1, 17)); plan[..., 3] = 7.3; plan[..., 7] = 7.3
+    plan[..., 8:11] = path[0] + rng.normal(0, 0.02, (B, 1, 3)); plan[..., 16] = 0.2
+    f_ext = rng.normal(0, 0.5, (B, 3))
+    toff = 0.05 * np.arange(T)[:, None] + rng.uniform(0, 0.02, (1, B))
+    inp, out = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(inp, "wb") as f:
+        np.array([B, N, K, len(cloud), T], dtype=np.int32).tofile(f)
+        for a in (path, cloud, plan, f_ext, toff):
+            np.ascontiguousarray(a, dtype=np.float64).tofile(f)
+    subprocess.check_call([exe, str(inp), str(out)])
+    raw = np.fromfile(out, dtype=np.uint8)
+    nb = B * (N + 1) * 17 * 8
+    plan_c = raw[:nb].view(np.float64).reshape(B, N + 1, 17)
+    ints = raw[nb:].view(np.int32)
+    flag_c, it_c, pi_c = ints[:B], ints[B:2 * B], ints[2 * B:].reshape(B, N)
+    fleet = solver.DeviceFleet(B, N, 30, 64, L.MODEL_NORMAL, (15.0, 3.0, 80.0, 15.0, 0.0))
+    fleet.mpc_output.copy_(fleet.to_device(plan)); fleet.solver.exitflag.fill_(1)
+    rp = torch.zeros((B, N, 3), dtype=torch.float64, device="cuda:0"); ry = torch.zeros((B, N), dtype=torch.float64, device="cuda:0")
+    d_path, d_cloud, d_f = fleet.to_device(path), fleet.to_device(cloud), fleet.to_device(f_ext)
+    for t in range(T):
+        fleet.full_tick(d_f, d_path, fleet.to_device(toff[t]), d_cloud, rp, ry)
+    torch.cuda.synchronize()
+    assert np.array_equal(flag_c, fleet.solver.exitflag.cpu().numpy()) and np.all(flag_c == 1)
+    assert np.array_equal(it_c, fleet.solver.iters.cpu().numpy())
+    assert np.array_equal(pi_c, fleet.poly_index.cpu().numpy())
+    assert np.array_equal(plan_c, fleet.mpc_output.cpu().numpy())
