@@ -1,6 +1,6 @@
 """ORACLE for SURVEY 8f row f-4, first half (stage references) -- TEST INFRASTRUCTURE ONLY.
 
-Only tests/, __graft_entry__.smoke() and tools' CPU-baseline legs may import this file; the product path
+Only tests/ (including tests/tools/) and __graft_entry__.smoke() may import this file; the product path
 (forces_resilient_planner_amd/csrc/frp_reference.hip) never does.
 
 Plain-Python restatement of NMPCSolver::getCurTraj (plan_manage/src/nmpc_solver.cpp:109-142) and

@@ -1,6 +1,6 @@
 """ORACLE for SURVEY 8f row f-2 (tube / ellipsoid propagation) -- TEST INFRASTRUCTURE ONLY.
 
-Only tests/, __graft_entry__.smoke() and tools' CPU-baseline legs may import this file; the product path
+Only tests/ (including tests/tools/) and __graft_entry__.smoke() may import this file; the product path
 (forces_resilient_planner_amd/csrc/frp_tube.hip) never does.
 
 CPU restatement, in numpy/scipy, of what NMPCSolver::setFORCESParams computes for every stage of the horizon

@@ -90,7 +90,7 @@ def reference_kkt(z, xinit, params, nfaces, N, M, model, active=1e-3):
     """
     import sys
     from scipy.optimize import lsq_linear
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import gen_golden as G
     nlp = G.RefNLP(N, M, model, np.asarray(xinit, float), np.asarray(params, float), np.asarray(nfaces))
     Z = np.ascontiguousarray(z, dtype=np.float64).ravel()

@@ -1,6 +1,7 @@
 """GPU vs oracle on a big batch: report problems whose exit flag / iteration count differ."""
 import sys, numpy as np
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from forces_resilient_planner_amd import solver, workloads
 import tests.oracle_lib as OL
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384

@@ -2,13 +2,13 @@
 """Measurement of the f-3 kernel (corridor generation / selection).  Memory-side work: every decomposition scans the
 whole cloud once (24 B per point; later scans only touch surviving 64-point words), so the algorithmic bytes are
 decompositions x P x 24 and the bound is L2/HBM bandwidth (the cloud is shared by the fleet and L2-resident).
-The numpy oracle is timed beside it on a bounded sample.     python tools/corridor_bench.py [B=4096] [P=20000]"""
+The numpy oracle is timed beside it on a bounded sample.     python tests/tools/corridor_bench.py [B=4096] [P=20000]"""
 import json
 import sys
 import time
 import numpy as np
 import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from forces_resilient_planner_amd import solver
 from oracle import corridor_oracle as C, tube_oracle as T   # CPU-baseline leg only

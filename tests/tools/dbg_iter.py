@@ -1,7 +1,8 @@
 """Debug helper: compare GPU and oracle iterates for increasing maxit (run on the GPU box)."""
 import sys
 import numpy as np
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from forces_resilient_planner_amd import solver, workloads
 import tests.oracle_lib as OL
 

@@ -1,8 +1,9 @@
 """Debug helper: one problem of a config2 batch, GPU vs oracle for increasing maxit (run on the GPU box).
-   python tools/dbg_one.py <batch> <index> [maxit_hi]"""
+   python tests/tools/dbg_one.py <batch> <index> [maxit_hi]"""
 import sys
 import numpy as np
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from forces_resilient_planner_amd import solver, workloads
 import tests.oracle_lib as OL
 B, b = int(sys.argv[1]), int(sys.argv[2]); hi = int(sys.argv[3]) if len(sys.argv) > 3 else 12

@@ -27,7 +27,7 @@ from multiprocessing import Pool
 import numpy as np
 from scipy.optimize import minimize
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from forces_resilient_planner_amd import layout as L  # noqa: E402
 from forces_resilient_planner_amd import workloads as W  # noqa: E402

@@ -1,8 +1,9 @@
 """Soak test (GPU box): many launches with random batch sizes / configs / horizons, exit flags and iteration counts against
-the oracle on every launch.   python tools/soak.py [seconds=90]"""
+the oracle on every launch.   python tests/tools/soak.py [seconds=90]"""
 import sys, time
 import numpy as np
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from forces_resilient_planner_amd import solver, workloads
 import tests.oracle_lib as OL
 T = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0

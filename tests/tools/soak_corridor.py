@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised agreement of the f-2 / f-3 / f-4 kernels with their oracles over many worlds (GPU box).
-   python tools/soak_corridor.py [seconds=120]
+   python tests/tools/soak_corridor.py [seconds=120]
 Per world: random cloud (300..20000 points, sometimes snapped to a voxel grid), random tunnel width, B = 8 planners;
 references from a random kinodynamic path through frp_nmpc_reference_batch, tube from frp_nmpc_tube_batch on random
 plans, corridor from frp_nmpc_corridor_batch -- each compared with its oracle on the same inputs."""
@@ -9,7 +9,7 @@ import os
 import sys
 import time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from forces_resilient_planner_amd import layout as L
 from forces_resilient_planner_amd import solver
 from oracle import corridor_oracle as C, tube_oracle as T, reference_oracle as R

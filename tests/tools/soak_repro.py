@@ -1,7 +1,8 @@
-"""Replay tools/soak.py's random launch sequence up to a given (kind, B, seed) and report the mismatching problems."""
+"""Replay tests/tools/soak.py's random launch sequence up to a given (kind, B, seed) and report the mismatching problems."""
 import sys
 import numpy as np
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from forces_resilient_planner_amd import solver, workloads
 import tests.oracle_lib as OL
 target = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))

@@ -1,7 +1,8 @@
 """Large GPU-vs-oracle sweep over the workload families (run on the GPU box): exit flags, iteration counts, solutions."""
 import sys, time
 import numpy as np
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from forces_resilient_planner_amd import solver, workloads
 import tests.oracle_lib as OL
 

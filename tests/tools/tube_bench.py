@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Measurement of the f-2 kernel (tube propagation): FP64-VALU-bound, so achieved = algorithmic flops / kernel time
 against the 78.6 TFLOP/s FP64 vector peak; the numpy/scipy oracle is timed beside it on a bounded sample.
-    python tools/tube_bench.py [B=4096] [N=20]"""
+    python tests/tools/tube_bench.py [B=4096] [N=20]"""
 import json
 import sys
 import time
 import numpy as np
 import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from forces_resilient_planner_amd import layout as L
 from forces_resilient_planner_amd import solver
