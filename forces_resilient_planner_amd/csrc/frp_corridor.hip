@@ -31,7 +31,8 @@
 //     result through LDS (struct Uni), so it costs the scanning waves no registers.
 // Memory-side work: 24 bytes per cloud point per decomposition, then 24-byte gathers of in-box points from L2 (the
 // cloud is shared by the planners of a fleet); lists of up to CR_TILE * 256 points live in registers (scan_tile).
-// Measured (profiles/r01_corridor_bench.json): full-cloud scan 32 us, then ~20-30 scans of ~1.9 us per decomposition.
+// Measured (profiles/r01_corridor_bench.json): full-cloud scan 32 us (8 us through the uniform grid of
+// frp_nmpc_cloud_grid_build, scan_grid), then ~20-30 scans of ~1.9 us per decomposition.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -364,6 +365,96 @@ __device__ __forceinline__ Best scan_cloud(const Scan &s, uint64_t *m0, uint64_t
     return block_min(best, s_red, phase);
 }
 
+// first scan of a decomposition when the cloud comes with a uniform grid (frp_nmpc_cloud_grid_build): only the cell
+// rows that meet the axis-aligned hull of the local box are read -- each row (cells ix0..ix1 of one (iy, iz)) is one
+// contiguous run of the cell-sorted points, CR_GROWS rows in flight per wave.  Produces the dense list only (no cloud
+// masks); minima are tie-broken by the ORIGINAL cloud index, so the result is the same as scanning the whole cloud.
+constexpr int CR_GROWS = 2;
+__device__ __forceinline__ Best scan_grid(const frp_nmpc_corridor &c, uint32_t *list, Uni &u, Best *s_red, int &phase)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const M3 Ci = ld3(u.Ci);
+    const double d[3] = {u.mid[0], u.mid[1], u.mid[2]};
+    double fr[3][3], o[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = u.p1[k];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) fr[k][j] = u.frame[k][j];
+    }
+    const double bh = c.bbox[1] + CR_EPS, bd_lo = -c.bbox[0] - CR_EPS, bd_hi = u.len + c.bbox[0] + CR_EPS, bv = c.bbox[2] + CR_EPS;
+    // axis-aligned hull of the box { o + h fr0 + t fr1 + v fr2 : |h| <= bh, bd_lo <= t <= bd_hi, |v| <= bv } in cells
+    int lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double ctr = o[k] + 0.5 * (bd_lo + bd_hi) * fr[1][k];
+        const double half = bh * fabs(fr[0][k]) + 0.5 * (bd_hi - bd_lo) * fabs(fr[1][k]) + bv * fabs(fr[2][k]);
+        const double a = floor((ctr - half - c.grid_origin[k]) / c.grid_cell), b = floor((ctr + half - c.grid_origin[k]) / c.grid_cell);
+        const int n = c.grid_dims[k];
+        lo[k] = a < 0 ? 0 : (a > n - 1 ? n - 1 : (int)a);   // points beyond the grid were binned into its border cells
+        hi[k] = b < 0 ? 0 : (b > n - 1 ? n - 1 : (int)b);
+    }
+    const int ny = hi[1] - lo[1] + 1, rows = ny * (hi[2] - lo[2] + 1), nx = c.grid_dims[0];
+    Best best{1.7976931348623157e308, 0x7fffffff, 0.0, 0.0, 0.0};
+    for (int r0 = wave; r0 < rows; r0 += CR_WAVES * CR_GROWS) {
+        int beg[CR_GROWS], end[CR_GROWS], most = 0;
+#pragma unroll
+        for (int k = 0; k < CR_GROWS; ++k) {
+            const int r = r0 + k * CR_WAVES;
+            beg[k] = end[k] = 0;
+            if (r < rows) {
+                const size_t row = ((size_t)(lo[2] + r / ny) * c.grid_dims[1] + (lo[1] + r % ny)) * nx;
+                beg[k] = c.grid_start[row + lo[0]];
+                end[k] = c.grid_start[row + hi[0] + 1];
+            }
+            most = max(most, end[k] - beg[k]);
+        }
+        for (int off = 0; off < most; off += 64) { // usually one trip: a row of cells holds a few dozen points
+            double x[CR_GROWS], y[CR_GROWS], z[CR_GROWS];
+            int id[CR_GROWS];
+#pragma unroll
+            for (int k = 0; k < CR_GROWS; ++k) {
+                const int p = beg[k] + off + lane;
+                const bool ok = p < end[k];
+                const size_t p3 = 3 * (size_t)(ok ? p : 0);
+                x[k] = ok ? c.grid_points[p3] : 0.0; y[k] = ok ? c.grid_points[p3 + 1] : 0.0; z[k] = ok ? c.grid_points[p3 + 2] : 0.0;
+                id[k] = ok ? c.grid_index[p] : -1;
+            }
+            uint64_t w0[CR_GROWS];
+            bool i1[CR_GROWS];
+            int total = 0;
+#pragma unroll
+            for (int k = 0; k < CR_GROWS; ++k) {
+                bool in0 = id[k] >= 0;
+                i1[k] = false;
+                const double ex = x[k] - o[0], ey = y[k] - o[1], ez = z[k] - o[2];
+                const double h = fr[0][0] * ex + fr[0][1] * ey + fr[0][2] * ez, t = fr[1][0] * ex + fr[1][1] * ey + fr[1][2] * ez,
+                             v = fr[2][0] * ex + fr[2][1] * ey + fr[2][2] * ez;
+                in0 = in0 && !(h > bh) && !(-h > bh) && !(t > bd_hi) && !(t < bd_lo) && !(v > bv) && !(-v > bv);
+                if (in0) {
+                    const double dist = ell_dist2(Ci, d, x[k], y[k], z[k]);
+                    i1[k] = dist <= 1;
+                    if (i1[k] && before(dist, id[k], best.dist, best.idx)) best = Best{dist, id[k], x[k], y[k], z[k]};
+                }
+                w0[k] = __ballot(in0);
+                total += (int)__popcll(w0[k]);
+            }
+            if (total) {
+                int at = 0;
+                if (lane == 0) at = atomicAdd(&u.count, total);
+                at = __builtin_amdgcn_readfirstlane(at);
+#pragma unroll
+                for (int k = 0; k < CR_GROWS; ++k) {
+                    const int mine = at + (int)__popcll(w0[k] & ((1ull << lane) - 1));
+                    if (((w0[k] >> lane) & 1) && mine < CR_LIST) list[mine] = (uint32_t)id[k] | (i1[k] ? 0x80000000u : 0u);
+                    at += (int)__popcll(w0[k]);
+                }
+            }
+        }
+    }
+    return block_min(best, s_red, phase);
+}
+
 // LinearConstraint row of hyperplane (q, n) seen from the seed centre (polyhedron.h:98-118); thread 0 only
 __device__ void emit_row(Uni &u, const double q[3], const double n_[3], int F, double *s_A, double *s_b, double *gA, double *gb)
 {
@@ -389,7 +480,12 @@ __device__ void emit_row(Uni &u, const double q[3], const double n_[3], int F, d
 #define CR_ACC(v)
 #endif
 
-__global__ __launch_bounds__(CR_THREADS) void corridor_kernel(frp_nmpc_corridor c)
+// GRID = true: the first scan of every decomposition goes through the uniform grid; a planner that meets a box with more
+// than CR_LIST points marks itself (poly_index[b][0] = -1) and leaves, and the GRID = false kernel launched right behind
+// with only_flagged = 1 redoes just those planners from the plain cloud.  Two kernels instead of one with both first
+// scans inlined: the combined one needs 256 VGPRs + 100 spilled SGPRs and loses the second resident workgroup per CU.
+template <bool GRID>
+__global__ __launch_bounds__(CR_THREADS) void corridor_kernel(frp_nmpc_corridor c, int only_flagged)
 {
 #ifdef FRP_CORRIDOR_PROFILE
     long long tp_check = 0, tp_init = 0, tp_cloud = 0, tp_lead = 0, tp_scan = 0, tp_emit = 0, tp_begin = wall_clock64();
@@ -411,6 +507,7 @@ __global__ __launch_bounds__(CR_THREADS) void corridor_kernel(frp_nmpc_corridor 
     uint32_t *list = reinterpret_cast<uint32_t *>(s_mask + 3 * sc.W);
     const double *ref = c.ref_pos + (size_t)b * c.N * 3, *yaw = c.ref_yaw + (size_t)b * c.N, *Eb = c.ellipsoid + (size_t)b * c.N * 9;
     const bool has_box = c.bbox[0] != 0.0 || c.bbox[1] != 0.0 || c.bbox[2] != 0.0;
+    if (!GRID && only_flagged && c.poly_index[(size_t)b * c.N] != -1) return;
     int npoly = 0, rows = 0; // rows = stored rows of the last polytope (s_A / s_b)
     // Every round of the reference's while-loops removes at least the closest point, so a list is exhausted after at
     // most Pn rounds; the bound only matters for non-finite input, where the reference would spin forever.
@@ -479,7 +576,15 @@ __global__ __launch_bounds__(CR_THREADS) void corridor_kernel(frp_nmpc_corridor 
         __syncthreads();
         CR_ACC(tp_init)
         sc.list = nullptr; sc.W = W_cloud; sc.Pn = P_cloud;
-        Best cp = scan_cloud(sc, m0, m1, m2, list, u, has_box, c.bbox, s_red, phase);
+        Best cp;
+        if (GRID) {
+            cp = scan_grid(c, list, u, s_red, phase);
+            if (u.count > CR_LIST) { // more points in the box than the list holds: leave this planner to the plain-cloud kernel
+                if (tid == 0) c.poly_index[(size_t)b * c.N] = -1;
+                return;
+            }
+        } else
+            cp = scan_cloud(sc, m0, m1, m2, list, u, has_box, c.bbox, s_red, phase);
         if (u.count <= CR_LIST) { // the usual case: from here on a position is an entry of the dense list
             sc.list = list; sc.Pn = u.count; sc.W = (u.count + 63) / 64;
             for (int g = tid >> 6; g < sc.W; g += CR_WAVES) {
@@ -594,13 +699,93 @@ __global__ __launch_bounds__(CR_THREADS) void corridor_kernel(frp_nmpc_corridor 
 
 } // namespace frp
 
+namespace frp {
+
+__device__ __forceinline__ int grid_cell_of(const double *pt, const double *origin, double cell, const int *dims)
+{
+    int ix[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double a = floor((pt[k] - origin[k]) / cell);
+        ix[k] = !(a > 0) ? 0 : (a > dims[k] - 1 ? dims[k] - 1 : (int)a); // NaN and points beyond the grid go to border cells
+    }
+    return (ix[2] * dims[1] + ix[1]) * dims[0] + ix[0];
+}
+
+struct GridArgs { const double *cloud; int P; double origin[3]; double cell; int dims[3]; double *points; int *index; int *start; int *cursor; };
+
+__global__ void grid_zero_kernel(GridArgs g, int cells)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= cells; i += gridDim.x * blockDim.x) { g.start[i] = 0; if (i < cells) g.cursor[i] = 0; }
+}
+__global__ void grid_count_kernel(GridArgs g)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.P; i += gridDim.x * blockDim.x)
+        atomicAdd(&g.start[grid_cell_of(g.cloud + 3 * (size_t)i, g.origin, g.cell, g.dims) + 1], 1);
+}
+// inclusive prefix sum of start[1..cells] in place, one workgroup walking the array in 1024-element chunks
+__global__ __launch_bounds__(1024) void grid_scan_kernel(GridArgs g, int cells)
+{
+    __shared__ int s_part[16], s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 1; base <= cells; base += 1024) {
+        const int i = base + tid;
+        int v = i <= cells ? g.start[i] : 0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(v, off); if (lane >= off) v += t; }
+        if (lane == 63) s_part[wave] = v;
+        __syncthreads();
+        int add = s_carry;
+        for (int w = 0; w < wave; ++w) add += s_part[w];
+        if (i <= cells) g.start[i] = v + add;
+        __syncthreads();
+        if (tid == 1023) s_carry = v + add;
+        __syncthreads();
+    }
+}
+__global__ void grid_scatter_kernel(GridArgs g)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.P; i += gridDim.x * blockDim.x) {
+        const double *pt = g.cloud + 3 * (size_t)i;
+        const int cell = grid_cell_of(pt, g.origin, g.cell, g.dims);
+        const int at = g.start[cell] + atomicAdd(&g.cursor[cell], 1); // order inside a cell is irrelevant (ties go by cloud index)
+        g.points[3 * (size_t)at] = pt[0]; g.points[3 * (size_t)at + 1] = pt[1]; g.points[3 * (size_t)at + 2] = pt[2];
+        g.index[at] = i;
+    }
+}
+
+} // namespace frp
+
+extern "C" int frp_nmpc_cloud_grid_build(const double *cloud, int P, const double origin[3], double cell, const int dims[3],
+                                         double *grid_points, int *grid_index, int *grid_start, int *scratch, void *stream)
+{
+    if (P < 0 || (P > 0 && !cloud) || !origin || !dims || !(cell > 0.0) || !grid_points || !grid_index || !grid_start || !scratch) return FRP_ERR_ARG;
+    if (dims[0] < 1 || dims[1] < 1 || dims[2] < 1 || (long long)dims[0] * dims[1] * dims[2] > FRP_CORRIDOR_MAX_CELLS) return FRP_ERR_ARG;
+    const int cells = dims[0] * dims[1] * dims[2];
+    frp::GridArgs g = {cloud, P, {origin[0], origin[1], origin[2]}, cell, {dims[0], dims[1], dims[2]}, grid_points, grid_index, grid_start, scratch};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(frp::grid_zero_kernel, dim3(256), dim3(256), 0, st, g, cells);
+    if (P > 0) hipLaunchKernelGGL(frp::grid_count_kernel, dim3(256), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(frp::grid_scan_kernel, dim3(1), dim3(1024), 0, st, g, cells);
+    if (P > 0) hipLaunchKernelGGL(frp::grid_scatter_kernel, dim3(256), dim3(256), 0, st, g);
+    return hipGetLastError() == hipSuccess ? FRP_OK : FRP_ERR_HIP;
+}
+
 extern "C" int frp_nmpc_corridor_batch(const frp_nmpc_corridor *p, void *stream)
 {
     if (!p || p->B <= 0 || p->N < 1 || p->N > 64 || p->F < 6 || p->F > FRP_CORRIDOR_MAX_F || p->P < 0 || p->P > FRP_CORRIDOR_MAX_POINTS ||
         (p->P > 0 && !p->cloud) || !p->ref_pos || !p->ref_yaw || !p->ellipsoid || !p->poly_A || !p->poly_b || !p->poly_nfaces || !p->poly_index)
         return FRP_ERR_ARG;
     if (!(p->seed_len > 0.0) || !(p->inflation >= 0.0)) return FRP_ERR_ARG;
+    if (p->grid_start && (!p->grid_points || !p->grid_index || !(p->grid_cell > 0.0) || p->grid_dims[0] < 1 || p->grid_dims[1] < 1 || p->grid_dims[2] < 1 ||
+                          p->cloud_per_planner))
+        return FRP_ERR_ARG;
     const size_t lds = (size_t)3 * ((p->P + 63) / 64) * sizeof(uint64_t) + frp::CR_LIST * sizeof(uint32_t);
-    hipLaunchKernelGGL(frp::corridor_kernel, dim3((unsigned)p->B), dim3(frp::CR_THREADS), lds, static_cast<hipStream_t>(stream), *p);
+    const bool has_box = p->bbox[0] != 0.0 || p->bbox[1] != 0.0 || p->bbox[2] != 0.0;
+    const bool grid = p->grid_start && has_box && !p->cloud_count;
+    if (grid) hipLaunchKernelGGL(frp::corridor_kernel<true>, dim3((unsigned)p->B), dim3(frp::CR_THREADS), lds, static_cast<hipStream_t>(stream), *p, 0);
+    hipLaunchKernelGGL(frp::corridor_kernel<false>, dim3((unsigned)p->B), dim3(frp::CR_THREADS), lds, static_cast<hipStream_t>(stream), *p, grid ? 1 : 0);
     return hipGetLastError() == hipSuccess ? FRP_OK : FRP_ERR_HIP;
 }

@@ -58,7 +58,9 @@ class Corridor(ctypes.Structure):  # frp_nmpc_corridor (include/frp_nmpc.h)
                 ("bbox", ctypes.c_double * 3), ("seed_len", ctypes.c_double), ("inflation", ctypes.c_double),
                 ("offset_x", ctypes.c_double),
                 ("poly_A", ctypes.c_void_p), ("poly_b", ctypes.c_void_p), ("poly_nfaces", ctypes.c_void_p),
-                ("poly_index", ctypes.c_void_p), ("poly_count", ctypes.c_void_p)]
+                ("poly_index", ctypes.c_void_p), ("poly_count", ctypes.c_void_p),
+                ("grid_origin", ctypes.c_double * 3), ("grid_cell", ctypes.c_double), ("grid_dims", ctypes.c_int * 3),
+                ("grid_points", ctypes.c_void_p), ("grid_index", ctypes.c_void_p), ("grid_start", ctypes.c_void_p)]
 
 
 class Reference(ctypes.Structure):  # frp_nmpc_reference (include/frp_nmpc.h)
@@ -102,7 +104,7 @@ EXPORTS = ["frp_nmpc_default_options", "frp_nmpc_workspace_bytes", "frp_nmpc_sol
            "frp_nmpc_version", "frp_nmpc_device_count", "FORCESNLPsolver_normal_solve",
            "FORCESNLPsolver_final_solve", "frp_nmpc_pack_batch", "frp_nmpc_update_batch", "frp_nmpc_tube_batch",
            "frp_nmpc_corridor_batch", "frp_nmpc_reference_batch",
-           "frp_nmpc_coldstart_batch"]
+           "frp_nmpc_coldstart_batch", "frp_nmpc_cloud_grid_build"]
 
 _lib = None
 
@@ -137,6 +139,8 @@ def lib():
         l.frp_nmpc_tube_batch.argtypes = [ctypes.POINTER(Tube), ctypes.c_void_p]
         l.frp_nmpc_corridor_batch.argtypes = [ctypes.POINTER(Corridor), ctypes.c_void_p]
         l.frp_nmpc_reference_batch.argtypes = [ctypes.POINTER(Reference), ctypes.c_void_p]
+        l.frp_nmpc_cloud_grid_build.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p,
+                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         l.frp_nmpc_coldstart_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
                                                ctypes.c_void_p, ctypes.c_void_p]
         _lib = l
@@ -285,8 +289,37 @@ def reference_batch_host(kino_path, time_offset, mpc_output, kino_size=None, Ts=
     return rp.cpu().numpy(), ry.cpu().numpy(), fl.cpu().numpy()
 
 
+class CloudGrid:
+    """Uniform grid over a shared obstacle cloud (frp_nmpc_cloud_grid_build): built once per cloud, handed to
+    corridor_batch_device / DeviceFleet.corridor so that a decomposition reads only the cells its local box touches."""
+
+    def __init__(self, cloud, cell=0.5, origin=None, dims=None, stream=None):
+        import torch
+        assert cloud.dim() == 2 and cloud.shape[1] == 3 and cloud.is_contiguous() and cloud.dtype == torch.float64
+        P = cloud.shape[0]
+        if origin is None or dims is None:  # bounds of the cloud itself (host round trip; a map normally knows its bounds)
+            finite = cloud[torch.isfinite(cloud).all(dim=1)]
+            lo = finite.min(dim=0).values.cpu().numpy() if finite.numel() else np.zeros(3)
+            hi = finite.max(dim=0).values.cpu().numpy() if finite.numel() else np.ones(3)
+            origin = lo - 1e-9
+            dims = np.maximum(1, np.ceil((hi - origin) / cell + 1e-9)).astype(int)
+        self.origin = tuple(float(v) for v in origin); self.dims = tuple(int(v) for v in dims); self.cell = float(cell)
+        cells = self.dims[0] * self.dims[1] * self.dims[2]
+        dev = cloud.device
+        self.points = torch.empty((max(P, 1), 3), dtype=torch.float64, device=dev)
+        self.index = torch.empty((max(P, 1),), dtype=torch.int32, device=dev)
+        self.start = torch.empty((cells + 1,), dtype=torch.int32, device=dev)
+        scratch = torch.empty((cells,), dtype=torch.int32, device=dev)
+        s = stream if stream is not None else torch.cuda.current_stream(dev)
+        _check(lib().frp_nmpc_cloud_grid_build(ctypes.c_void_p(cloud.data_ptr()) if P else None, P, (ctypes.c_double * 3)(*self.origin),
+                                               self.cell, (ctypes.c_int * 3)(*self.dims), ctypes.c_void_p(self.points.data_ptr()),
+                                               ctypes.c_void_p(self.index.data_ptr()), ctypes.c_void_p(self.start.data_ptr()),
+                                               ctypes.c_void_p(scratch.data_ptr()), ctypes.c_void_p(s.cuda_stream)), "frp_nmpc_cloud_grid_build")
+        s.synchronize()  # scratch may be freed
+
+
 def corridor_batch_device(cloud, ref_pos, ref_yaw, ellipsoid, poly_A, poly_b, poly_nfaces, poly_index, poly_count=None,
-                          cloud_count=None, consts=None, stream=None):
+                          cloud_count=None, consts=None, stream=None, grid=None):
     """frp_nmpc_corridor_batch on device tensors.  cloud [P,3] (shared) or [B,P,3]; ref_pos [B,N,3]; ref_yaw [B,N];
     ellipsoid [B,N,3,3]; outputs poly_A [B,N,F,3], poly_b [B,N,F], poly_nfaces / poly_index [B,N] int32."""
     import torch
@@ -304,10 +337,14 @@ def corridor_batch_device(cloud, ref_pos, ref_yaw, ellipsoid, poly_A, poly_b, po
                   ref_pos.data_ptr(), ref_yaw.data_ptr(), ellipsoid.data_ptr(), (ctypes.c_double * 3)(*c["bbox"]),
                   c["seed_len"], c["inflation"], c["offset_x"], poly_A.data_ptr(), poly_b.data_ptr(),
                   poly_nfaces.data_ptr(), poly_index.data_ptr(), poly_count.data_ptr() if poly_count is not None else None)
+    if grid is not None:
+        assert per == 0, "the grid belongs to a shared cloud"
+        cr.grid_origin = (ctypes.c_double * 3)(*grid.origin); cr.grid_cell = grid.cell; cr.grid_dims = (ctypes.c_int * 3)(*grid.dims)
+        cr.grid_points = grid.points.data_ptr(); cr.grid_index = grid.index.data_ptr(); cr.grid_start = grid.start.data_ptr()
     _check(lib().frp_nmpc_corridor_batch(ctypes.byref(cr), ctypes.c_void_p(s.cuda_stream)), "frp_nmpc_corridor_batch")
 
 
-def corridor_batch_host(cloud, ref_pos, ref_yaw, ellipsoid, F=CORRIDOR_MAX_F, consts=None, device="cuda:0"):
+def corridor_batch_host(cloud, ref_pos, ref_yaw, ellipsoid, F=CORRIDOR_MAX_F, consts=None, device="cuda:0", grid_cell=None):
     """Host convenience: numpy in, (poly_index [B,N], poly_A [B,N,F,3], poly_b [B,N,F], poly_nfaces [B,N], poly_count [B]) out."""
     import torch
     lib()
@@ -316,7 +353,9 @@ def corridor_batch_host(cloud, ref_pos, ref_yaw, ellipsoid, F=CORRIDOR_MAX_F, co
     A = torch.zeros((B, N, F, 3), dtype=torch.float64, device=device); b = torch.zeros((B, N, F), dtype=torch.float64, device=device)
     nf = torch.zeros((B, N), dtype=torch.int32, device=device); pi = torch.zeros((B, N), dtype=torch.int32, device=device)
     cnt = torch.zeros((B,), dtype=torch.int32, device=device)
-    corridor_batch_device(dev(cloud), dev(ref_pos), dev(ref_yaw), dev(ellipsoid), A, b, nf, pi, cnt, consts=consts)
+    d_cloud = dev(cloud).reshape(-1, 3)
+    grid = CloudGrid(d_cloud, grid_cell) if grid_cell else None
+    corridor_batch_device(d_cloud, dev(ref_pos), dev(ref_yaw), dev(ellipsoid), A, b, nf, pi, cnt, consts=consts, grid=grid)
     torch.cuda.synchronize(device)
     return pi.cpu().numpy(), A.cpu().numpy(), b.cpu().numpy(), nf.cpu().numpy(), cnt.cpu().numpy()
 
@@ -387,7 +426,7 @@ class DeviceFleet:
         s = stream if stream is not None else self.torch.cuda.current_stream(self.solver.device)
         tube_batch_device(self.mpc_output, self.ellipsoid, consts, s)
 
-    def corridor(self, cloud, ref_pos, ref_yaw, consts=None, stream=None, cloud_count=None):
+    def corridor(self, cloud, ref_pos, ref_yaw, consts=None, stream=None, cloud_count=None, grid=None):
         """polytopes and poly_indices of all B planners from the obstacle cloud, the stage
         references and the current tube (getSikangConst, nmpc_solver.cpp:288-332) -> self.poly_*, on the device."""
         t = self.torch
@@ -395,7 +434,7 @@ class DeviceFleet:
         if self.poly_index is None:
             self.poly_index = t.zeros((self.B, self.N), dtype=t.int32, device=self.solver.device)
         corridor_batch_device(cloud, ref_pos, ref_yaw, self.ellipsoid, self.poly_A, self.poly_b, self.poly_nfaces,
-                              self.poly_index, None, cloud_count, consts, stream)
+                              self.poly_index, None, cloud_count, consts, stream, grid)
 
     def coldstart(self, state=None, only_failed=True, thrust=7.3, stream=None):
         """initMPCOutput for the planners whose last solve failed (nmpc_solver.cpp:363-364, :265-286), on the device.
@@ -412,7 +451,7 @@ class DeviceFleet:
         reference_batch_device(kino_path, time_offset, self.mpc_output, ref_pos, ref_yaw, replan, kino_size, Ts, stream)
 
     def full_tick(self, external_acc, kino_path, time_offset, cloud, ref_pos, ref_yaw, stream=None, replan=None,
-                  kino_size=None, tube_consts=None, corridor_consts=None, Ts=0.05, coldstart=True, state=None):
+                  kino_size=None, tube_consts=None, corridor_consts=None, Ts=0.05, coldstart=True, state=None, grid=None):
         """The reference's whole per-tick computation downstream of the A* (NMPCSolver::solveNMPC,
         nmpc_solver.cpp:351-482) for B planners, asynchronous on `stream`, nothing touching the host:
         stage references (f-4) -> tube (f-2) -> corridor (f-3) -> parameter packing (f-1) -> NLP solve -> result
@@ -422,7 +461,7 @@ class DeviceFleet:
             self.coldstart(state, True, stream=stream)
         self.references(kino_path, time_offset, ref_pos, ref_yaw, replan, kino_size, Ts, stream)
         self.tube(tube_consts, stream)
-        self.corridor(cloud, ref_pos, ref_yaw, corridor_consts, stream)
+        self.corridor(cloud, ref_pos, ref_yaw, corridor_consts, stream, grid=grid)
         self.pack(external_acc, ref_pos, ref_yaw, stream)
         self.solver.solve(stream)
         self.update(stream)

@@ -194,7 +194,21 @@ typedef struct frp_nmpc_corridor {
     int *poly_index;        /* [B][N]        poly_indices(i)                                                        */
     int *poly_count;        /* [B] or NULL   polytopes made; negated when one had more than F rows, in which case the
                                              containment test of later stages saw only its first F rows              */
+    /* optional uniform grid over a SHARED cloud (frp_nmpc_cloud_grid_build); grid_start == NULL: scan the whole cloud  */
+    double grid_origin[3], grid_cell;
+    int grid_dims[3];
+    const double *grid_points; /* [P][3] the cloud sorted by cell                                                      */
+    const int *grid_index;     /* [P]    original cloud index of each sorted point                                     */
+    const int *grid_start;     /* [nx*ny*nz + 1] first sorted point of each cell (x fastest, then y, then z)           */
 } frp_nmpc_corridor;
+
+#define FRP_CORRIDOR_MAX_CELLS (1 << 22)
+/* Bins a cloud into a uniform grid so that a decomposition reads only the cells its local box touches instead of the
+ * whole cloud (same results: minima are tie-broken by the original cloud index).  Points outside the grid, NaNs
+ * included, are binned into its border cells.  Buffers (device): grid_points [P][3], grid_index [P], grid_start
+ * [cells + 1], scratch [cells].  Rebuild when the cloud changes (cloudCallback, nmpc_solver.cpp:989-996), not per tick. */
+int frp_nmpc_cloud_grid_build(const double *cloud, int P, const double origin[3], double cell, const int dims[3],
+                              double *grid_points, int *grid_index, int *grid_start, int *scratch, void *stream);
 
 /* For every planner, the getSikangConst calls of NMPCSolver::setFORCESParams (nmpc_solver.cpp:288-332, :515):
  * stage i keeps the latest polytope while its tube ellipsoid, inflated, fits; otherwise DecompROS'

@@ -472,6 +472,11 @@ def _check_corridor(cloud, ref, yaw, E, consts=None, F=64, ordered=True):
     by rounding (in the reference as much as here); the set of hyperplanes is the same."""
     C = _corridor_oracle()
     pi, A, b, nf, cnt = solver.corridor_batch_host(cloud, ref, yaw, E, F=F, consts=consts)
+    if len(cloud):  # the same launch reading the cloud through a uniform grid: same bits (minima are tie-broken by cloud index)
+        for cell in (0.5, 0.23):
+            g = solver.corridor_batch_host(cloud, ref, yaw, E, F=F, consts=consts, grid_cell=cell)
+            assert np.array_equal(g[0], pi) and np.array_equal(g[3], nf) and np.array_equal(g[4], cnt), cell
+            assert np.array_equal(g[1], A) and np.array_equal(g[2], b), cell
     kw = consts or {}
     for p in range(ref.shape[0]):
         idx, polys = C.corridor_one(ref[p], yaw[p], E[p], cloud, **kw)
@@ -800,3 +805,26 @@ def test_plain_c_program_drives_the_whole_tick_through_the_c_abi(tmp_path):
     assert np.array_equal(it_c, fleet.solver.iters.cpu().numpy())
     assert np.array_equal(pi_c, fleet.poly_index.cpu().numpy())
     assert np.array_equal(plan_c, fleet.mpc_output.cpu().numpy())
+
+
+def test_cloud_grid_is_a_cell_sorted_permutation_of_the_cloud():
+    """frp_nmpc_cloud_grid_build: counting sort of the cloud by cell -- every point exactly once, inside the cell range
+    that cell_start gives it, points beyond the grid (and NaNs) in border cells."""
+    import torch
+    rng = np.random.default_rng(12)
+    cloud = np.c_[rng.uniform(-3, 9, 5000), rng.uniform(-4, 4, 5000), rng.uniform(-0.5, 3, 5000)]
+    cloud[17] = np.nan; cloud[99] = [1e6, -1e6, 0.3]
+    origin, cell, dims = (-2.0, -3.0, 0.0), 0.4, (20, 12, 6)   # deliberately smaller than the cloud
+    g = solver.CloudGrid(torch.from_numpy(cloud).to("cuda:0"), cell, origin, dims)
+    torch.cuda.synchronize()
+    start, idx, pts = g.start.cpu().numpy(), g.index.cpu().numpy(), g.points.cpu().numpy()
+    assert start[0] == 0 and start[-1] == len(cloud) and np.all(np.diff(start) >= 0)
+    assert np.array_equal(np.sort(idx), np.arange(len(cloud)))
+    assert np.array_equal(pts, cloud[idx], equal_nan=True)
+    with np.errstate(invalid="ignore"):
+        ijk = np.floor((cloud - np.array(origin)) / cell)
+    ijk = np.where(ijk > 0, ijk, 0)                         # NaN -> 0 like the kernel
+    ijk = np.minimum(ijk, np.array(dims) - 1).astype(int)
+    want = (ijk[:, 2] * dims[1] + ijk[:, 1]) * dims[0] + ijk[:, 0]
+    cell_of_sorted = np.searchsorted(start, np.arange(len(cloud)), side="right") - 1
+    assert np.array_equal(cell_of_sorted, want[idx])

@@ -2,7 +2,7 @@
 """Measurement of the f-3 kernel (corridor generation / selection).  Memory-side work: every decomposition scans the
 whole cloud once (24 B per point; later scans only touch surviving 64-point words), so the algorithmic bytes are
 decompositions x P x 24 and the bound is L2/HBM bandwidth (the cloud is shared by the fleet and L2-resident).
-The numpy oracle is timed beside it on a bounded sample.     python tests/tools/corridor_bench.py [B=4096] [P=20000]"""
+The numpy oracle is timed beside it on a bounded sample.     python tests/tools/corridor_bench.py [B=4096] [P=20000] [grid_cell=0]"""
 import json
 import sys
 import time
@@ -33,7 +33,9 @@ d_cloud, d_ref, d_yaw = dev(cloud), dev(ref), dev(yaw)
 A = torch.zeros((B, N, F, 3), dtype=torch.float64, device="cuda:0"); b = torch.zeros((B, N, F), dtype=torch.float64, device="cuda:0")
 nf = torch.zeros((B, N), dtype=torch.int32, device="cuda:0"); pi = torch.zeros((B, N), dtype=torch.int32, device="cuda:0")
 cnt = torch.zeros((B,), dtype=torch.int32, device="cuda:0")
-fn = lambda: solver.corridor_batch_device(d_cloud, d_ref, d_yaw, E, A, b, nf, pi, cnt)
+GRID = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0   # cell size of the uniform grid, 0 = scan the whole cloud
+grid = solver.CloudGrid(d_cloud, GRID) if GRID > 0 else None
+fn = lambda: solver.corridor_batch_device(d_cloud, d_ref, d_yaw, E, A, b, nf, pi, cnt, grid=grid)
 fn(); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 reps = 10
@@ -50,7 +52,7 @@ for p in range(ns):
     C.corridor_one(ref[p], yaw[p], Eh[p], cloud)
 tc = time.time() - t0
 by = ndec * len(cloud) * 24
-print(json.dumps({"B": B, "N": N, "cloud_points": len(cloud), "seconds": t, "planners_per_s": B / t,
+print(json.dumps({"B": B, "N": N, "cloud_points": len(cloud), "grid_cell": GRID, "seconds": t, "planners_per_s": B / t,
                   "decompositions": ndec, "decompositions_per_planner": ndec / B, "mean_rows": float(rows[rows > 0].mean()),
                   "max_rows": int(rows.max()), "overflowed_planners": int((cnt < 0).sum().item()),
                   "algorithmic_bytes_first_scan": by, "GBps_first_scan": by / t / 1e9,

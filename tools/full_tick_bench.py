@@ -2,7 +2,7 @@
 """The reference's whole per-tick computation downstream of the A* for a fleet, on one GPU, nothing on the host:
 stage references (f-4) -> tube (f-2) -> corridor (f-3) -> packing (f-1) -> NLP solve -> bookkeeping
 (DeviceFleet.full_tick).  Prints ms per step of the chain (HIP events on the launch stream) and planner-ticks/s.
-   python tools/full_tick_bench.py [B=4096] [ticks=10] [P=20000]"""
+   python tools/full_tick_bench.py [B=4096] [ticks=10] [P=20000] [grid_cell=0.5]"""
 import json
 import sys
 import numpy as np
@@ -15,6 +15,7 @@ from forces_resilient_planner_amd import solver
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 TICKS = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 P = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
+GRID = float(sys.argv[4]) if len(sys.argv) > 4 else 0.5   # uniform-grid cell over the shared cloud, 0 = none
 N, M, F, K = 20, 30, 64, 120
 rng = np.random.default_rng(0)
 s = np.arange(K) * 0.05 * 1.6
@@ -28,10 +29,11 @@ fleet = solver.DeviceFleet(B, N, M, F, L.MODEL_NORMAL, (15.0, 3.0, 80.0, 15.0, 0
 fleet.mpc_output.copy_(fleet.to_device(plan))
 d_path, d_cloud = fleet.to_device(path), fleet.to_device(cloud)
 d_f = fleet.to_device(rng.normal(0, 0.5, (B, 3)))
+grid = solver.CloudGrid(d_cloud, GRID) if GRID > 0 else None   # built once per cloud, not per tick
 rp = torch.zeros((B, N, 3), dtype=torch.float64, device="cuda:0"); ry = torch.zeros((B, N), dtype=torch.float64, device="cuda:0")
 offs = [fleet.to_device(np.full(B, 0.05 * t) + rng.uniform(0, 0.01, B)) for t in range(TICKS + 1)]
 steps = [("reference", lambda t: fleet.references(d_path, offs[t], rp, ry)), ("tube", lambda t: fleet.tube()),
-         ("corridor", lambda t: fleet.corridor(d_cloud, rp, ry)), ("pack", lambda t: fleet.pack(d_f, rp, ry)),
+         ("corridor", lambda t: fleet.corridor(d_cloud, rp, ry, grid=grid)), ("pack", lambda t: fleet.pack(d_f, rp, ry)),
          ("solve", lambda t: fleet.solver.solve()), ("update", lambda t: fleet.update())]
 for _, fn in steps:  # warm-up tick
     fn(0)
@@ -63,7 +65,7 @@ def split_tick(t):
     for k, f2 in enumerate(fl2):
         r2, y2, fe, of = bufs[k]
         with torch.cuda.stream(st[k]):
-            f2.full_tick(fe, d_path, of[t], d_cloud, r2, y2, stream=st[k])
+            f2.full_tick(fe, d_path, of[t], d_cloud, r2, y2, stream=st[k], grid=grid)
 split_tick(0); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
@@ -74,7 +76,7 @@ for k in range(2):
 e1.record(); torch.cuda.synchronize()
 split_ms = e0.elapsed_time(e1) / TICKS
 print(json.dumps({"workload": f"{B} planners x {TICKS} ticks, N=20, shared cloud of {len(cloud)} points, shared kinodynamic path",
-                  "ms_per_tick": total, "planner_ticks_per_s": B / total * 1e3, "ms_per_step": ms,
+                  "grid_cell": GRID, "ms_per_tick": total, "planner_ticks_per_s": B / total * 1e3, "ms_per_step": ms,
                   "two_half_fleets_on_two_streams": {"ms_per_tick": split_ms, "planner_ticks_per_s": B / split_ms * 1e3},
                   "converged_frac": float((fl == 1).mean()), "mean_iters": float(it.mean()),
                   "polytopes_per_planner": float((fleet.poly_nfaces > 0).sum().item() / B)}))
