@@ -31,8 +31,8 @@
 //     result through LDS (struct Uni), so it costs the scanning waves no registers.
 // Memory-side work: 24 bytes per cloud point per decomposition, then 24-byte gathers of in-box points from L2 (the
 // cloud is shared by the planners of a fleet); lists of up to CR_TILE * 256 points live in registers (scan_tile).
-// Measured (profiles/r01_corridor_bench.json): full-cloud scan 32 us (8 us through the uniform grid of
-// frp_nmpc_cloud_grid_build, scan_grid), then ~20-30 scans of ~1.9 us per decomposition.
+// Measured (profiles/r01_corridor_bench.json): first scan + list + register-tile fill 32 us on the plain cloud, 16 us
+// through the uniform grid of frp_nmpc_cloud_grid_build (scan_grid), then ~20-30 scans of ~1.9 us per decomposition.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
