@@ -172,7 +172,6 @@ constexpr int CR_LIST = 8192; // capacity of the in-box index list (LDS); larger
 struct Uni {
     double Ri[9], Rf[9], Ci[9], CC[9]; // initial / final ellipsoid frame, C^-1, C^-1 C^-T
     double mid[3], ax[3];              // ellipsoid centre (p1 + p2) / 2, semi-axes
-    double q[3], n[3];                 // the hyperplane being applied
     double box[12][3];                 // local box: points 0..5, outward normals 6..11
     double frame[3][3], p1[3], len;    // the same box as a frame at p1: axes dir_h, dir, dir_v; segment length
     int rows, overflow, count;         // rows emitted, > F rows seen, in-box points appended to the list
@@ -190,7 +189,8 @@ enum { KEEP_OUTSIDE = 0, KEEP_INSIDE = 1, KEEP_ALL = 2, KEEP_BEHIND_PLANE = 3 };
 // One pass: out = { points of `in` that satisfy MODE }, returns the kept point closest to the centre in the metric
 // of u.Ci (first minimum in list order).  Word g of a mask is always handled by wave g % CR_WAVES.
 template <int MODE>
-__device__ __forceinline__ Best scan(const Scan &s, const uint64_t *in, uint64_t *out, const Uni &u, Best *s_red, int &phase)
+__device__ __forceinline__ Best scan(const Scan &s, const uint64_t *in, uint64_t *out, const Uni &u, Best *s_red, int &phase,
+                                     const double *pq = nullptr, const double *pn = nullptr)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #ifdef FRP_CORRIDOR_PROFILE
@@ -201,7 +201,7 @@ __device__ __forceinline__ Best scan(const Scan &s, const uint64_t *in, uint64_t
     double q[3] = {0, 0, 0}, n[3] = {0, 0, 0};
     if (MODE == KEEP_BEHIND_PLANE) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { q[k] = u.q[k]; n[k] = u.n[k]; }
+        for (int k = 0; k < 3; ++k) { q[k] = pq[k]; n[k] = pn[k]; } // the hyperplane, computed by every lane from the reduction's winner
     }
     Best best{1.7976931348623157e308, 0x7fffffff, 0.0, 0.0, 0.0};
     // Most words of a list are empty.  Each lane fetches one of the wave's next 64 words, a ballot tells which are
@@ -264,7 +264,8 @@ __device__ __forceinline__ Best scan(const Scan &s, const uint64_t *in, uint64_t
 struct Tile { double x[CR_TILE], y[CR_TILE], z[CR_TILE]; int id[CR_TILE]; };
 
 template <int MODE>
-__device__ __forceinline__ Best scan_tile(const Tile &t, int W, const uint64_t *in, uint64_t *out, const Uni &u, Best *s_red, int &phase)
+__device__ __forceinline__ Best scan_tile(const Tile &t, int W, const uint64_t *in, uint64_t *out, const Uni &u, Best *s_red, int &phase,
+                                          const double *pq = nullptr, const double *pn = nullptr)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const M3 Ci = ld3(u.Ci);
@@ -272,7 +273,7 @@ __device__ __forceinline__ Best scan_tile(const Tile &t, int W, const uint64_t *
     double q[3] = {0, 0, 0}, n[3] = {0, 0, 0};
     if (MODE == KEEP_BEHIND_PLANE) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { q[k] = u.q[k]; n[k] = u.n[k]; }
+        for (int k = 0; k < 3; ++k) { q[k] = pq[k]; n[k] = pn[k]; } // the hyperplane, computed by every lane from the reduction's winner
     }
     uint64_t w[CR_TILE];
 #pragma unroll
@@ -657,20 +658,19 @@ __global__ __launch_bounds__(CR_THREADS) void corridor_kernel(frp_nmpc_corridor 
         cp = tiled ? scan_tile<KEEP_ALL>(tile, sc.W, m0, m2, u, s_red, phase) : scan<KEEP_ALL>(sc, m0, m2, u, s_red, phase); // Ci is unchanged since the last barrier
         CR_ACC(tp_scan) CR_CNT(np_scan)
         for (int guard = 0; cp.idx != 0x7fffffff && guard < max_rounds; ++guard) {
-            if (tid == 0) {
-                const double q[3] = {cp.x, cp.y, cp.z};
-                const double w[3] = {q[0] - u.mid[0], q[1] - u.mid[1], q[2] - u.mid[2]};
-                double n[3];
+            // closest_hyperplane (ellipsoid.h:53-58) by every lane from the winner the reduction handed out: no
+            // publish-through-LDS, hence no barrier between "pick" and "cut"
+            const double q[3] = {cp.x, cp.y, cp.z};
+            const double w[3] = {q[0] - u.mid[0], q[1] - u.mid[1], q[2] - u.mid[2]};
+            double n[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) n[k] = u.CC[3 * k] * w[0] + u.CC[3 * k + 1] * w[1] + u.CC[3 * k + 2] * w[2];
-                const double nl = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            for (int k = 0; k < 3; ++k) n[k] = u.CC[3 * k] * w[0] + u.CC[3 * k + 1] * w[1] + u.CC[3 * k + 2] * w[2];
+            const double nl = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { n[k] /= nl; u.n[k] = n[k]; u.q[k] = q[k]; }
-                emit_row(u, q, n, c.F, s_A, s_b, gA, gb);
-            }
-            __syncthreads();
+            for (int k = 0; k < 3; ++k) n[k] /= nl;
+            if (tid == 0) emit_row(u, q, n, c.F, s_A, s_b, gA, gb);
             CR_ACC(tp_lead)
-            cp = tiled ? scan_tile<KEEP_BEHIND_PLANE>(tile, sc.W, m2, m2, u, s_red, phase) : scan<KEEP_BEHIND_PLANE>(sc, m2, m2, u, s_red, phase);
+            cp = tiled ? scan_tile<KEEP_BEHIND_PLANE>(tile, sc.W, m2, m2, u, s_red, phase, q, n) : scan<KEEP_BEHIND_PLANE>(sc, m2, m2, u, s_red, phase, q, n);
             CR_ACC(tp_scan) CR_CNT(np_scan)
         }
         if (tid == 0) {
