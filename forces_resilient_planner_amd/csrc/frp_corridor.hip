@@ -17,8 +17,9 @@
 // earlier stage while its inflated tube ellipsoid fits, so the stage loop is sequential by definition).  A
 // decomposition is a sequence of scans -- "keep the points that ..., and find the one closest to the ellipsoid
 // centre in the ellipsoid's metric" -- where the reference rebuilds std::vectors:
-//   * the first scan reads the whole cloud once (CR_UNROLL 64-point words in flight per wave), tests the local box
-//     in the box's own frame, and appends the indices of the in-box points to a dense list in LDS (one LDS atomic
+//   * the first scan reads the whole cloud once (CR_UNROLL 64-point words in flight per wave) -- or, when the caller
+//     supplies the uniform grid of frp_nmpc_cloud_grid_build, only the cell rows under the box's axis-aligned hull
+//     (scan_grid, a separate kernel instantiation) --, tests the local box in the box's own frame, and appends the indices of the in-box points to a dense list in LDS (one LDS atomic
 //     per CR_UNROLL words; the order of the list is irrelevant because minima are tie-broken by cloud index, which
 //     is the reference's first-minimum rule on its order-preserving lists);
 //   * every later scan runs over that list (typically 10 % of the cloud) with all lanes busy; point lists are bit
@@ -27,8 +28,9 @@
 //     CR_LIST points fall back to masks over the cloud itself;
 //   * "filter with the new ellipsoid, then take the closest of what is left" uses the same distances, so both happen
 //     in ONE scan; the workgroup minimum carries the winner's coordinates (one barrier, double-buffered);
-//   * the 3x3 algebra of an ellipsoid / hyperplane update is wave-uniform: thread 0 does it and publishes the
-//     result through LDS (struct Uni), so it costs the scanning waves no registers.
+//   * the 3x3 algebra of an ellipsoid update is wave-uniform: thread 0 does it and publishes the result through LDS
+//     (struct Uni), so it costs the scanning waves no registers; the hyperplane of a cut is a dozen operations and
+//     is computed by every lane from the winner the reduction hands out (no publish, no extra barrier).
 // Memory-side work: 24 bytes per cloud point per decomposition, then 24-byte gathers of in-box points from L2 (the
 // cloud is shared by the planners of a fleet); lists of up to CR_TILE * 256 points live in registers (scan_tile).
 // Measured (profiles/r01_corridor_bench.json): first scan + list + register-tile fill 32 us on the plain cloud, 16 us
