@@ -203,3 +203,40 @@ def test_header_is_plain_c99(tmp_path):
                    '  return sizeof(frp_forces_params) == 23600 ? 0 : 1; }\n')
     inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
+
+
+def test_widened_entry_points_reject_bad_arguments_before_touching_a_device():
+    """Argument checks of the f-1 .. f-4 entry points run on the host, so they are testable without a GPU: NULL
+    buffers, horizons beyond 64 stages, polytope capacities outside [6, 64], oversized clouds / grids, non-positive
+    physical constants all return FRP_ERR_ARG (-1003)."""
+    l = solver.lib()
+    ERR = -1003
+    one = ctypes.c_void_p(8)  # any non-NULL address: the checks must fail before it would be dereferenced on the device
+    tb = solver.Tube(4, 20, None, 0.74, 0.33, 0.27, 0.0425, (ctypes.c_double * 3)(0.5, 0.5, 0.5), 0.06, 0.05, one)
+    assert l.frp_nmpc_tube_batch(ctypes.byref(tb), None) == ERR                 # no plan
+    tb.mpc_output = 8; tb.N = 65
+    assert l.frp_nmpc_tube_batch(ctypes.byref(tb), None) == ERR                 # horizon > 64
+    tb.N = 20; tb.mass = 0.0
+    assert l.frp_nmpc_tube_batch(ctypes.byref(tb), None) == ERR                 # mass
+    tb.mass = 0.74; tb.noise = (ctypes.c_double * 3)(0.5, 0.0, 0.5)
+    assert l.frp_nmpc_tube_batch(ctypes.byref(tb), None) == ERR                 # a zero noise bound makes tr(X) = 0
+    cr = solver.Corridor()
+    cr.B, cr.N, cr.F, cr.P = 4, 20, 64, 100
+    for f in ("cloud", "ref_pos", "ref_yaw", "ellipsoid", "poly_A", "poly_b", "poly_nfaces", "poly_index"):
+        setattr(cr, f, 8)
+    cr.bbox = (ctypes.c_double * 3)(2, 2, 1); cr.seed_len = 0.1; cr.inflation = 1.1
+    for field, bad in (("F", 5), ("F", 65), ("N", 0), ("N", 65), ("P", 65537), ("seed_len", 0.0), ("poly_index", None), ("cloud", None)):
+        keep = getattr(cr, field)
+        setattr(cr, field, bad)
+        assert l.frp_nmpc_corridor_batch(ctypes.byref(cr), None) == ERR, field
+        setattr(cr, field, keep)
+    cr.grid_start = 8                                                            # a grid without its other arrays / cell size
+    assert l.frp_nmpc_corridor_batch(ctypes.byref(cr), None) == ERR
+    rf = solver.Reference(4, 20, 50, None, 0, None, 8, 8, 0.05, 3.1415926, 8, 8, None)
+    assert l.frp_nmpc_reference_batch(ctypes.byref(rf), None) == ERR           # no path
+    rf.kino_path = 8; rf.Ts = 0.0
+    assert l.frp_nmpc_reference_batch(ctypes.byref(rf), None) == ERR
+    assert l.frp_nmpc_coldstart_batch(4, 20, None, None, 7.3, None, None) == ERR
+    d3, i3 = (ctypes.c_double * 3)(0, 0, 0), (ctypes.c_int * 3)(1 << 11, 1 << 11, 2)   # 2^23 cells > FRP_CORRIDOR_MAX_CELLS
+    assert l.frp_nmpc_cloud_grid_build(one, 10, d3, 0.5, i3, one, one, one, one, None) == ERR
+    assert l.frp_nmpc_cloud_grid_build(one, 10, d3, 0.0, (ctypes.c_int * 3)(4, 4, 4), one, one, one, one, None) == ERR
