@@ -62,6 +62,8 @@ bool fill_args(const frp_nmpc_batch *b, const frp_nmpc_options *opt_in, void *ws
     a->xinit = b->xinit; a->x0 = b->x0; a->params = b->params; a->nfaces = b->nfaces;
     a->z = b->z; a->exitflag = b->exitflag; a->iters = b->iters; a->info = b->info;
     a->ws = static_cast<double *>(ws);
+    a->models = b->model_per_problem;
+    a->counter = nullptr; a->order = nullptr;
     return true;
 }
 
@@ -271,7 +273,7 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FRP_ERR_NO_DEVICE;
     const size_t B = h->B, N = h->N, np = FRP_NPAR(h->M);
-    DevMem xinit, x0, par, z, info, nf, flag, it, ws;
+    DevMem xinit, x0, par, z, info, nf, flag, it, ws, models;
     const size_t wsb = frp::ws_bytes(h->B, h->N, h->MF);
     FRP_HIP(xinit.alloc(B * 9 * sizeof(double)));
     FRP_HIP(x0.alloc(B * N * 17 * sizeof(double)));
@@ -288,7 +290,12 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
         FRP_HIP(nf.alloc(B * N * sizeof(int)));
         FRP_HIP(hipMemcpy(nf.p, h->nfaces, B * N * sizeof(int), hipMemcpyHostToDevice));
     }
+    if (h->model_per_problem) {
+        FRP_HIP(models.alloc(B * sizeof(int)));
+        FRP_HIP(hipMemcpy(models.p, h->model_per_problem, B * sizeof(int), hipMemcpyHostToDevice));
+    }
     frp_nmpc_batch d = *h;
+    d.model_per_problem = h->model_per_problem ? models.as<int>() : nullptr;
     d.xinit = xinit.as<double>(); d.x0 = x0.as<double>(); d.params = par.as<double>(); d.nfaces = h->nfaces ? nf.as<int>() : nullptr;
     d.z = z.as<double>(); d.exitflag = flag.as<int>(); d.iters = it.as<int>(); d.info = info.as<double>();
     const int rc = frp_nmpc_solve_batch(&d, opt, ws.p, wsb, nullptr);

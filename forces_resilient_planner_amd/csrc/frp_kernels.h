@@ -78,6 +78,7 @@ struct KernelArgs {
     double *ws;
     int *counter;     // work-queue head (set by the launcher)
     const int *order; // launch order of the problems, or null = index order (set by the launcher)
+    const int *models; // per-problem FRP_MODEL_*, or null = `model` for the whole batch
 };
 
 size_t ws_bytes(int B, int N, int MF);

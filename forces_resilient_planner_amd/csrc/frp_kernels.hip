@@ -1513,6 +1513,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     }
     const int nfk = ini.nfk, mtot = ini.mtot;
     const int hess = a.hessian ? 1 : 0;
+    const int model = a.models ? a.models[b] : a.model; // normal / final objective of THIS problem (switch_to_final, nmpc_solver.cpp:381)
     FULLSYNC();
 
     int flag = FRP_EXIT_MAXIT, it = 0, nfallback = 0;
@@ -1536,8 +1537,8 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         else if (it == FRP_PRIO_IT2) __builtin_amdgcn_s_setprio(2);
         else if (it == FRP_PRIO_IT3) __builtin_amdgcn_s_setprio(3);
         TICK();
-        const ModelOut mo_ = phase_model<NP>(w, xinit, N, a.model, hess);
-        const EvalOut e = phase_eval<NP>(w, N, MF, nfk, a.model, mo_.eq, mo_.obj);
+        const ModelOut mo_ = phase_model<NP>(w, xinit, N, model, hess);
+        const EvalOut e = phase_eval<NP>(w, N, MF, nfk, model, mo_.eq, mo_.obj);
         res_eq = wave_max(e.eq); res_in = wave_max(e.in); rs = wave_max(e.rs); rcomp = wave_max(e.rc);
         pobj = wave_sum(e.obj);
         mu = wave_sum(e.gap) / (double)mtot;
@@ -1563,7 +1564,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         TOCK(1);
         sweep_forward<NP, false>(w, N);
         TOCK(2);
-        const SlackOut s0 = phase_affine<NP>(w, N, MF, nfk, a.model, mu, mtot, a.tol_comp);
+        const SlackOut s0 = phase_affine<NP>(w, N, MF, nfk, model, mu, mtot, a.tol_comp);
         sigma = s0.sigma;
         TOCK(3);
         // corrector solve (same factorisation, new rhs)
@@ -1624,7 +1625,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_WAVES_PE
 // the iteration count ~0.45 on the BASELINE workloads, and the hardest problems are reliably in the upper half, i.e.
 // in the first wave of resident workgroups).  Only the ORDER in which the persistent workgroups pull problems
 // changes; every problem is solved exactly as before.
-__global__ __launch_bounds__(256) void order_keys_kernel(int B, int N, int np, int model, const double *__restrict__ x0,
+__global__ __launch_bounds__(256) void order_keys_kernel(int B, int N, int np, int model, const int *__restrict__ models, const double *__restrict__ x0,
                                                          const double *__restrict__ params, double *__restrict__ keys)
 {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), k = threadIdx.x & 63; // one wavefront per problem, lane = stage
@@ -1637,7 +1638,7 @@ __global__ __launch_bounds__(256) void order_keys_kernel(int B, int N, int np, i
         for (int i = 0; i < NZ; i++) zl[i] = x0[t * NZ + i];
 #pragma unroll
         for (int i = 0; i < NPRE; i++) p10[i] = params[t * np + i];
-        c = stage_cost(zl, p10, stage_class(k, N), model, nullptr);
+        c = stage_cost(zl, p10, stage_class(k, N), models ? models[b] : model, nullptr);
     }
     c = wave_sum(c);
     if (k == 0) keys[b] = (c == c && c < 1e300) ? c : 0.0;
@@ -1804,7 +1805,7 @@ hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
         int *order = reinterpret_cast<int *>(keys + a.B);
         k.order = order;
         hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, stream, a.B, a.N, NPRE + 4 * a.M, a.model,
-                           a.x0, a.params, keys);
+                           a.models, a.x0, a.params, keys);
         hipLaunchKernelGGL(order_bucket_kernel, dim3(1), dim3(1024), 0, stream, a.B, keys, order, k.counter);
     } else {
         // a one-thread kernel rather than hipMemsetAsync: as a node of a captured hipGraph the 4-byte memset was not

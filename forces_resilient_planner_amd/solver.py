@@ -31,7 +31,7 @@ class Batch(ctypes.Structure):
                 ("model", ctypes.c_int),
                 ("xinit", ctypes.c_void_p), ("x0", ctypes.c_void_p), ("params", ctypes.c_void_p),
                 ("nfaces", ctypes.c_void_p), ("z", ctypes.c_void_p), ("exitflag", ctypes.c_void_p),
-                ("iters", ctypes.c_void_p), ("info", ctypes.c_void_p)]
+                ("iters", ctypes.c_void_p), ("info", ctypes.c_void_p), ("model_per_problem", ctypes.c_void_p)]
 
 
 class Pack(ctypes.Structure):  # frp_nmpc_pack (include/frp_nmpc.h)
@@ -172,9 +172,10 @@ def solve_batch_host(w, opt: Options | None = None, MF: int | None = None, x0=No
         MF = int(nf.max()) if nf is not None and nf.size else M
     z = np.zeros((B, N, L.NZ)); flag = np.zeros(B, dtype=np.int32); iters = np.zeros(B, dtype=np.int32)
     info = np.zeros((B, INFO_STRIDE))
+    models = None if w.get("models") is None else np.ascontiguousarray(w["models"], dtype=np.int32)  # per-problem normal / final
     b = Batch(B, N, M, MF, int(w["model"]), xinit.ctypes.data, z0.ctypes.data, params.ctypes.data,
               nf.ctypes.data if nf is not None else None, z.ctypes.data, flag.ctypes.data, iters.ctypes.data,
-              info.ctypes.data)
+              info.ctypes.data, models.ctypes.data if models is not None else None)
     _check(lib().frp_nmpc_solve_batch_host(ctypes.byref(b), ctypes.byref(opt) if opt is not None else None),
            "frp_nmpc_solve_batch_host")
     return z, flag, iters, info
@@ -223,7 +224,8 @@ class DeviceSolver:
     def _batch(self):
         return Batch(self.B, self.N, self.M, self.MF, self.model, self.xinit.data_ptr(), self.x0.data_ptr(),
                      self.params.data_ptr(), self.nfaces.data_ptr() if self.use_nfaces else None, self.z.data_ptr(),
-                     self.exitflag.data_ptr(), self.iters.data_ptr(), self.info.data_ptr())
+                     self.exitflag.data_ptr(), self.iters.data_ptr(), self.info.data_ptr(),
+                     self.models.data_ptr() if getattr(self, "models", None) is not None else None)
 
     def solve(self, stream=None):
         """Asynchronous launch on `stream` (a torch.cuda.Stream) or torch's current stream."""

@@ -89,6 +89,9 @@ typedef struct frp_nmpc_batch {
     int *iters;           /* [B] out, interior-point iterations (info.it)                */
     double *info;         /* [B][FRP_INFO_STRIDE] out or NULL:
                              res_eq, res_ineq, rsnorm, rcompnorm, pobj, mu, step_cc, n_gn_fallback */
+    const int *model_per_problem; /* [B] FRP_MODEL_* of each problem, or NULL: `model` for all.  A fleet whose
+                             planners switch to the final solver one by one (switch_to_final,
+                             nmpc_solver.cpp:381, 446-447) stays one batch.                    */
 } frp_nmpc_batch;
 
 void frp_nmpc_default_options(frp_nmpc_options *opt);

@@ -828,3 +828,25 @@ def test_cloud_grid_is_a_cell_sorted_permutation_of_the_cloud():
     want = (ijk[:, 2] * dims[1] + ijk[:, 1]) * dims[0] + ijk[:, 0]
     cell_of_sorted = np.searchsorted(start, np.arange(len(cloud)), side="right") - 1
     assert np.array_equal(cell_of_sorted, want[idx])
+
+
+def test_per_problem_model_equals_two_single_model_batches():
+    """frp_nmpc_batch.model_per_problem: a fleet whose planners switch to the final solver one by one
+    (switch_to_final, nmpc_solver.cpp:381, 446-447) is one launch; every problem gets exactly the solve its own
+    model would have given it in a single-model batch (which is what the oracle checks elsewhere)."""
+    w = workloads.config2(300)
+    rng = np.random.default_rng(2)
+    models = rng.integers(0, 2, 300).astype(np.int32)
+    zm, fm, im, _ = solver.solve_batch_host(dict(w, models=models))
+    z0, f0, i0, _ = solver.solve_batch_host(dict(w, model=L.MODEL_NORMAL))
+    z1, f1, i1, _ = solver.solve_batch_host(dict(w, model=L.MODEL_FINAL))
+    pick = lambda a0, a1: np.where(models.reshape((-1,) + (1,) * (a0.ndim - 1)) == 1, a1, a0)
+    assert np.array_equal(fm, pick(f0, f1)) and np.array_equal(im, pick(i0, i1))
+    assert np.array_equal(zm, pick(z0, z1))
+    assert np.max(np.abs(z0 - z1)) > 1e-3  # the two models really differ on this batch
+    # and through the ordered-queue path (B > resident slots)
+    w = workloads.config2(3000)
+    models = rng.integers(0, 2, 3000).astype(np.int32)
+    zm, fm, _, _ = solver.solve_batch_host(dict(w, models=models))
+    z0, _, _, _ = solver.solve_batch_host(dict(w, model=L.MODEL_NORMAL)); z1, _, _, _ = solver.solve_batch_host(dict(w, model=L.MODEL_FINAL))
+    assert np.array_equal(zm, np.where(models[:, None, None] == 1, z1, z0))
