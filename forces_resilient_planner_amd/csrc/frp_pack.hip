@@ -42,6 +42,9 @@ __global__ __launch_bounds__(256) void pack_kernel(frp_nmpc_pack p)
         p.nfaces[(size_t)b * p.N + tid] = nf;
     }
     __syncthreads();
+    const bool fin = p.mode && p.mode[b] == FRP_MODEL_FINAL; // this planner runs the final solver: setParasFinal's weights
+    const double w_wp = fin ? p.wf_stage_wp : p.w_stage_wp, w_in = fin ? p.wf_stage_input : p.w_stage_input, w_rate = fin ? p.wf_input_rate : p.w_input_rate;
+    const double wt_wp = fin ? p.wf_terminal_wp : p.w_terminal_wp, wt_in = fin ? p.wf_terminal_input : p.w_terminal_input;
     const float inv_np = 1.0f / (float)np;
     auto element = [&](int e) -> double {
         int i = (int)(((float)e + 0.5f) * inv_np); // stage (exact: e < 2^16)
@@ -53,9 +56,9 @@ __global__ __launch_bounds__(256) void pack_kernel(frp_nmpc_pack p)
         double v = 0.0;
         if (c < 3) v = p.ref_pos[((size_t)b * p.N + i) * 3 + c];                         // :99-102
         else if (c < 6) v = p.external_acc[(p.external_acc_per_stage ? (size_t)b * p.N + i : (size_t)b) * 3 + c - 3]; // :103-106
-        else if (c == 6) v = last ? p.w_terminal_wp : p.w_stage_wp;                      // :36-52
-        else if (c == 7) v = last ? p.w_terminal_input : p.w_stage_input;
-        else if (c == 8) v = p.w_input_rate;
+        else if (c == 6) v = last ? wt_wp : w_wp;                                        // :36-52
+        else if (c == 7) v = last ? wt_in : w_in;
+        else if (c == 8) v = w_rate;
         else if (c == 9) v = p.ref_yaw[(size_t)b * p.N + i];                             // :107-108
         else if (c < PK_NPRE + 3 * p.M) {                                                // A row-major (:116-123)
             const int j = (c - PK_NPRE) / 3;

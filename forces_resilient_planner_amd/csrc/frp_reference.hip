@@ -69,7 +69,31 @@ __global__ __launch_bounds__(64) void reference_kernel(frp_nmpc_reference p)
     if (i < p.N) p.ref_yaw[(size_t)b * p.N + i] = s_yaw[i];
 }
 
+// switch_to_final (nmpc_solver.cpp:436-447); one thread per planner
+__global__ void mode_kernel(int B, int N, const double *mpc_output, const double *time_offset, const int *kino_size, int size_per_planner,
+                            const double *end_pt, int end_per_planner, double Ts, double radius, int *mode)
+{
+#pragma clang fp contract(off)
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int max_index = (int)((N * Ts + time_offset[b]) / Ts);
+    const double *last = mpc_output + ((size_t)b * (N + 1) + (N - 1)) * 17 + 8; // ref_end = mpc_output_.at(N - 1) position
+    const double *e = end_pt + (end_per_planner ? 3 * (size_t)b : 0);
+    const double d0 = last[0] - e[0], d1 = last[1] - e[1], d2 = last[2] - e[2];
+    if (max_index >= kino_size[size_per_planner ? b : 0] || sqrt(d0 * d0 + d1 * d1 + d2 * d2) < radius) mode[b] = FRP_MODEL_FINAL;
+}
+
 } // namespace frp
+
+extern "C" int frp_nmpc_mode_batch(int B, int N, const double *mpc_output, const double *time_offset, const int *kino_size,
+                                   int size_per_planner, const double *end_pt, int end_per_planner, double Ts, double radius,
+                                   int *mode, void *stream)
+{
+    if (B <= 0 || N < 1 || !mpc_output || !time_offset || !kino_size || !end_pt || !mode || !(Ts > 0.0)) return FRP_ERR_ARG;
+    hipLaunchKernelGGL(frp::mode_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), B, N, mpc_output,
+                       time_offset, kino_size, size_per_planner, end_pt, end_per_planner, Ts, radius, mode);
+    return hipGetLastError() == hipSuccess ? FRP_OK : FRP_ERR_HIP;
+}
 
 extern "C" int frp_nmpc_reference_batch(const frp_nmpc_reference *p, void *stream)
 {

@@ -41,7 +41,9 @@ class Pack(ctypes.Structure):  # frp_nmpc_pack (include/frp_nmpc.h)
                 ("poly_b", ctypes.c_void_p), ("poly_nfaces", ctypes.c_void_p), ("poly_index", ctypes.c_void_p),
                 ("w_stage_wp", ctypes.c_double), ("w_stage_input", ctypes.c_double), ("w_input_rate", ctypes.c_double),
                 ("w_terminal_wp", ctypes.c_double), ("w_terminal_input", ctypes.c_double),
-                ("xinit", ctypes.c_void_p), ("x0", ctypes.c_void_p), ("params", ctypes.c_void_p), ("nfaces", ctypes.c_void_p)]
+                ("xinit", ctypes.c_void_p), ("x0", ctypes.c_void_p), ("params", ctypes.c_void_p), ("nfaces", ctypes.c_void_p),
+                ("mode", ctypes.c_void_p), ("wf_stage_wp", ctypes.c_double), ("wf_stage_input", ctypes.c_double),
+                ("wf_input_rate", ctypes.c_double), ("wf_terminal_wp", ctypes.c_double), ("wf_terminal_input", ctypes.c_double)]
 
 
 class Tube(ctypes.Structure):  # frp_nmpc_tube (include/frp_nmpc.h)
@@ -104,7 +106,8 @@ EXPORTS = ["frp_nmpc_default_options", "frp_nmpc_workspace_bytes", "frp_nmpc_sol
            "frp_nmpc_version", "frp_nmpc_device_count", "FORCESNLPsolver_normal_solve",
            "FORCESNLPsolver_final_solve", "frp_nmpc_pack_batch", "frp_nmpc_update_batch", "frp_nmpc_tube_batch",
            "frp_nmpc_corridor_batch", "frp_nmpc_reference_batch",
-           "frp_nmpc_coldstart_batch", "frp_nmpc_cloud_grid_build"]
+           "frp_nmpc_coldstart_batch", "frp_nmpc_cloud_grid_build",
+           "frp_nmpc_mode_batch"]
 
 _lib = None
 
@@ -141,6 +144,8 @@ def lib():
         l.frp_nmpc_reference_batch.argtypes = [ctypes.POINTER(Reference), ctypes.c_void_p]
         l.frp_nmpc_cloud_grid_build.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p,
                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        l.frp_nmpc_mode_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                          ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
         l.frp_nmpc_coldstart_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
                                                ctypes.c_void_p, ctypes.c_void_p]
         _lib = l
@@ -383,7 +388,10 @@ class DeviceFleet:
     Host data is uploaded once (plans, polytopes, tube matrices); references / external forces per tick are device
     tensors handed to tick()."""
 
-    def __init__(self, B, N, M, F, model, weights, device="cuda:0", npoly=None):
+    def __init__(self, B, N, M, F, model, weights, device="cuda:0", npoly=None, weights_final=None):
+        """weights_final: setParasFinal's five weights.  When given, every planner carries its own mode
+        (self.mode [B], all FRP_MODEL_NORMAL at first): pack() picks its weights and solve() its objective by it, and
+        update_mode() applies the reference's switch rule (nmpc_solver.cpp:436-447)."""
         import torch
         self.torch = torch
         self.B, self.N, self.M, self.F, self.model = B, N, M, F, model
@@ -398,6 +406,25 @@ class DeviceFleet:
         self.poly_b = torch.zeros((B, self.NPOLY, F), **f64)
         self.poly_nfaces = torch.zeros((B, self.NPOLY), dtype=torch.int32, device=dev)
         self.poly_index = None
+        self.weights_final = None if weights_final is None else tuple(float(x) for x in weights_final)
+        self.mode = None
+        if self.weights_final is not None:
+            self.mode = torch.full((B,), int(model), dtype=torch.int32, device=dev)
+            self.solver.models = self.mode
+
+    def update_mode(self, time_offset, kino_size, end_pt, Ts=0.05, radius=1.0, stream=None):
+        """switch_to_final for every planner (nmpc_solver.cpp:436-447): time_offset [B] f64, kino_size int32 [1] or [B],
+        end_pt f64 [3] or [B,3] (device tensors).  Sticky until reset_mode()."""
+        assert self.mode is not None, "construct the fleet with weights_final"
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.solver.device)
+        _check(lib().frp_nmpc_mode_batch(self.B, self.N, ctypes.c_void_p(self.mpc_output.data_ptr()), ctypes.c_void_p(time_offset.data_ptr()),
+                                         ctypes.c_void_p(kino_size.data_ptr()), 1 if kino_size.numel() > 1 else 0,
+                                         ctypes.c_void_p(end_pt.data_ptr()), 1 if end_pt.dim() == 2 else 0, float(Ts), float(radius),
+                                         ctypes.c_void_p(self.mode.data_ptr()), ctypes.c_void_p(s.cuda_stream)), "frp_nmpc_mode_batch")
+
+    def reset_mode(self):
+        """A new kinodynamic path puts every planner back on the normal solver (nmpc_solver.cpp:218)."""
+        self.mode.fill_(L.MODEL_NORMAL)
 
     def to_device(self, a, dtype=None):
         t = self.torch
@@ -411,7 +438,8 @@ class DeviceFleet:
                   ref_pos.data_ptr(), ref_yaw.data_ptr(), self.ellipsoid.data_ptr(), self.poly_A.data_ptr(),
                   self.poly_b.data_ptr(), self.poly_nfaces.data_ptr(),
                   self.poly_index.data_ptr() if self.poly_index is not None else None, *self.weights,
-                  ds.xinit.data_ptr(), ds.x0.data_ptr(), ds.params.data_ptr(), ds.nfaces.data_ptr())
+                  ds.xinit.data_ptr(), ds.x0.data_ptr(), ds.params.data_ptr(), ds.nfaces.data_ptr(),
+                  self.mode.data_ptr() if self.mode is not None else None, *(self.weights_final or (0.0,) * 5))
         _check(lib().frp_nmpc_pack_batch(ctypes.byref(pk), ctypes.c_void_p(s.cuda_stream)), "frp_nmpc_pack_batch")
 
     def update(self, stream=None, keep_failed=True):

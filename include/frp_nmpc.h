@@ -146,6 +146,9 @@ typedef struct frp_nmpc_pack {
     double *x0;     /* [B][N][17]    */
     double *params; /* [B][N][10+4M] */
     int *nfaces;    /* [B][N]        */
+    /* optional: planners in final mode (switch_to_final) get setParasFinal's weights (forces_final.cpp:36-52)  */
+    const int *mode; /* [B] FRP_MODEL_NORMAL / FRP_MODEL_FINAL per planner, or NULL: the weights above for everyone */
+    double wf_stage_wp, wf_stage_input, wf_input_rate, wf_terminal_wp, wf_terminal_input;
 } frp_nmpc_pack;
 
 /* forces_normal.cpp:36-136 for B planners: weights, xinit / shifted x0, per-stage parameters with the robust
@@ -237,6 +240,15 @@ typedef struct frp_nmpc_reference {
 /* NMPCSolver::getCurTraj (nmpc_solver.cpp:109-142) + calculate_yaw (:834-862) for all stages of B planners.
  * Asynchronous on `stream`. */
 int frp_nmpc_reference_batch(const frp_nmpc_reference *p, void *stream);
+
+/* The mode switch at the end of NMPCSolver::solveNMPC (nmpc_solver.cpp:436-447) for B planners: a planner whose
+ * horizon runs past its kinodynamic path ((int)((N Ts + time_offset) / Ts) >= kino_size) or whose plan's last stage
+ * is within `radius` (1.0 m) of the goal end_pt switches to the final solver -- mode[b] = FRP_MODEL_FINAL -- and stays
+ * there until the caller resets it (a new path, :218).  kino_size: [1] or [B] (size_per_planner), end_pt: [3] or [B][3]
+ * (end_per_planner).  mode feeds frp_nmpc_pack.mode and frp_nmpc_batch.model_per_problem.  Asynchronous on `stream`. */
+int frp_nmpc_mode_batch(int B, int N, const double *mpc_output, const double *time_offset, const int *kino_size,
+                        int size_per_planner, const double *end_pt, int end_per_planner, double Ts, double radius,
+                        int *mode, void *stream);
 
 /* NMPCSolver::initMPCOutput (nmpc_solver.cpp:265-286) as applied at the start of solveNMPC (:363-364) for B planners:
  * every planner whose exitflag != 1 (all of them when exitflag is NULL) gets the constant cold-start plan

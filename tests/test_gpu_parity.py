@@ -850,3 +850,47 @@ def test_per_problem_model_equals_two_single_model_batches():
     zm, fm, _, _ = solver.solve_batch_host(dict(w, models=models))
     z0, _, _, _ = solver.solve_batch_host(dict(w, model=L.MODEL_NORMAL)); z1, _, _, _ = solver.solve_batch_host(dict(w, model=L.MODEL_FINAL))
     assert np.array_equal(zm, np.where(models[:, None, None] == 1, z1, z0))
+
+
+def test_fleet_with_per_planner_mode_switch():
+    """switch_to_final per planner (nmpc_solver.cpp:381, 436-447): the mode rule on the device against its statement,
+    the packer's weights by mode against the adapter with setParasNormal / setParasFinal weights, and the solve by
+    mode against single-model batches."""
+    import torch
+    from forces_resilient_planner_amd.adapter import ForcesAdapter
+    B, N, M, F = 24, 20, 30, 6
+    wn, wf = (7.0, 1.0, 80.0, 12.0, 0.5), (12.0, 1.5, 80.0, 15.0, 0.5)      # rotors_sim.launch:56-66
+    w = workloads.config2(B)
+    fleet = solver.DeviceFleet(B, N, M, F, L.MODEL_NORMAL, wn, weights_final=wf)
+    fleet.mpc_output.copy_(fleet.to_device(w["mpc_output"])); fleet.ellipsoid.copy_(fleet.to_device(w["E"]))
+    fleet.poly_A.copy_(fleet.to_device(w["poly_A"])); fleet.poly_b.copy_(fleet.to_device(w["poly_b"]))
+    fleet.poly_nfaces.copy_(fleet.to_device(w["nfaces"], dtype=torch.int32))
+    rng = np.random.default_rng(6)
+    toff = rng.uniform(0, 3.0, B); ksize = rng.integers(30, 90, B).astype(np.int32)
+    end_pt = w["mpc_output"][:, N - 1, 8:11] + rng.normal(0, 0.8, (B, 3))
+    fleet.update_mode(fleet.to_device(toff), fleet.to_device(ksize, dtype=torch.int32), fleet.to_device(end_pt))
+    torch.cuda.synchronize()
+    want = np.array([(int((N * 0.05 + toff[b]) / 0.05) >= ksize[b]) or np.linalg.norm(w["mpc_output"][b, N - 1, 8:11] - end_pt[b]) < 1.0
+                     for b in range(B)])
+    mode = fleet.mode.cpu().numpy()
+    assert np.array_equal(mode == L.MODEL_FINAL, want) and want.any() and not want.all()
+    fleet.update_mode(fleet.to_device(np.zeros(B)), fleet.to_device(np.array([10 ** 6], np.int32), dtype=torch.int32),
+                      fleet.to_device(np.array([1e3, 1e3, 1e3])))
+    assert np.array_equal(fleet.mode.cpu().numpy(), mode)                    # sticky
+    fleet.pack(fleet.to_device(w["f_ext"]), fleet.to_device(w["ref_pos"]), fleet.to_device(w["ref_yaw"]))
+    fleet.solver.solve(); torch.cuda.synchronize()
+    params = fleet.solver.params.cpu().numpy()
+    res = {}
+    for m, wts in ((L.MODEL_NORMAL, wn), (L.MODEL_FINAL, wf)):
+        ad = ForcesAdapter(B, m, N, M); ad.set_paras(*wts)
+        xinit, x0, par, nf = ad.pack(w["mpc_output"], w["f_ext"], w["ref_pos"], w["ref_yaw"], w["E"], w["poly_A"], w["poly_b"], w["nfaces"])
+        sel = mode == m
+        assert np.max(np.abs(params[sel] - par[sel])) < 1e-12
+        res[m] = solver.solve_batch_host(dict(xinit=xinit.copy(), x0=x0.copy(), params=par.copy(), nfaces=nf.copy(), N=N, M=M, model=m, B=B))
+    z = fleet.solver.z.cpu().numpy()
+    for m in res:
+        sel = mode == m
+        assert np.array_equal(fleet.solver.exitflag.cpu().numpy()[sel], res[m][1][sel])
+        assert np.max(np.abs(z[sel] - res[m][0][sel])) < 1e-9
+    fleet.reset_mode()
+    assert int((fleet.mode != L.MODEL_NORMAL).sum()) == 0
