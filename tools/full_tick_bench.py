@@ -2,7 +2,7 @@
 """The reference's whole per-tick computation downstream of the A* for a fleet, on one GPU, nothing on the host:
 stage references (f-4) -> tube (f-2) -> corridor (f-3) -> packing (f-1) -> NLP solve -> bookkeeping
 (DeviceFleet.full_tick).  Prints ms per step of the chain (HIP events on the launch stream) and planner-ticks/s.
-   python tools/full_tick_bench.py [B=4096] [ticks=10] [P=20000] [grid_cell=0.5]"""
+   python tools/full_tick_bench.py [B=4096] [ticks=10] [P=20000] [grid_cell=0.5] [sub_fleets=2]"""
 import json
 import sys
 import numpy as np
@@ -52,9 +52,10 @@ total = float(np.mean([ev[t][0].elapsed_time(ev[t][-1]) for t in range(TICKS)]))
 fl = torch.stack(flags).cpu().numpy(); it = torch.stack(iters).cpu().numpy()
 # the same fleet as two half-fleets on two streams: the solver's few long problems at the end of one half overlap the
 # corridor / tube work of the other
-half = B // 2
-fl2 = [solver.DeviceFleet(half, N, M, F, L.MODEL_NORMAL, (15.0, 3.0, 80.0, 15.0, 0.0)) for _ in range(2)]
-st = [torch.cuda.Stream(device="cuda:0") for _ in range(2)]
+SPLIT = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+half = B // SPLIT
+fl2 = [solver.DeviceFleet(half, N, M, F, L.MODEL_NORMAL, (15.0, 3.0, 80.0, 15.0, 0.0)) for _ in range(SPLIT)]
+st = [torch.cuda.Stream(device="cuda:0") for _ in range(SPLIT)]
 bufs = []
 for k, f2 in enumerate(fl2):
     f2.mpc_output.copy_(fleet.to_device(plan[k * half:(k + 1) * half]))
@@ -71,12 +72,12 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for t in range(TICKS):
     split_tick(t + 1)
-for k in range(2):
+for k in range(SPLIT):
     torch.cuda.current_stream().wait_stream(st[k])
 e1.record(); torch.cuda.synchronize()
 split_ms = e0.elapsed_time(e1) / TICKS
 print(json.dumps({"workload": f"{B} planners x {TICKS} ticks, N=20, shared cloud of {len(cloud)} points, shared kinodynamic path",
                   "grid_cell": GRID, "ms_per_tick": total, "planner_ticks_per_s": B / total * 1e3, "ms_per_step": ms,
-                  "two_half_fleets_on_two_streams": {"ms_per_tick": split_ms, "planner_ticks_per_s": B / split_ms * 1e3},
+                  "sub_fleets_on_own_streams": {"parts": SPLIT, "ms_per_tick": split_ms, "planner_ticks_per_s": B / split_ms * 1e3},
                   "converged_frac": float((fl == 1).mean()), "mean_iters": float(it.mean()),
                   "polytopes_per_planner": float((fleet.poly_nfaces > 0).sum().item() / B)}))
