@@ -25,6 +25,7 @@ __global__ __launch_bounds__(64) void reference_kernel(frp_nmpc_reference p)
     const double *path = p.kino_path + (p.path_per_planner ? (size_t)b * p.K * 3 : 0);
     int size = p.kino_size ? p.kino_size[p.path_per_planner ? b : 0] : p.K;
     size = size < p.K ? size : p.K;
+    size = size > 1 ? size : 1; // an empty path degenerates to its first sample rather than to an out-of-bounds read
     const double *plan1 = p.mpc_output + ((size_t)b * (p.N + 1) + 1) * 17; // mpc_output_.at(1)
     if (i < p.N) {
         // getCurTraj (:111-132)
