@@ -7,8 +7,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libfrp_nmpc_amd.so")
-SOURCES = ["frp_kernels.hip", "frp_capi.hip", "frp_pack.hip", "frp_tube.hip", "frp_corridor.hip", "frp_reference.hip"]
-HEADERS = ["frp_kernels.h", "frp_model.hpp", "frp_adapter.hpp", os.path.join(ROOT, "include", "frp_nmpc.h")]
+SOURCES = ["frp_kernels.hip", "frp_ipm_lds.hip", "frp_capi.hip", "frp_pack.hip", "frp_tube.hip", "frp_corridor.hip", "frp_reference.hip"]
+HEADERS = ["frp_kernels.h", "frp_device.hpp", "frp_model.hpp", "frp_adapter.hpp", os.path.join(ROOT, "include", "frp_nmpc.h")]
 
 
 def hipcc():

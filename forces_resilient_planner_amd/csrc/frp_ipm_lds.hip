@@ -1,0 +1,1204 @@
+// frp_ipm_lds.hip -- gfx950 interior-point NMPC solver, LDS-resident, four cooperating wavefronts per problem.
+//
+// Replaces the reference's closed NLP solver FORCESNLPsolver_{normal,final}_solve (FORCESNLPsolver_normal.h:323,
+// called at forces_normal.cpp:139) and its model callback (FORCESNLPsolver_normal_casadi2forces.c:42-245).
+// Same iteration as the CPU oracle (oracle/nmpc_ipm.c): Mehrotra predictor-corrector primal-dual interior point,
+// multiplier safeguard, exact dynamics Hessian with Gauss-Newton fallback, Riccati recursion over the stage chain.
+//
+// One workgroup = 4 wavefronts = one NMPC problem at a time; persistent workgroups pull problems from a device queue.
+// Nothing of the per-iteration state lives in HBM:
+//   * the per-stage records the Riccati sweeps work on (linearisation, barrier Hessian, T', packed P, rhs vectors,
+//     Newton step) stay in LDS for the whole solve: RS = 307 doubles per stage, 49 KB at N = 20 -> 3 problems per CU;
+//   * slacks, multipliers, second-order terms, corridor faces, the iterate z and the equality multipliers y live in the
+//     REGISTERS of the wave that owns them.
+// Wave roles (wave-uniform control flow, 5 workgroup barriers per interior-point iteration):
+//   wave 0  "Riccati": factorisation sweep (16x16x4 FP64 MFMA register tiles), forward / backward vector sweeps
+//           (4x4x4 FP64 MFMA mat-vec chains); gathers its operands straight from the LDS records;
+//   wave 1  "model":   lane = stage; owns z and y; Heun step, compact Jacobian, exact Hessian, equality residuals;
+//   wave 2  "bounds":  lane = (row group, stage); owns the 34 bound slacks / multipliers of every stage;
+//   wave 3  "faces":   lane = (face group, stage); owns the corridor rows (A pos - b <= 1e-5) of every stage.
+// Norms, step lengths and the centring parameter are combined from per-wave partial results in LDS by every wave
+// redundantly (bitwise identical), so all four waves take the same branches without a second barrier.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "frp_model.hpp"
+#include "../../include/frp_nmpc.h"
+#include "frp_kernels.h"
+#include "frp_device.hpp"
+
+namespace frp {
+namespace lr {
+
+// ------------------------------------------------------------------ per-stage LDS record (doubles)
+constexpr int R_LIN = 0;     // compact linearisation (51): Apv Ape Avv Ave BpT BvT Bvw
+constexpr int R_D = 51;      // d = prev(z_k) - s_{k+1}, s-order [w; x] (13)            } the "M row": 64 slots
+constexpr int R_T = 64;      // T' = [R | Kbar_x | kbar | hc]: lane (g, c) <-> T'[g][c] (64)
+// overlay region (104): the barrier-augmented Hessian is dead once the factorisation step of the stage has gathered
+// it, and that step's output P_k takes its place
+constexpr int R_PHID = 128;  // diag of Phi = cost Hessian + bound barriers (17)
+constexpr int R_PHIPOS = 145; // corridor barrier block on pos (3 x 3)
+constexpr int R_PHI = 154;   // predictor rhs gradient phi_aff without its corridor part (17)
+constexpr int R_HD = 171;    // exact Hessian of y'c(z): 45 structurally non-zero entries (hd_pack)
+constexpr int R_P = 128;     // P_k, packed lower triangle (91)
+constexpr int R_PV = 219;    // p_k of the corrector solve (13)
+constexpr int R_PD = 232;    // P_{k+1} d_k (13); after the corrector's backward sweep: y+_k of the Newton system
+constexpr int R_PHIB = 245;  // corrector rhs phi_cc = PHIB + (sigma mu) PHIC (17 + 17), bound rows and cost;
+constexpr int R_PHIC = 262;  //   evaluation phase: PHIB = cost gradient + bound multipliers (stationarity residual)
+constexpr int R_CB = 279;    // corridor part (pos entries) of PHIB; evaluation phase: A' lam (stationarity residual)
+constexpr int R_CC = 282;    // corridor part of PHIC; evaluation phase: corridor part of phi_aff
+constexpr int R_HC = 285;    // (u_i, w_i) cost coupling -2 w_rate of this stage
+constexpr int R_ZERO = 286, R_ONE = 287, R_DT = 288; // constants the gathers pick up
+constexpr int R_DUMP = 289;  // target of masked-out writes (never read)
+constexpr int R_DZ = 290;    // Newton step [du(4); ds(13)]; evaluation phase: M'y part of the stationarity residual
+constexpr int RS = 307;      // odd stride: lane == stage accesses are conflict-free
+static_assert(R_HD + REC_HD_SIZE <= R_PV && R_PV + 13 <= R_PD, "overlay region");
+
+// workgroup-shared scratch (doubles)
+constexpr int X_MI = 0, X_DI = 6;     // pivot block handed from uniform registers to lanes: m = L^-1 (6), D^-1 (4)
+constexpr int X_RW = 16;              // stage-0 solve: Pww^-1 (16)
+constexpr int X_PWX = 32;             // stage-0 solve: Pwx (4 x 9)
+constexpr int X_DS0 = 68;             // ds_0 = [dw_0; dx_0] (16)
+constexpr int X_XINIT = 84;           // xinit (9)
+constexpr int X_DX0 = 96;             // xinit - x_0 (9)
+constexpr int X_C0 = 106, X_C1 = 107; // constants 0, 1
+constexpr int X_RED = 108;            // per-wave partial results: [4][16] (evaluation 0..2, affine 3..7, step 8..12: no slot is reused inside an iteration)
+constexpr int X_TOTAL = 172;
+
+// ------------------------------------------------------------------ per-lane gather tables (record offsets)
+// 16x16 register tiles (factorisation sweep): lane (g, c), register r <-> element (4r+g, c).
+// 4x4x4 mat-vec operands (vector sweeps): register m, lane l <-> A[4 qI + qj][4 ((qI + m) & 3) + qk].
+__host__ __device__ constexpr int zi_of(int a) { return a < 4 ? a : a + 4; }          // tile index (u, x) -> z index
+__host__ __device__ constexpr int hidx_of(int a) { return a < 4 ? a : (a >= 7 && a <= 12 ? a - 3 : -1); }
+// Mt[row][col], the augmented transition matrix: rows s+ = [w+(0..3); x+(4..12)], cols [u(0..3); x(4..12); 13 = d]
+__host__ __device__ constexpr int m_src(int row, int col)
+{
+    if (row > 12 || col > 13) return R_ZERO;
+    if (col == 13) return R_D + row;
+    if (row < 4) return (col == row) ? R_ONE : R_ZERO;
+    const int i = row - 4, bi = i / 3, ii = i % 3;
+    if (col < 4) { // B[i][col]
+        if (col == 3) return bi == 0 ? R_LIN + 36 + ii : (bi == 1 ? R_LIN + 39 + ii : R_ZERO);
+        if (bi == 1) return R_LIN + 42 + ii * 3 + col;
+        if (bi == 2) return ii == col ? R_DT : R_ZERO;
+        return R_ZERO;
+    }
+    const int j = col - 4, bj = j / 3, jj = j % 3;
+    if (bi == 0) return bj == 0 ? (ii == jj ? R_ONE : R_ZERO) : R_LIN + (bj == 1 ? 0 : 9) + ii * 3 + jj;
+    if (bi == 1) return bj == 0 ? R_ZERO : R_LIN + (bj == 1 ? 18 : 27) + ii * 3 + jj;
+    return (bj == 2 && ii == jj) ? R_ONE : R_ZERO;
+}
+// the three sources summed into C~[row][col] = Phi~ (diag + corridor + theta Hessian), rhs in column 13
+__host__ __device__ constexpr int c_src(int row, int col, int which)
+{
+    int o1 = R_ZERO, o2 = R_ZERO, o3 = R_ZERO;
+    if (row <= 12) {
+        if (col == 13) {
+            o1 = R_PHI + zi_of(row);
+            if (row >= 4 && row <= 6) o2 = R_CC + (row - 4);
+        } else if (col <= 12) {
+            if (col == row) o1 = R_PHID + zi_of(row);
+            if (row >= 4 && row <= 6 && col >= 4 && col <= 6) o2 = R_PHIPOS + (row - 4) * 3 + (col - 4);
+            const int hr = hidx_of(row), hc_ = hidx_of(col);
+            if (hr >= 0 && hc_ >= 0 && hd_pack(hr, hc_) >= 0) o3 = R_HD + hd_pack(hr, hc_);
+        }
+    }
+    return which == 0 ? o1 : (which == 1 ? o2 : o3);
+}
+enum { T_M = 0, T_C1 = 4, T_C2 = 8, T_C3 = 12, T_PP = 16, T_PD = 20, T4_MT = 24, T4_MTT = 28, T4_TT = 32, T4_P = 36, T_ROWS = 40 };
+struct LaneTables {
+    unsigned short v[T_ROWS][64];
+};
+constexpr LaneTables make_tables()
+{
+    LaneTables t{};
+    for (int lane = 0; lane < 64; lane++) {
+        const int g = lane >> 4, c = lane & 15;
+        const int qk = lane >> 4, qI = (lane >> 2) & 3, qj = lane & 3;
+        for (int r = 0; r < 4; r++) {
+            const int trow = 4 * r + g;
+            t.v[T_M + r][lane] = (unsigned short)m_src(trow, c);
+            t.v[T_C1 + r][lane] = (unsigned short)c_src(trow, c, 0);
+            t.v[T_C2 + r][lane] = (unsigned short)c_src(trow, c, 1);
+            t.v[T_C3 + r][lane] = (unsigned short)c_src(trow, c, 2);
+            t.v[T_PP + r][lane] = (unsigned short)((trow <= 12 && c <= trow) ? R_P + trow * (trow + 1) / 2 + c : R_DUMP);
+            t.v[T_PD + r][lane] = (unsigned short)((c == 13 && trow <= 12) ? R_PD + trow : R_DUMP);
+            const int row = 4 * qI + qj, col = 4 * ((qI + r) & 3) + qk;
+            t.v[T4_MT + r][lane] = (unsigned short)m_src(row, col);
+            t.v[T4_MTT + r][lane] = (unsigned short)m_src(col, row);
+            t.v[T4_TT + r][lane] = (unsigned short)(row < 4 ? R_T + 16 * row + col : R_ZERO);
+            const int hi = row > col ? row : col, lo = row > col ? col : row;
+            t.v[T4_P + r][lane] = (unsigned short)((row <= 12 && col <= 12) ? R_P + hi * (hi + 1) / 2 + lo : R_ZERO);
+        }
+    }
+    return t;
+}
+__device__ const LaneTables g_tab = make_tables();
+
+__device__ __forceinline__ int tab(int row, int lane) { return (int)g_tab.v[row][lane]; }
+
+#define BAR() __syncthreads()
+
+// ------------------------------------------------------------------ values every wave derives from the LDS partials
+struct Norms {
+    double eq, in, rs, rc, gap, obj;
+};
+
+// rows of the element-wise lane mapping: lane = sub * NP + k, sub < H = 64 / NP, row i = r * H + sub
+template <int NP>
+struct RowMap {
+    static constexpr int H = 64 / NP;
+    static constexpr int R = (NZ + H - 1) / H;
+};
+
+// value of a per-row constant for row i = ib + half, chosen among the H compile-time candidates of round r
+#define ROW_PICK(expr_of_i)                                                                          \
+    ([&]() {                                                                                           \
+        double v_ = [&](int i) { return (double)(expr_of_i); }(ib < NZ ? ib : NZ - 1);                  \
+        if (H > 1 && half == 1) v_ = [&](int i) { return (double)(expr_of_i); }(ib + 1 < NZ ? ib + 1 : NZ - 1); \
+        if (H > 2 && half == 2) v_ = [&](int i) { return (double)(expr_of_i); }(ib + 2 < NZ ? ib + 2 : NZ - 1); \
+        if (H > 3 && half == 3) v_ = [&](int i) { return (double)(expr_of_i); }(ib + 3 < NZ ? ib + 3 : NZ - 1); \
+        return v_;                                                                                     \
+    }())
+
+template <int NP>
+__device__ __forceinline__ double xsub_sum(double v) // sum over the H lanes that share a stage (valid in every lane of the group for H = 2, 4; in sub == 0 for H = 3)
+{
+    constexpr int H = 64 / NP;
+    if (H == 2) return v + __shfl_xor(v, 32);
+    if (H == 4) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+    if (H == 3) {
+        const int lane = threadIdx.x & 63;
+        const double a = __shfl(v, lane + NP < 64 ? lane + NP : lane), b = __shfl(v, lane + 2 * NP < 64 ? lane + 2 * NP : lane);
+        return v + a + b;
+    }
+    return v;
+}
+
+// max |stationarity residual| from the three parts the evaluation phase left in the records (all waves, redundantly)
+template <int NP>
+__device__ __forceinline__ double stationarity_norm(const double *recs, int N)
+{
+    constexpr int H = RowMap<NP>::H, R = RowMap<NP>::R;
+    const int lane = threadIdx.x & 63, k = lane % NP, half = lane / NP;
+    double rs = 0.0;
+    if (k < N && half < H) {
+        const double *rec = recs + k * RS;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i = r * H + half;
+            if (i >= NZ) continue;
+            double g = rec[R_PHIB + i] + rec[R_DZ + i];
+            if (i >= 8 && i < 11) g += rec[R_CB + i - 8];
+            rs = fmax(rs, fabs(g));
+        }
+    }
+    return wave_max(rs);
+}
+
+struct Ctl { // workgroup-shared control words
+    int next, fail, bad, mtot;
+};
+
+// ================================================================== wave 0: Riccati sweeps
+// ---- stage-0 solve (both passes): dx_0 = xinit - x_0, dw_0 = -Pww^-1 (Pwx dx_0 + p_w); leaves ds_0 in X_DS0.
+// pw_here: p_w[g] in the lanes (g, 13).
+__device__ __forceinline__ void stage0_solve(double *xs, int lane, double pw_here)
+{
+    const int g = lane >> 4, c = lane & 15;
+    const bool xc = (c >= 4 && c <= 12);
+    const double dxc = xc ? xs[X_DX0 + c - 4] : 0.0;
+    WSYNC();
+    const double prod = xc ? xs[X_PWX + g * 9 + c - 4] * dxc : (c == 13 ? pw_here : 0.0);
+    const double rhs = row16_sum(prod);
+    const double r0 = lane_bcast(rhs, 0), r1 = lane_bcast(rhs, 16), r2 = lane_bcast(rhs, 32), r3 = lane_bcast(rhs, 48);
+    if (lane < 4) {
+        xs[X_DS0 + lane] = -(xs[X_RW + lane * 4 + 0] * r0 + xs[X_RW + lane * 4 + 1] * r1 +
+                             xs[X_RW + lane * 4 + 2] * r2 + xs[X_RW + lane * 4 + 3] * r3);
+    } else if (lane <= 12) {
+        xs[X_DS0 + lane] = dxc; // g == 0: index 4 + (c - 4) = c
+    } else if (lane < 16) {
+        xs[X_DS0 + lane] = 0.0;
+    }
+    WSYNC();
+}
+
+// ---- factorisation sweep (predictor).  Backward Riccati recursion on 16x16 FP64 register tiles:
+//   X = P M (col 13: P d + p+),  G = M'X + C~ (col 13: q~),  Guu = L D L',  K = L^-1 G_u,
+//   T = L^-T D^-1 K (Kbar, kbar),  S = G - K' D^-1 K,  P <- [Phi_w - hc^2 R, -hc Kbar_x; -hc Kbar_x', S_xx].
+// The tiles of stage k-1 are gathered from its LDS record as soon as the MFMAs that read the tiles of stage k have
+// been issued: the gathers land while those MFMAs and the pivot-block factorisation execute.
+// Returns 1 when a pivot block is not positive definite.
+__device__ __forceinline__ void gather_tiles(const double *rn, const int (&c1)[4], const int (&c2)[4], const int (&c3)[4],
+                                             const int (&mo)[4], int g, double theta, d4 &C, d4 &Mt, double &hc, double &PhiDw, double &phiw)
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        C[r] = rn[c1[r]] + rn[c2[r]] + theta * rn[c3[r]];
+        Mt[r] = rn[mo[r]];
+    }
+    hc = rn[R_HC];
+    PhiDw = rn[R_PHID + 4 + g];
+    phiw = rn[R_PHI + 4 + g];
+}
+
+__device__ __noinline__ int sweep_factor(double *recs, double *xs, int N, double theta)
+{
+    N = uni(N); theta = uni(theta);
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    int mo[4], c1[4], c2[4], c3[4], ppo[4], pdo[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        mo[r] = tab(T_M + r, lane); c1[r] = tab(T_C1 + r, lane); c2[r] = tab(T_C2 + r, lane);
+        c3[r] = tab(T_C3 + r, lane); ppo[r] = tab(T_PP + r, lane); pdo[r] = tab(T_PD + r, lane);
+    }
+    // scratch slot of m[g][c] / m[c][g] for this lane (m = L^-1 of the pivot block, strictly lower part in X_MI)
+    const int mgo = c < 4 ? (c < g ? X_MI + g * (g - 1) / 2 + c : (c == g ? X_C1 : X_C0)) : X_C0;
+    const int mco = c < 4 ? (g < c ? X_MI + c * (c - 1) / 2 + g : (c == g ? X_C1 : X_C0)) : X_C0;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    d4 P = zero, pv = zero, C, Mt;
+    double hcn, PhiDwn, phiwn;
+    gather_tiles(recs + (N - 1) * RS, c1, c2, c3, mo, g, theta, C, Mt, hcn, PhiDwn, phiwn);
+    int fail = 0;
+    for (int kk = N - 1; kk >= 0; kk--) {
+        double *rec = recs + kk * RS;
+        const double hc = hcn, PhiDw = PhiDwn, phiw = phiwn; // of stage kk
+        d4 G = C;
+        if (kk < N - 1) {
+            d4 X = mm_tn(P, Mt, zero);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                rec[pdo[r]] = X[r]; // P d (column 13; every other lane writes the dump slot)
+                X[r] += pv[r];      // pv is zero outside column 13
+            }
+            G = mm_tn(Mt, X, C);
+        }
+        // the tiles of stage kk are consumed: gather those of stage kk-1 (clamped at 0: unused after the last step)
+        gather_tiles(recs + (kk > 0 ? kk - 1 : 0) * RS, c1, c2, c3, mo, g, theta, C, Mt, hcn, PhiDwn, phiwn);
+        // ---- pivot block Guu = L D L' (4 x 4): lower triangle to uniform registers, factored redundantly
+        double q[16], Mi[6], Di[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) q[i * 4 + j] = lane_bcast(G[0], 16 * i + j);
+        if (!ldl4(q, Mi, Di)) { fail = 1; break; }
+#pragma unroll
+        for (int i = 0; i < 6; i++) xs[X_MI + i] = Mi[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) xs[X_DI + i] = Di[i];
+        WSYNC();
+        // elimination in factored form: an explicit inverse of Guu cancels O(1e10) barrier terms against cond(Guu) eps errors
+        const double m_gc = xs[mgo], m_cg = xs[mco]; // m[g][c], m[c][g] (unit diagonal / zeros from the constant slots)
+        const double dg = xs[X_DI + g];
+        const double md = dg * m_gc;
+        const d4 K = mm_tn4(m_cg, G[0], zero);
+        const d4 Rt = mm_tn4(m_gc, md, zero);
+        const double rt = Rt[0]; // R[g][c] in the lanes c < 4 (zero elsewhere)
+        const double Kd = dg * K[0];
+        const d4 T = mm_tn4(m_gc, Kd, zero);
+        const d4 TT = mm_tn4(K[0], md, zero);
+        const d4 S = mm_tn4(-Kd, K[0], G);
+        rec[R_T + lane] = (c < 4) ? rt : (c <= 13 ? T[0] : (lane == 14 ? hc : 0.0));
+        P[0] = (c < 4) ? ((g == c ? PhiDw : 0.0) - hc * hc * rt) : (c <= 12 ? -hc * T[0] : 0.0);
+        pv[0] = (c == 13) ? (phiw - hc * T[0]) : 0.0;
+#pragma unroll
+        for (int r = 1; r < 4; r++) {
+            const bool inb = (4 * r + g) <= 12;
+            P[r] = (inb && c <= 12) ? (c < 4 ? -hc * TT[r] : S[r]) : 0.0;
+            pv[r] = (inb && c == 13) ? S[r] : 0.0;
+        }
+        // P_k (packed lower triangle) for the multiplier recovery y_k = P_k ds_k + p_k; it overwrites the Hessian part
+        // of this stage's record, which was gathered one step ago
+#pragma unroll
+        for (int r = 0; r < 4; r++) rec[ppo[r]] = P[r];
+    }
+    if (!fail) {
+        // stage 0: keep Pww^-1 and Pwx for the corrector pass, then solve for ds_0
+        double q[16], Rw[16];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) q[i * 4 + j] = lane_bcast(P[0], 16 * i + j);
+        if (!spd4_inverse(q, Rw)) fail = 1;
+        else {
+            WSYNC();
+#pragma unroll
+            for (int i = 0; i < 16; i++) xs[X_RW + i] = Rw[i];
+            if (c >= 4 && c <= 12) xs[X_PWX + g * 9 + c - 4] = P[0];
+            stage0_solve(xs, lane, pv[0]);
+        }
+    }
+    WSYNC();
+    return fail;
+}
+
+// ---- vector-only backward sweep (corrector): new rhs phi_cc = PHIB + smu PHIC (+ the corridor parts on the pos rows):
+//   q~ = phi~ + M'(P d + p+),  [kbar; Kbar'q_u] = T'' q_u,  p_x = q~_x - Kbar' q_u,  p_w = phi_w - hc kbar.
+// Updates the kbar column of T' and stores p_k.  All mat-vec products on the 4x4x4 MFMA, vectors in V layout.
+__device__ __noinline__ void sweep_backvec(double *recs, double *xs, int N, double smu)
+{
+    N = uni(N); smu = uni(smu);
+    const int lane = threadIdx.x & 63;
+    const int idx = 4 * ((lane >> 2) & 3) + (lane >> 4); // V layout: the vector row this lane holds
+    const int qI = (lane >> 2) & 3;
+    int mo[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) mo[r] = tab(T4_MTT + r, lane);
+    const int pho = idx <= 12 ? zi_of(idx) : 0;                       // q~ rows [u; x] -> z index
+    const int cbo = (idx >= 4 && idx <= 6) ? R_CB + idx - 4 : R_ZERO;  // corridor parts: pos rows only
+    const int cco = (idx >= 4 && idx <= 6) ? R_CC + idx - 4 : R_ZERO;
+    const int pwo = 4 + (idx & 3);                                    // p_w rows -> z index of w
+    const int pdo = idx <= 12 ? R_PD + idx : R_ZERO;
+    const bool q0 = idx < 4;
+    double pv = 0.0;
+    d4 Mt;
+    double phi, hc, phiw, tp, pd;
+    auto gather = [&](const double *rn) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) Mt[r] = rn[mo[r]];
+        phi = (rn[R_PHIB + pho] + rn[cbo]) + smu * (rn[R_PHIC + pho] + rn[cco]);
+        phi = (idx <= 12) ? phi : 0.0;
+        phiw = rn[R_PHIB + pwo] + smu * rn[R_PHIC + pwo];
+        hc = rn[R_HC];
+        tp = rn[R_T + lane]; // read before the stage's own step rewrites its kbar column
+        pd = rn[pdo];
+    };
+    gather(recs + (N - 1) * RS);
+    for (int kk = N - 1; kk >= 0; kk--) {
+        double *rec = recs + kk * RS;
+        double q = phi;
+        if (kk < N - 1) q = matvec4(Mt, pd + pv, phi);
+        const double ctp = tp, chc = hc, cphiw = phiw;
+        gather(recs + (kk > 0 ? kk - 1 : 0) * RS);
+        // q_u (rows 0..3, quad 0) to every quad of its row, then E[c] = sum_k T'[k][c] q_u[k]
+        const double r1 = quad_rot<1>(q), r2 = quad_rot<2>(q), r3 = quad_rot<3>(q);
+        const double qu = qI == 0 ? q : (qI == 1 ? r3 : (qI == 2 ? r2 : r1));
+        const double E = mfma4(ctp, qu, 0.0);
+        const double pn = q0 ? cphiw - chc * E : (idx <= 12 ? q - E : 0.0);
+        if ((lane & 3) == 0) {
+            if (q0) rec[R_T + 16 * idx + 13] = E;      // kbar
+            rec[idx <= 12 ? R_PV + idx : R_DUMP] = pn; // p_k for y_k = P_k ds_k + p_k
+        }
+        pv = pn;
+    }
+    // p_w[g] sits in the quad-0 lanes of row g; the stage-0 solve wants it in the lanes (g, 13)
+    stage0_solve(xs, lane, __shfl(pv, lane & 48));
+    WSYNC();
+}
+
+// ---- forward sweep: dz for all stages.  du = -T' [hc dw; dx; 1],  ds+ = Mt [du; dx; 1].
+// WITH_Y (corrector pass): also y+_k = P_k ds_k + p_k (stored in the P d slot of the stage, which is dead by then).
+template <bool WITH_Y>
+__device__ __noinline__ void sweep_forward(double *recs, double *xs, int N)
+{
+    N = uni(N);
+    const int lane = threadIdx.x & 63;
+    const int idx = 4 * ((lane >> 2) & 3) + (lane >> 4); // V layout: the vector row this lane holds
+    int mto[4], tto[4], pmo[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        mto[s] = tab(T4_MT + s, lane);
+        tto[s] = tab(T4_TT + s, lane);
+        pmo[s] = tab(T4_P + s, lane);
+    }
+    const int pvo = idx <= 12 ? R_PV + idx : R_ZERO;
+    const bool q0 = idx < 4 && (lane & 12) == 0; // rows 0..3 (quad 0 of every 16-lane row)
+    const int duo = q0 ? R_DZ + idx : R_DUMP, dso = idx <= 12 ? R_DZ + 4 + idx : R_DUMP, yo = idx <= 12 ? R_PD + idx : R_DUMP;
+    double v = xs[X_DS0 + idx]; // ds_0 (entries 13..15 are zero)
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    d4 tt, mt, Pk = zero;
+    double hc, pk = 0.0;
+    {
+        const double *rn = recs;
+#pragma unroll
+        for (int s = 0; s < 4; s++) { tt[s] = rn[tto[s]]; mt[s] = rn[mto[s]]; }
+        hc = rn[R_T + 14];
+        if (WITH_Y) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) Pk[r] = rn[pmo[r]];
+            pk = rn[pvo];
+        }
+    }
+    for (int kk = 0; kk < N; kk++) {
+        double *rec = recs + kk * RS;
+        const double *rn = recs + (kk + 1 < N ? kk + 1 : N - 1) * RS; // next stage (clamped: the tail re-reads the last record, unused)
+        const double v1 = q0 ? hc * v : (idx == 13 ? 1.0 : v); // row 13 multiplies the kbar column
+        const double D1 = matvec4(tt, v1, 0.0);
+#pragma unroll
+        for (int s = 0; s < 4; s++) tt[s] = rn[tto[s]];
+        hc = rn[R_T + 14];
+        double Y = 0.0;
+        if (WITH_Y) {
+            Y = matvec4(Pk, v, pk); // y+_k = P_k ds_k + p_k
+#pragma unroll
+            for (int r = 0; r < 4; r++) Pk[r] = rn[pmo[r]];
+            pk = rn[pvo];
+        }
+        const double du = -D1;
+        const double v2 = q0 ? du : (idx == 13 ? 1.0 : v); // row 13 multiplies the d column
+        const double D2 = matvec4(mt, v2, 0.0);
+#pragma unroll
+        for (int s = 0; s < 4; s++) mt[s] = rn[mto[s]];
+        // branch-free LDS writes: the four replicas of a row (lane & 3) write the same value to the same slot
+        rec[duo] = du;
+        rec[dso] = v;
+        if (WITH_Y) rec[yo] = Y;
+        v = D2; // rows 13..15 of Mt are zero
+    }
+    WSYNC();
+}
+
+// ================================================================== wave 1: model (lane == stage)
+// Owns the iterate z and the equality multipliers y of its stage.  Heun step + compact Jacobian -> the stage record,
+// equality residual, and the M'y part of the stationarity residual.  d needs the next stage's [w; x] and gm its
+// multipliers: lane k+1 hands them over.  (The exact Hessian of the same step is evaluated by wave 3 at the same time.)
+struct ModelState {
+    double z[NZ], y[NS], fext[3];
+};
+
+template <int NP>
+__device__ __forceinline__ void model_phase(double *recs, double *xs, const ModelState &st, int N, double &l_eq)
+{
+    const int lane = threadIdx.x & 63;
+    const int k = lane;
+    const double *zk = st.z;
+    l_eq = 0.0;
+    double *rec = recs + (k < N ? k : 0) * RS;
+    // ---- part 1: the step and its linearisation (no multipliers involved)
+    {
+        double zn[NS]; // s_{k+1} = [w; x] of the next stage
+#pragma unroll
+        for (int i = 0; i < NS; i++) zn[i] = __shfl_down(st.z[4 + i], 1);
+        if (k == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const double dx = xs[X_XINIT + i] - zk[8 + i];
+                xs[X_DX0 + i] = dx;
+                l_eq = fmax(l_eq, fabs(dx));
+            }
+        }
+        if (k < N - 1) {
+            AccJac J1, J2;
+            double a1[3], a2[3], et[3], vt[3];
+            {
+                const Trig tg1 = make_trig(zk + 14);
+                accel_t<true>(zk + 11, tg1, zk[3], st.fext, a1, &J1);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                vt[i] = zk[11 + i] + DT * a1[i];
+                et[i] = zk[14 + i] + DT * zk[i];
+            }
+            {
+                const Trig tg2 = make_trig(et);
+                accel_t<true>(vt, tg2, zk[3], st.fext, a2, &J2);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const double d = zk[i] - zn[i];
+                rec[R_D + i] = d;
+                l_eq = fmax(l_eq, fabs(d));
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const double xp = zk[8 + i] + 0.5 * DT * (zk[11 + i] + vt[i]);
+                const double xv = zk[11 + i] + 0.5 * DT * (a1[i] + a2[i]);
+                const double dp = xp - zn[4 + i];
+                const double dv = xv - zn[7 + i];
+                const double de = et[i] - zn[10 + i];
+                rec[R_D + 4 + i] = dp; rec[R_D + 7 + i] = dv; rec[R_D + 10 + i] = de;
+                l_eq = fmax(l_eq, fmax(fabs(dp), fmax(fabs(dv), fabs(de))));
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                double sT = J2.gT[i];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    double sv = J2.Fvv[i * 3 + j], se = J2.Fve[i * 3 + j];
+#pragma unroll
+                    for (int l = 0; l < 3; l++) {
+                        sv += DT * J2.Fvv[i * 3 + l] * J1.Fvv[l * 3 + j];
+                        se += DT * J2.Fvv[i * 3 + l] * J1.Fve[l * 3 + j];
+                    }
+                    rec[R_LIN + i * 3 + j] = (i == j ? DT : 0.0) + 0.5 * DT * DT * J1.Fvv[i * 3 + j];      // Apv
+                    rec[R_LIN + 9 + i * 3 + j] = 0.5 * DT * DT * J1.Fve[i * 3 + j];                       // Ape
+                    rec[R_LIN + 18 + i * 3 + j] = (i == j ? 1.0 : 0.0) + 0.5 * DT * (J1.Fvv[i * 3 + j] + sv); // Avv
+                    rec[R_LIN + 27 + i * 3 + j] = 0.5 * DT * (J1.Fve[i * 3 + j] + se);                    // Ave
+                    rec[R_LIN + 42 + i * 3 + j] = 0.5 * DT * DT * J2.Fve[i * 3 + j];                      // Bvw
+                    sT += DT * J2.Fvv[i * 3 + j] * J1.gT[j];
+                }
+                rec[R_LIN + 36 + i] = 0.5 * DT * DT * J1.gT[i];      // BpT
+                rec[R_LIN + 39 + i] = 0.5 * DT * (J1.gT[i] + sT);    // BvT
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0); // keep the two parts apart: their live ranges must not overlap (168-register budget)
+    // ---- part 2: gm = M' y_{k+1} - [0; y_k], the linearisation read back from the record this lane has just written
+    {
+        double yn[NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++) yn[i] = __shfl_down(st.y[i], 1);
+        if (k < N) {
+            double gm[NZ];
+#pragma unroll
+            for (int i = 0; i < 4; i++) gm[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < NS; i++) gm[4 + i] = -st.y[i];
+            if (k < N - 1) {
+                const double *yw = yn, *yp = yn + 4, *yv = yn + 7, *ye = yn + 10;
+#pragma unroll
+                for (int i = 0; i < 4; i++) gm[i] += yw[i];
+                double gT = 0.0;
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    gm[i] += DT * ye[i];
+                    gm[8 + i] += yp[i];
+                    gm[14 + i] += ye[i];
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        gm[j] += rec[R_LIN + 42 + i * 3 + j] * yv[i];
+                        gm[11 + j] += rec[R_LIN + i * 3 + j] * yp[i] + rec[R_LIN + 18 + i * 3 + j] * yv[i];
+                        gm[14 + j] += rec[R_LIN + 9 + i * 3 + j] * yp[i] + rec[R_LIN + 27 + i * 3 + j] * yv[i];
+                    }
+                    gT += rec[R_LIN + 36 + i] * yp[i] + rec[R_LIN + 39 + i] * yv[i];
+                }
+                gm[3] += gT;
+            }
+#pragma unroll
+            for (int i = 0; i < NZ; i++) rec[R_DZ + i] = gm[i];
+        }
+    }
+}
+
+// ================================================================== wave 3, lanes of face group 0: exact Hessian (lane == stage)
+// Keeps its own copy of what the Hessian of y_{k+1}' c(z_k) depends on: rates, thrust, velocity, attitude of the
+// stage and the pos / vel multipliers of the next one (updated from the same dz / y+ as the owners' copies).
+struct HessState {
+    double u[4], ve[6], y6[6], fext[3]; // u = (rates, T); ve = (v, e); y6 = (y_p, y_v) of stage k+1
+};
+__device__ __forceinline__ void hessian_phase(double *rec, const HessState &hs, bool dyn, int hess)
+{
+    if (dyn && hess) {
+        double x[9];
+        x[0] = x[1] = x[2] = 0.0; // the position does not enter
+#pragma unroll
+        for (int i = 0; i < 6; i++) x[3 + i] = hs.ve[i];
+        rk2_hessian(x, hs.u, hs.fext, hs.y6, hs.y6 + 3, [&](int i, int j, double val) {
+            if (hd_index(i, j) >= 0) rec[R_HD + hd_index(i, j)] = val;
+        });
+    } else {
+        // the Hessian slots are overwritten by P every iteration: stages without a dynamics Hessian clear them again
+#pragma unroll
+        for (int i = 0; i < REC_HD_SIZE; i++) rec[R_HD + i] = 0.0;
+    }
+}
+
+// ================================================================== the solve, one role per wave
+struct Shared {
+    double *recs, *xs;
+    Ctl *ctl;
+};
+
+__device__ __forceinline__ void publish(double *xs, int wave, int lane, int slot, double v)
+{
+    if (lane == 0) xs[X_RED + wave * 16 + slot] = v;
+}
+__device__ __forceinline__ double red(const double *xs, int wave, int slot) { return xs[X_RED + wave * 16 + slot]; }
+
+template <int NP, int FL, bool FREG, int ROLE>
+__device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, const Shared &sh)
+{
+    constexpr int H = RowMap<NP>::H, R = RowMap<NP>::R;
+    constexpr int wave = ROLE; // == threadIdx.x >> 6: every role is compiled on its own, so only ITS state occupies registers
+    const int lane = threadIdx.x & 63;
+    const int N = a.N, M = a.M, MF = a.MF, np = NPRE + 4 * M;
+    double *recs = sh.recs, *xs = sh.xs;
+    const int k = (wave == 1) ? lane : lane % NP, half = lane / NP; // stage of this lane; row / face group
+    const bool kact = k < N && (wave == 1 || half < H);
+    const double *pk = a.params + ((size_t)b * N + (k < N ? k : 0)) * np;
+    const int hess = a.hessian ? 1 : 0;
+    const int model = a.models ? a.models[b] : a.model; // normal / final objective of THIS problem (switch_to_final, nmpc_solver.cpp:381)
+
+    // ---------------------------------------------------------------- per-wave state
+    ModelState ms;                         // wave 1
+    double bz[R], bzp[R], bsl[R], bsu[R], bll[R], blu[R], bcl[R], bcu[R], pc[NPRE]; // wave 2
+    double fa0[FL], fa1[FL], fa2[FL], fbb[FL], fs[FL], fl_[FL], fcr[FL], fpos[3];    // wave 3 (fa*, fbb only when FREG)
+    int nfk = 0;
+#pragma unroll
+    for (int i = 0; i < NZ; i++) ms.z[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; i++) ms.y[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NPRE; i++) pc[i] = 0.0;
+    ms.fext[0] = ms.fext[1] = ms.fext[2] = 0.0;
+    HessState hs; // wave 3, face group 0
+#pragma unroll
+    for (int i = 0; i < 4; i++) hs.u[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { hs.ve[i] = 0.0; hs.y6[i] = 0.0; }
+    hs.fext[0] = hs.fext[1] = hs.fext[2] = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; r++) { bz[r] = bzp[r] = 0.0; bsl[r] = bsu[r] = bll[r] = blu[r] = 1.0; bcl[r] = bcu[r] = 0.0; }
+#pragma unroll
+    for (int t = 0; t < FL; t++) { fa0[t] = fa1[t] = fa2[t] = fbb[t] = 0.0; fs[t] = fl_[t] = 1.0; fcr[t] = 0.0; }
+    fpos[0] = fpos[1] = fpos[2] = 0.0;
+
+    // face t of this lane is row j = t * H + half of its stage; its constants come from registers or from the parameters
+    auto face_consts = [&](int t, double &a0, double &a1, double &a2, double &bb) {
+        if (FREG) { a0 = fa0[t]; a1 = fa1[t]; a2 = fa2[t]; bb = fbb[t]; }
+        else {
+            const int j = t * H + half;
+            a0 = pk[NPRE + 3 * j]; a1 = pk[NPRE + 3 * j + 1]; a2 = pk[NPRE + 3 * j + 2]; bb = pk[NPRE + 3 * M + j] + HU;
+        }
+    };
+
+    // ---------------------------------------------------------------- init
+    double smin = 1e300;
+    int bad_param = 0, mcount = 0;
+    if constexpr (wave == 1) {
+        if (lane < 9) xs[X_XINIT + lane] = a.xinit[(size_t)b * 9 + lane];
+        if (kact) {
+            const double *z0 = a.x0 + ((size_t)b * N + k) * NZ;
+#pragma unroll
+            for (int i = 0; i < NZ; i++) ms.z[i] = z0[i];
+            ms.fext[0] = pk[3]; ms.fext[1] = pk[4]; ms.fext[2] = pk[5];
+            double *rec = recs + k * RS;
+            rec[R_HC] = -2.0 * pk[8]; // (u_i, w_i) cost coupling of this stage (constant)
+            rec[R_ZERO] = 0.0; rec[R_ONE] = 1.0; rec[R_DT] = DT; rec[R_DUMP] = 0.0;
+            if (k == N - 1) { // no dynamics behind the last stage: its M row stays zero
+#pragma unroll
+                for (int i = 0; i < 64; i++) rec[R_LIN + i] = 0.0;
+            }
+            rec[R_CB + 0] = rec[R_CB + 1] = rec[R_CB + 2] = 0.0;
+            rec[R_CC + 0] = rec[R_CC + 1] = rec[R_CC + 2] = 0.0;
+        }
+    } else if constexpr (wave == 2) {
+        if (kact) {
+            const double *z0 = a.x0 + ((size_t)b * N + k) * NZ;
+            pc[0] = pk[0]; pc[1] = pk[1]; pc[2] = pk[2]; pc[6] = pk[6]; pc[7] = pk[7]; pc[8] = pk[8]; pc[9] = pk[9];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int ib = r * H, i = ib + half;
+                if (i >= NZ) continue;
+                const double lb = ROW_PICK(lower_bound(i));
+                const double ub = ROW_PICK(upper_bound(i));
+                bz[r] = z0[i];
+                if (ib < 8) bzp[r] = z0[i < 4 ? i + 4 : (i < 8 ? i - 4 : i)];
+                bsl[r] = bz[r] - lb;
+                bsu[r] = ub - bz[r];
+                smin = fmin(smin, fmin(bsl[r], bsu[r]));
+            }
+        }
+    } else if constexpr (wave == 3) {
+        int nf = 0;
+        if (kact) {
+            if (a.nfaces) nf = a.nfaces[(size_t)b * N + k];
+            else { // trailing all-zero rows are padding (forces_normal.cpp:127-135)
+                nf = M;
+                while (nf > 0) {
+                    const double *r = pk + NPRE + 3 * (nf - 1);
+                    if (r[0] == 0.0 && r[1] == 0.0 && r[2] == 0.0 && pk[NPRE + 3 * M + nf - 1] >= -HU) nf--;
+                    else break;
+                }
+            }
+            if (nf > MF || nf < 0 || nf > FL * H) { bad_param = 1; nf = 0; }
+            if (half == 0) mcount = 34 + nf;
+            const double *z0 = a.x0 + ((size_t)b * N + k) * NZ;
+            fpos[0] = z0[8]; fpos[1] = z0[9]; fpos[2] = z0[10];
+            if (half == 0) { // this lane also evaluates the stage's dynamics Hessian
+#pragma unroll
+                for (int i = 0; i < 4; i++) hs.u[i] = z0[i];
+#pragma unroll
+                for (int i = 0; i < 6; i++) hs.ve[i] = z0[11 + i];
+                hs.fext[0] = pk[3]; hs.fext[1] = pk[4]; hs.fext[2] = pk[5];
+            }
+#pragma unroll
+            for (int t = 0; t < FL; t++) {
+                const int j = t * H + half;
+                if (j < nf) {
+                    const double a0 = pk[NPRE + 3 * j], a1 = pk[NPRE + 3 * j + 1], a2 = pk[NPRE + 3 * j + 2];
+                    const double bb = pk[NPRE + 3 * M + j] + HU;
+                    if (FREG) { fa0[t] = a0; fa1[t] = a1; fa2[t] = a2; fbb[t] = bb; }
+                    fs[t] = -(a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb);
+                    smin = fmin(smin, fs[t]);
+                }
+            }
+        }
+        nfk = nf;
+    }
+    smin = wave_min(smin);
+    if constexpr (wave == 3) {
+        const int mt = (int)wave_sum((double)mcount);
+        const int bd = wave_max((double)bad_param) > 0.0 ? 1 : 0;
+        if (lane == 0) { sh.ctl->mtot = mt; sh.ctl->bad = bd; }
+    }
+    publish(xs, wave, lane, 13, smin);
+    BAR();
+    const int mtot = sh.ctl->mtot;
+    if (sh.ctl->bad) { // a stage has more live corridor rows than the caller sized the problem for (MF)
+        if (threadIdx.x == 0) { a.exitflag[b] = FRP_EXIT_PARAM_VALUE; a.iters[b] = 0; }
+        if (wave == 1 && kact) {
+            double *zo = a.z + ((size_t)b * N + k) * NZ;
+#pragma unroll
+            for (int i = 0; i < NZ; i++) zo[i] = ms.z[i];
+        }
+        return;
+    }
+    {
+        // infeasible-start initialisation: uniform slack shift (see oracle/nmpc_ipm.c)
+        smin = fmin(red(xs, 2, 13), red(xs, 3, 13));
+        const double shift = (smin >= S_MIN) ? 0.0 : (S_MIN - smin) + fmax(0.0, -smin);
+        if constexpr (wave == 2) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                bsl[r] += shift; bsu[r] += shift;
+                bll[r] = a.mu0 / bsl[r]; blu[r] = a.mu0 / bsu[r];
+            }
+        } else if constexpr (wave == 3) {
+#pragma unroll
+            for (int t = 0; t < FL; t++) { fs[t] += shift; fl_[t] = a.mu0 / fs[t]; }
+        }
+    }
+
+    int flag = FRP_EXIT_MAXIT, it = 0, nfallback = 0;
+    double theta_h = hess ? 1.0 : 0.0; // weight of the dynamics Hessian
+    bool gn_retry = false;              // this iteration is being redone with the Gauss-Newton Hessian
+    Norms nm = {0, 0, 0, 0, 0, 0};
+    double mu = 0.0, step_cc = 0.0;
+    if constexpr (wave == 0) __builtin_amdgcn_s_setprio(2); // the Riccati sweeps are the critical path of every iteration
+
+    for (it = 0;;) {
+        // ============================================================ evaluation phase
+        if constexpr (wave == 1) {
+            double l_eq;
+            model_phase<NP>(recs, xs, ms, N, l_eq);
+            publish(xs, 1, lane, 0, wave_max(l_eq));
+        } else if constexpr (wave == 2) {
+            double l_in = 0.0, l_rc = 0.0, l_gap = 0.0;
+            if (kact) {
+                const CostQ cq = make_cost(pc, stage_class(k, N), model);
+                double *rec = recs + k * RS;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int ib = r * H, i = ib + half;
+                    if (i >= NZ) continue;
+                    const double hd = ROW_PICK(cq.hd(i));
+                    const double qi = ROW_PICK(cq.q(i));
+                    const double lb = ROW_PICK(lower_bound(i));
+                    const double ub = ROW_PICK(upper_bound(i));
+                    const double zi = bz[r];
+                    double cg = hd * zi + qi; // cost gradient
+                    if (ib < 8) cg += (i < 8 ? cq.hc() : 0.0) * bzp[r];
+                    const double sl = bsl[r], su = bsu[r], ll = bll[r], lu = blu[r];
+                    const double vl = lb - zi, vu = zi - ub;
+                    const double rl = vl + sl, ru = vu + su;
+                    l_in = fmax(l_in, fmax(fmax(vl, vu), fmax(fabs(rl), fabs(ru))));
+                    l_rc = fmax(l_rc, fmax(sl * ll, su * lu));
+                    l_gap += sl * ll + su * lu;
+                    const double sgl = ll * fast_rcp(sl), sgu = lu * fast_rcp(su);
+                    rec[R_PHIB + i] = cg + lu - ll;          // cost and bound part of the stationarity residual
+                    rec[R_PHID + i] = hd + sgl + sgu;
+                    rec[R_PHI + i] = cg + sgu * ru - sgl * rl;
+                }
+            }
+            publish(xs, 2, lane, 0, wave_max(l_in)); publish(xs, 2, lane, 1, wave_max(l_rc)); publish(xs, 2, lane, 2, wave_sum(l_gap));
+        } else if constexpr (wave == 3) {
+            double l_in = 0.0, l_rc = 0.0, l_gap = 0.0;
+            double gp0 = 0, gp1 = 0, gp2 = 0, fp0 = 0, fp1 = 0, fp2 = 0, p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0;
+            if (kact) {
+#pragma unroll
+                for (int t = 0; t < FL; t++) {
+                    if (t * H + half < nfk) {
+                        double a0, a1, a2, bb;
+                        face_consts(t, a0, a1, a2, bb);
+                        const double hj = a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb;
+                        const double sc = fs[t], lc = fl_[t];
+                        const double rc = hj + sc;
+                        l_in = fmax(l_in, fmax(hj, fabs(rc)));
+                        l_rc = fmax(l_rc, sc * lc);
+                        l_gap += sc * lc;
+                        gp0 += a0 * lc; gp1 += a1 * lc; gp2 += a2 * lc;
+                        const double sg = lc * fast_rcp(sc), tt = sg * rc;
+                        fp0 += a0 * tt; fp1 += a1 * tt; fp2 += a2 * tt;
+                        p0 += sg * a0 * a0; p1 += sg * a0 * a1; p2 += sg * a0 * a2;
+                        p3 += sg * a1 * a1; p4 += sg * a1 * a2; p5 += sg * a2 * a2;
+                    }
+                }
+            }
+            if (H > 1) {
+                gp0 = xsub_sum<NP>(gp0); gp1 = xsub_sum<NP>(gp1); gp2 = xsub_sum<NP>(gp2);
+                fp0 = xsub_sum<NP>(fp0); fp1 = xsub_sum<NP>(fp1); fp2 = xsub_sum<NP>(fp2);
+                p0 = xsub_sum<NP>(p0); p1 = xsub_sum<NP>(p1); p2 = xsub_sum<NP>(p2);
+                p3 = xsub_sum<NP>(p3); p4 = xsub_sum<NP>(p4); p5 = xsub_sum<NP>(p5);
+            }
+            if (kact && half == 0) {
+                double *rec = recs + k * RS;
+                rec[R_PHIPOS + 0] = p0; rec[R_PHIPOS + 1] = p1; rec[R_PHIPOS + 2] = p2;
+                rec[R_PHIPOS + 3] = p1; rec[R_PHIPOS + 4] = p3; rec[R_PHIPOS + 5] = p4;
+                rec[R_PHIPOS + 6] = p2; rec[R_PHIPOS + 7] = p4; rec[R_PHIPOS + 8] = p5;
+                rec[R_CB + 0] = gp0; rec[R_CB + 1] = gp1; rec[R_CB + 2] = gp2;
+                rec[R_CC + 0] = fp0; rec[R_CC + 1] = fp1; rec[R_CC + 2] = fp2;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kact && half == 0) hessian_phase(recs + k * RS, hs, k < N - 1, hess);
+            publish(xs, 3, lane, 0, wave_max(l_in)); publish(xs, 3, lane, 1, wave_max(l_rc)); publish(xs, 3, lane, 2, wave_sum(l_gap));
+        }
+        BAR(); // ---------------------------------------------------------------- A
+        nm.eq = red(xs, 1, 0);
+        nm.in = fmax(red(xs, 2, 0), red(xs, 3, 0));
+        nm.rc = fmax(red(xs, 2, 1), red(xs, 3, 1));
+        nm.gap = red(xs, 2, 2) + red(xs, 3, 2);
+        nm.rs = stationarity_norm<NP>(recs, N);
+        mu = nm.gap / (double)mtot;
+        if (!gn_retry) {
+            if (!(nm.eq == nm.eq) || !(nm.rs == nm.rs) || !(nm.gap == nm.gap)) { flag = FRP_EXIT_BADFUNCEVAL; break; }
+            if (nm.eq <= a.tol_eq && nm.in <= a.tol_ineq && nm.rs <= a.tol_stat && nm.rc <= a.tol_comp) { flag = FRP_EXIT_OPTIMAL; break; }
+            if (it >= a.maxit) { flag = FRP_EXIT_MAXIT; break; }
+            if (mu > DIVERGE_MU * fmax(1.0, a.mu0) || nm.rs > DIVERGE_RS) { flag = FRP_EXIT_NOPROGRESS; break; }
+        }
+
+        // ============================================================ predictor: factorisation + forward sweep
+        if constexpr (wave == 0) {
+            const int fr = sweep_factor(recs, xs, N, gn_retry ? 0.0 : theta_h);
+            if (!fr) sweep_forward<false>(recs, xs, N);
+            if (lane == 0) sh.ctl->fail = fr;
+        }
+        BAR(); // ---------------------------------------------------------------- C
+        {
+            const int fr = sh.ctl->fail;
+            if (fr && !gn_retry && theta_h > 0.0) {
+                // indefinite pivot block with the exact Hessian: the iteration is redone with the Gauss-Newton Hessian.
+                // P has overwritten part of the barrier Hessian in the records, so the evaluation phase runs again.
+                nfallback++;
+                theta_h *= THETA_DOWN;
+                gn_retry = true;
+                continue;
+            }
+            if (fr) { flag = FRP_EXIT_FACTORIZATION; break; }
+            if (!gn_retry && hess) theta_h = fmin(1.0, theta_h + THETA_UP);
+            gn_retry = false;
+        }
+
+        // ============================================================ affine step: lengths, second-order term, corrector rhs
+        if constexpr (wave == 2) {
+            double m_p = 0.0, m_d = 0.0, s_sdl = 0.0, s_lds = 0.0, s_dsdl = 0.0;
+            if (kact) {
+                const CostQ cq = make_cost(pc, stage_class(k, N), model);
+                double *rec = recs + k * RS;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int ib = r * H, i = ib + half;
+                    if (i >= NZ) continue;
+                    const double hd = ROW_PICK(cq.hd(i));
+                    const double qi = ROW_PICK(cq.q(i));
+                    const double lb = ROW_PICK(lower_bound(i));
+                    const double ub = ROW_PICK(upper_bound(i));
+                    const double zi = bz[r], dzi = rec[R_DZ + i];
+                    double pb = hd * zi + qi; // cost gradient
+                    if (ib < 8) pb += (i < 8 ? cq.hc() : 0.0) * bzp[r];
+                    // one constraint of the affine step (smu = 0, corr = 0): t1 = (l r_in - corr)/s, sinv = 1/s
+                    auto cstep = [&](double s, double l, double gdz, double viol, double &cr, double &t1, double &sinv) {
+                        const double u = fast_rcp(s * l);
+                        sinv = u * l;
+                        const double linv = u * s;
+                        const double rin = viol + s;
+                        const double ds = -rin - gdz;
+                        const double dl = -l * (1.0 + ds * sinv); // (-(s l) - l ds) / s
+                        m_p = fmax(m_p, -ds * sinv);
+                        m_d = fmax(m_d, -dl * linv);
+                        s_sdl += s * dl; s_lds += l * ds;
+                        cr = ds * dl;
+                        s_dsdl += cr;
+                        t1 = (l * rin - cr) * sinv;
+                    };
+                    double tl, tu, sil, siu;
+                    cstep(bsl[r], bll[r], -dzi, lb - zi, bcl[r], tl, sil);
+                    cstep(bsu[r], blu[r], dzi, zi - ub, bcu[r], tu, siu);
+                    rec[R_PHIB + i] = pb + tu - tl;
+                    rec[R_PHIC + i] = siu - sil;
+                }
+            }
+            publish(xs, 2, lane, 3, wave_max(m_p)); publish(xs, 2, lane, 4, wave_max(m_d));
+            publish(xs, 2, lane, 5, wave_sum(s_sdl)); publish(xs, 2, lane, 6, wave_sum(s_lds)); publish(xs, 2, lane, 7, wave_sum(s_dsdl));
+        } else if constexpr (wave == 3) {
+            double m_p = 0.0, m_d = 0.0, s_sdl = 0.0, s_lds = 0.0, s_dsdl = 0.0;
+            double b0 = 0, b1 = 0, b2 = 0, c0 = 0, c1 = 0, c2 = 0;
+            if (kact) {
+                const double *rec = recs + k * RS;
+                const double d8 = rec[R_DZ + 8], d9 = rec[R_DZ + 9], d10 = rec[R_DZ + 10];
+#pragma unroll
+                for (int t = 0; t < FL; t++) {
+                    if (t * H + half < nfk) {
+                        double a0, a1, a2, bb;
+                        face_consts(t, a0, a1, a2, bb);
+                        const double s = fs[t], l = fl_[t];
+                        const double gdz = a0 * d8 + a1 * d9 + a2 * d10, viol = a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb;
+                        const double u = fast_rcp(s * l);
+                        const double sinv = u * l, linv = u * s;
+                        const double rin = viol + s;
+                        const double ds = -rin - gdz;
+                        const double dl = -l * (1.0 + ds * sinv);
+                        m_p = fmax(m_p, -ds * sinv);
+                        m_d = fmax(m_d, -dl * linv);
+                        s_sdl += s * dl; s_lds += l * ds;
+                        const double cr = ds * dl;
+                        s_dsdl += cr;
+                        fcr[t] = cr;
+                        const double t1 = (l * rin - cr) * sinv;
+                        b0 += a0 * t1; b1 += a1 * t1; b2 += a2 * t1;
+                        c0 += a0 * sinv; c1 += a1 * sinv; c2 += a2 * sinv;
+                    }
+                }
+            }
+            if (H > 1) {
+                b0 = xsub_sum<NP>(b0); b1 = xsub_sum<NP>(b1); b2 = xsub_sum<NP>(b2);
+                c0 = xsub_sum<NP>(c0); c1 = xsub_sum<NP>(c1); c2 = xsub_sum<NP>(c2);
+            }
+            if (kact && half == 0) {
+                double *rec = recs + k * RS;
+                rec[R_CB + 0] = b0; rec[R_CB + 1] = b1; rec[R_CB + 2] = b2;
+                rec[R_CC + 0] = c0; rec[R_CC + 1] = c1; rec[R_CC + 2] = c2;
+            }
+            publish(xs, 3, lane, 3, wave_max(m_p)); publish(xs, 3, lane, 4, wave_max(m_d));
+            publish(xs, 3, lane, 5, wave_sum(s_sdl)); publish(xs, 3, lane, 6, wave_sum(s_lds)); publish(xs, 3, lane, 7, wave_sum(s_dsdl));
+        }
+        BAR(); // ---------------------------------------------------------------- D
+        double smu;
+        {
+            const double m_p = fmax(red(xs, 2, 3), red(xs, 3, 3)), m_d = fmax(red(xs, 2, 4), red(xs, 3, 4));
+            const double ap = (m_p > 1.0) ? 1.0 / m_p : 1.0;
+            const double ad = (m_d > 1.0) ? 1.0 / m_d : 1.0;
+            const double gap_aff = mu * (double)mtot + ad * (red(xs, 2, 5) + red(xs, 3, 5)) + ap * (red(xs, 2, 6) + red(xs, 3, 6)) +
+                                   ap * ad * (red(xs, 2, 7) + red(xs, 3, 7));
+            double sigma = gap_aff / ((double)mtot * mu);
+            sigma = sigma * sigma * sigma;
+            if (sigma > 1.0) sigma = 1.0;
+            smu = sigma * mu;
+            if (smu < MU_FLOOR_FRAC * a.tol_comp) smu = MU_FLOOR_FRAC * a.tol_comp;
+        }
+
+        // ============================================================ corrector: vector backward sweep + forward sweep with y+
+        if constexpr (wave == 0) {
+            sweep_backvec(recs, xs, N, smu);
+            sweep_forward<true>(recs, xs, N);
+        }
+        BAR(); // ---------------------------------------------------------------- E
+
+        // ============================================================ step: pass A (ratios), pass B (commit)
+        double m_p = 0.0, m_d = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0; // q: sums of ds l, s dl, ds dl
+        double dzr[NZ], ypl[NS], dzp[R];                            // wave 1: Newton step / y+ of its stage; wave 2: dz of its rows (dzr[0..R)) and of their (u, w) partners; wave 3: dz of pos
+        // one constraint of the corrector step
+        auto cstep = [&](double s, double l, double corr, double gdz, double viol, double &ds, double &dl) {
+            const double u = fast_rcp(s * l);
+            const double sinv = u * l, linv = u * s;
+            ds = -(viol + s) - gdz;
+            const double rc = s * l - smu + corr;
+            dl = (-rc - l * ds) * sinv;
+            m_p = fmax(m_p, -ds * sinv);
+            m_d = fmax(m_d, -dl * linv);
+            q1 = fma(ds, l, q1); q2 = fma(s, dl, q2); q3 = fma(ds, dl, q3);
+        };
+        if constexpr (wave == 1) {
+            if (kact) {
+                const double *rec = recs + k * RS;
+#pragma unroll
+                for (int i = 0; i < NZ; i++) dzr[i] = rec[R_DZ + i];
+#pragma unroll
+                for (int i = 0; i < NS; i++) ypl[i] = rec[R_PD + i];
+            }
+        } else if constexpr (wave == 2) {
+            if (kact) {
+                const double *rec = recs + k * RS;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int ib = r * H, i = ib + half;
+                    if (i >= NZ) continue;
+                    const double lb = ROW_PICK(lower_bound(i));
+                    const double ub = ROW_PICK(upper_bound(i));
+                    const double zi = bz[r], dzi = rec[R_DZ + i];
+                    dzr[r < NZ ? r : 0] = dzi;
+                    if (ib < 8) dzp[r] = rec[R_DZ + (i < 4 ? i + 4 : (i < 8 ? i - 4 : i))];
+                    double ds, dl;
+                    cstep(bsl[r], bll[r], bcl[r], -dzi, lb - zi, ds, dl);
+                    cstep(bsu[r], blu[r], bcu[r], dzi, zi - ub, ds, dl);
+                }
+            }
+        } else if constexpr (wave == 3) {
+            if (kact) {
+                const double *rec = recs + k * RS;
+                dzr[0] = rec[R_DZ + 8]; dzr[1] = rec[R_DZ + 9]; dzr[2] = rec[R_DZ + 10];
+                if (half == 0) { // Newton step of the Hessian lane's copies: (rates, T), (v, e), (y_p, y_v)+ of the next stage
+#pragma unroll
+                    for (int i = 0; i < 4; i++) dzr[3 + i] = rec[R_DZ + i];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) dzr[7 + i] = rec[R_DZ + 11 + i];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) ypl[i] = (k < N - 1) ? rec[RS + R_PD + 4 + i] : 0.0;
+                }
+#pragma unroll
+                for (int t = 0; t < FL; t++) {
+                    if (t * H + half < nfk) {
+                        double a0, a1, a2, bb, ds, dl;
+                        face_consts(t, a0, a1, a2, bb);
+                        cstep(fs[t], fl_[t], fcr[t], a0 * dzr[0] + a1 * dzr[1] + a2 * dzr[2],
+                              a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb, ds, dl);
+                    }
+                }
+            }
+        }
+        if constexpr (wave >= 2) {
+            publish(xs, wave, lane, 8, wave_max(m_p)); publish(xs, wave, lane, 9, wave_max(m_d));
+            publish(xs, wave, lane, 10, wave_sum(q1)); publish(xs, wave, lane, 11, wave_sum(q2)); publish(xs, wave, lane, 12, wave_sum(q3));
+        }
+        BAR(); // ---------------------------------------------------------------- F
+        {
+            const double mp = fmax(red(xs, 2, 8), red(xs, 3, 8)), md = fmax(red(xs, 2, 9), red(xs, 3, 9));
+            const double ap = (mp > a.ftb) ? a.ftb / mp : 1.0;
+            const double ad = (md > a.ftb) ? a.ftb / md : 1.0;
+            // multiplier safeguard: s_i lam_i >= mu_new / KAPPA_LAM for every pair after the step
+            const double fprod = (mu * (double)mtot + ap * (red(xs, 2, 10) + red(xs, 3, 10)) +
+                                  ad * ((red(xs, 2, 11) + red(xs, 3, 11)) + ap * (red(xs, 2, 12) + red(xs, 3, 12)))) / (KAPPA_LAM * (double)mtot);
+            step_cc = ap;
+            auto commit = [&](double &s, double &l, double corr, double gdz, double viol) {
+                const double sinv = fast_rcp(s);
+                const double ds = -(viol + s) - gdz;
+                const double rc = s * l - smu + corr;
+                const double dl = (-rc - l * ds) * sinv;
+                const double sn = s + ap * ds;
+                double ln = l + ad * dl;
+                if (ln * sn < fprod) ln = fprod * fast_rcp(sn);
+                s = sn; l = ln;
+            };
+            if constexpr (wave == 1) {
+#pragma unroll
+                for (int i = 0; i < NZ; i++) ms.z[i] += ap * dzr[i];
+#pragma unroll
+                for (int i = 0; i < NS; i++) ms.y[i] += ap * (ypl[i] - ms.y[i]); // y <- y + ap (y+ - y)
+            } else if constexpr (wave == 2) {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int ib = r * H, i = ib + half;
+                    if (i >= NZ) continue;
+                    const double lb = ROW_PICK(lower_bound(i));
+                    const double ub = ROW_PICK(upper_bound(i));
+                    const double zi = bz[r], dzi = dzr[r < NZ ? r : 0];
+                    commit(bsl[r], bll[r], bcl[r], -dzi, lb - zi);
+                    commit(bsu[r], blu[r], bcu[r], dzi, zi - ub);
+                    bz[r] = zi + ap * dzi;
+                    if (ib < 8) bzp[r] += ap * dzp[r];
+                }
+            } else if constexpr (wave == 3) {
+#pragma unroll
+                for (int t = 0; t < FL; t++) {
+                    if (t * H + half < nfk) {
+                        double a0, a1, a2, bb;
+                        face_consts(t, a0, a1, a2, bb);
+                        commit(fs[t], fl_[t], fcr[t], a0 * dzr[0] + a1 * dzr[1] + a2 * dzr[2], a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb);
+                    }
+                }
+                fpos[0] += ap * dzr[0]; fpos[1] += ap * dzr[1]; fpos[2] += ap * dzr[2];
+                if (kact && half == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) hs.u[i] += ap * dzr[3 + i];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) hs.ve[i] += ap * dzr[7 + i];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) hs.y6[i] += ap * (ypl[i] - hs.y6[i]);
+                }
+            }
+        }
+        it++;
+    }
+
+    // ---------------------------------------------------------------- outputs
+    if constexpr (wave == 0) __builtin_amdgcn_s_setprio(0);
+    if constexpr (wave == 1) {
+        // the objective is reported, not iterated on: evaluated once, at the returned iterate
+        double l_obj = 0.0;
+        if (kact) {
+            double *zo = a.z + ((size_t)b * N + k) * NZ;
+#pragma unroll
+            for (int i = 0; i < NZ; i++) zo[i] = ms.z[i];
+            double p10[NPRE];
+#pragma unroll
+            for (int i = 0; i < NPRE; i++) p10[i] = pk[i];
+            l_obj = stage_cost(ms.z, p10, stage_class(k, N), model, nullptr);
+        }
+        l_obj = wave_sum(l_obj);
+        if (a.info && lane == 0) a.info[(size_t)b * FRP_INFO_STRIDE + 4] = l_obj;
+    }
+    if (threadIdx.x == 0) {
+        a.exitflag[b] = flag;
+        a.iters[b] = it;
+        if (a.info) {
+            double *o = a.info + (size_t)b * FRP_INFO_STRIDE;
+            o[0] = nm.eq; o[1] = nm.in; o[2] = nm.rs; o[3] = nm.rc; o[5] = mu; o[6] = step_cc; o[7] = (double)nfallback; // o[4] = objective: wave 1
+        }
+    }
+}
+
+// Persistent workgroups: grid = min(B, resident workgroups); each pulls the next problem index from a device counter
+// (zeroed by the launcher) until the batch is exhausted.
+template <int NP, int FL, bool FREG, int ROLE>
+__device__ __forceinline__ void role_loop(const KernelArgs &a, const Shared &sh)
+{
+    for (;;) {
+        if (ROLE == 0 && threadIdx.x == 0) sh.ctl->next = atomicAdd(a.counter, 1);
+        BAR();
+        int b = sh.ctl->next;
+        if (b >= a.B) break;
+        if (a.order) b = a.order[b]; // longest-expected-first launch order (see order_keys_kernel)
+        solve_one<NP, FL, FREG, ROLE>(a, b, sh);
+        BAR();
+    }
+}
+
+template <int NP, int FL, bool FREG, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void nmpc_ipm_lds_kernel(KernelArgs a)
+{
+    __shared__ double s_recs[NP * RS];
+    __shared__ double s_xs[X_TOTAL];
+    __shared__ Ctl s_ctl;
+    Shared sh;
+    sh.recs = s_recs; sh.xs = s_xs; sh.ctl = &s_ctl;
+    if (threadIdx.x == 0) { s_xs[X_C0] = 0.0; s_xs[X_C1] = 1.0; }
+    // one copy of the solver loop per role: the four waves run different code between the same barriers
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave == 0) role_loop<NP, FL, FREG, 0>(a, sh);
+    else if (wave == 1) role_loop<NP, FL, FREG, 1>(a, sh);
+    else if (wave == 2) role_loop<NP, FL, FREG, 2>(a, sh);
+    else role_loop<NP, FL, FREG, 3>(a, sh);
+}
+
+template <int NP, int FL, bool FREG, int WPE>
+static hipError_t launch_variant(const KernelArgs &k, int slots, hipStream_t stream)
+{
+    hipLaunchKernelGGL((nmpc_ipm_lds_kernel<NP, FL, FREG, WPE>), dim3(slots), dim3(256), 0, stream, k);
+    return hipGetLastError();
+}
+
+} // namespace lr
+
+// workgroups resident per CU: LDS-bound (3 x 49 KB, 2 x 79 KB, 1 x 157 KB)
+int lds_workgroups_per_cu(int N) { return N <= 20 ? 3 : (N <= 32 ? 2 : 1); }
+
+bool lds_kernel_supports(int N, int MF) { return N >= 1 && N <= 64 && MF >= 0 && MF <= 30; }
+
+// counter / order already set up by launch_ipm
+hipError_t launch_ipm_lds(const KernelArgs &k, int slots, hipStream_t stream)
+{
+    const int MF = k.MF;
+    if (k.N <= 20) {
+        if (MF <= 6) return lr::launch_variant<20, 2, true, 3>(k, slots, stream);
+        if (MF <= 15) return lr::launch_variant<20, 5, true, 3>(k, slots, stream);
+        return lr::launch_variant<20, 10, false, 3>(k, slots, stream);
+    }
+    if (k.N <= 32) {
+        if (MF <= 6) return lr::launch_variant<32, 3, true, 2>(k, slots, stream);
+        if (MF <= 16) return lr::launch_variant<32, 8, true, 2>(k, slots, stream);
+        return lr::launch_variant<32, 15, false, 2>(k, slots, stream);
+    }
+    if (MF <= 8) return lr::launch_variant<64, 8, true, 1>(k, slots, stream);
+    return lr::launch_variant<64, 30, false, 1>(k, slots, stream);
+}
+
+} // namespace frp

@@ -83,6 +83,10 @@ struct KernelArgs {
 
 size_t ws_bytes(int B, int N, int MF);
 hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream);
+// frp_ipm_lds.hip: the LDS-resident kernel (queue counter / order already set up by launch_ipm)
+int lds_workgroups_per_cu(int N);
+bool lds_kernel_supports(int N, int MF);
+hipError_t launch_ipm_lds(const KernelArgs &k, int slots, hipStream_t stream);
 hipError_t launch_stage_eval(int B, int N, int M, int model, const double *z, const double *params, double *f,
                              double *gf, double *c, double *Jc, double *h, hipStream_t stream);
 
