@@ -138,6 +138,58 @@ __device__ __forceinline__ int tab(int row, int lane) { return (int)g_tab.v[row]
 
 #define BAR() __syncthreads()
 
+// LDS pointers carry their address space: through a generic double* every access of a non-inlined function would pay
+// 64-bit address arithmetic and the null check of the address-space cast
+typedef __attribute__((address_space(3))) double ldouble;
+typedef __attribute__((address_space(3))) const double cldouble;
+
+// -DFRP_PROFILE: per-wave cycle counts of the work before each of the five barriers of an iteration and of the wait at it
+#ifdef FRP_PROFILE
+__device__ long long g_prof_lds[4][16];
+#define PROF_DECL() long long pw_[5] = {0, 0, 0, 0, 0}, pb_[5] = {0, 0, 0, 0, 0}, pt_ = clock64()
+#define BAR_P(i)                                                    \
+    do {                                                            \
+        const long long t0_ = clock64();                            \
+        pw_[i] += t0_ - pt_;                                        \
+        __syncthreads();                                            \
+        pt_ = clock64();                                            \
+        pb_[i] += pt_ - t0_;                                        \
+    } while (0)
+#define PROF_FLUSH(wave, its)                                                                         \
+    do {                                                                                              \
+        if ((threadIdx.x & 63) == 0) {                                                                \
+            for (int q_ = 0; q_ < 5; q_++) {                                                          \
+                atomicAdd((unsigned long long *)&g_prof_lds[wave][q_], (unsigned long long)pw_[q_]);       \
+                atomicAdd((unsigned long long *)&g_prof_lds[wave][5 + q_], (unsigned long long)pb_[q_]);   \
+            }                                                                                         \
+            atomicAdd((unsigned long long *)&g_prof_lds[wave][10], (unsigned long long)(its));          \
+        }                                                                                             \
+    } while (0)
+#else
+#define PROF_DECL()
+#define BAR_P(i) __syncthreads()
+#define PROF_FLUSH(wave, its)
+#endif
+#ifdef FRP_PROFILE
+__device__ long long g_prof_seg[16];
+#endif
+#ifdef FRP_PROFILE_SEG // (each timer read drains lgkmcnt: the segments are serialised, use them for proportions only) // factor sweep: mfma X/G, gather, pivot, tail mfma, P update + stores; then whole sweeps: factor, forward, backvec, forward+y
+#define SEG_DECL() long long sg_[6] = {0, 0, 0, 0, 0, 0}, st_ = clock64()
+#define SEG(i) do { const long long tn_ = clock64(); sg_[i] += tn_ - st_; st_ = tn_; } while (0)
+#define SEG_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int q_ = 0; q_ < 6; q_++) atomicAdd((unsigned long long *)&g_prof_seg[q_], (unsigned long long)sg_[q_]); } while (0)
+#else
+#define SEG_DECL()
+#define SEG(i)
+#define SEG_FLUSH()
+#endif
+#ifdef FRP_PROFILE
+#define SWEEP_T0() const long long sw0_ = clock64()
+#define SWEEP_T1(i) do { if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&g_prof_seg[8 + (i)], (unsigned long long)(clock64() - sw0_)); } while (0)
+#else
+#define SWEEP_T0()
+#define SWEEP_T1(i)
+#endif
+
 // ------------------------------------------------------------------ values every wave derives from the LDS partials
 struct Norms {
     double eq, in, rs, rc, gap, obj;
@@ -176,13 +228,13 @@ __device__ __forceinline__ double xsub_sum(double v) // sum over the H lanes tha
 
 // max |stationarity residual| from the three parts the evaluation phase left in the records (all waves, redundantly)
 template <int NP>
-__device__ __forceinline__ double stationarity_norm(const double *recs, int N)
+__device__ __forceinline__ double stationarity_norm(cldouble *recs, int N)
 {
     constexpr int H = RowMap<NP>::H, R = RowMap<NP>::R;
     const int lane = threadIdx.x & 63, k = lane % NP, half = lane / NP;
     double rs = 0.0;
     if (k < N && half < H) {
-        const double *rec = recs + k * RS;
+        cldouble *rec = recs + k * RS;
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int i = r * H + half;
@@ -202,7 +254,7 @@ struct Ctl { // workgroup-shared control words
 // ================================================================== wave 0: Riccati sweeps
 // ---- stage-0 solve (both passes): dx_0 = xinit - x_0, dw_0 = -Pww^-1 (Pwx dx_0 + p_w); leaves ds_0 in X_DS0.
 // pw_here: p_w[g] in the lanes (g, 13).
-__device__ __forceinline__ void stage0_solve(double *xs, int lane, double pw_here)
+__device__ __forceinline__ void stage0_solve(ldouble *xs, int lane, double pw_here)
 {
     const int g = lane >> 4, c = lane & 15;
     const bool xc = (c >= 4 && c <= 12);
@@ -222,13 +274,34 @@ __device__ __forceinline__ void stage0_solve(double *xs, int lane, double pw_her
     WSYNC();
 }
 
+// quad 0 of every 16-lane row copied to the other three quads of the row (DPP row_shr with a bank mask: no selects)
+__device__ __forceinline__ double bcast_quad0(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    int lo = (int)(unsigned)b, hi = (int)(unsigned)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x114, 0xF, 0x2, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x114, 0xF, 0x2, false); // row_shr:4 -> quad 1
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x118, 0xF, 0x4, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x118, 0xF, 0x4, false); // row_shr:8 -> quad 2
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x11C, 0xF, 0x8, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x11C, 0xF, 0x8, false); // row_shr:12 -> quad 3
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+template <int N4> // lane c of a 16-lane row <- lane c + N4 (row_shl)
+__device__ __forceinline__ double row_shl(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)b, 0x100 + N4, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), 0x100 + N4, 0xF, 0xF, true);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+
 // ---- factorisation sweep (predictor).  Backward Riccati recursion on 16x16 FP64 register tiles:
 //   X = P M (col 13: P d + p+),  G = M'X + C~ (col 13: q~),  Guu = L D L',  K = L^-1 G_u,
 //   T = L^-T D^-1 K (Kbar, kbar),  S = G - K' D^-1 K,  P <- [Phi_w - hc^2 R, -hc Kbar_x; -hc Kbar_x', S_xx].
 // The tiles of stage k-1 are gathered from its LDS record as soon as the MFMAs that read the tiles of stage k have
-// been issued: the gathers land while those MFMAs and the pivot-block factorisation execute.
+// been issued: the gathers land while those MFMAs and the pivot-block factorisation execute.  The rank-4 products
+// around the pivot block (K, R, T, T') run on the 4x4x4 MFMA (24 cycles instead of 64), whose block layout coincides
+// with register 0 of the 16x16 tiles: A[i][k] in lane 16k+4b+i, B[k][j] in lane 16k+4b+j, D[i][j] in lane 16i+4b+j.
 // Returns 1 when a pivot block is not positive definite.
-__device__ __forceinline__ void gather_tiles(const double *rn, const int (&c1)[4], const int (&c2)[4], const int (&c3)[4],
+__device__ __forceinline__ void gather_tiles(cldouble *rn, const int (&c1)[4], const int (&c2)[4], const int (&c3)[4],
                                              const int (&mo)[4], int g, double theta, d4 &C, d4 &Mt, double &hc, double &PhiDw, double &phiw)
 {
 #pragma unroll
@@ -241,76 +314,119 @@ __device__ __forceinline__ void gather_tiles(const double *rn, const int (&c1)[4
     phiw = rn[R_PHI + 4 + g];
 }
 
-__device__ __noinline__ int sweep_factor(double *recs, double *xs, int N, double theta)
+__device__ __noinline__ int sweep_factor(ldouble *recs, ldouble *xs, int N, double theta)
 {
     N = uni(N); theta = uni(theta);
-    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15, c3_ = c & 3;
     int mo[4], c1[4], c2[4], c3[4], ppo[4], pdo[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         mo[r] = tab(T_M + r, lane); c1[r] = tab(T_C1 + r, lane); c2[r] = tab(T_C2 + r, lane);
         c3[r] = tab(T_C3 + r, lane); ppo[r] = tab(T_PP + r, lane); pdo[r] = tab(T_PD + r, lane);
     }
-    // scratch slot of m[g][c] / m[c][g] for this lane (m = L^-1 of the pivot block, strictly lower part in X_MI)
-    const int mgo = c < 4 ? (c < g ? X_MI + g * (g - 1) / 2 + c : (c == g ? X_C1 : X_C0)) : X_C0;
-    const int mco = c < 4 ? (g < c ? X_MI + c * (c - 1) / 2 + g : (c == g ? X_C1 : X_C0)) : X_C0;
+    // which entry of m = L^-1 of the pivot block this lane needs as m[g][c & 3] / m[c & 3][g]: index into the strictly
+    // lower triangle (1,0) (2,0) (2,1) (3,0) (3,1) (3,2), 6 = unit diagonal, 7 = zero
+    const int mgs = c3_ < g ? g * (g - 1) / 2 + c3_ : (c3_ == g ? 6 : 7);
+    const int mcs = g < c3_ ? c3_ * (c3_ - 1) / 2 + g : (c3_ == g ? 6 : 7);
+    const bool row3 = g == 0; // tile rows 12..15: only row 12 is a state row
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     d4 P = zero, pv = zero, C, Mt;
     double hcn, PhiDwn, phiwn;
     gather_tiles(recs + (N - 1) * RS, c1, c2, c3, mo, g, theta, C, Mt, hcn, PhiDwn, phiwn);
-    int fail = 0;
-    for (int kk = N - 1; kk >= 0; kk--) {
-        double *rec = recs + kk * RS;
+    d4 G = C; // the last stage has no successor: G = C~
+    bool ok = true;
+    SEG_DECL();
+    // Loop body in the order of the dependency chain, rotated so that independent work sits next to the MFMA chains:
+    //   gather(k-1) [while the G MFMAs of stage k, issued at the end of the previous pass, execute] -> pivot block of G
+    //   -> rank-4 products -> P_k -> X = P_k M_{k-1} [its MFMAs interleave with the assembly of P_k's rows 4..15 and
+    //   the packed-P stores] -> G of stage k-1.
+    for (int kk = N - 1;; kk--) {
+        SEG(5);
+        ldouble *rec = recs + kk * RS;
         const double hc = hcn, PhiDw = PhiDwn, phiw = phiwn; // of stage kk
-        d4 G = C;
-        if (kk < N - 1) {
-            d4 X = mm_tn(P, Mt, zero);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                rec[pdo[r]] = X[r]; // P d (column 13; every other lane writes the dump slot)
-                X[r] += pv[r];      // pv is zero outside column 13
-            }
-            G = mm_tn(Mt, X, C);
-        }
         // the tiles of stage kk are consumed: gather those of stage kk-1 (clamped at 0: unused after the last step)
         gather_tiles(recs + (kk > 0 ? kk - 1 : 0) * RS, c1, c2, c3, mo, g, theta, C, Mt, hcn, PhiDwn, phiwn);
+        SEG(1);
         // ---- pivot block Guu = L D L' (4 x 4): lower triangle to uniform registers, factored redundantly
         double q[16], Mi[6], Di[4];
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int j = 0; j <= i; j++) q[i * 4 + j] = lane_bcast(G[0], 16 * i + j);
-        if (!ldl4(q, Mi, Di)) { fail = 1; break; }
+        ok &= ldl4(q, Mi, Di); // (a failed pivot poisons the rest of the sweep, which is discarded: no branch in the loop)
+        // the uniform factors reach the lanes through selects on lane-constant predicates (an LDS round trip costs ~250 cycles
+        // of the dependency chain)
+        auto pick = [&](int sel) {
+            double v = sel == 6 ? 1.0 : 0.0;
 #pragma unroll
-        for (int i = 0; i < 6; i++) xs[X_MI + i] = Mi[i];
-#pragma unroll
-        for (int i = 0; i < 4; i++) xs[X_DI + i] = Di[i];
-        WSYNC();
+            for (int i = 0; i < 6; i++) v = sel == i ? Mi[i] : v;
+            return v;
+        };
         // elimination in factored form: an explicit inverse of Guu cancels O(1e10) barrier terms against cond(Guu) eps errors
-        const double m_gc = xs[mgo], m_cg = xs[mco]; // m[g][c], m[c][g] (unit diagonal / zeros from the constant slots)
-        const double dg = xs[X_DI + g];
+        const double m_gc = pick(mgs), m_cg = pick(mcs); // m[g][c & 3], m[c & 3][g]
+        const double dg = g == 0 ? Di[0] : (g == 1 ? Di[1] : (g == 2 ? Di[2] : Di[3]));
         const double md = dg * m_gc;
-        const d4 K = mm_tn4(m_cg, G[0], zero);
-        const d4 Rt = mm_tn4(m_gc, md, zero);
-        const double rt = Rt[0]; // R[g][c] in the lanes c < 4 (zero elsewhere)
-        const double Kd = dg * K[0];
-        const d4 T = mm_tn4(m_gc, Kd, zero);
-        const d4 TT = mm_tn4(K[0], md, zero);
-        const d4 S = mm_tn4(-Kd, K[0], G);
-        rec[R_T + lane] = (c < 4) ? rt : (c <= 13 ? T[0] : (lane == 14 ? hc : 0.0));
-        P[0] = (c < 4) ? ((g == c ? PhiDw : 0.0) - hc * hc * rt) : (c <= 12 ? -hc * T[0] : 0.0);
-        pv[0] = (c == 13) ? (phiw - hc * T[0]) : 0.0;
+        SEG(2);
+        const double K0 = mfma4(m_cg, G[0], 0.0);  // K = m G_u          (4 x 16, register-0 layout)
+        const double rt = mfma4(m_gc, md, 0.0);    // R = m' D^-1 m      (replicated in every column block)
+        const double Kd = dg * K0;
+        const double T0 = mfma4(m_gc, Kd, 0.0);    // T = m' D^-1 K = R G_u
+        const double TTb = mfma4(K0, md, 0.0);     // (K' D^-1 m)[4b + i][j] in lane (i, 4b + j)
+        d4 S = G;
+        S = __builtin_amdgcn_mfma_f64_16x16x4f64(-Kd, K0, S, 0, 0, 0); // S = G - K' D^-1 K
+        SEG(3);
+        // (every candidate is computed first and then selected: expressions inside nested selects compile to exec-mask branches)
+        const double hT = hc * T0, hhr = hc * hc * rt, pdiag = PhiDw - hhr, pw = phiw - hT, hc14 = lane == 14 ? hc : 0.0;
+        rec[R_T + lane] = c < 4 ? rt : (c <= 13 ? T0 : hc14);
+        P[0] = c < 4 ? (g == c ? pdiag : -hhr) : (c <= 12 ? -hT : 0.0);
+        pv[0] = c == 13 ? pw : 0.0;
+        // rows 4..15, columns 0..3: -hc Kbar_x' = -hc (K' D^-1 m) moved from column block r to column block 0
+        const double tt1 = -hc * row_shl<4>(TTb), tt2 = -hc * row_shl<8>(TTb), tt3 = -hc * row_shl<12>(TTb);
+        if (kk == 0) {
+            P[1] = c < 4 ? tt1 : (c <= 12 ? S[1] : 0.0);
+            P[2] = c < 4 ? tt2 : (c <= 12 ? S[2] : 0.0);
+            P[3] = row3 ? (c < 4 ? tt3 : (c <= 12 ? S[3] : 0.0)) : 0.0;
+            pv[1] = c == 13 ? S[1] : 0.0;
+            pv[2] = c == 13 ? S[2] : 0.0;
+            pv[3] = (row3 && c == 13) ? S[3] : 0.0;
 #pragma unroll
-        for (int r = 1; r < 4; r++) {
-            const bool inb = (4 * r + g) <= 12;
-            P[r] = (inb && c <= 12) ? (c < 4 ? -hc * TT[r] : S[r]) : 0.0;
-            pv[r] = (inb && c == 13) ? S[r] : 0.0;
+            for (int r = 0; r < 4; r++) rec[ppo[r]] = P[r];
+            break;
         }
+        // ---- X = P_k M_{k-1} (col 13: P d), register by register as the rows of P_k become available
+        d4 X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[0], Mt[0], zero, 0, 0, 0);
+        P[1] = c < 4 ? tt1 : (c <= 12 ? S[1] : 0.0);
+        pv[1] = c == 13 ? S[1] : 0.0;
+        X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[1], Mt[1], X, 0, 0, 0);
+        P[2] = c < 4 ? tt2 : (c <= 12 ? S[2] : 0.0);
+        pv[2] = c == 13 ? S[2] : 0.0;
+        X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[2], Mt[2], X, 0, 0, 0);
+        P[3] = row3 ? (c < 4 ? tt3 : (c <= 12 ? S[3] : 0.0)) : 0.0;
+        pv[3] = (row3 && c == 13) ? S[3] : 0.0;
+        X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[3], Mt[3], X, 0, 0, 0);
         // P_k (packed lower triangle) for the multiplier recovery y_k = P_k ds_k + p_k; it overwrites the Hessian part
         // of this stage's record, which was gathered one step ago
 #pragma unroll
         for (int r = 0; r < 4; r++) rec[ppo[r]] = P[r];
+        SEG(4);
+        // ---- G of stage kk-1 = M'X + C~ (col 13: q~)
+        ldouble *recn = rec - RS;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            recn[pdo[r]] = X[r]; // P d (column 13; every other lane writes the dump slot)
+            X[r] += pv[r];       // pv is zero outside column 13
+        }
+        // the rows w+ of M (tile rows 0..3) are [I 0 | d_w], so their slice adds X[w+_j][.] to G[u_j][.] (and something to
+        // the unused row 13): one vector add instead of an MFMA
+        G = C;
+        G[0] += X[0];
+        G = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[1], X[1], G, 0, 0, 0);
+        G = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[2], X[2], G, 0, 0, 0);
+        G = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[3], X[3], G, 0, 0, 0);
+        SEG(0);
     }
+    SEG_FLUSH();
+    int fail = ok ? 0 : 1;
     if (!fail) {
         // stage 0: keep Pww^-1 and Pwx for the corrector pass, then solve for ds_0
         double q[16], Rw[16];
@@ -334,52 +450,69 @@ __device__ __noinline__ int sweep_factor(double *recs, double *xs, int N, double
 // ---- vector-only backward sweep (corrector): new rhs phi_cc = PHIB + smu PHIC (+ the corridor parts on the pos rows):
 //   q~ = phi~ + M'(P d + p+),  [kbar; Kbar'q_u] = T'' q_u,  p_x = q~_x - Kbar' q_u,  p_w = phi_w - hc kbar.
 // Updates the kbar column of T' and stores p_k.  All mat-vec products on the 4x4x4 MFMA, vectors in V layout.
-__device__ __noinline__ void sweep_backvec(double *recs, double *xs, int N, double smu)
+// Two operand sets alternate: the set a step has consumed is refilled for the stage two steps on, so every gather has
+// a whole step to land.
+struct BackOps {
+    d4 Mt;
+    double phi, hc, phiw, tp, pd;
+};
+struct BackTabs {
+    int mo[4], pho, cbo, cco, pwo, pdo, kbo, pvo;
+};
+__device__ __forceinline__ void back_gather(cldouble *rn, const BackTabs &t, int lane, double smu, double fx, BackOps &o)
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) o.Mt[r] = rn[t.mo[r]];
+    const double ph = (rn[R_PHIB + t.pho] + rn[t.cbo]) + smu * (rn[R_PHIC + t.pho] + rn[t.cco]);
+    o.phi = fx != 0.0 ? ph : 0.0;
+    o.phiw = rn[R_PHIB + t.pwo] + smu * rn[R_PHIC + t.pwo];
+    o.hc = rn[R_HC];
+    o.tp = rn[R_T + lane]; // read before the stage's own step rewrites its kbar column
+    o.pd = rn[t.pdo];
+}
+__device__ __forceinline__ void back_step(ldouble *recs, int kk, bool last, int lane, double smu, double fx, double f0, const BackTabs &t, BackOps &o, double &pv)
+{
+    ldouble *rec = recs + kk * RS;
+    double q = o.phi;
+    if (!last) q = matvec4(o.Mt, o.pd + pv, o.phi);
+    const double ctp = o.tp, chc = o.hc, cphiw = o.phiw;
+    back_gather(recs + (kk > 1 ? kk - 2 : 0) * RS, t, lane, smu, fx, o); // this set's next stage (clamped: unused at the end)
+    // q_u (rows 0..3, quad 0) to every quad of its row, then E[c] = sum_k T'[k][c] q_u[k]
+    const double E = mfma4(ctp, bcast_quad0(q), 0.0);
+    // rows 0..3: p_w = phi_w - hc kbar;  rows 4..12: p_x = q~_x - Kbar' q_u;  rows 13..15: 0   (f0 = rows 0..3, fx = rows 0..12)
+    const double pw = cphiw - chc * E, px = q - E;
+    const double pn = f0 != 0.0 ? pw : (fx != 0.0 ? px : 0.0);
+    rec[t.kbo] = E;  // kbar (rows 0..3; the other lanes write the dump slot)
+    rec[t.pvo] = pn; // p_k for y_k = P_k ds_k + p_k
+    pv = pn;
+}
+
+__device__ __noinline__ void sweep_backvec(ldouble *recs, ldouble *xs, int N, double smu)
 {
     N = uni(N); smu = uni(smu);
     const int lane = threadIdx.x & 63;
     const int idx = 4 * ((lane >> 2) & 3) + (lane >> 4); // V layout: the vector row this lane holds
-    const int qI = (lane >> 2) & 3;
-    int mo[4];
+    BackTabs t;
 #pragma unroll
-    for (int r = 0; r < 4; r++) mo[r] = tab(T4_MTT + r, lane);
-    const int pho = idx <= 12 ? zi_of(idx) : 0;                       // q~ rows [u; x] -> z index
-    const int cbo = (idx >= 4 && idx <= 6) ? R_CB + idx - 4 : R_ZERO;  // corridor parts: pos rows only
-    const int cco = (idx >= 4 && idx <= 6) ? R_CC + idx - 4 : R_ZERO;
-    const int pwo = 4 + (idx & 3);                                    // p_w rows -> z index of w
-    const int pdo = idx <= 12 ? R_PD + idx : R_ZERO;
-    const bool q0 = idx < 4;
+    for (int r = 0; r < 4; r++) t.mo[r] = tab(T4_MTT + r, lane);
+    t.pho = idx <= 12 ? zi_of(idx) : 0;                       // q~ rows [u; x] -> z index
+    t.cbo = (idx >= 4 && idx <= 6) ? R_CB + idx - 4 : R_ZERO;  // corridor parts: pos rows only
+    t.cco = (idx >= 4 && idx <= 6) ? R_CC + idx - 4 : R_ZERO;
+    t.pwo = 4 + (idx & 3);                                    // p_w rows -> z index of w
+    t.pdo = idx <= 12 ? R_PD + idx : R_ZERO;
+    t.kbo = idx < 4 ? R_T + 16 * idx + 13 : R_DUMP;
+    t.pvo = idx <= 12 ? R_PV + idx : R_DUMP;
+    const double fx = idx <= 12 ? 1.0 : 0.0, f0 = idx < 4 ? 1.0 : 0.0;
     double pv = 0.0;
-    d4 Mt;
-    double phi, hc, phiw, tp, pd;
-    auto gather = [&](const double *rn) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) Mt[r] = rn[mo[r]];
-        phi = (rn[R_PHIB + pho] + rn[cbo]) + smu * (rn[R_PHIC + pho] + rn[cco]);
-        phi = (idx <= 12) ? phi : 0.0;
-        phiw = rn[R_PHIB + pwo] + smu * rn[R_PHIC + pwo];
-        hc = rn[R_HC];
-        tp = rn[R_T + lane]; // read before the stage's own step rewrites its kbar column
-        pd = rn[pdo];
-    };
-    gather(recs + (N - 1) * RS);
-    for (int kk = N - 1; kk >= 0; kk--) {
-        double *rec = recs + kk * RS;
-        double q = phi;
-        if (kk < N - 1) q = matvec4(Mt, pd + pv, phi);
-        const double ctp = tp, chc = hc, cphiw = phiw;
-        gather(recs + (kk > 0 ? kk - 1 : 0) * RS);
-        // q_u (rows 0..3, quad 0) to every quad of its row, then E[c] = sum_k T'[k][c] q_u[k]
-        const double r1 = quad_rot<1>(q), r2 = quad_rot<2>(q), r3 = quad_rot<3>(q);
-        const double qu = qI == 0 ? q : (qI == 1 ? r3 : (qI == 2 ? r2 : r1));
-        const double E = mfma4(ctp, qu, 0.0);
-        const double pn = q0 ? cphiw - chc * E : (idx <= 12 ? q - E : 0.0);
-        if ((lane & 3) == 0) {
-            if (q0) rec[R_T + 16 * idx + 13] = E;      // kbar
-            rec[idx <= 12 ? R_PV + idx : R_DUMP] = pn; // p_k for y_k = P_k ds_k + p_k
-        }
-        pv = pn;
+    BackOps A, B;
+    back_gather(recs + (N - 1) * RS, t, lane, smu, fx, A);
+    back_gather(recs + (N > 1 ? N - 2 : 0) * RS, t, lane, smu, fx, B);
+    int kk = N - 1;
+    for (; kk >= 1; kk -= 2) {
+        back_step(recs, kk, kk == N - 1, lane, smu, fx, f0, t, A, pv);
+        back_step(recs, kk - 1, false, lane, smu, fx, f0, t, B, pv);
     }
+    if (kk == 0) back_step(recs, 0, N == 1, lane, smu, fx, f0, t, A, pv);
     // p_w[g] sits in the quad-0 lanes of row g; the stage-0 solve wants it in the lanes (g, 13)
     stage0_solve(xs, lane, __shfl(pv, lane & 48));
     WSYNC();
@@ -387,63 +520,76 @@ __device__ __noinline__ void sweep_backvec(double *recs, double *xs, int N, doub
 
 // ---- forward sweep: dz for all stages.  du = -T' [hc dw; dx; 1],  ds+ = Mt [du; dx; 1].
 // WITH_Y (corrector pass): also y+_k = P_k ds_k + p_k (stored in the P d slot of the stage, which is dead by then).
+// Two alternating operand sets as in the backward sweep.
+struct FwdOps {
+    d4 tt, mt, Pk;
+    double hc, pk;
+};
+struct FwdTabs {
+    int mto[4], tto[4], pmo[4], pvo, duo, dso, yo;
+};
 template <bool WITH_Y>
-__device__ __noinline__ void sweep_forward(double *recs, double *xs, int N)
+__device__ __forceinline__ void fwd_gather(cldouble *rn, const FwdTabs &t, FwdOps &o)
+{
+#pragma unroll
+    for (int s = 0; s < 4; s++) { o.tt[s] = rn[t.tto[s]]; o.mt[s] = rn[t.mto[s]]; }
+    o.hc = rn[R_T + 14];
+    if (WITH_Y) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) o.Pk[r] = rn[t.pmo[r]];
+        o.pk = rn[t.pvo];
+    }
+}
+template <bool WITH_Y>
+__device__ __forceinline__ void fwd_step(ldouble *recs, int N, int kk, double f0, double f13, const FwdTabs &t, FwdOps &o, double &v)
+{
+    ldouble *rec = recs + kk * RS;
+    // rows 0..3 (f0): hc dw;  row 13 (f13): the constant 1 that multiplies the kbar / d column;  other rows: v
+    const double hv = o.hc * v;
+    const double v1 = f0 != 0.0 ? hv : (f13 != 0.0 ? 1.0 : v);
+    const double D1 = matvec4(o.tt, v1, 0.0);
+    double Y = 0.0;
+    if (WITH_Y) Y = matvec4(o.Pk, v, o.pk); // y+_k = P_k ds_k + p_k
+    const double du = -D1;
+    const double v2 = f0 != 0.0 ? du : (f13 != 0.0 ? 1.0 : v);
+    const double D2 = matvec4(o.mt, v2, 0.0);
+    fwd_gather<WITH_Y>(recs + (kk + 2 < N ? kk + 2 : N - 1) * RS, t, o); // this set's next stage (clamped: unused at the end)
+    // branch-free LDS writes: the four replicas of a row (lane & 3) write the same value to the same slot
+    rec[t.duo] = du;
+    rec[t.dso] = v;
+    if (WITH_Y) rec[t.yo] = Y;
+    v = D2; // rows 13..15 of Mt are zero
+}
+
+template <bool WITH_Y>
+__device__ __noinline__ void sweep_forward(ldouble *recs, ldouble *xs, int N)
 {
     N = uni(N);
     const int lane = threadIdx.x & 63;
     const int idx = 4 * ((lane >> 2) & 3) + (lane >> 4); // V layout: the vector row this lane holds
-    int mto[4], tto[4], pmo[4];
+    FwdTabs t;
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        mto[s] = tab(T4_MT + s, lane);
-        tto[s] = tab(T4_TT + s, lane);
-        pmo[s] = tab(T4_P + s, lane);
+        t.mto[s] = tab(T4_MT + s, lane);
+        t.tto[s] = tab(T4_TT + s, lane);
+        t.pmo[s] = tab(T4_P + s, lane);
     }
-    const int pvo = idx <= 12 ? R_PV + idx : R_ZERO;
+    t.pvo = idx <= 12 ? R_PV + idx : R_ZERO;
     const bool q0 = idx < 4 && (lane & 12) == 0; // rows 0..3 (quad 0 of every 16-lane row)
-    const int duo = q0 ? R_DZ + idx : R_DUMP, dso = idx <= 12 ? R_DZ + 4 + idx : R_DUMP, yo = idx <= 12 ? R_PD + idx : R_DUMP;
+    t.duo = q0 ? R_DZ + idx : R_DUMP; t.dso = idx <= 12 ? R_DZ + 4 + idx : R_DUMP; t.yo = idx <= 12 ? R_PD + idx : R_DUMP;
+    const double f0 = q0 ? 1.0 : 0.0, f13 = idx == 13 ? 1.0 : 0.0;
     double v = xs[X_DS0 + idx]; // ds_0 (entries 13..15 are zero)
+    FwdOps A, B;
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
-    d4 tt, mt, Pk = zero;
-    double hc, pk = 0.0;
-    {
-        const double *rn = recs;
-#pragma unroll
-        for (int s = 0; s < 4; s++) { tt[s] = rn[tto[s]]; mt[s] = rn[mto[s]]; }
-        hc = rn[R_T + 14];
-        if (WITH_Y) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) Pk[r] = rn[pmo[r]];
-            pk = rn[pvo];
-        }
+    A.Pk = zero; B.Pk = zero; A.pk = 0.0; B.pk = 0.0;
+    fwd_gather<WITH_Y>(recs, t, A);
+    fwd_gather<WITH_Y>(recs + (N > 1 ? 1 : 0) * RS, t, B);
+    int kk = 0;
+    for (; kk + 1 < N; kk += 2) {
+        fwd_step<WITH_Y>(recs, N, kk, f0, f13, t, A, v);
+        fwd_step<WITH_Y>(recs, N, kk + 1, f0, f13, t, B, v);
     }
-    for (int kk = 0; kk < N; kk++) {
-        double *rec = recs + kk * RS;
-        const double *rn = recs + (kk + 1 < N ? kk + 1 : N - 1) * RS; // next stage (clamped: the tail re-reads the last record, unused)
-        const double v1 = q0 ? hc * v : (idx == 13 ? 1.0 : v); // row 13 multiplies the kbar column
-        const double D1 = matvec4(tt, v1, 0.0);
-#pragma unroll
-        for (int s = 0; s < 4; s++) tt[s] = rn[tto[s]];
-        hc = rn[R_T + 14];
-        double Y = 0.0;
-        if (WITH_Y) {
-            Y = matvec4(Pk, v, pk); // y+_k = P_k ds_k + p_k
-#pragma unroll
-            for (int r = 0; r < 4; r++) Pk[r] = rn[pmo[r]];
-            pk = rn[pvo];
-        }
-        const double du = -D1;
-        const double v2 = q0 ? du : (idx == 13 ? 1.0 : v); // row 13 multiplies the d column
-        const double D2 = matvec4(mt, v2, 0.0);
-#pragma unroll
-        for (int s = 0; s < 4; s++) mt[s] = rn[mto[s]];
-        // branch-free LDS writes: the four replicas of a row (lane & 3) write the same value to the same slot
-        rec[duo] = du;
-        rec[dso] = v;
-        if (WITH_Y) rec[yo] = Y;
-        v = D2; // rows 13..15 of Mt are zero
-    }
+    if (kk < N) fwd_step<WITH_Y>(recs, N, kk, f0, f13, t, A, v);
     WSYNC();
 }
 
@@ -456,13 +602,13 @@ struct ModelState {
 };
 
 template <int NP>
-__device__ __forceinline__ void model_phase(double *recs, double *xs, const ModelState &st, int N, double &l_eq)
+__device__ __forceinline__ void model_phase(ldouble *recs, ldouble *xs, const ModelState &st, int N, double &l_eq)
 {
     const int lane = threadIdx.x & 63;
     const int k = lane;
     const double *zk = st.z;
     l_eq = 0.0;
-    double *rec = recs + (k < N ? k : 0) * RS;
+    ldouble *rec = recs + (k < N ? k : 0) * RS;
     // ---- part 1: the step and its linearisation (no multipliers involved)
     {
         double zn[NS]; // s_{k+1} = [w; x] of the next stage
@@ -575,7 +721,7 @@ __device__ __forceinline__ void model_phase(double *recs, double *xs, const Mode
 struct HessState {
     double u[4], ve[6], y6[6], fext[3]; // u = (rates, T); ve = (v, e); y6 = (y_p, y_v) of stage k+1
 };
-__device__ __forceinline__ void hessian_phase(double *rec, const HessState &hs, bool dyn, int hess)
+__device__ __forceinline__ void hessian_phase(ldouble *rec, const HessState &hs, bool dyn, int hess)
 {
     if (dyn && hess) {
         double x[9];
@@ -594,15 +740,15 @@ __device__ __forceinline__ void hessian_phase(double *rec, const HessState &hs, 
 
 // ================================================================== the solve, one role per wave
 struct Shared {
-    double *recs, *xs;
+    ldouble *recs, *xs;
     Ctl *ctl;
 };
 
-__device__ __forceinline__ void publish(double *xs, int wave, int lane, int slot, double v)
+__device__ __forceinline__ void publish(ldouble *xs, int wave, int lane, int slot, double v)
 {
     if (lane == 0) xs[X_RED + wave * 16 + slot] = v;
 }
-__device__ __forceinline__ double red(const double *xs, int wave, int slot) { return xs[X_RED + wave * 16 + slot]; }
+__device__ __forceinline__ double red(cldouble *xs, int wave, int slot) { return xs[X_RED + wave * 16 + slot]; }
 
 template <int NP, int FL, bool FREG, int ROLE>
 __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, const Shared &sh)
@@ -611,7 +757,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     constexpr int wave = ROLE; // == threadIdx.x >> 6: every role is compiled on its own, so only ITS state occupies registers
     const int lane = threadIdx.x & 63;
     const int N = a.N, M = a.M, MF = a.MF, np = NPRE + 4 * M;
-    double *recs = sh.recs, *xs = sh.xs;
+    ldouble *recs = sh.recs, *xs = sh.xs;
     const int k = (wave == 1) ? lane : lane % NP, half = lane / NP; // stage of this lane; row / face group
     const bool kact = k < N && (wave == 1 || half < H);
     const double *pk = a.params + ((size_t)b * N + (k < N ? k : 0)) * np;
@@ -630,7 +776,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 #pragma unroll
     for (int i = 0; i < NPRE; i++) pc[i] = 0.0;
     ms.fext[0] = ms.fext[1] = ms.fext[2] = 0.0;
-    HessState hs; // wave 3, face group 0
+    HessState hs; // wave 0, lanes of row group 0 (lane == stage)
 #pragma unroll
     for (int i = 0; i < 4; i++) hs.u[i] = 0.0;
 #pragma unroll
@@ -651,17 +797,115 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         }
     };
 
+    // The 17 bound pairs of a stage are shared by waves 2 and 3: rounds [RB0, RB1) of the row mapping each (wave 3 also
+    // owns the corridor rows), so that neither is the long pole of the element-wise phases.
+    // (measured: a corridor row costs about as much as 1.5 bound pairs because of its cross-lane sums)
+    constexpr int RSPLIT = R - (FL <= 2 ? R / 3 : (FL <= 5 ? R / 6 : 0));
+    constexpr int RB0 = wave == 3 ? RSPLIT : 0, RB1 = wave == 2 ? RSPLIT : R;
+    // evaluation: residuals, barrier Hessian / predictor rhs of this wave's bound rows -> record; norms
+    auto bounds_eval = [&](double &l_in, double &l_rc, double &l_gap) {
+        if (!kact) return;
+        const CostQ cq = make_cost(pc, stage_class(k, N), model);
+        ldouble *rec = recs + k * RS;
+#pragma unroll
+        for (int r = RB0; r < RB1; r++) {
+            const int ib = r * H, i = ib + half;
+            if (i >= NZ) continue;
+            const double hd = ROW_PICK(cq.hd(i));
+            const double qi = ROW_PICK(cq.q(i));
+            const double lb = ROW_PICK(lower_bound(i));
+            const double ub = ROW_PICK(upper_bound(i));
+            const double zi = bz[r];
+            double cg = hd * zi + qi; // cost gradient
+            if (ib < 8) cg += (i < 8 ? cq.hc() : 0.0) * bzp[r];
+            const double sl = bsl[r], su = bsu[r], ll = bll[r], lu = blu[r];
+            const double vl = lb - zi, vu = zi - ub;
+            const double rl = vl + sl, ru = vu + su;
+            l_in = fmax(l_in, fmax(fmax(vl, vu), fmax(fabs(rl), fabs(ru))));
+            l_rc = fmax(l_rc, fmax(sl * ll, su * lu));
+            l_gap += sl * ll + su * lu;
+            const double sgl = ll * fast_rcp(sl), sgu = lu * fast_rcp(su);
+            rec[R_PHIB + i] = cg + lu - ll;          // cost and bound part of the stationarity residual
+            rec[R_PHID + i] = hd + sgl + sgu;
+            rec[R_PHI + i] = cg + sgu * ru - sgl * rl;
+        }
+    };
+    // affine step: lengths, second-order terms (kept in registers), corrector rhs of the bound rows -> record
+    auto bounds_affine = [&](double &m_p, double &m_d, double &s_sdl, double &s_lds, double &s_dsdl) {
+        if (!kact) return;
+        const CostQ cq = make_cost(pc, stage_class(k, N), model);
+        ldouble *rec = recs + k * RS;
+#pragma unroll
+        for (int r = RB0; r < RB1; r++) {
+            const int ib = r * H, i = ib + half;
+            if (i >= NZ) continue;
+            const double hd = ROW_PICK(cq.hd(i));
+            const double qi = ROW_PICK(cq.q(i));
+            const double lb = ROW_PICK(lower_bound(i));
+            const double ub = ROW_PICK(upper_bound(i));
+            const double zi = bz[r], dzi = rec[R_DZ + i];
+            double pb = hd * zi + qi; // cost gradient
+            if (ib < 8) pb += (i < 8 ? cq.hc() : 0.0) * bzp[r];
+            // one constraint of the affine step (smu = 0, corr = 0): t1 = (l r_in - corr)/s, sinv = 1/s
+            auto cstep = [&](double s, double l, double gdz, double viol, double &cr, double &t1, double &sinv) {
+                const double u = fast_rcp(s * l);
+                sinv = u * l;
+                const double linv = u * s;
+                const double rin = viol + s;
+                const double ds = -rin - gdz;
+                const double dl = -l * (1.0 + ds * sinv); // (-(s l) - l ds) / s
+                m_p = fmax(m_p, -ds * sinv);
+                m_d = fmax(m_d, -dl * linv);
+                s_sdl += s * dl; s_lds += l * ds;
+                cr = ds * dl;
+                s_dsdl += cr;
+                t1 = (l * rin - cr) * sinv;
+            };
+            double tl, tu, sil, siu;
+            cstep(bsl[r], bll[r], -dzi, lb - zi, bcl[r], tl, sil);
+            cstep(bsu[r], blu[r], dzi, zi - ub, bcu[r], tu, siu);
+            rec[R_PHIB + i] = pb + tu - tl;
+            rec[R_PHIC + i] = siu - sil;
+        }
+    };
+
     // ---------------------------------------------------------------- init
     double smin = 1e300;
     int bad_param = 0, mcount = 0;
-    if constexpr (wave == 1) {
+    auto bounds_init = [&]() {
+        if (!kact) return;
+        const double *z0 = a.x0 + ((size_t)b * N + k) * NZ;
+        pc[0] = pk[0]; pc[1] = pk[1]; pc[2] = pk[2]; pc[6] = pk[6]; pc[7] = pk[7]; pc[8] = pk[8]; pc[9] = pk[9];
+#pragma unroll
+        for (int r = RB0; r < RB1; r++) {
+            const int ib = r * H, i = ib + half;
+            if (i >= NZ) continue;
+            const double lb = ROW_PICK(lower_bound(i));
+            const double ub = ROW_PICK(upper_bound(i));
+            bz[r] = z0[i];
+            if (ib < 8) bzp[r] = z0[i < 4 ? i + 4 : (i < 8 ? i - 4 : i)];
+            bsl[r] = bz[r] - lb;
+            bsu[r] = ub - bz[r];
+            smin = fmin(smin, fmin(bsl[r], bsu[r]));
+        }
+    };
+    if constexpr (wave == 0) {
+        if (kact && half == 0) { // this wave is idle in the evaluation phase: it evaluates the dynamics Hessian there
+            const double *z0 = a.x0 + ((size_t)b * N + k) * NZ;
+#pragma unroll
+            for (int i = 0; i < 4; i++) hs.u[i] = z0[i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) hs.ve[i] = z0[11 + i];
+            hs.fext[0] = pk[3]; hs.fext[1] = pk[4]; hs.fext[2] = pk[5];
+        }
+    } else if constexpr (wave == 1) {
         if (lane < 9) xs[X_XINIT + lane] = a.xinit[(size_t)b * 9 + lane];
         if (kact) {
             const double *z0 = a.x0 + ((size_t)b * N + k) * NZ;
 #pragma unroll
             for (int i = 0; i < NZ; i++) ms.z[i] = z0[i];
             ms.fext[0] = pk[3]; ms.fext[1] = pk[4]; ms.fext[2] = pk[5];
-            double *rec = recs + k * RS;
+            ldouble *rec = recs + k * RS;
             rec[R_HC] = -2.0 * pk[8]; // (u_i, w_i) cost coupling of this stage (constant)
             rec[R_ZERO] = 0.0; rec[R_ONE] = 1.0; rec[R_DT] = DT; rec[R_DUMP] = 0.0;
             if (k == N - 1) { // no dynamics behind the last stage: its M row stays zero
@@ -672,23 +916,9 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             rec[R_CC + 0] = rec[R_CC + 1] = rec[R_CC + 2] = 0.0;
         }
     } else if constexpr (wave == 2) {
-        if (kact) {
-            const double *z0 = a.x0 + ((size_t)b * N + k) * NZ;
-            pc[0] = pk[0]; pc[1] = pk[1]; pc[2] = pk[2]; pc[6] = pk[6]; pc[7] = pk[7]; pc[8] = pk[8]; pc[9] = pk[9];
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int ib = r * H, i = ib + half;
-                if (i >= NZ) continue;
-                const double lb = ROW_PICK(lower_bound(i));
-                const double ub = ROW_PICK(upper_bound(i));
-                bz[r] = z0[i];
-                if (ib < 8) bzp[r] = z0[i < 4 ? i + 4 : (i < 8 ? i - 4 : i)];
-                bsl[r] = bz[r] - lb;
-                bsu[r] = ub - bz[r];
-                smin = fmin(smin, fmin(bsl[r], bsu[r]));
-            }
-        }
+        bounds_init();
     } else if constexpr (wave == 3) {
+        bounds_init();
         int nf = 0;
         if (kact) {
             if (a.nfaces) nf = a.nfaces[(size_t)b * N + k];
@@ -704,13 +934,6 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             if (half == 0) mcount = 34 + nf;
             const double *z0 = a.x0 + ((size_t)b * N + k) * NZ;
             fpos[0] = z0[8]; fpos[1] = z0[9]; fpos[2] = z0[10];
-            if (half == 0) { // this lane also evaluates the stage's dynamics Hessian
-#pragma unroll
-                for (int i = 0; i < 4; i++) hs.u[i] = z0[i];
-#pragma unroll
-                for (int i = 0; i < 6; i++) hs.ve[i] = z0[11 + i];
-                hs.fext[0] = pk[3]; hs.fext[1] = pk[4]; hs.fext[2] = pk[5];
-            }
 #pragma unroll
             for (int t = 0; t < FL; t++) {
                 const int j = t * H + half;
@@ -747,13 +970,14 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         // infeasible-start initialisation: uniform slack shift (see oracle/nmpc_ipm.c)
         smin = fmin(red(xs, 2, 13), red(xs, 3, 13));
         const double shift = (smin >= S_MIN) ? 0.0 : (S_MIN - smin) + fmax(0.0, -smin);
-        if constexpr (wave == 2) {
+        if constexpr (wave >= 2) {
 #pragma unroll
-            for (int r = 0; r < R; r++) {
+            for (int r = RB0; r < RB1; r++) {
                 bsl[r] += shift; bsu[r] += shift;
                 bll[r] = a.mu0 / bsl[r]; blu[r] = a.mu0 / bsu[r];
             }
-        } else if constexpr (wave == 3) {
+        }
+        if constexpr (wave == 3) {
 #pragma unroll
             for (int t = 0; t < FL; t++) { fs[t] += shift; fl_[t] = a.mu0 / fs[t]; }
         }
@@ -764,45 +988,27 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     bool gn_retry = false;              // this iteration is being redone with the Gauss-Newton Hessian
     Norms nm = {0, 0, 0, 0, 0, 0};
     double mu = 0.0, step_cc = 0.0;
-    if constexpr (wave == 0) __builtin_amdgcn_s_setprio(2); // the Riccati sweeps are the critical path of every iteration
+#ifndef FRP_R_PRIO
+#define FRP_R_PRIO 2
+#endif
+    if constexpr (wave == 0) __builtin_amdgcn_s_setprio(FRP_R_PRIO); // the Riccati sweeps are the critical path of every iteration
 
+    PROF_DECL();
     for (it = 0;;) {
         // ============================================================ evaluation phase
-        if constexpr (wave == 1) {
+        if constexpr (wave == 0) {
+            if (kact && half == 0) hessian_phase(recs + k * RS, hs, k < N - 1, hess);
+        } else if constexpr (wave == 1) {
             double l_eq;
             model_phase<NP>(recs, xs, ms, N, l_eq);
             publish(xs, 1, lane, 0, wave_max(l_eq));
         } else if constexpr (wave == 2) {
             double l_in = 0.0, l_rc = 0.0, l_gap = 0.0;
-            if (kact) {
-                const CostQ cq = make_cost(pc, stage_class(k, N), model);
-                double *rec = recs + k * RS;
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const int ib = r * H, i = ib + half;
-                    if (i >= NZ) continue;
-                    const double hd = ROW_PICK(cq.hd(i));
-                    const double qi = ROW_PICK(cq.q(i));
-                    const double lb = ROW_PICK(lower_bound(i));
-                    const double ub = ROW_PICK(upper_bound(i));
-                    const double zi = bz[r];
-                    double cg = hd * zi + qi; // cost gradient
-                    if (ib < 8) cg += (i < 8 ? cq.hc() : 0.0) * bzp[r];
-                    const double sl = bsl[r], su = bsu[r], ll = bll[r], lu = blu[r];
-                    const double vl = lb - zi, vu = zi - ub;
-                    const double rl = vl + sl, ru = vu + su;
-                    l_in = fmax(l_in, fmax(fmax(vl, vu), fmax(fabs(rl), fabs(ru))));
-                    l_rc = fmax(l_rc, fmax(sl * ll, su * lu));
-                    l_gap += sl * ll + su * lu;
-                    const double sgl = ll * fast_rcp(sl), sgu = lu * fast_rcp(su);
-                    rec[R_PHIB + i] = cg + lu - ll;          // cost and bound part of the stationarity residual
-                    rec[R_PHID + i] = hd + sgl + sgu;
-                    rec[R_PHI + i] = cg + sgu * ru - sgl * rl;
-                }
-            }
+            bounds_eval(l_in, l_rc, l_gap);
             publish(xs, 2, lane, 0, wave_max(l_in)); publish(xs, 2, lane, 1, wave_max(l_rc)); publish(xs, 2, lane, 2, wave_sum(l_gap));
         } else if constexpr (wave == 3) {
             double l_in = 0.0, l_rc = 0.0, l_gap = 0.0;
+            bounds_eval(l_in, l_rc, l_gap);
             double gp0 = 0, gp1 = 0, gp2 = 0, fp0 = 0, fp1 = 0, fp2 = 0, p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0;
             if (kact) {
 #pragma unroll
@@ -831,18 +1037,16 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 p3 = xsub_sum<NP>(p3); p4 = xsub_sum<NP>(p4); p5 = xsub_sum<NP>(p5);
             }
             if (kact && half == 0) {
-                double *rec = recs + k * RS;
+                ldouble *rec = recs + k * RS;
                 rec[R_PHIPOS + 0] = p0; rec[R_PHIPOS + 1] = p1; rec[R_PHIPOS + 2] = p2;
                 rec[R_PHIPOS + 3] = p1; rec[R_PHIPOS + 4] = p3; rec[R_PHIPOS + 5] = p4;
                 rec[R_PHIPOS + 6] = p2; rec[R_PHIPOS + 7] = p4; rec[R_PHIPOS + 8] = p5;
                 rec[R_CB + 0] = gp0; rec[R_CB + 1] = gp1; rec[R_CB + 2] = gp2;
                 rec[R_CC + 0] = fp0; rec[R_CC + 1] = fp1; rec[R_CC + 2] = fp2;
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (kact && half == 0) hessian_phase(recs + k * RS, hs, k < N - 1, hess);
             publish(xs, 3, lane, 0, wave_max(l_in)); publish(xs, 3, lane, 1, wave_max(l_rc)); publish(xs, 3, lane, 2, wave_sum(l_gap));
         }
-        BAR(); // ---------------------------------------------------------------- A
+        BAR_P(0); // ------------------------------------------------------------- A
         nm.eq = red(xs, 1, 0);
         nm.in = fmax(red(xs, 2, 0), red(xs, 3, 0));
         nm.rc = fmax(red(xs, 2, 1), red(xs, 3, 1));
@@ -858,11 +1062,14 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 
         // ============================================================ predictor: factorisation + forward sweep
         if constexpr (wave == 0) {
+            SWEEP_T0();
             const int fr = sweep_factor(recs, xs, N, gn_retry ? 0.0 : theta_h);
+            SWEEP_T1(0);
             if (!fr) sweep_forward<false>(recs, xs, N);
+            SWEEP_T1(1);
             if (lane == 0) sh.ctl->fail = fr;
         }
-        BAR(); // ---------------------------------------------------------------- C
+        BAR_P(1); // ------------------------------------------------------------- C
         {
             const int fr = sh.ctl->fail;
             if (fr && !gn_retry && theta_h > 0.0) {
@@ -881,49 +1088,15 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         // ============================================================ affine step: lengths, second-order term, corrector rhs
         if constexpr (wave == 2) {
             double m_p = 0.0, m_d = 0.0, s_sdl = 0.0, s_lds = 0.0, s_dsdl = 0.0;
-            if (kact) {
-                const CostQ cq = make_cost(pc, stage_class(k, N), model);
-                double *rec = recs + k * RS;
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const int ib = r * H, i = ib + half;
-                    if (i >= NZ) continue;
-                    const double hd = ROW_PICK(cq.hd(i));
-                    const double qi = ROW_PICK(cq.q(i));
-                    const double lb = ROW_PICK(lower_bound(i));
-                    const double ub = ROW_PICK(upper_bound(i));
-                    const double zi = bz[r], dzi = rec[R_DZ + i];
-                    double pb = hd * zi + qi; // cost gradient
-                    if (ib < 8) pb += (i < 8 ? cq.hc() : 0.0) * bzp[r];
-                    // one constraint of the affine step (smu = 0, corr = 0): t1 = (l r_in - corr)/s, sinv = 1/s
-                    auto cstep = [&](double s, double l, double gdz, double viol, double &cr, double &t1, double &sinv) {
-                        const double u = fast_rcp(s * l);
-                        sinv = u * l;
-                        const double linv = u * s;
-                        const double rin = viol + s;
-                        const double ds = -rin - gdz;
-                        const double dl = -l * (1.0 + ds * sinv); // (-(s l) - l ds) / s
-                        m_p = fmax(m_p, -ds * sinv);
-                        m_d = fmax(m_d, -dl * linv);
-                        s_sdl += s * dl; s_lds += l * ds;
-                        cr = ds * dl;
-                        s_dsdl += cr;
-                        t1 = (l * rin - cr) * sinv;
-                    };
-                    double tl, tu, sil, siu;
-                    cstep(bsl[r], bll[r], -dzi, lb - zi, bcl[r], tl, sil);
-                    cstep(bsu[r], blu[r], dzi, zi - ub, bcu[r], tu, siu);
-                    rec[R_PHIB + i] = pb + tu - tl;
-                    rec[R_PHIC + i] = siu - sil;
-                }
-            }
+            bounds_affine(m_p, m_d, s_sdl, s_lds, s_dsdl);
             publish(xs, 2, lane, 3, wave_max(m_p)); publish(xs, 2, lane, 4, wave_max(m_d));
             publish(xs, 2, lane, 5, wave_sum(s_sdl)); publish(xs, 2, lane, 6, wave_sum(s_lds)); publish(xs, 2, lane, 7, wave_sum(s_dsdl));
         } else if constexpr (wave == 3) {
             double m_p = 0.0, m_d = 0.0, s_sdl = 0.0, s_lds = 0.0, s_dsdl = 0.0;
+            bounds_affine(m_p, m_d, s_sdl, s_lds, s_dsdl);
             double b0 = 0, b1 = 0, b2 = 0, c0 = 0, c1 = 0, c2 = 0;
             if (kact) {
-                const double *rec = recs + k * RS;
+                cldouble *rec = recs + k * RS;
                 const double d8 = rec[R_DZ + 8], d9 = rec[R_DZ + 9], d10 = rec[R_DZ + 10];
 #pragma unroll
                 for (int t = 0; t < FL; t++) {
@@ -954,14 +1127,14 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 c0 = xsub_sum<NP>(c0); c1 = xsub_sum<NP>(c1); c2 = xsub_sum<NP>(c2);
             }
             if (kact && half == 0) {
-                double *rec = recs + k * RS;
+                ldouble *rec = recs + k * RS;
                 rec[R_CB + 0] = b0; rec[R_CB + 1] = b1; rec[R_CB + 2] = b2;
                 rec[R_CC + 0] = c0; rec[R_CC + 1] = c1; rec[R_CC + 2] = c2;
             }
             publish(xs, 3, lane, 3, wave_max(m_p)); publish(xs, 3, lane, 4, wave_max(m_d));
             publish(xs, 3, lane, 5, wave_sum(s_sdl)); publish(xs, 3, lane, 6, wave_sum(s_lds)); publish(xs, 3, lane, 7, wave_sum(s_dsdl));
         }
-        BAR(); // ---------------------------------------------------------------- D
+        BAR_P(2); // ------------------------------------------------------------- D
         double smu;
         {
             const double m_p = fmax(red(xs, 2, 3), red(xs, 3, 3)), m_d = fmax(red(xs, 2, 4), red(xs, 3, 4));
@@ -978,14 +1151,17 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 
         // ============================================================ corrector: vector backward sweep + forward sweep with y+
         if constexpr (wave == 0) {
+            SWEEP_T0();
             sweep_backvec(recs, xs, N, smu);
-            sweep_forward<true>(recs, xs, N);
+            SWEEP_T1(2);
+            sweep_forward<false>(recs, xs, N);
+            SWEEP_T1(3);
         }
-        BAR(); // ---------------------------------------------------------------- E
+        BAR_P(3); // ------------------------------------------------------------- E
 
         // ============================================================ step: pass A (ratios), pass B (commit)
         double m_p = 0.0, m_d = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0; // q: sums of ds l, s dl, ds dl
-        double dzr[NZ], ypl[NS], dzp[R];                            // wave 1: Newton step / y+ of its stage; wave 2: dz of its rows (dzr[0..R)) and of their (u, w) partners; wave 3: dz of pos
+        double dzr[NZ], ypl[NS], dzb[R], dzp[R], dzf[3];            // waves 0, 1: Newton step / y+ of their copies; waves 2, 3: dz of their bound rows and of the (u, w) partners; wave 3: dz of pos
         // one constraint of the corrector step
         auto cstep = [&](double s, double l, double corr, double gdz, double viol, double &ds, double &dl) {
             const double u = fast_rcp(s * l);
@@ -997,49 +1173,61 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             m_d = fmax(m_d, -dl * linv);
             q1 = fma(ds, l, q1); q2 = fma(s, dl, q2); q3 = fma(ds, dl, q3);
         };
-        if constexpr (wave == 1) {
+        // y+_k = P_k ds_k + p_k of the Newton system (P_k packed lower triangle): formed by the waves that consume it, off
+        // the forward sweep's dependency chain
+        auto y_plus = [&](cldouble *rec, int i) {
+            double acc = rec[R_PV + i];
+#pragma unroll
+            for (int j = 0; j < NS; j++) acc = fma(rec[R_P + (i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i)], rec[R_DZ + 4 + j], acc);
+            return acc;
+        };
+        if constexpr (wave == 0) {
+            if (kact && half == 0) { // Newton step of the Hessian lanes' copies: (rates, T), (v, e), (y_p, y_v)+ of the next stage
+                cldouble *rec = recs + k * RS;
+#pragma unroll
+                for (int i = 0; i < 4; i++) dzr[i] = rec[R_DZ + i];
+#pragma unroll
+                for (int i = 0; i < 6; i++) dzr[4 + i] = rec[R_DZ + 11 + i];
+#pragma unroll
+                for (int i = 0; i < 6; i++) ypl[i] = (k < N - 1) ? y_plus(rec + RS, 4 + i) : 0.0;
+            }
+        } else if constexpr (wave == 1) {
             if (kact) {
-                const double *rec = recs + k * RS;
+                cldouble *rec = recs + k * RS;
 #pragma unroll
                 for (int i = 0; i < NZ; i++) dzr[i] = rec[R_DZ + i];
 #pragma unroll
-                for (int i = 0; i < NS; i++) ypl[i] = rec[R_PD + i];
+                for (int i = 0; i < NS; i++) ypl[i] = y_plus(rec, i);
             }
-        } else if constexpr (wave == 2) {
+        }
+        if constexpr (wave >= 2) { // bound rows of this wave
             if (kact) {
-                const double *rec = recs + k * RS;
+                cldouble *rec = recs + k * RS;
 #pragma unroll
-                for (int r = 0; r < R; r++) {
+                for (int r = RB0; r < RB1; r++) {
                     const int ib = r * H, i = ib + half;
                     if (i >= NZ) continue;
                     const double lb = ROW_PICK(lower_bound(i));
                     const double ub = ROW_PICK(upper_bound(i));
                     const double zi = bz[r], dzi = rec[R_DZ + i];
-                    dzr[r < NZ ? r : 0] = dzi;
+                    dzb[r] = dzi;
                     if (ib < 8) dzp[r] = rec[R_DZ + (i < 4 ? i + 4 : (i < 8 ? i - 4 : i))];
                     double ds, dl;
                     cstep(bsl[r], bll[r], bcl[r], -dzi, lb - zi, ds, dl);
                     cstep(bsu[r], blu[r], bcu[r], dzi, zi - ub, ds, dl);
                 }
             }
-        } else if constexpr (wave == 3) {
+        }
+        if constexpr (wave == 3) { // corridor rows
             if (kact) {
-                const double *rec = recs + k * RS;
-                dzr[0] = rec[R_DZ + 8]; dzr[1] = rec[R_DZ + 9]; dzr[2] = rec[R_DZ + 10];
-                if (half == 0) { // Newton step of the Hessian lane's copies: (rates, T), (v, e), (y_p, y_v)+ of the next stage
-#pragma unroll
-                    for (int i = 0; i < 4; i++) dzr[3 + i] = rec[R_DZ + i];
-#pragma unroll
-                    for (int i = 0; i < 6; i++) dzr[7 + i] = rec[R_DZ + 11 + i];
-#pragma unroll
-                    for (int i = 0; i < 6; i++) ypl[i] = (k < N - 1) ? rec[RS + R_PD + 4 + i] : 0.0;
-                }
+                cldouble *rec = recs + k * RS;
+                dzf[0] = rec[R_DZ + 8]; dzf[1] = rec[R_DZ + 9]; dzf[2] = rec[R_DZ + 10];
 #pragma unroll
                 for (int t = 0; t < FL; t++) {
                     if (t * H + half < nfk) {
                         double a0, a1, a2, bb, ds, dl;
                         face_consts(t, a0, a1, a2, bb);
-                        cstep(fs[t], fl_[t], fcr[t], a0 * dzr[0] + a1 * dzr[1] + a2 * dzr[2],
+                        cstep(fs[t], fl_[t], fcr[t], a0 * dzf[0] + a1 * dzf[1] + a2 * dzf[2],
                               a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb, ds, dl);
                     }
                 }
@@ -1049,7 +1237,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             publish(xs, wave, lane, 8, wave_max(m_p)); publish(xs, wave, lane, 9, wave_max(m_d));
             publish(xs, wave, lane, 10, wave_sum(q1)); publish(xs, wave, lane, 11, wave_sum(q2)); publish(xs, wave, lane, 12, wave_sum(q3));
         }
-        BAR(); // ---------------------------------------------------------------- F
+        BAR_P(4); // ------------------------------------------------------------- F
         {
             const double mp = fmax(red(xs, 2, 8), red(xs, 3, 8)), md = fmax(red(xs, 2, 9), red(xs, 3, 9));
             const double ap = (mp > a.ftb) ? a.ftb / mp : 1.0;
@@ -1068,48 +1256,52 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 if (ln * sn < fprod) ln = fprod * fast_rcp(sn);
                 s = sn; l = ln;
             };
-            if constexpr (wave == 1) {
+            if constexpr (wave == 0) {
+                if (kact && half == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) hs.u[i] += ap * dzr[i];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) hs.ve[i] += ap * dzr[4 + i];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) hs.y6[i] += ap * (ypl[i] - hs.y6[i]);
+                }
+            } else if constexpr (wave == 1) {
 #pragma unroll
                 for (int i = 0; i < NZ; i++) ms.z[i] += ap * dzr[i];
 #pragma unroll
                 for (int i = 0; i < NS; i++) ms.y[i] += ap * (ypl[i] - ms.y[i]); // y <- y + ap (y+ - y)
-            } else if constexpr (wave == 2) {
+            }
+            if constexpr (wave >= 2) {
 #pragma unroll
-                for (int r = 0; r < R; r++) {
+                for (int r = RB0; r < RB1; r++) {
                     const int ib = r * H, i = ib + half;
                     if (i >= NZ) continue;
                     const double lb = ROW_PICK(lower_bound(i));
                     const double ub = ROW_PICK(upper_bound(i));
-                    const double zi = bz[r], dzi = dzr[r < NZ ? r : 0];
+                    const double zi = bz[r], dzi = dzb[r];
                     commit(bsl[r], bll[r], bcl[r], -dzi, lb - zi);
                     commit(bsu[r], blu[r], bcu[r], dzi, zi - ub);
                     bz[r] = zi + ap * dzi;
                     if (ib < 8) bzp[r] += ap * dzp[r];
                 }
-            } else if constexpr (wave == 3) {
+            }
+            if constexpr (wave == 3) {
 #pragma unroll
                 for (int t = 0; t < FL; t++) {
                     if (t * H + half < nfk) {
                         double a0, a1, a2, bb;
                         face_consts(t, a0, a1, a2, bb);
-                        commit(fs[t], fl_[t], fcr[t], a0 * dzr[0] + a1 * dzr[1] + a2 * dzr[2], a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb);
+                        commit(fs[t], fl_[t], fcr[t], a0 * dzf[0] + a1 * dzf[1] + a2 * dzf[2], a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb);
                     }
                 }
-                fpos[0] += ap * dzr[0]; fpos[1] += ap * dzr[1]; fpos[2] += ap * dzr[2];
-                if (kact && half == 0) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) hs.u[i] += ap * dzr[3 + i];
-#pragma unroll
-                    for (int i = 0; i < 6; i++) hs.ve[i] += ap * dzr[7 + i];
-#pragma unroll
-                    for (int i = 0; i < 6; i++) hs.y6[i] += ap * (ypl[i] - hs.y6[i]);
-                }
+                fpos[0] += ap * dzf[0]; fpos[1] += ap * dzf[1]; fpos[2] += ap * dzf[2];
             }
         }
         it++;
     }
 
     // ---------------------------------------------------------------- outputs
+    PROF_FLUSH(wave, it);
     if constexpr (wave == 0) __builtin_amdgcn_s_setprio(0);
     if constexpr (wave == 1) {
         // the objective is reported, not iterated on: evaluated once, at the returned iterate
@@ -1159,7 +1351,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     __shared__ double s_xs[X_TOTAL];
     __shared__ Ctl s_ctl;
     Shared sh;
-    sh.recs = s_recs; sh.xs = s_xs; sh.ctl = &s_ctl;
+    sh.recs = (ldouble *)s_recs; sh.xs = (ldouble *)s_xs; sh.ctl = &s_ctl;
     if (threadIdx.x == 0) { s_xs[X_C0] = 0.0; s_xs[X_C1] = 1.0; }
     // one copy of the solver loop per role: the four waves run different code between the same barriers
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1177,6 +1369,17 @@ static hipError_t launch_variant(const KernelArgs &k, int slots, hipStream_t str
 }
 
 } // namespace lr
+
+#ifdef FRP_PROFILE
+void debug_read_prof_lds(long long *out)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lr::g_prof_lds), sizeof(long long) * 64);
+    (void)hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(lr::g_prof_seg), sizeof(long long) * 16);
+    long long z[64] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(lr::g_prof_lds), z, sizeof z);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(lr::g_prof_seg), z, sizeof(long long) * 16);
+}
+#endif
 
 // workgroups resident per CU: LDS-bound (3 x 49 KB, 2 x 79 KB, 1 x 157 KB)
 int lds_workgroups_per_cu(int N) { return N <= 20 ? 3 : (N <= 32 ? 2 : 1); }
@@ -1202,3 +1405,7 @@ hipError_t launch_ipm_lds(const KernelArgs &k, int slots, hipStream_t stream)
 }
 
 } // namespace frp
+
+#ifdef FRP_PROFILE
+extern "C" void frp_debug_read_prof_lds(long long *out) { frp::debug_read_prof_lds(out); }
+#endif

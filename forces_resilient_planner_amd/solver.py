@@ -13,7 +13,7 @@ import numpy as np
 from . import layout as L
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libfrp_nmpc_amd.so")
+LIB_PATH = os.environ.get("FRP_LIB") or os.path.join(_PKG, "libfrp_nmpc_amd.so")  # FRP_LIB: an experiment build (tools/build_variant.sh)
 INFO_STRIDE = 8
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
