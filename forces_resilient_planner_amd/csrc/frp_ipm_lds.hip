@@ -62,7 +62,8 @@ constexpr int X_XINIT = 84;           // xinit (9)
 constexpr int X_DX0 = 96;             // xinit - x_0 (9)
 constexpr int X_C0 = 106, X_C1 = 107; // constants 0, 1
 constexpr int X_RED = 108;            // per-wave partial results: [4][16] (evaluation 0..2, affine 3..7, step 8..12: no slot is reused inside an iteration)
-constexpr int X_TOTAL = 172;
+constexpr int X_FEXT = 172;           // external-force acceleration of every stage: [3][NP]
+constexpr int X_TOTAL = 172;          // (+ 3 NP)
 
 // ------------------------------------------------------------------ per-lane gather tables (record offsets)
 // 16x16 register tiles (factorisation sweep): lane (g, c), register r <-> element (4r+g, c).
@@ -146,7 +147,8 @@ typedef __attribute__((address_space(3))) const double cldouble;
 // -DFRP_PROFILE: per-wave cycle counts of the work before each of the five barriers of an iteration and of the wait at it
 #ifdef FRP_PROFILE
 __device__ long long g_prof_lds[4][16];
-#define PROF_DECL() long long pw_[5] = {0, 0, 0, 0, 0}, pb_[5] = {0, 0, 0, 0, 0}, pt_ = clock64()
+#define PROF_T0() const long long pinit0_ = clock64()
+#define PROF_DECL() long long pw_[5] = {0, 0, 0, 0, 0}, pb_[5] = {0, 0, 0, 0, 0}, pt_ = clock64(); const long long pinit_ = pt_ - pinit0_
 #define BAR_P(i)                                                    \
     do {                                                            \
         const long long t0_ = clock64();                            \
@@ -163,24 +165,29 @@ __device__ long long g_prof_lds[4][16];
                 atomicAdd((unsigned long long *)&g_prof_lds[wave][5 + q_], (unsigned long long)pb_[q_]);   \
             }                                                                                         \
             atomicAdd((unsigned long long *)&g_prof_lds[wave][10], (unsigned long long)(its));          \
+            atomicAdd((unsigned long long *)&g_prof_lds[wave][11], (unsigned long long)pinit_);         \
+            atomicAdd((unsigned long long *)&g_prof_lds[wave][12], 1ull);                               \
         }                                                                                             \
     } while (0)
 #else
+#define PROF_T0()
 #define PROF_DECL()
 #define BAR_P(i) __syncthreads()
 #define PROF_FLUSH(wave, its)
 #endif
 #ifdef FRP_PROFILE
-__device__ long long g_prof_seg[16];
+__device__ long long g_prof_seg[32];
 #endif
 #ifdef FRP_PROFILE_SEG // (each timer read drains lgkmcnt: the segments are serialised, use them for proportions only) // factor sweep: mfma X/G, gather, pivot, tail mfma, P update + stores; then whole sweeps: factor, forward, backvec, forward+y
 #define SEG_DECL() long long sg_[6] = {0, 0, 0, 0, 0, 0}, st_ = clock64()
 #define SEG(i) do { const long long tn_ = clock64(); sg_[i] += tn_ - st_; st_ = tn_; } while (0)
 #define SEG_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int q_ = 0; q_ < 6; q_++) atomicAdd((unsigned long long *)&g_prof_seg[q_], (unsigned long long)sg_[q_]); } while (0)
+#define SEGM_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int q_ = 0; q_ < 6; q_++) atomicAdd((unsigned long long *)&g_prof_seg[16 + q_], (unsigned long long)sg_[q_]); } while (0)
 #else
 #define SEG_DECL()
 #define SEG(i)
 #define SEG_FLUSH()
+#define SEGM_FLUSH()
 #endif
 #ifdef FRP_PROFILE
 #define SWEEP_T0() const long long sw0_ = clock64()
@@ -291,6 +298,19 @@ __device__ __forceinline__ double row_shl(double v)
     const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)b, 0x100 + N4, 0xF, 0xF, true);
     const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), 0x100 + N4, 0xF, 0xF, true);
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+
+// y = A x + c on the 4x4x4 MFMA (see matvec4 in frp_device.hpp) with the four K-steps on two independent accumulators:
+// a dependent MFMA issues every ~25 cycles and its result reaches the VALU ~23 cycles later, so two chains of two plus
+// one add (~95 cycles) beat one chain of four (~125) on the serial path of the vector sweeps.
+__device__ __forceinline__ double matvec4s(const d4 &A, double x, double c)
+{
+    const double x1 = quad_rot<1>(x), x2 = quad_rot<2>(x), x3 = quad_rot<3>(x);
+    double d0 = mfma4(A[0], x, c);
+    double d1 = mfma4(A[1], x1, 0.0);
+    d0 = mfma4(A[2], x2, d0);
+    d1 = mfma4(A[3], x3, d1);
+    return d0 + d1;
 }
 
 // ---- factorisation sweep (predictor).  Backward Riccati recursion on 16x16 FP64 register tiles:
@@ -474,7 +494,7 @@ __device__ __forceinline__ void back_step(ldouble *recs, int kk, bool last, int 
 {
     ldouble *rec = recs + kk * RS;
     double q = o.phi;
-    if (!last) q = matvec4(o.Mt, o.pd + pv, o.phi);
+    if (!last) q = matvec4s(o.Mt, o.pd + pv, o.phi);
     const double ctp = o.tp, chc = o.hc, cphiw = o.phiw;
     back_gather(recs + (kk > 1 ? kk - 2 : 0) * RS, t, lane, smu, fx, o); // this set's next stage (clamped: unused at the end)
     // q_u (rows 0..3, quad 0) to every quad of its row, then E[c] = sum_k T'[k][c] q_u[k]
@@ -547,12 +567,12 @@ __device__ __forceinline__ void fwd_step(ldouble *recs, int N, int kk, double f0
     // rows 0..3 (f0): hc dw;  row 13 (f13): the constant 1 that multiplies the kbar / d column;  other rows: v
     const double hv = o.hc * v;
     const double v1 = f0 != 0.0 ? hv : (f13 != 0.0 ? 1.0 : v);
-    const double D1 = matvec4(o.tt, v1, 0.0);
+    const double D1 = matvec4s(o.tt, v1, 0.0);
     double Y = 0.0;
     if (WITH_Y) Y = matvec4(o.Pk, v, o.pk); // y+_k = P_k ds_k + p_k
     const double du = -D1;
     const double v2 = f0 != 0.0 ? du : (f13 != 0.0 ? 1.0 : v);
-    const double D2 = matvec4(o.mt, v2, 0.0);
+    const double D2 = matvec4s(o.mt, v2, 0.0);
     fwd_gather<WITH_Y>(recs + (kk + 2 < N ? kk + 2 : N - 1) * RS, t, o); // this set's next stage (clamped: unused at the end)
     // branch-free LDS writes: the four replicas of a row (lane & 3) write the same value to the same slot
     rec[t.duo] = du;
@@ -601,95 +621,144 @@ struct ModelState {
     double z[NZ], y[NS], fext[3];
 };
 
+// Register budget (168 per lane with z and y resident): the phase is cut into sections that hand data to each other
+// through the T' slots of the stage record, which are dead between the last forward sweep and the next factorisation:
+// J1 (21) while J2 is formed, y (13) during the whole linearisation.
+constexpr int RT_J1 = R_T, RT_Y = R_T + 24;
+// after the last forward sweep of an iteration wave 1 leaves here what wave 0 needs to rebuild its Hessian inputs for the
+// next one (so that nothing of it occupies registers across the sweeps): (rates, T, v, e) before the step, (y_p, y_v) too
+constexpr int RT_HZ = R_T + 40, RT_HY = R_T + 50;
 template <int NP>
-__device__ __forceinline__ void model_phase(ldouble *recs, ldouble *xs, const ModelState &st, int N, double &l_eq)
+__device__ __forceinline__ void model_phase(ldouble *recs, ldouble *xs, ModelState &st, int N, double &l_eq)
 {
     const int lane = threadIdx.x & 63;
     const int k = lane;
     const double *zk = st.z;
     l_eq = 0.0;
     ldouble *rec = recs + (k < N ? k : 0) * RS;
+    const bool dyn = k < N - 1;
+    SEG_DECL();
     // ---- part 1: the step and its linearisation (no multipliers involved)
-    {
-        double zn[NS]; // s_{k+1} = [w; x] of the next stage
+    if (k < N) {
 #pragma unroll
-        for (int i = 0; i < NS; i++) zn[i] = __shfl_down(st.z[4 + i], 1);
-        if (k == 0) {
+        for (int i = 0; i < NS; i++) rec[RT_Y + i] = st.y[i];
+    }
+    if (k == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const double dx = xs[X_XINIT + i] - zk[8 + i];
+            xs[X_DX0 + i] = dx;
+            l_eq = fmax(l_eq, fabs(dx));
+        }
+    }
+    SEG(0);
+    double xn[9]; // x+ = RK2 step of (p, v, e)
+#pragma unroll
+    for (int i = 0; i < 9; i++) xn[i] = 0.0;
+    if (dyn) {
+        double a1[3], vt[3], et[3];
+        {
+            AccJac J1;
+            const Trig tg1 = make_trig(zk + 14);
+            accel_t<true>(zk + 11, tg1, zk[3], st.fext, a1, &J1);
 #pragma unroll
             for (int i = 0; i < 9; i++) {
-                const double dx = xs[X_XINIT + i] - zk[8 + i];
-                xs[X_DX0 + i] = dx;
-                l_eq = fmax(l_eq, fabs(dx));
+                rec[RT_J1 + i] = J1.Fvv[i];
+                rec[RT_J1 + 9 + i] = J1.Fve[i];
+                rec[R_LIN + i] = (i % 4 == 0 ? DT : 0.0) + 0.5 * DT * DT * J1.Fvv[i]; // Apv (i % 4 == 0: the diagonal of a row-major 3 x 3)
+                rec[R_LIN + 9 + i] = 0.5 * DT * DT * J1.Fve[i];                       // Ape
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                rec[RT_J1 + 18 + i] = J1.gT[i];
+                rec[R_LIN + 36 + i] = 0.5 * DT * DT * J1.gT[i];                        // BpT
             }
         }
-        if (k < N - 1) {
-            AccJac J1, J2;
-            double a1[3], a2[3], et[3], vt[3];
-            {
-                const Trig tg1 = make_trig(zk + 14);
-                accel_t<true>(zk + 11, tg1, zk[3], st.fext, a1, &J1);
-            }
+        __builtin_amdgcn_sched_barrier(0);
+        SEG(1);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            vt[i] = zk[11 + i] + DT * a1[i];
+            et[i] = zk[14 + i] + DT * zk[i];
+        }
+        AccJac J2;
+        double a2[3];
+        {
+            const Trig tg2 = make_trig(et);
+            accel_t<true>(vt, tg2, zk[3], st.fext, a2, &J2);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            xn[i] = zk[8 + i] + 0.5 * DT * (zk[11 + i] + vt[i]);
+            xn[3 + i] = zk[11 + i] + 0.5 * DT * (a1[i] + a2[i]);
+            xn[6 + i] = et[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        SEG(2);
+        // products J2 J1, one column j of J1 at a time (read back from the record)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const double f0 = rec[RT_J1 + 0 + j], f1 = rec[RT_J1 + 3 + j], f2 = rec[RT_J1 + 6 + j];   // J1.Fvv[:, j]
+            const double e0 = rec[RT_J1 + 9 + j], e1 = rec[RT_J1 + 12 + j], e2 = rec[RT_J1 + 15 + j]; // J1.Fve[:, j]
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                vt[i] = zk[11 + i] + DT * a1[i];
-                et[i] = zk[14 + i] + DT * zk[i];
+                const double sv = J2.Fvv[i * 3 + j] + DT * (J2.Fvv[i * 3 + 0] * f0 + J2.Fvv[i * 3 + 1] * f1 + J2.Fvv[i * 3 + 2] * f2);
+                const double se = J2.Fve[i * 3 + j] + DT * (J2.Fvv[i * 3 + 0] * e0 + J2.Fvv[i * 3 + 1] * e1 + J2.Fvv[i * 3 + 2] * e2);
+                const double fij = i == 0 ? f0 : (i == 1 ? f1 : f2), eij = i == 0 ? e0 : (i == 1 ? e1 : e2);
+                rec[R_LIN + 18 + i * 3 + j] = (i == j ? 1.0 : 0.0) + 0.5 * DT * (fij + sv); // Avv
+                rec[R_LIN + 27 + i * 3 + j] = 0.5 * DT * (eij + se);                         // Ave
+                rec[R_LIN + 42 + i * 3 + j] = 0.5 * DT * DT * J2.Fve[i * 3 + j];             // Bvw
             }
-            {
-                const Trig tg2 = make_trig(et);
-                accel_t<true>(vt, tg2, zk[3], st.fext, a2, &J2);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const double d = zk[i] - zn[i];
-                rec[R_D + i] = d;
-                l_eq = fmax(l_eq, fabs(d));
-            }
+        }
+        {
+            const double g0 = rec[RT_J1 + 18], g1 = rec[RT_J1 + 19], g2 = rec[RT_J1 + 20]; // J1.gT
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                const double xp = zk[8 + i] + 0.5 * DT * (zk[11 + i] + vt[i]);
-                const double xv = zk[11 + i] + 0.5 * DT * (a1[i] + a2[i]);
-                const double dp = xp - zn[4 + i];
-                const double dv = xv - zn[7 + i];
-                const double de = et[i] - zn[10 + i];
-                rec[R_D + 4 + i] = dp; rec[R_D + 7 + i] = dv; rec[R_D + 10 + i] = de;
-                l_eq = fmax(l_eq, fmax(fabs(dp), fmax(fabs(dv), fabs(de))));
-            }
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                double sT = J2.gT[i];
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    double sv = J2.Fvv[i * 3 + j], se = J2.Fve[i * 3 + j];
-#pragma unroll
-                    for (int l = 0; l < 3; l++) {
-                        sv += DT * J2.Fvv[i * 3 + l] * J1.Fvv[l * 3 + j];
-                        se += DT * J2.Fvv[i * 3 + l] * J1.Fve[l * 3 + j];
-                    }
-                    rec[R_LIN + i * 3 + j] = (i == j ? DT : 0.0) + 0.5 * DT * DT * J1.Fvv[i * 3 + j];      // Apv
-                    rec[R_LIN + 9 + i * 3 + j] = 0.5 * DT * DT * J1.Fve[i * 3 + j];                       // Ape
-                    rec[R_LIN + 18 + i * 3 + j] = (i == j ? 1.0 : 0.0) + 0.5 * DT * (J1.Fvv[i * 3 + j] + sv); // Avv
-                    rec[R_LIN + 27 + i * 3 + j] = 0.5 * DT * (J1.Fve[i * 3 + j] + se);                    // Ave
-                    rec[R_LIN + 42 + i * 3 + j] = 0.5 * DT * DT * J2.Fve[i * 3 + j];                      // Bvw
-                    sT += DT * J2.Fvv[i * 3 + j] * J1.gT[j];
-                }
-                rec[R_LIN + 36 + i] = 0.5 * DT * DT * J1.gT[i];      // BpT
-                rec[R_LIN + 39 + i] = 0.5 * DT * (J1.gT[i] + sT);    // BvT
+                const double sT = J2.gT[i] + DT * (J2.Fvv[i * 3 + 0] * g0 + J2.Fvv[i * 3 + 1] * g1 + J2.Fvv[i * 3 + 2] * g2);
+                const double gi = i == 0 ? g0 : (i == 1 ? g1 : g2);
+                rec[R_LIN + 39 + i] = 0.5 * DT * (gi + sT); // BvT
             }
         }
     }
-    __builtin_amdgcn_sched_barrier(0); // keep the two parts apart: their live ranges must not overlap (168-register budget)
+    __builtin_amdgcn_sched_barrier(0);
+    SEG(3);
+    // ---- d = prev(z_k) - s_{k+1}: the next stage's [w; x] comes from lane k+1
+    {
+        double dmax = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const double zn = dpp_move<0x130>(st.z[4 + i]); // wave_shl:1, lane k <- lane k+1
+            const double d = zk[i] - zn;
+            if (dyn) rec[R_D + i] = d;
+            dmax = fmax(dmax, fabs(d));
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const double zn = dpp_move<0x130>(st.z[8 + i]);
+            const double d = xn[i] - zn;
+            if (dyn) rec[R_D + 4 + i] = d;
+            dmax = fmax(dmax, fabs(d));
+        }
+        if (dyn) l_eq = fmax(l_eq, dmax);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SEG(4);
     // ---- part 2: gm = M' y_{k+1} - [0; y_k], the linearisation read back from the record this lane has just written
     {
+        if (k < N) {
+#pragma unroll
+            for (int i = 0; i < NS; i++) st.y[i] = rec[RT_Y + i];
+        }
         double yn[NS];
 #pragma unroll
-        for (int i = 0; i < NS; i++) yn[i] = __shfl_down(st.y[i], 1);
+        for (int i = 0; i < NS; i++) yn[i] = dpp_move<0x130>(st.y[i]);
         if (k < N) {
             double gm[NZ];
 #pragma unroll
             for (int i = 0; i < 4; i++) gm[i] = 0.0;
 #pragma unroll
             for (int i = 0; i < NS; i++) gm[4 + i] = -st.y[i];
-            if (k < N - 1) {
+            if (dyn) {
                 const double *yw = yn, *yp = yn + 4, *yv = yn + 7, *ye = yn + 10;
 #pragma unroll
                 for (int i = 0; i < 4; i++) gm[i] += yw[i];
@@ -713,6 +782,8 @@ __device__ __forceinline__ void model_phase(ldouble *recs, ldouble *xs, const Mo
             for (int i = 0; i < NZ; i++) rec[R_DZ + i] = gm[i];
         }
     }
+    SEG(5);
+    SEGM_FLUSH();
 }
 
 // ================================================================== wave 3, lanes of face group 0: exact Hessian (lane == stage)
@@ -764,6 +835,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     const int hess = a.hessian ? 1 : 0;
     const int model = a.models ? a.models[b] : a.model; // normal / final objective of THIS problem (switch_to_final, nmpc_solver.cpp:381)
 
+    PROF_T0();
     // ---------------------------------------------------------------- per-wave state
     ModelState ms;                         // wave 1
     double bz[R], bzp[R], bsl[R], bsu[R], bll[R], blu[R], bcl[R], bcu[R], pc[NPRE]; // wave 2
@@ -896,7 +968,6 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             for (int i = 0; i < 4; i++) hs.u[i] = z0[i];
 #pragma unroll
             for (int i = 0; i < 6; i++) hs.ve[i] = z0[11 + i];
-            hs.fext[0] = pk[3]; hs.fext[1] = pk[4]; hs.fext[2] = pk[5];
         }
     } else if constexpr (wave == 1) {
         if (lane < 9) xs[X_XINIT + lane] = a.xinit[(size_t)b * 9 + lane];
@@ -905,6 +976,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 #pragma unroll
             for (int i = 0; i < NZ; i++) ms.z[i] = z0[i];
             ms.fext[0] = pk[3]; ms.fext[1] = pk[4]; ms.fext[2] = pk[5];
+            xs[X_FEXT + k] = ms.fext[0]; xs[X_FEXT + NP + k] = ms.fext[1]; xs[X_FEXT + 2 * NP + k] = ms.fext[2];
             ldouble *rec = recs + k * RS;
             rec[R_HC] = -2.0 * pk[8]; // (u_i, w_i) cost coupling of this stage (constant)
             rec[R_ZERO] = 0.0; rec[R_ONE] = 1.0; rec[R_DT] = DT; rec[R_DUMP] = 0.0;
@@ -983,6 +1055,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         }
     }
 
+    const double inv_kmtot = 1.0 / (KAPPA_LAM * (double)mtot);
     int flag = FRP_EXIT_MAXIT, it = 0, nfallback = 0;
     double theta_h = hess ? 1.0 : 0.0; // weight of the dynamics Hessian
     bool gn_retry = false;              // this iteration is being redone with the Gauss-Newton Hessian
@@ -997,7 +1070,10 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     for (it = 0;;) {
         // ============================================================ evaluation phase
         if constexpr (wave == 0) {
-            if (kact && half == 0) hessian_phase(recs + k * RS, hs, k < N - 1, hess);
+            if (kact && half == 0) {
+                hs.fext[0] = xs[X_FEXT + k]; hs.fext[1] = xs[X_FEXT + NP + k]; hs.fext[2] = xs[X_FEXT + 2 * NP + k];
+                hessian_phase(recs + k * RS, hs, k < N - 1, hess);
+            }
         } else if constexpr (wave == 1) {
             double l_eq;
             model_phase<NP>(recs, xs, ms, N, l_eq);
@@ -1052,7 +1128,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         nm.rc = fmax(red(xs, 2, 1), red(xs, 3, 1));
         nm.gap = red(xs, 2, 2) + red(xs, 3, 2);
         nm.rs = stationarity_norm<NP>(recs, N);
-        mu = nm.gap / (double)mtot;
+        mu = nm.gap * (KAPPA_LAM * inv_kmtot);
         if (!gn_retry) {
             if (!(nm.eq == nm.eq) || !(nm.rs == nm.rs) || !(nm.gap == nm.gap)) { flag = FRP_EXIT_BADFUNCEVAL; break; }
             if (nm.eq <= a.tol_eq && nm.in <= a.tol_ineq && nm.rs <= a.tol_stat && nm.rc <= a.tol_comp) { flag = FRP_EXIT_OPTIMAL; break; }
@@ -1138,11 +1214,11 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         double smu;
         {
             const double m_p = fmax(red(xs, 2, 3), red(xs, 3, 3)), m_d = fmax(red(xs, 2, 4), red(xs, 3, 4));
-            const double ap = (m_p > 1.0) ? 1.0 / m_p : 1.0;
-            const double ad = (m_d > 1.0) ? 1.0 / m_d : 1.0;
+            const double ap = (m_p > 1.0) ? fast_rcp(m_p) : 1.0;
+            const double ad = (m_d > 1.0) ? fast_rcp(m_d) : 1.0;
             const double gap_aff = mu * (double)mtot + ad * (red(xs, 2, 5) + red(xs, 3, 5)) + ap * (red(xs, 2, 6) + red(xs, 3, 6)) +
                                    ap * ad * (red(xs, 2, 7) + red(xs, 3, 7));
-            double sigma = gap_aff / ((double)mtot * mu);
+            double sigma = gap_aff * fast_rcp((double)mtot * mu);
             sigma = sigma * sigma * sigma;
             if (sigma > 1.0) sigma = 1.0;
             smu = sigma * mu;
@@ -1193,11 +1269,16 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             }
         } else if constexpr (wave == 1) {
             if (kact) {
-                cldouble *rec = recs + k * RS;
+                ldouble *rec = recs + k * RS;
 #pragma unroll
                 for (int i = 0; i < NZ; i++) dzr[i] = rec[R_DZ + i];
 #pragma unroll
                 for (int i = 0; i < NS; i++) ypl[i] = y_plus(rec, i);
+                // (T' is dead from here to the next factorisation)
+#pragma unroll
+                for (int i = 0; i < 4; i++) rec[RT_HZ + i] = ms.z[i];
+#pragma unroll
+                for (int i = 0; i < 6; i++) { rec[RT_HZ + 4 + i] = ms.z[11 + i]; rec[RT_HY + i] = ms.y[4 + i]; }
             }
         }
         if constexpr (wave >= 2) { // bound rows of this wave
@@ -1240,11 +1321,11 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         BAR_P(4); // ------------------------------------------------------------- F
         {
             const double mp = fmax(red(xs, 2, 8), red(xs, 3, 8)), md = fmax(red(xs, 2, 9), red(xs, 3, 9));
-            const double ap = (mp > a.ftb) ? a.ftb / mp : 1.0;
-            const double ad = (md > a.ftb) ? a.ftb / md : 1.0;
+            const double ap = (mp > a.ftb) ? a.ftb * fast_rcp(mp) : 1.0;
+            const double ad = (md > a.ftb) ? a.ftb * fast_rcp(md) : 1.0;
             // multiplier safeguard: s_i lam_i >= mu_new / KAPPA_LAM for every pair after the step
             const double fprod = (mu * (double)mtot + ap * (red(xs, 2, 10) + red(xs, 3, 10)) +
-                                  ad * ((red(xs, 2, 11) + red(xs, 3, 11)) + ap * (red(xs, 2, 12) + red(xs, 3, 12)))) / (KAPPA_LAM * (double)mtot);
+                                  ad * ((red(xs, 2, 11) + red(xs, 3, 11)) + ap * (red(xs, 2, 12) + red(xs, 3, 12)))) * inv_kmtot;
             step_cc = ap;
             auto commit = [&](double &s, double &l, double corr, double gdz, double viol) {
                 const double sinv = fast_rcp(s);
@@ -1257,13 +1338,17 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 s = sn; l = ln;
             };
             if constexpr (wave == 0) {
-                if (kact && half == 0) {
+                if (kact && half == 0) { // the Hessian inputs of the next iteration: the owners' values before the step + the step
+                    cldouble *rec = recs + k * RS;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) hs.u[i] += ap * dzr[i];
+                    for (int i = 0; i < 4; i++) hs.u[i] = rec[RT_HZ + i] + ap * dzr[i];
 #pragma unroll
-                    for (int i = 0; i < 6; i++) hs.ve[i] += ap * dzr[4 + i];
+                    for (int i = 0; i < 6; i++) hs.ve[i] = rec[RT_HZ + 4 + i] + ap * dzr[4 + i];
 #pragma unroll
-                    for (int i = 0; i < 6; i++) hs.y6[i] += ap * (ypl[i] - hs.y6[i]);
+                    for (int i = 0; i < 6; i++) {
+                        const double yo = (k < N - 1) ? rec[RS + RT_HY + i] : 0.0;
+                        hs.y6[i] = yo + ap * (ypl[i] - yo);
+                    }
                 }
             } else if constexpr (wave == 1) {
 #pragma unroll
@@ -1333,14 +1418,16 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 template <int NP, int FL, bool FREG, int ROLE>
 __device__ __forceinline__ void role_loop(const KernelArgs &a, const Shared &sh)
 {
+    // the queue head is pulled one problem ahead (while the current one is being solved), so its latency is never exposed
+    if (ROLE == 0 && threadIdx.x == 0) sh.ctl->next = atomicAdd(a.counter, 1);
     for (;;) {
-        if (ROLE == 0 && threadIdx.x == 0) sh.ctl->next = atomicAdd(a.counter, 1);
         BAR();
         int b = sh.ctl->next;
         if (b >= a.B) break;
         if (a.order) b = a.order[b]; // longest-expected-first launch order (see order_keys_kernel)
+        BAR(); // everybody has read the index: the slot can take the next one
+        if (ROLE == 0 && threadIdx.x == 0) sh.ctl->next = atomicAdd(a.counter, 1);
         solve_one<NP, FL, FREG, ROLE>(a, b, sh);
-        BAR();
     }
 }
 
@@ -1348,7 +1435,7 @@ template <int NP, int FL, bool FREG, int WPE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void nmpc_ipm_lds_kernel(KernelArgs a)
 {
     __shared__ double s_recs[NP * RS];
-    __shared__ double s_xs[X_TOTAL];
+    __shared__ double s_xs[X_TOTAL + 3 * NP];
     __shared__ Ctl s_ctl;
     Shared sh;
     sh.recs = (ldouble *)s_recs; sh.xs = (ldouble *)s_xs; sh.ctl = &s_ctl;
@@ -1374,10 +1461,10 @@ static hipError_t launch_variant(const KernelArgs &k, int slots, hipStream_t str
 void debug_read_prof_lds(long long *out)
 {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lr::g_prof_lds), sizeof(long long) * 64);
-    (void)hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(lr::g_prof_seg), sizeof(long long) * 16);
+    (void)hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(lr::g_prof_seg), sizeof(long long) * 32);
     long long z[64] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(lr::g_prof_lds), z, sizeof z);
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(lr::g_prof_seg), z, sizeof(long long) * 16);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(lr::g_prof_seg), z, sizeof(long long) * 32);
 }
 #endif
 

@@ -7,17 +7,18 @@ from forces_resilient_planner_amd import solver, workloads
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 cfg = sys.argv[2] if len(sys.argv) > 2 else "2"
 w = {"1": workloads.config1, "2": workloads.config2, "3": workloads.config3}[cfg](B)
-buf = (ctypes.c_longlong * 80)()
+buf = (ctypes.c_longlong * 96)()
 solver.solve_batch_host(w)
 solver.lib().frp_debug_read_prof_lds(buf)
 z, fl, it, info = solver.solve_batch_host(w)
 solver.lib().frp_debug_read_prof_lds(buf)
-p = np.array(buf[:64]).reshape(4, 16); sg = np.array(buf[64:80])
+p = np.array(buf[:64]).reshape(4, 16); sg = np.array(buf[64:96])
 its = p[0, 10]
 names = ["eval->A", "predictor->C", "affine->D", "corrector->E", "stepA->F"]
 print(f"B {B} cfg {cfg}: solves {B}, iterations {its} (mean {its / B:.2f}); cycles per iteration, per wave: work before the barrier | wait at it")
 for wv, role in enumerate(["riccati", "model", "bounds", "faces"]):
     print(f"  wave {wv} {role:8s}: " + "  ".join(f"{names[i]} {p[wv, i] / its:7.0f}|{p[wv, 5 + i] / its:7.0f}" for i in range(5)) +
-          f"   total {(p[wv, :10].sum()) / its:8.0f}")
+          f"   total {(p[wv, :10].sum()) / its:8.0f}   init/problem {p[wv, 11] / max(p[wv, 12], 1):7.0f}")
 print("  factor sweep segments (cycles per iteration): " + "  ".join(f"{n} {sg[i] / its:6.0f}" for i, n in enumerate(["mfma X/G", "gather", "pivot", "tail mfma", "P update+stores", "loop"])))
 print("  whole sweeps (cycles per iteration; forward and forward+y are cumulative with the sweep before them): " + "  ".join(f"{n} {sg[8 + i] / its:6.0f}" for i, n in enumerate(["factor", "+forward", "backvec", "+forward y"])))
+print("  model phase segments (cycles per iteration): " + "  ".join(f"{n} {sg[16 + i] / its:6.0f}" for i, n in enumerate(["park y, dx0", "trig1+accel1+J1", "trig2+accel2", "J2 J1 products", "d + shifts", "gm"])))

@@ -29,10 +29,10 @@ cf, _ = counter(os.path.join(src, "calib_fetch", "calib_counter_collection.csv")
 cw, _ = counter(os.path.join(src, "calib_write", "calib_counter_collection.csv"), "write_kernel", "WRITE_SIZE")
 fetch_factor = calib_bytes / (cf * 1024.0)   # bytes per reported KiB unit / 1024
 write_factor = calib_bytes / (cw * 1024.0)
-f, nf = counter(os.path.join(src, "fetch", "bench_counter_collection.csv"), "nmpc_ipm_kernel", "FETCH_SIZE")
-w, nw = counter(os.path.join(src, "write", "bench_counter_collection.csv"), "nmpc_ipm_kernel", "WRITE_SIZE")
+f, nf = counter(os.path.join(src, "fetch", "bench_counter_collection.csv"), "nmpc_ipm_", "FETCH_SIZE")
+w, nw = counter(os.path.join(src, "write", "bench_counter_collection.csv"), "nmpc_ipm_", "WRITE_SIZE")
 stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(src, "stats", "bench_kernel_stats.csv")))}
-kname = [k for k in stats if "nmpc_ipm_kernel" in k][0]
+kname = [k for k in stats if "nmpc_ipm_" in k][0]
 bench_prof = json.loads(open(os.path.join(src, "bench_stats.json")).read().strip().splitlines()[-1])
 bench_plain = json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().splitlines()[-1])
 traffic = {
