@@ -76,7 +76,7 @@ struct DropInCtx {
     double *d_xinit = nullptr, *d_x0 = nullptr, *d_par = nullptr, *d_z = nullptr, *d_info = nullptr, *d_ws = nullptr;
     int *d_flag = nullptr, *d_it = nullptr;
     size_t ws_bytes = 0;
-    bool probed[2] = {false, false};
+    frp_forces_extfunc probed[2] = {nullptr, nullptr}; // the callback last probed per model (a different pointer is probed again)
     bool probe_ok[2] = {false, false};
     std::mutex mtx;
     ~DropInCtx()
@@ -160,9 +160,9 @@ int forces_solve(int model, frp_forces_params *params, frp_forces_output *output
         return FRP_EXIT_PARAM_VALUE;
     }
     if (fn) {
-        if (!g_ctx.probed[model]) {
+        if (g_ctx.probed[model] != fn) {
             g_ctx.probe_ok[model] = probe_callback(fn, model);
-            g_ctx.probed[model] = true;
+            g_ctx.probed[model] = fn;
         }
         if (!g_ctx.probe_ok[model]) {
             if (fs) fprintf(fs, "frp_nmpc: the supplied model callback differs from the built-in device model\n");
@@ -194,6 +194,8 @@ int forces_solve(int model, frp_forces_params *params, frp_forces_output *output
     info->it = it; info->it2opt = it;
     info->res_eq = inf[0]; info->res_ineq = inf[1]; info->rsnorm = inf[2]; info->rcompnorm = inf[3];
     info->pobj = inf[4]; info->mu = inf[5]; info->step_cc = inf[6]; info->sigma = 0.0;
+    // not computed by this solver (plan_manage never reads them, nmpc_solver.cpp:398-429): the dual objective is reported equal
+    // to the primal one, the gaps and sigma as zero
     info->dobj = inf[4]; info->dgap = 0.0; info->rdgap = 0.0;
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     info->solvetime = secs;
@@ -252,24 +254,28 @@ int frp_nmpc_time_solve(const frp_nmpc_batch *batch, const frp_nmpc_options *opt
     frp::KernelArgs a;
     if (!fill_args(batch, opt, workspace, workspace_bytes, &a) || reps <= 0 || !avg_ms) return FRP_ERR_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipEvent_t e0, e1;
-    FRP_HIP(hipEventCreate(&e0));
-    FRP_HIP(hipEventCreate(&e1));
-    FRP_HIP(hipEventRecord(e0, st));
+    struct Events { // destroyed on every exit path
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } ev;
+    FRP_HIP(hipEventCreate(&ev.e0));
+    FRP_HIP(hipEventCreate(&ev.e1));
+    FRP_HIP(hipEventRecord(ev.e0, st));
     for (int r = 0; r < reps; r++) FRP_HIP(frp::launch_ipm(a, st));
-    FRP_HIP(hipEventRecord(e1, st));
-    FRP_HIP(hipEventSynchronize(e1));
+    FRP_HIP(hipEventRecord(ev.e1, st));
+    FRP_HIP(hipEventSynchronize(ev.e1));
     float ms = 0.f;
-    FRP_HIP(hipEventElapsedTime(&ms, e0, e1));
+    FRP_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
     *avg_ms = ms / reps;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return FRP_OK;
 }
 
 int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *opt)
 {
-    if (!h || h->B <= 0 || h->N < 2 || h->N > 64) return FRP_ERR_ARG;
+    // the same checks as fill_args, before anything is sized or copied from the caller's pointers
+    if (!h || h->B <= 0 || h->N < 2 || h->N > 64 || h->M < 0 || h->MF < 0 || h->MF > h->M) return FRP_ERR_ARG;
+    if (!h->xinit || !h->x0 || !h->params || !h->z || !h->exitflag || !h->iters) return FRP_ERR_ARG;
+    if (h->model != FRP_MODEL_NORMAL && h->model != FRP_MODEL_FINAL) return FRP_ERR_ARG;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FRP_ERR_NO_DEVICE;
     const size_t B = h->B, N = h->N, np = FRP_NPAR(h->M);

@@ -64,7 +64,7 @@ constexpr double MU_FLOOR_FRAC = 0.3;   // centring target floor = 0.3 * tol_com
 constexpr double THETA_DOWN = 0.25;     // dynamics-Hessian weight after an indefinite pivot block ...
 constexpr double THETA_UP = 0.1;        // ... and its recovery per successful iteration
 constexpr double KAPPA_LAM = 2.0;       // multiplier safeguard: s_i lam_i >= mu / KAPPA_LAM after every step
-constexpr double DIVERGE_MU = 1e6;
+constexpr double DIVERGE_MU = 10.0;     // mu > 10 max(1, mu0): a (locally) infeasible instance, exit -7 (see oracle/nmpc_ipm.c)
 constexpr double DIVERGE_RS = 1e12;
 
 struct KernelArgs {

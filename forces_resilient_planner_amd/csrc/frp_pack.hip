@@ -34,10 +34,12 @@ __global__ __launch_bounds__(256) void pack_kernel(frp_nmpc_pack p)
     // per stage: its polytope (poly_constraints[poly_indices(i)], forces_normal.cpp:112) and live face count
     __shared__ int s_pi[64], s_nf[64];
     if (tid < p.N) {
-        const int pi = p.poly_index ? p.poly_index[(size_t)b * p.N + tid] : tid;
+        int pi = p.poly_index ? p.poly_index[(size_t)b * p.N + tid] : tid;
+        pi = pi < 0 ? 0 : (pi < p.NPOLY ? pi : p.NPOLY - 1); // a corrupt index must not read outside the polytope arrays
         int nf = p.poly_nfaces[(size_t)b * p.NPOLY + pi];
         nf = nf < p.M ? nf : p.M;              // faces beyond num_const are dropped (:114)
         nf = nf < p.F ? nf : p.F;
+        nf = nf > 0 ? nf : 0;
         s_pi[tid] = pi; s_nf[tid] = nf;
         p.nfaces[(size_t)b * p.N + tid] = nf;
     }

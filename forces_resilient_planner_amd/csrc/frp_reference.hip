@@ -30,7 +30,11 @@ __global__ __launch_bounds__(64) void reference_kernel(frp_nmpc_reference p)
     if (i < p.N) {
         // getCurTraj (:111-132)
         const double index_time = i * p.Ts + p.time_offset[b];
-        const unsigned int ki = (unsigned int)(int)(index_time / p.Ts);
+        // (a time offset of -Ts or less before the path start, or a non-finite one: the reference's unsigned index wraps and
+        // reads far outside the path; here such a planner gets the end of the path instead of faulting the launch.
+        // Offsets in (-Ts, 0) truncate to sample 0 as in the reference.)
+        const double qf = index_time / p.Ts;
+        const unsigned int ki = (qf > -1.0 && qf < 2147483647.0) ? (unsigned int)(int)qf : 0x7fffffffu;
         const double *last = path + 3 * (size_t)(size - 1);
         double r[3], f[3];
         if (ki + 1 < (unsigned int)size) {

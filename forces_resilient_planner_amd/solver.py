@@ -210,9 +210,11 @@ class DeviceSolver:
         self.x0 = torch.empty((B, N, L.NZ), **f64)
         self.params = torch.empty((B, N, L.npar(M)), **f64)
         self.nfaces = torch.empty((B, N), dtype=torch.int32, device=self.device)
-        self.z = torch.empty((B, N, L.NZ), **f64)
-        self.exitflag = torch.empty((B,), dtype=torch.int32, device=self.device)
-        self.iters = torch.empty((B,), dtype=torch.int32, device=self.device)
+        self.z = torch.zeros((B, N, L.NZ), **f64)
+        # zero = "no solve yet / MAXIT": DeviceFleet's cold start and update branch on exitflag == 1 before the first solve has
+        # written it, so a fresh solver must not expose recycled allocator memory (the reference's !initialized_output_)
+        self.exitflag = torch.zeros((B,), dtype=torch.int32, device=self.device)
+        self.iters = torch.zeros((B,), dtype=torch.int32, device=self.device)
         self.info = torch.empty((B, INFO_STRIDE), **f64)
         self.ws_bytes = int(lib().frp_nmpc_workspace_bytes(B, N, MF))
         self.ws = torch.empty((self.ws_bytes // 8 + 1,), **f64)
@@ -463,8 +465,16 @@ class DeviceFleet:
         assert self.NPOLY == self.N
         if self.poly_index is None:
             self.poly_index = t.zeros((self.B, self.N), dtype=t.int32, device=self.solver.device)
+        if getattr(self, "poly_count", None) is None:
+            # per planner: polytopes produced, negative when one of them needed more than F rows and was truncated
+            # (getSikangConst tests all rows; callers that size F below FRP_CORRIDOR_MAX_F should check overflowed())
+            self.poly_count = t.zeros((self.B,), dtype=t.int32, device=self.solver.device)
         corridor_batch_device(cloud, ref_pos, ref_yaw, self.ellipsoid, self.poly_A, self.poly_b, self.poly_nfaces,
-                              self.poly_index, None, cloud_count, consts, stream, grid)
+                              self.poly_index, self.poly_count, cloud_count, consts, stream, grid)
+
+    def overflowed(self):
+        """Planners whose last corridor() truncated a polytope to F rows (device tensor of bool)."""
+        return self.poly_count < 0
 
     def coldstart(self, state=None, only_failed=True, thrust=7.3, stream=None):
         """initMPCOutput for the planners whose last solve failed (nmpc_solver.cpp:363-364, :265-286), on the device.

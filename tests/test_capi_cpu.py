@@ -45,6 +45,67 @@ def test_dropin_struct_layouts_match_reference_sizes():
     assert solver.ForcesInfo.res_eq.offset == 8 and solver.ForcesInfo.solvetime.offset == 120
 
 
+REF_INC = "/root/reference/src/resilient_planner/plan_manage/solver/{m}/FORCESNLPsolver_{m}/include"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_INC.format(m="normal")), reason="reference tree absent (GPU box)")
+@pytest.mark.parametrize("m", ["normal", "final"])
+def test_dropin_matches_the_references_own_header(m, tmp_path):
+    """Build-container check against the header plan_manage compiles with (FORCESNLPsolver_normal.h:153-323, included by
+    forces_normal.cpp:2-3): one translation unit sees BOTH headers, compares every struct field, the callback type and
+    the solve prototype, and then links the reference's prototype against libfrp_nmpc_amd.so."""
+    src = tmp_path / "hdr.cpp"
+    R = f"FORCESNLPsolver_{m}"
+    src.write_text(f"""
+#include "{R}.h"
+// this repo's header declares the same two C symbols with its own (layout-compatible) struct names
+#define FORCESNLPsolver_normal_solve frp_shadow_normal_solve
+#define FORCESNLPsolver_final_solve frp_shadow_final_solve
+#include "frp_nmpc.h"
+#undef FORCESNLPsolver_normal_solve
+#undef FORCESNLPsolver_final_solve
+#include <cstddef>
+#include <cstdio>
+#include <type_traits>
+#define SAME_FIELD(RT, FT, rf, ff) static_assert(offsetof(RT, rf) == offsetof(FT, ff) && sizeof(((RT *)0)->rf) == sizeof(((FT *)0)->ff), #rf)
+static_assert(sizeof({R}_params) == sizeof(frp_forces_params), "params");
+SAME_FIELD({R}_params, frp_forces_params, xinit, xinit);
+SAME_FIELD({R}_params, frp_forces_params, x0, x0);
+SAME_FIELD({R}_params, frp_forces_params, all_parameters, all_parameters);
+SAME_FIELD({R}_params, frp_forces_params, num_of_threads, num_of_threads);
+static_assert(sizeof({R}_output) == sizeof(frp_forces_output), "output");
+static_assert(offsetof({R}_output, x01) == 0 && offsetof({R}_output, x02) == 17 * sizeof(double) && offsetof({R}_output, x20) == 19 * 17 * sizeof(double), "x01..x20 contiguous");
+static_assert(sizeof({R}_info) == sizeof(frp_forces_info), "info");
+SAME_FIELD({R}_info, frp_forces_info, it, it); SAME_FIELD({R}_info, frp_forces_info, it2opt, it2opt);
+SAME_FIELD({R}_info, frp_forces_info, res_eq, res_eq); SAME_FIELD({R}_info, frp_forces_info, res_ineq, res_ineq);
+SAME_FIELD({R}_info, frp_forces_info, rsnorm, rsnorm); SAME_FIELD({R}_info, frp_forces_info, rcompnorm, rcompnorm);
+SAME_FIELD({R}_info, frp_forces_info, pobj, pobj); SAME_FIELD({R}_info, frp_forces_info, dobj, dobj);
+SAME_FIELD({R}_info, frp_forces_info, dgap, dgap); SAME_FIELD({R}_info, frp_forces_info, rdgap, rdgap);
+SAME_FIELD({R}_info, frp_forces_info, mu, mu); SAME_FIELD({R}_info, frp_forces_info, mu_aff, mu_aff);
+SAME_FIELD({R}_info, frp_forces_info, sigma, sigma); SAME_FIELD({R}_info, frp_forces_info, lsit_aff, lsit_aff);
+SAME_FIELD({R}_info, frp_forces_info, lsit_cc, lsit_cc); SAME_FIELD({R}_info, frp_forces_info, step_aff, step_aff);
+SAME_FIELD({R}_info, frp_forces_info, step_cc, step_cc); SAME_FIELD({R}_info, frp_forces_info, solvetime, solvetime);
+SAME_FIELD({R}_info, frp_forces_info, fevalstime, fevalstime);
+static_assert(std::is_same<{R}_extfunc, frp_forces_extfunc>::value, "callback type");
+static_assert(std::is_same<decltype(&{R}_solve), int (*)({R}_params *, {R}_output *, {R}_info *, FILE *, {R}_extfunc)>::value, "reference prototype");
+static_assert(std::is_same<decltype(&frp_shadow_{m}_solve), int (*)(frp_forces_params *, frp_forces_output *, frp_forces_info *, FILE *, frp_forces_extfunc)>::value, "this repo's prototype");
+// return codes the caller distinguishes (nmpc_solver.cpp:398-421)
+static_assert(OPTIMAL_{R} == FRP_EXIT_OPTIMAL && MAXITREACHED_{R} == FRP_EXIT_MAXIT && FACTORIZATION_ERROR_{R} == FRP_EXIT_FACTORIZATION &&
+              BADFUNCEVAL_{R} == FRP_EXIT_BADFUNCEVAL && NOPROGRESS_{R} == FRP_EXIT_NOPROGRESS && PARAM_VALUE_ERROR_{R} == FRP_EXIT_PARAM_VALUE, "exit codes");
+int main() {{
+    // the reference's prototype resolved by this repo's library, exactly what plan_manage's link step does
+    int (*solve)({R}_params *, {R}_output *, {R}_info *, FILE *, {R}_extfunc) = &{R}_solve;
+    return solve ? 0 : 1;
+}}
+""")
+    exe = tmp_path / "hdr"
+    cmd = ["g++", "-std=c++17", "-Wall", "-Werror", "-I" + REF_INC.format(m=m), "-I" + os.path.join(ROOT, "include"), str(src),
+           "-L" + os.path.dirname(solver.LIB_PATH), "-l:" + os.path.basename(solver.LIB_PATH), "-Wl,-rpath," + os.path.dirname(solver.LIB_PATH),
+           "-Wl,--unresolved-symbols=ignore-in-shared-libs", "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_workspace_size_formula():
     """Workspace = (resident slots) x (per-problem solver state) + work queue (counter 256 B, one key and one order
     entry per problem): the solver state grows with the batch only up to the number of slots the library sizes for

@@ -161,6 +161,99 @@ def test_long_horizon_uses_wide_lane_mapping():
     assert np.max(np.abs(z[ok] - zo[ok])) < 1e-3
 
 
+def _libc():
+    lc = ctypes.CDLL(None)
+    lc.fopen.restype = ctypes.c_void_p; lc.fopen.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    lc.fclose.argtypes = [ctypes.c_void_p]
+    return lc
+
+
+@pytest.mark.skipif(not OL.ref_model_available(), reason="oracle/_ref not built (reference tree absent)")
+def test_dropin_called_the_way_the_reference_calls_it(tmp_path):
+    """forces_normal.cpp:30,139 passes &FORCESNLPsolver_normal_casadi2forces and (in its debug builds) a FILE*: the
+    reference's own compiled callback must be accepted (probe against the device model), give the same plan as a NULL
+    callback, and the summary must carry the reference's strings (normal.h printlevel 1)."""
+    ref = ctypes.CDLL(os.path.join(OL.ORC_DIR, "_ref", "libref_model_normal.so"))
+    cb = ctypes.cast(ref.FORCESNLPsolver_normal_casadi2forces, solver.EXTFUNC)
+    w0 = workloads.config0(0, (0.0, 0.0, 0.0), workloads.NORMAL_WEIGHTS)
+    flag0, z0, info0 = _forces_call(w0, 0)
+    p = solver.ForcesParams(); o = solver.ForcesOutput(); info = solver.ForcesInfo()
+    p.xinit[:] = w0["xinit"][0]; p.x0[:] = w0["x0"][0].ravel(); p.all_parameters[:] = w0["params"][0].ravel()
+    p.num_of_threads = 1
+    lc = _libc()
+    path = str(tmp_path / "summary.txt").encode()
+    fs = lc.fopen(path, b"w")
+    f = solver.lib().FORCESNLPsolver_normal_solve
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, solver.EXTFUNC]
+    try:
+        flag = f(ctypes.byref(p), ctypes.byref(o), ctypes.byref(info), fs, cb)
+        lc.fclose(fs)
+        text = open(path.decode()).read()
+        assert flag == 1 and flag0 == 1
+        assert np.array_equal(np.array(o.x).reshape(20, 17), z0)
+        assert "OPTIMAL (within EQTOL=" in text and "Solve time:" in text and "iterations)" in text
+
+        # a callback that implements a different model is refused with PARAM_VALUE (-11): there is no host path that
+        # could honour it, and silently solving the built-in model instead would be wrong
+        @solver.EXTFUNC
+        def other_model(x, y, lam, par, pobj, g, c, Jeq, h, Jineq, H, stage, it, tid):
+            cb(x, y, lam, par, pobj, g, c, Jeq, h, Jineq, H, stage, it, tid)
+            if pobj:
+                pobj[0] += 1.0
+        fs2 = lc.fopen(path, b"w")
+        flag_bad = f(ctypes.byref(p), ctypes.byref(o), ctypes.byref(info), fs2, other_model)
+        lc.fclose(fs2)
+        assert flag_bad == L.PARAM_VALUE_ERROR
+        assert "differs from the built-in device model" in open(path.decode()).read()
+        assert f(ctypes.byref(p), ctypes.byref(o), ctypes.byref(info), None, cb) == 1  # the good callback is probed again
+    finally:
+        f.argtypes = None
+
+
+def test_iteration_limit_returns_maxit_and_the_last_iterate():
+    """exit 0 (MAXITREACHED, normal.h:113): every problem stops after maxit iterations with its current iterate in the
+    output, the same iterate the oracle holds after as many iterations."""
+    w = workloads.config2(64)
+    z, fl, it, info = solver.solve_batch_host(w, solver.default_options(maxit=2))
+    zo, flo, io = OL.solve_batch(w, OL.default_options(maxit=2))
+    assert np.all(fl == 0) and np.all(flo == 0) and np.all(it == 2)
+    assert np.max(np.abs(z - zo)) < 1e-9
+    assert not np.array_equal(z, w["x0"])
+    # through the drop-in struct: info.it counts the iterations done
+    w0 = workloads.config0(0, (0.0, 0.0, 0.0), workloads.NORMAL_WEIGHTS)
+    flag, z0, info0 = _forces_call(w0, 0)
+    assert flag == 1 and info0.it >= 3
+
+
+def test_indefinite_cost_reports_factorization_error():
+    """exit -5 (FACTORIZATION_ERROR, normal.h:119): a negative input-rate weight makes the reduced Hessian of every stage
+    indefinite under the exact AND the Gauss-Newton Hessian; both implementations give up in the first iteration."""
+    w = workloads.config2(16)
+    p = w["params"].copy()
+    p[:, :, 8] = -50.0  # w_input_rate (setup.m:62)
+    w["params"] = p
+    z, fl, it, info = solver.solve_batch_host(w)
+    zo, flo, _ = OL.solve_batch(w)
+    assert np.all(fl == L.FACTORIZATION_ERROR) and np.array_equal(fl, flo)
+    assert np.all(it == 0) and np.all(np.isfinite(z))
+
+
+def test_fresh_fleet_cold_starts_without_touching_exitflag():
+    """A new DeviceFleet must cold-start every planner on its first full tick: exitflag starts at zero (never recycled
+    allocator memory), so coldstart_kernel's exitflag != 1 test fires for all of them."""
+    import torch
+    B, N = 8, 20
+    junk = torch.ones((4096,), dtype=torch.int32, device="cuda:0"); del junk  # a block of ones for the allocator to recycle
+    fl = solver.DeviceFleet(B, N, 30, 6, 0, workloads.NORMAL_WEIGHTS)
+    assert int(fl.solver.exitflag.abs().sum()) == 0 and int(fl.solver.iters.abs().sum()) == 0
+    state = torch.zeros((B, 9), dtype=torch.float64, device="cuda:0"); state[:, 2] = 1.0
+    fl.mpc_output.fill_(123.0)
+    fl.coldstart(state, only_failed=True)
+    torch.cuda.synchronize()
+    mo = fl.mpc_output.cpu().numpy()
+    assert np.allclose(mo[:, :, 3], 7.3) and np.allclose(mo[:, :, 10], 1.0) and np.allclose(mo[:, :, :3], 0.0)
+
+
 def test_more_faces_than_workspace_is_a_parameter_error():
     w = workloads.config3(4)
     z, fl, it, info = solver.solve_batch_host(w, MF=5)   # stages have 6..15 live rows
