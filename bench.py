@@ -3,10 +3,10 @@
 
 A "step" = one pass of the hot path over one batch: solve B = 4096 independent N = 20 NMPC problems
 (BASELINE.json configs[2]: constant f_ext, 6-face tightened corridor per stage, cold start) with the
-HIP solver, inputs already resident in HBM, outputs left in HBM.  Steps are issued round-robin on 2 HIP streams
-(own workspace / outputs each) so that the few long solves at the end of one launch overlap the next launch;
-config.single_stream_solves_per_s is the same measurement with strictly serial launches.  N GPUs -> each rank solves its own
-4096-problem shard (different seed), no data-path collective ("weak").
+HIP solver, inputs already resident in HBM, outputs left in HBM, strictly serial launches on one stream; the K-step
+region is timed 5 times and the median reported (config.pipelined_solves_per_s: the same steps round-robin on 2 streams,
+informational).  N GPUs -> each rank solves its own 4096-problem shard (different seed), no data-path collective ("weak").
+--scaling strong / --config 3 / --config 4: the other BASELINE configs and the scatter -> solve -> gather form of SURVEY 8e.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -54,10 +54,30 @@ def usable_cores():
     return n
 
 
+def native_oracle():
+    """The CPU baseline runs the oracle compiled FOR THIS HOST (-O3 -march=native, OpenMP), as SURVEY 8d asks: the in-tree
+    oracle/liboracle.so is built in the build container for a generic x86-64-v3 target.  Built into a temp dir at bench
+    time (gcc is in the image); falls back to the in-tree library if that fails."""
+    import ctypes, subprocess, tempfile
+    import tests.oracle_lib as OL
+    try:
+        d = tempfile.mkdtemp(prefix="frp_oracle_native_")
+        so = os.path.join(d, "liboracle_native.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-fopenmp", "-shared", os.path.join(OL.ORC_DIR, "nmpc_model.c"),
+                               os.path.join(OL.ORC_DIR, "nmpc_ipm.c"), "-o", so, "-lm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        lib = ctypes.CDLL(so)
+        lib.orc_solve.restype = ctypes.c_int
+        OL._lib = lib
+        return "-O3 -march=native (built on this host)"
+    except Exception:
+        return "-O3 -march=x86-64-v3 (in-tree build)"
+
+
 def cpu_baseline(w, seconds_target=12.0):
     """The CPU oracle (same algorithm, FP64, OpenMP over problems) timed on a bounded sample of the
     same workload on this box's host cores.  Test infrastructure used only as the reported baseline."""
     import tests.oracle_lib as OL
+    flags = native_oracle()
     cores = usable_cores()
     B = w["xinit"].shape[0]
     OL.solve_batch(w, nthreads=cores)  # warm up threads / page in
@@ -87,12 +107,17 @@ def cpu_baseline(w, seconds_target=12.0):
     n1 = min(B, 512)
     sub = {k: (v[:n1] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in w.items()}
     t1 = time.perf_counter(); OL.solve_batch(sub, nthreads=1); dt1 = time.perf_counter() - t1
+    cpu_model = ""
+    try:
+        cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
     return dict(value=solved / dt, unit="solves/s", cores=cores, kind="port",
-                sample=f"the same {B}-problem batch solved {reps}x by oracle/liboracle.so (FP64 CPU restatement of the "
-                       f"same interior-point method, not ForcesPro: its binary is licence-locked), OpenMP over problems on "
-                       f"{cores} threads (os.cpu_count()={os.cpu_count()}, affinity/cgroup-limited to {cores}), {dt:.1f} s; "
+                sample=f"the same {B}-problem batch solved {reps}x by the oracle (FP64 CPU restatement of the "
+                       f"same interior-point method, not ForcesPro: its binary is licence-locked), compiled {flags}, OpenMP over problems on "
+                       f"{cores} threads (os.cpu_count()={os.cpu_count()}, affinity/cgroup-limited to {cores}; {cpu_model}), {dt:.1f} s; "
                        f"single-thread {n1 / dt1:.0f} solves/s",
-                converged_frac=conv / solved, reference_anchor=anchor)
+                single_thread_solves_per_s=n1 / dt1, converged_frac=conv / solved, reference_anchor=anchor)
 
 
 def pmc_traffic(batch):
@@ -115,15 +140,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="HIP streams the steps are issued round-robin on (each with its own workspace and outputs); "
-                         "1 = strictly back-to-back launches.  Default 2: the tail of one launch (a few long solves) overlaps "
-                         "the head of the next; the strictly serial rate is measured as well and reported in config")
+    ap.add_argument("--batch", type=int, default=0, help="problems per GPU (weak) / in total (strong); default: the BASELINE size of the config")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4],
+                    help="BASELINE.json configs[i]: 2 = headline (N=20, 6 faces), 3 = N=30 / <=15 faces / time-varying f_ext, "
+                         "4 = Monte-Carlo receding horizon (a step is one tick of every planner)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank solves its own batch (no data-path communication).  strong: rank 0 owns the whole batch in "
+                         "HBM; every step scatters the shards (grouped RCCL send/recv), solves, gathers the plans back (SURVEY 8e); "
+                         "configs[4]: one nominal problem is broadcast, the samples are drawn on every rank's device")
+    ap.add_argument("--repeats", type=int, default=5, help="the K-step region is timed this many times; the MEDIAN is reported")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / end-to-end / drop-in latency legs")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="informational: `value` is always the strictly serial single-stream rate; the rate with the steps issued "
+                         "round-robin on 2 streams (the tail of one launch overlapping the next) is reported in config.pipelined_*")
     args = ap.parse_args()
 
     import torch
+    from forces_resilient_planner_amd import distributed as D
+    from forces_resilient_planner_amd import layout as L
     from forces_resilient_planner_amd import solver, workloads
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,18 +172,108 @@ def main():
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    strong = args.scaling == "strong"
+    if strong and dist is None:
+        class _Solo:  # one rank: scatter / gather degenerate to device copies, same code path
+            P2POp = None
+            @staticmethod
+            def get_world_size(): return 1
+            @staticmethod
+            def get_rank(): return 0
+            @staticmethod
+            def batch_isend_irecv(ops): return []
+            @staticmethod
+            def broadcast(t, src): return None
+        sdist = _Solo
+    else:
+        sdist = dist
 
-    B = args.batch
-    w = workloads.config2(B, seed=workloads.SEED0 + 3 + 1000 * rank)
-    ds = solver.DeviceSolver(B, w["N"], w["M"], 6, w["model"], f"cuda:{local_rank}")
-    ds.upload(w)
+    cfg = args.config
+    base_B = {2: 4096, 3: 16384, 4: 65536}[cfg]
+    f64 = dict(dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream(dev)
-    lanes = [(ds, stream)]
-    for _ in range(1, max(1, args.streams)):  # further streams: own solver state / outputs, same resident inputs
-        d2 = solver.DeviceSolver(B, w["N"], w["M"], 6, w["model"], f"cuda:{local_rank}")
-        d2.xinit, d2.x0, d2.params, d2.nfaces = ds.xinit, ds.x0, ds.params, ds.nfaces
-        lanes.append((d2, torch.cuda.Stream(dev)))
+    phases = None
+    fleet = None
+    if cfg in (2, 3):
+        gen = workloads.config2 if cfg == 2 else workloads.config3
+        MF = 6 if cfg == 2 else 15
+        if strong:
+            B_total = args.batch or base_B
+            lo, hi = D.shard_range(B_total, rank, world)
+            B = hi - lo
+            w = gen(B_total, seed=workloads.SEED0 + 3) if rank == 0 else None  # the same problems as rank 0 of the weak-scaling run
+            wcpu = w
+            N, M = (w["N"], w["M"]) if rank == 0 else (20 if cfg == 2 else 30, 30 if cfg == 2 else 15)
+            model = 0
+            ds = solver.DeviceSolver(max(B, 1), N, M, MF, model, f"cuda:{local_rank}")
+            if rank == 0:  # the whole batch lives in rank 0's HBM
+                full_in = [torch.from_numpy(np.ascontiguousarray(w[k])).to(dev) for k in ("xinit", "x0", "params")] + \
+                          [torch.from_numpy(np.ascontiguousarray(w["nfaces"], dtype=np.int32)).to(dev)]
+                full_out = [torch.zeros((B_total, N, L.NZ), **f64), torch.zeros((B_total,), dtype=torch.int32, device=dev),
+                            torch.zeros((B_total,), dtype=torch.int32, device=dev)]
+            else:
+                full_in, full_out = [None] * 4, [None] * 3
+            shard_in = [ds.xinit[:B], ds.x0[:B], ds.params[:B], ds.nfaces[:B]]
+            shard_out = [ds.z[:B], ds.exitflag[:B], ds.iters[:B]]
+
+            def step():
+                D.scatter_batch(full_in, shard_in, B_total, sdist)
+                if B > 0:
+                    ds.solve(stream)
+                D.gather_batch(shard_out, full_out, B_total, sdist)
+            phases = (lambda: D.scatter_batch(full_in, shard_in, B_total, sdist), lambda: ds.solve(stream) if B > 0 else None,
+                      lambda: D.gather_batch(shard_out, full_out, B_total, sdist))
+        else:
+            B = args.batch or (base_B if cfg == 2 else base_B // max(1, args.gpus))
+            B_total = B * world
+            w = gen(B, seed=workloads.SEED0 + 3 + 1000 * rank)
+            wcpu = w
+            N, M, model = w["N"], w["M"], w["model"]
+            ds = solver.DeviceSolver(B, N, M, MF, model, f"cuda:{local_rank}")
+            ds.upload(w)
+
+            def step():
+                ds.solve(stream)
+    else:
+        # configs[4]: Monte-Carlo f_ext around ONE nominal problem, warm-started receding horizon; a step = one tick
+        from forces_resilient_planner_amd.workloads import _bbox_faces, _weights
+        B_total = args.batch or base_B
+        if not strong:
+            B_total = (args.batch or base_B // max(1, args.gpus)) * world
+        lo, hi = D.shard_range(B_total, rank, world)
+        B = hi - lo
+        ticks = args.warmup + args.steps * (args.repeats + 2) + 4
+        w1 = workloads.config4_nominal(1, ticks=ticks)
+        N, M, model = w1["N"], w1["M"], w1["model"]
+        wcpu = workloads.config4_nominal(min(B_total, 4096), ticks=1)
+        # one nominal problem from rank 0 to everybody (a few KB), the samples drawn where they are used
+        nominal = [torch.from_numpy(np.ascontiguousarray(w1[k])).to(dev) for k in ("mpc_output", "E")]
+        fbar = torch.from_numpy(np.ascontiguousarray(w1["f_ext"].mean(0))).to(dev)
+        if sdist is not None:
+            D.broadcast_nominal(nominal + [fbar], sdist)
+        fleet = solver.DeviceFleet(max(B, 1), N, M, 6, model, _weights(model), f"cuda:{local_rank}")
+        ds = fleet.solver
+        fleet.mpc_output.copy_(nominal[0].expand(max(B, 1), N + 1, L.NZ))
+        fleet.ellipsoid.copy_(nominal[1].expand(max(B, 1), N, 3, 3))
+        fleet.poly_nfaces.fill_(6)
+        f_ext = D.monte_carlo_fext(fbar.cpu().numpy(), 0.5, lo, max(hi, lo + 1), workloads.SEED0 + 5, dev)
+        yaw = float(w1["heading"][0])
+        ref_yaw = torch.full((max(B, 1), N), yaw, **f64)
+        refs, As, bs = [], [], []
+        for t in range(ticks):
+            r1 = w1["ref_long"][:, t:t + N]
+            A1, b1 = _bbox_faces(r1, np.full((1, N), yaw))
+            refs.append(torch.from_numpy(r1).to(dev)); As.append(torch.from_numpy(A1).to(dev)); bs.append(torch.from_numpy(b1).to(dev))
+        tick = [0]
+
+        def step():
+            t = tick[0]; tick[0] += 1
+            fleet.poly_A.copy_(As[t].expand(max(B, 1), N, 6, 3)); fleet.poly_b.copy_(bs[t].expand(max(B, 1), N, 6))
+            if t > 0:
+                fleet.coldstart(thrust=7.3)
+            fleet.tick(f_ext, refs[t].expand(max(B, 1), N, 3).contiguous(), ref_yaw)
     torch.cuda.synchronize(dev)
 
     def barrier():
@@ -158,72 +282,138 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
-        lanes[i % len(lanes)][0].solve(lanes[i % len(lanes)][1])
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        lanes[i % len(lanes)][0].solve(lanes[i % len(lanes)][1])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # the same K steps strictly back to back on ONE stream (no overlap between launches), for reference
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        ds.solve(stream)
-    barrier()
-    elapsed_serial = time.perf_counter() - t1
-    if dist is not None:
-        t = torch.tensor([elapsed, elapsed_serial], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, elapsed_serial = float(t[0].item()), float(t[1].item())
+    def timed(fn, k):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        barrier()
+        return time.perf_counter() - t0
 
-    fl = ds.exitflag.cpu().numpy(); it = ds.iters.cpu().numpy()
-    stats = torch.tensor([float((fl == 1).sum()), float(it.sum()), float(B)], dtype=torch.float64, device=dev)
+    for _ in range(args.warmup):
+        step()
+    reps = [timed(step, args.steps) for _ in range(max(1, args.repeats))]
     if dist is not None:
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)  # 3 scalars of summary statistics, not on the data path
+        t = torch.tensor(reps, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # every repeat: the slowest rank
+        reps = [float(x) for x in t.cpu()]
+    elapsed = float(np.median(reps))
+
+    # informational: the same steps issued round-robin on two streams (own solver state / outputs each)
+    pipelined = None
+    if cfg in (2, 3) and not strong:
+        d2 = solver.DeviceSolver(B, N, M, ds.MF, model, f"cuda:{local_rank}")
+        d2.xinit, d2.x0, d2.params, d2.nfaces = ds.xinit, ds.x0, ds.params, ds.nfaces
+        s2 = torch.cuda.Stream(dev)
+        lanes = [(ds, stream), (d2, s2)]
+        cnt = [0]
+
+        def step2():
+            l = lanes[cnt[0] % 2]; cnt[0] += 1
+            l[0].solve(l[1])
+        timed(step2, 2)
+        t2 = float(np.median([timed(step2, args.steps) for _ in range(3)]))
+        if dist is not None:
+            tt = torch.tensor([t2], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); t2 = float(tt.item())
+        pipelined = B_total * args.steps / t2
+
+    # per-phase times of a strong-scaling step (not inside the timed region: each phase is bracketed by a barrier here)
+    phase_ms = None
+    if phases is not None:
+        acc = [0.0, 0.0, 0.0]
+        for _ in range(5):
+            for i, ph in enumerate(phases):
+                acc[i] += timed(ph, 1)
+        if dist is not None:
+            tt = torch.tensor(acc, dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); acc = [float(x) for x in tt.cpu()]
+        phase_ms = {"scatter_ms": acc[0] / 5 * 1e3, "solve_ms": acc[1] / 5 * 1e3, "gather_ms": acc[2] / 5 * 1e3}
+
+    fl = ds.exitflag[:max(B, 1)].cpu().numpy(); it = ds.iters[:max(B, 1)].cpu().numpy()
+    if B == 0:
+        fl = fl[:0]; it = it[:0]
+    stats = torch.tensor([float((fl == 1).sum()), float(it.sum()), float(len(fl)), float(it.max() if len(it) else 0)], **f64)
+    if dist is not None:
+        mx = stats[3:].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)  # summary statistics, not on the data path
+        stats[3] = mx[0]
     conv_frac = float(stats[0] / stats[2]); mean_it = float(stats[1] / stats[2])
 
     # dominant kernel: average duration over the same launches, HIP events on the launch stream
-    kernel_ms = ds.time_solve(max(1, args.steps), stream)
+    kernel_ms = ds.time_solve(max(1, args.steps), stream) if B > 0 else 0.0
     torch.cuda.synchronize(dev)
 
     if rank == 0:
-        total = world * B * args.steps
+        total = B_total * args.steps
         value = total / elapsed
-        f_solve = mean_it * w["N"] * F_STAGE
-        achieved_tf = B * f_solve / (kernel_ms * 1e-3) / 1e12
-        achieved_gbs = B * ALG_BYTES_PER_SOLVE / (kernel_ms * 1e-3) / 1e9
+        MFc = {2: 6, 3: 15, 4: 6}[cfg]
+        f_stage = F_STAGE + 18.0 * (MFc - 6)  # the 18 m term of F_stage
+        f_solve = mean_it * N * f_stage
+        achieved_tf = B * f_solve / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        alg_bytes = 8.0 * (9 + 17 * N + N * (10 + 4 * M) + 1) + 8.0 * 17 * N + 136.0  # dense ABI image of one solve: params + output + info (26 456 B at N = 20, M = 30)
+        achieved_gbs = B * alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic(B)
+        names = {2: "BASELINE.json configs[2]: N=20, constant f_ext~U[-3,3]^3, 6-face tightened corridor per stage, cold start, reference 30-row parameter layout",
+                 3: "BASELINE.json configs[3]: N=30, time-varying f_ext, per-stage polytopes with <=15 faces, cold start",
+                 4: "BASELINE.json configs[4]: Monte-Carlo f_ext~N(fbar,0.5^2 I) around one nominal problem, N=20, warm-started receding horizon, one step = one tick (pack + solve + update on the device)"}
         out = {
             "metric": "NMPC solves/sec, batch=4096 horizons N=20", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: batch=4096 per GPU, N=20, constant f_ext~U[-3,3]^3, "
-                                   "6-face tightened corridor per stage, cold start, reference 30-row parameter layout",
-                       "batch_per_gpu": B, "horizon": int(w["N"]), "converged_frac": conv_frac,
-                       "mean_ipm_iterations": mean_it, "streams": len(lanes),
-                       "single_stream_solves_per_s": world * B * args.steps / elapsed_serial,
-                       "single_stream_ms_per_step": elapsed_serial / args.steps * 1e3, "p95_ipm_iterations": float(np.percentile(it, 95)),
-                       "max_ipm_iterations": int(it.max()), "tolerances": 1e-4},
+            "config": {"workload": names[cfg] + f"; batch {B} per GPU" + (f" of {B_total} in total, scattered from / gathered to rank 0 every step" if strong and cfg != 4 else ""),
+                       "baseline_config": cfg, "batch_per_gpu": B, "batch_total": B_total, "horizon": int(N), "converged_frac": conv_frac,
+                       "mean_ipm_iterations": mean_it, "max_ipm_iterations": int(stats[3]), "p95_ipm_iterations": float(np.percentile(it, 95)) if len(it) else 0.0,
+                       "timing": f"median of {len(reps)} repeats of the {args.steps}-step region, strictly serial launches on one stream; max over ranks per repeat",
+                       "repeat_ms_per_step": [r / args.steps * 1e3 for r in reps],
+                       "pipelined_solves_per_s": pipelined,
+                       "pipelined_note": "the same steps issued round-robin on 2 HIP streams (the few long solves at the end of a launch overlap the head of the next); informational, never `value`",
+                       "tolerances": 1e-4},
             "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel": "nmpc_ipm_kernel", "kernel_ms": kernel_ms,
+                         "kernel": "nmpc_ipm_lds_kernel" if os.environ.get("FRP_KERNEL", "") == "" else "nmpc_ipm_kernel (FRP_KERNEL=r01)", "kernel_ms": kernel_ms,
                          "flops_per_launch": B * f_solve,
                          "note": "FP64 (vector == matrix peak 78.6 TFLOP/s); flops = SURVEY 8d definition "
-                                 "mean_it * N * 31.5 kflop per solve",
+                                 "mean_it * N * F_stage per solve (F_stage = 31.5 kflop at 6 faces)",
                          "hbm_algorithmic": {"achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                             "frac": achieved_gbs / HBM_PEAK_GBS}},
+                                             "frac": achieved_gbs / HBM_PEAK_GBS, "bytes_per_solve": alg_bytes}},
         }
+        if phase_ms is not None:
+            out["config"]["strong_scaling_phases"] = phase_ms
+        if not args.no_cpu and world == 1 and not strong and cfg == 2:
+            # secondary timings of SURVEY 8d (never `value`): host buffers in and out, and the single-problem drop-in call
+            t0 = time.perf_counter(); solver.solve_batch_host(wcpu); t0 = time.perf_counter() - t0
+            e2e = []
+            for _ in range(5):
+                t1 = time.perf_counter(); solver.solve_batch_host(wcpu); e2e.append(time.perf_counter() - t1)
+            out["end_to_end"] = {"solves_per_s": B / float(np.median(e2e)), "ms_per_batch": float(np.median(e2e)) * 1e3,
+                                 "what": "frp_nmpc_solve_batch_host: pageable host buffers, hipMalloc + H2D + solve + D2H + hipFree per call (PCIe-inclusive, median of 5)"}
+            import ctypes
+            w0 = workloads.config0()
+            p = solver.ForcesParams(); o = solver.ForcesOutput(); info = solver.ForcesInfo()
+            p.xinit[:] = w0["xinit"][0]; p.x0[:] = w0["x0"][0].ravel(); p.all_parameters[:] = w0["params"][0].ravel(); p.num_of_threads = 1
+            lat = []
+            for i in range(25):
+                t1 = time.perf_counter()
+                flag = solver.lib().FORCESNLPsolver_normal_solve(ctypes.byref(p), ctypes.byref(o), ctypes.byref(info), None, None)
+                lat.append(time.perf_counter() - t1)
+            out["dropin_latency_ms"] = {"value": float(np.median(lat[5:])) * 1e3, "exitflag": int(flag), "iterations": int(info.it),
+                                        "what": "BASELINE configs[0] through FORCESNLPsolver_normal_solve (H2D of the 23.6 KB params, one-problem solve, D2H), warm, median of 20"}
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(w)
+            out["cpu_baseline"] = cpu_baseline(wcpu)
         elif not args.no_cpu:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        try:  # RCCL prints its version banner through C stdio: flush it first so that the JSON line is the LAST line of stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

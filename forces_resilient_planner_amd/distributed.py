@@ -1,8 +1,18 @@
 """Multi-GPU sharding of a batch of independent NMPC problems (one process per GPU).
 
-The path partitions by problem: contiguous batch ranges, no exchange during the solve.
-The only communication is the trivial split/gather around it -- and a 3-scalar reduction for summary
-statistics.  `backend` is "nccl" (= RCCL over xGMI) on the GPU box and "gloo" in the CPU tests.
+The path partitions by problem: contiguous batch ranges, no exchange during the solve.  The only
+communication is the trivial split / gather around it:
+
+  * ``scatter_batch`` / ``gather_batch``: rank 0 owns the full batch; every other rank receives / returns its contiguous
+    shard by point-to-point transfers issued as ONE group (``batch_isend_irecv`` = ncclGroupStart / ncclSend /
+    ncclRecv / ncclGroupEnd on the GPU box, so the seven xGMI links of the root carry the seven shards in parallel);
+  * ``broadcast_nominal`` + ``monte_carlo_fext``: the Monte-Carlo workload (BASELINE configs[4]) ships ONE nominal
+    problem and every rank draws the external-force samples of its own shard on its device (counter-based, so a sample
+    depends on its global index only, not on the sharding);
+  * ``summary_stats``: a 3-scalar reduction for reporting.
+
+The tensors are torch tensors on the rank's device: HBM with backend "nccl" (= RCCL over xGMI) on the GPU box, host
+memory with "gloo" in the CPU tests -- the same code path.
 """
 from __future__ import annotations
 
@@ -24,6 +34,81 @@ def shard_workload(w: dict, rank: int, world: int) -> dict:
         out[k] = v[lo:hi] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v
     out["B"] = hi - lo
     return out
+
+
+def scatter_batch(full, shard, B: int, dist, src: int = 0):
+    """full: list of tensors [B, ...] (meaningful on `src` only, may be None elsewhere); shard: list of tensors
+    [hi - lo, ...] of this rank (allocated by the caller, filled here).  One grouped P2P exchange for all tensors."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ops = []
+    if rank == src:
+        for r in range(world):
+            lo, hi = shard_range(B, r, world)
+            for f, s in zip(full, shard):
+                if r == src:
+                    s.copy_(f[lo:hi])
+                elif hi > lo:
+                    ops.append(dist.P2POp(dist.isend, f[lo:hi].contiguous(), r))
+    else:
+        lo, hi = shard_range(B, rank, world)
+        if hi > lo:
+            for s in shard:
+                ops.append(dist.P2POp(dist.irecv, s, src))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
+def gather_batch(shard, full, B: int, dist, dst: int = 0):
+    """The reverse of scatter_batch: every rank's shard tensors end up in full[lo:hi] on `dst`."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ops = []
+    if rank == dst:
+        for r in range(world):
+            lo, hi = shard_range(B, r, world)
+            for f, s in zip(full, shard):
+                if r == dst:
+                    f[lo:hi].copy_(s)
+                elif hi > lo:
+                    ops.append(dist.P2POp(dist.irecv, f[lo:hi], r))  # a leading-dimension slice is contiguous
+    else:
+        lo, hi = shard_range(B, rank, world)
+        if hi > lo:
+            for s in shard:
+                ops.append(dist.P2POp(dist.isend, s, dst))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
+def broadcast_nominal(tensors, dist, src: int = 0):
+    """One nominal problem (a handful of small tensors) to every rank."""
+    for t in tensors:
+        dist.broadcast(t, src)
+
+
+def _splitmix64(x):
+    """Counter-based 64-bit mixer (Steele, Lea & Flood's SplitMix64 finaliser) on int64 tensors; wrap-around arithmetic."""
+    import torch
+    x = x + torch.tensor(-7046029254386353131, dtype=torch.int64, device=x.device)             # 0x9E3779B97F4A7C15
+    x = (x ^ ((x >> 30) & 0x3FFFFFFFF)) * torch.tensor(-4658895280553007687, dtype=torch.int64, device=x.device)  # 0xBF58476D1CE4E5B9
+    x = (x ^ ((x >> 27) & 0x1FFFFFFFFF)) * torch.tensor(-7723592293110705685, dtype=torch.int64, device=x.device)  # 0x94D049BB133111EB
+    return x ^ ((x >> 31) & 0x1FFFFFFFF)
+
+
+def monte_carlo_fext(fbar, sigma: float, lo: int, hi: int, seed: int, device):
+    """f_ext samples [hi - lo, 3] ~ N(fbar, sigma^2 I) of the problems lo..hi-1 of a Monte-Carlo batch, generated on
+    `device`.  Sample i depends on (seed, i) only: Box-Muller on two SplitMix64 streams indexed by the global problem
+    number, so any sharding of the batch reproduces the single-process batch bit for bit."""
+    import torch
+    idx = torch.arange(lo, hi, dtype=torch.int64, device=device)[:, None] * 8 + torch.arange(3, dtype=torch.int64, device=device)[None, :]
+    base = torch.tensor(int(seed) * 2654435761 % (1 << 62), dtype=torch.int64, device=device)
+    a = _splitmix64(idx * 2 + base)
+    b = _splitmix64(idx * 2 + 1 + base)
+    u1 = (((a >> 11) & ((1 << 53) - 1)).to(torch.float64) + 1.0) / 9007199254740993.0   # (0, 1)
+    u2 = ((b >> 11) & ((1 << 53) - 1)).to(torch.float64) / 9007199254740992.0           # [0, 1)
+    n = torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(2.0 * np.pi * u2)
+    return torch.as_tensor(fbar, dtype=torch.float64, device=device)[None, :] + sigma * n
 
 
 def gather_solutions(z_local, flag_local, iters_local, B: int, dist, device="cpu"):

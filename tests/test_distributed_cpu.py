@@ -55,6 +55,65 @@ def test_two_rank_shard_solve_gather_matches_single_process(B):
     assert stats[2] == B and stats[0] == (fl == 1).sum()
 
 
+def _sg_worker(rank, world, port, B, outq):
+    """rank 0 owns the full batch; scatter the shards (grouped P2P), 'solve' with the oracle, gather back to rank 0:
+    the exact code path bench.py --scaling strong runs on HBM tensors over RCCL."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = workloads.config2(B) if rank == 0 else None
+    N, npar = 20, 130
+    lo, hi = D.shard_range(B, rank, world)
+    f64 = torch.float64
+    full = [torch.from_numpy(w["xinit"]), torch.from_numpy(w["x0"]), torch.from_numpy(w["params"]),
+            torch.from_numpy(w["nfaces"].astype(np.int32))] if rank == 0 else [None] * 4
+    shard = [torch.zeros((hi - lo, 9), dtype=f64), torch.zeros((hi - lo, N, 17), dtype=f64),
+             torch.zeros((hi - lo, N, npar), dtype=f64), torch.zeros((hi - lo, N), dtype=torch.int32)]
+    D.scatter_batch(full, shard, B, dist)
+    ws = dict(xinit=shard[0].numpy(), x0=shard[1].numpy(), params=shard[2].numpy(), nfaces=shard[3].numpy(), N=N, M=30, model=0)
+    if hi > lo:
+        z, fl, info = OL.solve_batch(ws, nthreads=2)
+        it = np.array([i.it for i in info], dtype=np.int32)
+    else:
+        z = np.zeros((0, N, 17)); fl = np.zeros(0, np.int32); it = np.zeros(0, np.int32)
+    out_full = [torch.zeros((B, N, 17), dtype=f64), torch.zeros((B,), dtype=torch.int32), torch.zeros((B,), dtype=torch.int32)] if rank == 0 else [None] * 3
+    D.gather_batch([torch.from_numpy(np.ascontiguousarray(z)), torch.from_numpy(fl.astype(np.int32)), torch.from_numpy(it)], out_full, B, dist)
+    if rank == 0:
+        outq.put(tuple(t.numpy() for t in out_full))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B,world", [(9, 2), (4, 3), (2, 3)])
+def test_scatter_solve_gather_from_rank0_matches_single_process(B, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sg_worker, args=(r, world, port, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    zg, fg, ig = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w = workloads.config2(B)
+    z, fl, info = OL.solve_batch(w)
+    assert np.array_equal(fg, fl) and np.array_equal(zg, z)
+    assert np.array_equal(ig, np.array([i.it for i in info]))
+
+
+def test_monte_carlo_samples_do_not_depend_on_the_sharding():
+    fbar = np.array([0.3, -1.2, 0.8])
+    full = D.monte_carlo_fext(fbar, 0.5, 0, 4099, 7, "cpu").numpy()
+    for world in (2, 8):
+        parts = [D.monte_carlo_fext(fbar, 0.5, *D.shard_range(4099, r, world), 7, "cpu").numpy() for r in range(world)]
+        assert np.array_equal(np.concatenate(parts), full)
+    assert np.all(np.isfinite(full))
+    big = D.monte_carlo_fext(fbar, 0.5, 0, 200000, 11, "cpu").numpy()
+    assert np.max(np.abs(big.mean(0) - fbar)) < 0.01 and np.max(np.abs(big.std(0) - 0.5)) < 0.01
+    assert abs(np.corrcoef(big[:, 0], big[:, 1])[0, 1]) < 0.01 and abs(np.corrcoef(big[:-1, 0], big[1:, 0])[0, 1]) < 0.01
+    assert not np.array_equal(D.monte_carlo_fext(fbar, 0.5, 0, 16, 8, "cpu").numpy(), full[:16])
+
+
 def test_shard_ranges_cover_batch_exactly():
     for B in (1, 7, 4096, 4099):
         for world in (1, 2, 4, 8):
