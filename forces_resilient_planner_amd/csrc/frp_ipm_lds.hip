@@ -639,10 +639,12 @@ __device__ __forceinline__ void model_phase(ldouble *recs, ldouble *xs, ModelSta
     const bool dyn = k < N - 1;
     SEG_DECL();
     // ---- part 1: the step and its linearisation (no multipliers involved)
+#ifndef FRP_NO_YPARK
     if (k < N) {
 #pragma unroll
         for (int i = 0; i < NS; i++) rec[RT_Y + i] = st.y[i];
     }
+#endif
     if (k == 0) {
 #pragma unroll
         for (int i = 0; i < 9; i++) {
@@ -745,10 +747,12 @@ __device__ __forceinline__ void model_phase(ldouble *recs, ldouble *xs, ModelSta
     SEG(4);
     // ---- part 2: gm = M' y_{k+1} - [0; y_k], the linearisation read back from the record this lane has just written
     {
+#ifndef FRP_NO_YPARK
         if (k < N) {
 #pragma unroll
             for (int i = 0; i < NS; i++) st.y[i] = rec[RT_Y + i];
         }
+#endif
         double yn[NS];
 #pragma unroll
         for (int i = 0; i < NS; i++) yn[i] = dpp_move<0x130>(st.y[i]);
@@ -768,13 +772,20 @@ __device__ __forceinline__ void model_phase(ldouble *recs, ldouble *xs, ModelSta
                     gm[i] += DT * ye[i];
                     gm[8 + i] += yp[i];
                     gm[14 + i] += ye[i];
+                    double apv[3], ape[3], avv[3], ave[3], bvw[3]; // row i of the five 3 x 3 blocks: one batch of LDS reads
 #pragma unroll
                     for (int j = 0; j < 3; j++) {
-                        gm[j] += rec[R_LIN + 42 + i * 3 + j] * yv[i];
-                        gm[11 + j] += rec[R_LIN + i * 3 + j] * yp[i] + rec[R_LIN + 18 + i * 3 + j] * yv[i];
-                        gm[14 + j] += rec[R_LIN + 9 + i * 3 + j] * yp[i] + rec[R_LIN + 27 + i * 3 + j] * yv[i];
+                        apv[j] = rec[R_LIN + i * 3 + j]; ape[j] = rec[R_LIN + 9 + i * 3 + j]; avv[j] = rec[R_LIN + 18 + i * 3 + j];
+                        ave[j] = rec[R_LIN + 27 + i * 3 + j]; bvw[j] = rec[R_LIN + 42 + i * 3 + j];
                     }
-                    gT += rec[R_LIN + 36 + i] * yp[i] + rec[R_LIN + 39 + i] * yv[i];
+                    const double bpt = rec[R_LIN + 36 + i], bvt = rec[R_LIN + 39 + i];
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        gm[j] += bvw[j] * yv[i];
+                        gm[11 + j] += apv[j] * yp[i] + avv[j] * yv[i];
+                        gm[14 + j] += ape[j] * yp[i] + ave[j] * yv[i];
+                    }
+                    gT += bpt * yp[i] + bvt * yv[i];
                 }
                 gm[3] += gT;
             }
@@ -1062,9 +1073,17 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     Norms nm = {0, 0, 0, 0, 0, 0};
     double mu = 0.0, step_cc = 0.0;
 #ifndef FRP_R_PRIO
-#define FRP_R_PRIO 2
+#define FRP_R_PRIO 0
 #endif
-    if constexpr (wave == 0) __builtin_amdgcn_s_setprio(FRP_R_PRIO); // the Riccati sweeps are the critical path of every iteration
+#ifndef FRP_H_PRIO
+#define FRP_H_PRIO 2
+#endif
+    // Issue priority: the element-wise waves above the Riccati waves.  A SIMD hosts one wave of each of the three resident
+    // workgroups; the short VALU-dense phases of one problem (model, bounds, faces) otherwise queue behind the long sweep
+    // of another and take twice their stand-alone time, while a sweep (MFMA / latency bound) barely notices the extra
+    // VALU traffic: measured 1.712 vs 1.743 ms per 4096-problem launch (the opposite assignment: no difference to none).
+    if constexpr (wave == 0) __builtin_amdgcn_s_setprio(FRP_R_PRIO);
+    else __builtin_amdgcn_s_setprio(FRP_H_PRIO);
 
     PROF_DECL();
     for (it = 0;;) {
@@ -1387,7 +1406,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 
     // ---------------------------------------------------------------- outputs
     PROF_FLUSH(wave, it);
-    if constexpr (wave == 0) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
     if constexpr (wave == 1) {
         // the objective is reported, not iterated on: evaluated once, at the returned iterate
         double l_obj = 0.0;

@@ -192,16 +192,17 @@ def gen_stage_vectors(path, n=240, seed=W.SEED0):
     print('wrote', path)
 
 
-def gen_solutions(outdir, workers=8):
+def gen_solutions(outdir, workers=int(os.environ.get('GEN_WORKERS', '8'))):
     import tests.oracle_lib as OL
     fams = {
         'config0': [(W.config0(L.MODEL_NORMAL), [0]), (W.config0(L.MODEL_FINAL, weights=W.NORMAL_WEIGHTS), [0]),
                     (W.config0(L.MODEL_NORMAL, (1.5, -2.0, 0.5)), [0]), (W.config0(L.MODEL_FINAL), [0])],
-        'config1': [(W.config1(48), list(range(48)))],
-        'config2': [(W.config2(64), list(range(64))), (W.config2(16, model=L.MODEL_FINAL, seed=W.SEED0 + 33), list(range(16)))],
-        'config3': [(W.config3(24), list(range(24)))],
+        # >= 100 seeded problems per family, at least half of them solved by SLSQP from the caller's own cold
+        # start (fully independent of the oracle); a `final`-model group in every family that the final solver sees
+        'config1': [(W.config1(80), list(range(80))), (W.config1(24, model=L.MODEL_FINAL, seed=W.SEED0 + 32), list(range(24)))],
+        'config2': [(W.config2(100), list(range(100))), (W.config2(24, model=L.MODEL_FINAL, seed=W.SEED0 + 33), list(range(24)))],
+        'config3': [(W.config3(80), list(range(80))), (W.config3(24, model=L.MODEL_FINAL, seed=W.SEED0 + 34), list(range(24)))],
     }
-    ncold = dict(config0=4, config1=8, config2=10, config3=4)
     only = sys.argv[2:] if len(sys.argv) > 2 else None
     for fam, groups in fams.items():
         if only and fam not in only:
@@ -212,7 +213,7 @@ def gen_solutions(outdir, workers=8):
             for b in idx:
                 w1 = dict(N=w['N'], M=w['M'], model=w['model'], xinit=w['xinit'][b], x0=w['x0'][b],
                           params=w['params'][b], nfaces=w['nfaces'][b], z_oracle=zo[b])
-                start = 'cold' if len(jobs) < ncold[fam] or fl[b] != 1 else 'near'
+                start = 'cold' if fam == 'config0' or len(jobs) % 2 == 0 or fl[b] != 1 else 'near'
                 jobs.append((fam, w1, start, 1000 + len(jobs)))
                 meta.append(w1)
         t = time.time()
