@@ -1599,9 +1599,9 @@ static int lds_resident_slots(int B, int N)
         const int v = atoi(e);
         if (v > 0) cap = v;
     }
-    if (B <= cap) return B;
-    const int rounds = (B + cap - 1) / cap;
-    return (B + rounds - 1) / rounds;
+    // every resident workgroup is used: the queue is pulled dynamically, so evening the slots over the "rounds" of the batch
+    // (what the single-wave kernel does) only lowers the residency -- measured 1.58 vs 1.71 ms at B = 4096 (768 vs 683)
+    return B <= cap ? B : cap;
 }
 
 hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
