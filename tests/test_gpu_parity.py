@@ -80,10 +80,10 @@ def test_batch_matches_oracle(cfg, B):
     z, fl, it, info = solver.solve_batch_host(w)
     zo, flo, io = OL.solve_batch(w)
     ito = np.array([i.it for i in io])
-    assert (fl == flo).mean() >= 0.99, (fl != flo).sum()
+    assert (fl == flo).mean() >= 0.995, (fl != flo).sum()
     ok = (fl == 1) & (flo == 1)
     assert ok.mean() > 0.8
-    assert (it[ok] == ito[ok]).mean() >= 0.95
+    assert (it[ok] == ito[ok]).mean() >= 0.99
     # same iteration count -> the same iterates up to summation order; a problem that stops one iteration apart (a
     # residual within rounding of its tolerance) still agrees to the accuracy the 1e-4 tolerances define
     same = ok & (it == ito)
@@ -105,7 +105,7 @@ def test_batch_matches_scipy_fixtures(fam, golden_dir):
                  N=N, M=M, model=int(model))
         z, fl, it, info = solver.solve_batch_host(w)
         conv = fl == 1
-        assert conv.mean() > 0.9
+        assert conv.all(), (fam, int(model), np.where(~conv)[0])  # every problem SLSQP solved is solved here too (as by the oracle)
         dz = np.max(np.abs(z[conv] - g["z"][sel][conv]), axis=(1, 2))
         df = np.abs(info[conv, 4] - g["f"][sel][conv]) / np.maximum(1e-9, np.abs(g["f"][sel][conv]))
         # reference tolerances (1e-4): weakly active bounds are resolved to ~sqrt(tol_comp) only (see test_oracle.py)
@@ -324,11 +324,13 @@ def test_horizon_lengths_cover_every_lane_mapping(N):
     w = workloads.config3(24, N=N, M=15)
     z, fl, it, info = solver.solve_batch_host(w)
     zo, flo, io = OL.solve_batch(w)
-    assert (fl == flo).mean() >= 0.9
+    # thresholds = what the randomised soak shows (profiles/r02_soak.txt: 5.0 M problems over all horizons, no launch with
+    # more than 0.5 % differing flags; profiles/r02_sweep_check.txt: none in 147 k): a 24-problem batch must agree exactly
+    assert np.array_equal(fl, flo), (fl, flo)
     ok = (fl == 1) & (flo == 1)
     assert ok.sum() >= 12
     same = ok & (it == np.array([i.it for i in io]))
-    assert same.sum() >= 0.9 * ok.sum() and np.max(np.abs(z[same] - zo[same])) < 1e-6
+    assert same.sum() >= ok.sum() - 1 and np.max(np.abs(z[same] - zo[same])) < 1e-6
     assert np.max(np.abs(z[ok] - zo[ok])) < 1e-3
 
 

@@ -94,7 +94,7 @@ def test_solver_matches_scipy_fixtures(fam, golden_dir):
         assert flt == 1 and np.max(np.abs(zt - g["z"][i])) < 3e-4, (fam, i, flt, np.max(np.abs(zt - g["z"][i])))
         assert abs(info.pobj - g["f"][i]) / max(1e-9, abs(g["f"][i])) < 1e-4
         assert info.res_eq <= 1e-4 and info.rsnorm <= 1e-4 and info.rcompnorm <= 1e-4 and info.res_ineq <= 1e-4
-    assert nconv >= 0.7 * n
+    assert nconv == int((g["status"] == 0).sum()) and nconv >= 0.7 * n
 
 
 def test_padding_detection_equals_explicit_face_counts():
