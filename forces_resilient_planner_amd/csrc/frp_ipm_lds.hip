@@ -820,6 +820,21 @@ __device__ __forceinline__ void hessian_phase(ldouble *rec, const HessState &hs,
     }
 }
 
+// Live corridor rows of a stage when the caller gives no face counts: trailing all-zero rows are padding
+// (forces_normal.cpp:127-135).  The loop is lane-divergent (face counts differ per stage), so it lives in a function of its
+// own that must compile WITHOUT scratch: the gfx950 backend can place a VGPR spill at the exit of a lane-divergent loop,
+// where it executes with an empty EXEC mask and saves nothing (tests/test_capi_cpu.py checks the scratch size).
+__device__ __noinline__ int count_live_faces(const double *pk, int M)
+{
+    int nf = M;
+    while (nf > 0) {
+        const double *r = pk + NPRE + 3 * (nf - 1);
+        if (r[0] == 0.0 && r[1] == 0.0 && r[2] == 0.0 && pk[NPRE + 3 * M + nf - 1] >= -HU) nf--;
+        else break;
+    }
+    return nf;
+}
+
 // ================================================================== the solve, one role per wave
 struct Shared {
     ldouble *recs, *xs;
@@ -1005,14 +1020,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         int nf = 0;
         if (kact) {
             if (a.nfaces) nf = a.nfaces[(size_t)b * N + k];
-            else { // trailing all-zero rows are padding (forces_normal.cpp:127-135)
-                nf = M;
-                while (nf > 0) {
-                    const double *r = pk + NPRE + 3 * (nf - 1);
-                    if (r[0] == 0.0 && r[1] == 0.0 && r[2] == 0.0 && pk[NPRE + 3 * M + nf - 1] >= -HU) nf--;
-                    else break;
-                }
-            }
+            else nf = count_live_faces(pk, M);
             if (nf > MF || nf < 0 || nf > FL * H) { bad_param = 1; nf = 0; }
             if (half == 0) mcount = 34 + nf;
             const double *z0 = a.x0 + ((size_t)b * N + k) * NZ;

@@ -254,6 +254,25 @@ def test_stage_divergent_phases_do_not_spill(tmp_path):
         assert "s_cbranch_execnz" not in body
 
 
+def test_lds_kernel_has_no_spill_behind_a_lane_divergent_loop(tmp_path):
+    """The same hazard in the LDS-resident kernel (frp_ipm_lds.hip): its only lane-divergent loop (the padding-row
+    detection) is a function of its own and must use no scratch."""
+    import re
+    import subprocess
+    from forces_resilient_planner_amd import build
+    src = os.path.join(build.CSRC, "frp_ipm_lds.hip")
+    out = tmp_path / "lds.s"
+    subprocess.check_call([build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                           "-I" + os.path.join(build.ROOT, "include"), src, "-o", str(out)], stderr=subprocess.DEVNULL)
+    txt = out.read_text()
+    scratch = {name: int(sz) for name, sz in re.findall(r"^(_ZN3frp\w+):.*?^; ScratchSize: (\d+)", txt, flags=re.M | re.S)}
+    det = [n for n in scratch if "count_live_faces" in n]
+    assert len(det) == 1 and scratch[det[0]] == 0, scratch
+    # (every other loop of that file runs over the wave-uniform horizon length or a compile-time face count: the kernel
+    # bodies, which do use scratch, contain no per-lane trip count)
+    assert len([n for n in scratch if "nmpc_ipm_lds_kernel" in n]) >= 6
+
+
 def test_header_is_plain_c99(tmp_path):
     """The boundary is a C ABI: include/frp_nmpc.h must compile as strict C99 on its own (no C++, no torch types)."""
     import subprocess
