@@ -120,15 +120,15 @@ def cpu_baseline(w, seconds_target=12.0):
                 single_thread_solves_per_s=n1 / dt1, converged_frac=conv / solved, reference_anchor=anchor)
 
 
-def pmc_traffic(batch):
+def pmc_traffic(batch, kernel):
     """HBM-side bytes per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes of this
-    same command, calibrated on this solver's access width -- tools/collect_profiles.sh, tools/summarize_profiles.py),
-    taken from the newest committed profiles/*_pmc_traffic.json whose batch size matches; None otherwise."""
+    same command, calibrated on this solver's access width -- tools/collect_r02.sh, tools/summarize_profiles.py),
+    taken from the newest committed profiles/*_pmc_traffic.json of the same kernel and batch size; None otherwise."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         try:
             t = json.load(open(f))
-            if int(t["batch"]) == int(batch):
+            if int(t["batch"]) == int(batch) and (kernel + "<") in t.get("kernel", ""):
                 return float(t["bytes_per_launch"]), os.path.basename(f)
         except Exception:
             pass
@@ -351,7 +351,8 @@ def main():
         achieved_tf = B * f_solve / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
         alg_bytes = 8.0 * (9 + 17 * N + N * (10 + 4 * M) + 1) + 8.0 * 17 * N + 136.0  # dense ABI image of one solve: params + output + info (26 456 B at N = 20, M = 30)
         achieved_gbs = B * alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(B)
+        kname = "nmpc_ipm_kernel" if os.environ.get("FRP_KERNEL", "") == "r01" else "nmpc_ipm_lds_kernel"
+        traffic, traffic_src = pmc_traffic(B, kname) if cfg == 2 else (None, None)
         names = {2: "BASELINE.json configs[2]: N=20, constant f_ext~U[-3,3]^3, 6-face tightened corridor per stage, cold start, reference 30-row parameter layout",
                  3: "BASELINE.json configs[3]: N=30, time-varying f_ext, per-stage polytopes with <=15 faces, cold start",
                  4: "BASELINE.json configs[4]: Monte-Carlo f_ext~N(fbar,0.5^2 I) around one nominal problem, N=20, warm-started receding horizon, one step = one tick (pack + solve + update on the device)"}
@@ -371,7 +372,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel": "nmpc_ipm_lds_kernel" if os.environ.get("FRP_KERNEL", "") == "" else "nmpc_ipm_kernel (FRP_KERNEL=r01)", "kernel_ms": kernel_ms,
+                         "kernel": kname, "kernel_ms": kernel_ms,
                          "flops_per_launch": B * f_solve,
                          "note": "FP64 (vector == matrix peak 78.6 TFLOP/s); flops = SURVEY 8d definition "
                                  "mean_it * N * F_stage per solve (F_stage = 31.5 kflop at 6 faces)",
