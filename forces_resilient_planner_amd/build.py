@@ -47,7 +47,11 @@ def build_ubench(verbose=True):
         if not f.endswith(".hip"):
             continue
         src, exe = os.path.join(d, f), os.path.join(d, f[:-4])
-        if os.path.exists(exe) and os.path.getmtime(exe) >= os.path.getmtime(src):
+        deps = [src]
+        if "csrc/" in open(src).read():  # a probe that includes the product kernels is rebuilt with them
+            c = os.path.join(ROOT, "forces_resilient_planner_amd", "csrc")
+            deps += [os.path.join(c, g) for g in os.listdir(c)]
+        if os.path.exists(exe) and os.path.getmtime(exe) >= max(os.path.getmtime(g) for g in deps):
             continue
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-Wno-unused-value", src, "-o", exe]
         if verbose:

@@ -43,14 +43,17 @@ constexpr int R_P = 128;     // P_k, packed lower triangle (91)
 constexpr int R_PV = 219;    // p_k of the corrector solve (13)
 constexpr int R_PD = 232;    // P_{k+1} d_k (13); after the corrector's backward sweep: y+_k of the Newton system
 constexpr int R_PHIB = 245;  // corrector rhs phi_cc = PHIB + (sigma mu) PHIC (17 + 17), bound rows and cost;
-constexpr int R_PHIC = 262;  //   evaluation phase: PHIB = cost gradient + bound multipliers (stationarity residual)
-constexpr int R_CB = 279;    // corridor part (pos entries) of PHIB; evaluation phase: A' lam (stationarity residual)
-constexpr int R_CC = 282;    // corridor part of PHIC; evaluation phase: corridor part of phi_aff
-constexpr int R_HC = 285;    // (u_i, w_i) cost coupling -2 w_rate of this stage
-constexpr int R_ZERO = 286, R_ONE = 287, R_DT = 288; // constants the gathers pick up
-constexpr int R_DUMP = 289;  // target of masked-out writes (never read)
-constexpr int R_DZ = 290;    // Newton step [du(4); ds(13)]; evaluation phase: M'y part of the stationarity residual
-constexpr int RS = 307;      // odd stride: lane == stage accesses are conflict-free
+constexpr int R_CB = 262;    //   corridor part (pos entries) of PHIB; evaluation phase: A' lam (stationarity residual)
+constexpr int R_BC = 21;     // distance from every "B" slot (PHIB, CB) to its "C" twin (PHIC, CC): one ds_read2 fetches both
+constexpr int R_PHIC = R_PHIB + R_BC; // evaluation phase: PHIB = cost gradient + bound multipliers (stationarity residual)
+constexpr int R_CC = R_CB + R_BC;     // corridor part of PHIC; evaluation phase: corridor part of phi_aff
+constexpr int R_HC = 286;    // (u_i, w_i) cost coupling -2 w_rate of this stage
+constexpr int R_ZERO = 287, R_ONE = 288, R_DT = 289; // constants the gathers pick up
+constexpr int R_DUMP = 290;  // target of masked-out writes (never read)
+constexpr int R_DZ = 291;    // Newton step [du(4); ds(13)]; evaluation phase: M'y part of the stationarity residual
+constexpr int R_ZERO2 = R_ZERO + R_BC; // second zero, R_BC behind the first: masked (B, C) pair reads
+constexpr int RS = 309;      // odd stride: lane == stage accesses are conflict-free
+static_assert(R_PHIC + 17 <= R_CC && R_CC + 3 <= R_HC && R_DZ + 17 <= R_ZERO2 && R_ZERO2 < RS, "record tail");
 static_assert(R_HD + REC_HD_SIZE <= R_PV && R_PV + 13 <= R_PD, "overlay region");
 
 // workgroup-shared scratch (doubles)
@@ -105,7 +108,7 @@ __host__ __device__ constexpr int c_src(int row, int col, int which)
     }
     return which == 0 ? o1 : (which == 1 ? o2 : o3);
 }
-enum { T_M = 0, T_C1 = 4, T_C2 = 8, T_C3 = 12, T_PP = 16, T_PD = 20, T4_MT = 24, T4_MTT = 28, T4_TT = 32, T4_P = 36, T_ROWS = 40 };
+enum { T_M = 0, T_C1 = 4, T_C2 = 8, T_C3 = 12, T_PP = 16, T_PD = 20, T4_MT = 24, T4_MTT = 28, T4_P = 32, T4_MU = 36, T4_MTTU = 37, T4_TS = 38, T_ROWS = 39 };
 struct LaneTables {
     unsigned short v[T_ROWS][64];
 };
@@ -124,12 +127,18 @@ constexpr LaneTables make_tables()
             t.v[T_PP + r][lane] = (unsigned short)((trow <= 12 && c <= trow) ? R_P + trow * (trow + 1) / 2 + c : R_DUMP);
             t.v[T_PD + r][lane] = (unsigned short)((c == 13 && trow <= 12) ? R_PD + trow : R_DUMP);
             const int row = 4 * qI + qj, col = 4 * ((qI + r) & 3) + qk;
-            t.v[T4_MT + r][lane] = (unsigned short)m_src(row, col);
-            t.v[T4_MTT + r][lane] = (unsigned short)m_src(col, row);
-            t.v[T4_TT + r][lane] = (unsigned short)(row < 4 ? R_T + 16 * row + col : R_ZERO);
+            // forward sweep: the u columns go through T4_MU, row 13 carries the constant 1 from stage to stage
+            t.v[T4_MT + r][lane] = (unsigned short)(col < 4 ? R_ZERO : (row == 13 && col == 13 ? R_ONE : m_src(row, col)));
+            // backward vector sweep: q rows 0..3 come from T4_MTTU (the full product keeps phi_w there), rows 13..15 are unused
+            t.v[T4_MTT + r][lane] = (unsigned short)((row < 4 || row > 12) ? R_ZERO : m_src(col, row));
             const int hi = row > col ? row : col, lo = row > col ? col : row;
             t.v[T4_P + r][lane] = (unsigned short)((row <= 12 && col <= 12) ? R_P + hi * (hi + 1) / 2 + lo : R_ZERO);
         }
+        // "sliced" operands (one register): block qI contracts ITS quarter 4 qI .. 4 qI + 3 of the long dimension, the four
+        // blocks are summed afterwards -- for products with only four output rows (du, q_u) and for Mt[:, u] du
+        t.v[T4_MU][lane] = (unsigned short)m_src(4 * qI + qj, qk);                  // A_b[i][k] = Mt[4b+i][k], k = u column
+        t.v[T4_MTTU][lane] = (unsigned short)m_src(4 * qI + qk, qj);                // A_b[i][k] = Mt[4b+k][i] = Mt'[i][4b+k]
+        t.v[T4_TS][lane] = (unsigned short)(R_T + 16 * qj + 4 * qI + qk);           // A_b[i][k] = T'[i][4b+k]
     }
     return t;
 }
@@ -138,6 +147,7 @@ __device__ const LaneTables g_tab = make_tables();
 __device__ __forceinline__ int tab(int row, int lane) { return (int)g_tab.v[row][lane]; }
 
 #define BAR() __syncthreads()
+#define FRP_SB() __builtin_amdgcn_sched_barrier(0)
 
 // LDS pointers carry their address space: through a generic double* every access of a non-inlined function would pay
 // 64-bit address arithmetic and the null check of the address-space cast
@@ -281,16 +291,6 @@ __device__ __forceinline__ void stage0_solve(ldouble *xs, int lane, double pw_he
     WSYNC();
 }
 
-// quad 0 of every 16-lane row copied to the other three quads of the row (DPP row_shr with a bank mask: no selects)
-__device__ __forceinline__ double bcast_quad0(double v)
-{
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    int lo = (int)(unsigned)b, hi = (int)(unsigned)(b >> 32);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x114, 0xF, 0x2, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x114, 0xF, 0x2, false); // row_shr:4 -> quad 1
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x118, 0xF, 0x4, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x118, 0xF, 0x4, false); // row_shr:8 -> quad 2
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x11C, 0xF, 0x8, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x11C, 0xF, 0x8, false); // row_shr:12 -> quad 3
-    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
-}
 template <int N4> // lane c of a 16-lane row <- lane c + N4 (row_shl)
 __device__ __forceinline__ double row_shl(double v)
 {
@@ -467,149 +467,256 @@ __device__ __noinline__ int sweep_factor(ldouble *recs, ldouble *xs, int N, doub
     return fail;
 }
 
-// ---- vector-only backward sweep (corrector): new rhs phi_cc = PHIB + smu PHIC (+ the corridor parts on the pos rows):
-//   q~ = phi~ + M'(P d + p+),  [kbar; Kbar'q_u] = T'' q_u,  p_x = q~_x - Kbar' q_u,  p_w = phi_w - hc kbar.
-// Updates the kbar column of T' and stores p_k.  All mat-vec products on the 4x4x4 MFMA, vectors in V layout.
-// Two operand sets alternate: the set a step has consumed is refilled for the stage two steps on, so every gather has
-// a whole step to land.
-struct BackOps {
-    d4 Mt;
-    double phi, hc, phiw, tp, pd;
-};
-struct BackTabs {
-    int mo[4], pho, cbo, cco, pwo, pdo, kbo, pvo;
-};
-__device__ __forceinline__ void back_gather(cldouble *rn, const BackTabs &t, int lane, double smu, double fx, BackOps &o)
+// ---- the two vector sweeps.  One wavefront issues in order and its MFMAs do not overlap its own VALU / LDS instructions
+// (tools/ubench/issue_rate.hip, fwd_model.hip: a 4x4x4 FP64 MFMA costs 16 issue cycles, every other instruction ~4.5, and
+// independent work only ADDS its issue cycles), so a sweep costs the SUM of its instructions plus the dependency stalls
+// that are left: both sweeps are written for instruction count.
+//   * masks are encoded in the gather addresses (a lane that must see 0 / 1 / hc reads the record's constant slots), the
+//     constant 1 of the affine column rides along as row 13 of the sweep vector: no selects on the serial path;
+//   * products with four output rows (du, q_u) are ONE "sliced" MFMA (block b contracts quarter b of the long dimension)
+//     followed by a sum over the quads of every 16-lane row, which also leaves the result where the next MFMA wants it;
+//   * the LDS traffic is issued through inline asm: every operand has its own per-lane byte address that advances once
+//     per pass of four stages, the stage offset is the instruction's immediate (the compiler re-derives every address
+//     from the tables each stage and, with branches around, waits for ALL outstanding LDS operations), and the waits
+//     count exactly the operations younger than the operand set a step is about to consume.
+// Vectors are in V layout: lane 16 a + 4 b + j holds row 4 b + a.  Two operand sets alternate, each refilled for the
+// stage two steps on, so a gather has a whole step to land.
+template <int OFF>
+__device__ __forceinline__ double lds_ld(unsigned addr)
 {
-#pragma unroll
-    for (int r = 0; r < 4; r++) o.Mt[r] = rn[t.mo[r]];
-    const double ph = (rn[R_PHIB + t.pho] + rn[t.cbo]) + smu * (rn[R_PHIC + t.pho] + rn[t.cco]);
-    o.phi = fx != 0.0 ? ph : 0.0;
-    o.phiw = rn[R_PHIB + t.pwo] + smu * rn[R_PHIC + t.pwo];
-    o.hc = rn[R_HC];
-    o.tp = rn[R_T + lane]; // read before the stage's own step rewrites its kbar column
-    o.pd = rn[t.pdo];
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
 }
-__device__ __forceinline__ void back_step(ldouble *recs, int kk, bool last, int lane, double smu, double fx, double f0, const BackTabs &t, BackOps &o, double &pv)
+template <int OFF>
+__device__ __forceinline__ void lds_st(unsigned addr, double v)
 {
-    ldouble *rec = recs + kk * RS;
-    double q = o.phi;
-    if (!last) q = matvec4s(o.Mt, o.pd + pv, o.phi);
-    const double ctp = o.tp, chc = o.hc, cphiw = o.phiw;
-    back_gather(recs + (kk > 1 ? kk - 2 : 0) * RS, t, lane, smu, fx, o); // this set's next stage (clamped: unused at the end)
-    // q_u (rows 0..3, quad 0) to every quad of its row, then E[c] = sum_k T'[k][c] q_u[k]
-    const double E = mfma4(ctp, bcast_quad0(q), 0.0);
-    // rows 0..3: p_w = phi_w - hc kbar;  rows 4..12: p_x = q~_x - Kbar' q_u;  rows 13..15: 0   (f0 = rows 0..3, fx = rows 0..12)
-    const double pw = cphiw - chc * E, px = q - E;
-    const double pn = f0 != 0.0 ? pw : (fx != 0.0 ? px : 0.0);
-    rec[t.kbo] = E;  // kbar (rows 0..3; the other lanes write the dump slot)
-    rec[t.pvo] = pn; // p_k for y_k = P_k ds_k + p_k
+    asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(ldouble *p) { return (unsigned)(unsigned long long)p; }
+constexpr int RSB = RS * 8; // record stride in bytes
+
+// vector-only backward sweep (corrector): new rhs phi_cc = PHIB + smu PHIC (+ the corridor parts on the pos rows):
+//   q~ = phi~ + M'(P d + p+),  E = T'' q_u,  p_x = q~_x - E_x,  p_w = phi_w - hc E_w;  kbar = E_w replaces column 13 of T'.
+// The addresses sit on the LOWEST stage a pass touches (DS offsets are unsigned): a pass of two steps at stages kk, kk-1
+// refills for kk-2, kk-3 with the addresses at kk-3.
+struct BackAddr {
+    unsigned m0, m1, m2, m3, mu, ph, cb, pu, hf, tp, pd, wk, wp;
+    __device__ __forceinline__ void step(int n)
+    {
+        m0 += n; m1 += n; m2 += n; m3 += n; mu += n; ph += n; cb += n; pu += n; hf += n; tp += n; pd += n; wk += n; wp += n;
+        // opaque to the optimiser: otherwise every address is re-derived from the tables and the induction variable at
+        // every use (two VALU additions per LDS access instead of thirteen per pass)
+        asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "+v"(mu), "+v"(ph), "+v"(cb), "+v"(pu), "+v"(hf), "+v"(tp), "+v"(pd), "+v"(wk), "+v"(wp));
+    }
+};
+struct BackOps {
+    double m0, m1, m2, m3, mu, phb, phc, cbb, cbc, pub, puc, hf, tp, pd;
+};
+template <int K>
+__device__ __forceinline__ void back_gather(const BackAddr &p, BackOps &x)
+{
+    x.pd = lds_ld<K * RSB>(p.pd);
+    x.mu = lds_ld<K * RSB>(p.mu);
+    x.pub = lds_ld<K * RSB>(p.pu);               // quad 0: phi_u parts, other quads: 0
+    x.puc = lds_ld<K * RSB + R_BC * 8>(p.pu);
+    x.m0 = lds_ld<K * RSB>(p.m0);
+    x.m1 = lds_ld<K * RSB>(p.m1);
+    x.m2 = lds_ld<K * RSB>(p.m2);
+    x.m3 = lds_ld<K * RSB>(p.m3);
+    x.phb = lds_ld<K * RSB>(p.ph);               // rows 0..3 of the full q carry phi_w (their M' rows are masked out), rows 4..12 phi_x
+    x.phc = lds_ld<K * RSB + R_BC * 8>(p.ph);
+    x.cbb = lds_ld<K * RSB>(p.cb);               // corridor parts: pos rows, 0 elsewhere
+    x.cbc = lds_ld<K * RSB + R_BC * 8>(p.cb);
+    x.tp = lds_ld<K * RSB>(p.tp);                // read before the stage's own step rewrites its kbar column
+    x.hf = lds_ld<K * RSB>(p.hf);                // quad 0: hc, other quads: 1
+}
+template <int YOUNGER>
+__device__ __forceinline__ void back_wait(BackOps &x)
+{
+    asm volatile("s_waitcnt lgkmcnt(%14)"
+                 : "+v"(x.m0), "+v"(x.m1), "+v"(x.m2), "+v"(x.m3), "+v"(x.mu), "+v"(x.phb), "+v"(x.phc), "+v"(x.cbb), "+v"(x.cbc), "+v"(x.pub),
+                   "+v"(x.puc), "+v"(x.hf), "+v"(x.tp), "+v"(x.pd)
+                 : "n"(YOUNGER));
+}
+template <int K, bool FIRST>
+__device__ __forceinline__ void back_step(const BackAddr &p, const BackOps &x, double smu, double &pv)
+{
+    // serial path: p+ -> q_u -> E -> p;  the full q (needed only for p_x = q_x - E) runs beside it
+    double d = __builtin_fma(smu, x.puc, x.pub);
+    double q = __builtin_fma(smu, x.phc + x.cbc, x.phb + x.cbb);
+    if (!FIRST) { // (the last stage of the horizon has no successor)
+        const double tv = x.pd + pv;
+        FRP_SB();
+        d = mfma4(x.mu, tv, d);
+        FRP_SB();
+        const double t1 = quad_rot<1>(tv), t2 = quad_rot<2>(tv), t3 = quad_rot<3>(tv);
+        q = mfma4(x.m0, tv, q);
+        FRP_SB();
+        const double r = d + quad_rot<1>(d);
+        FRP_SB();
+        q = mfma4(x.m1, t1, q);
+        FRP_SB();
+        d = r + quad_rot<2>(r);
+        FRP_SB();
+        q = mfma4(x.m2, t2, q);
+        q = mfma4(x.m3, t3, q);
+        FRP_SB();
+    } else {
+        const double r = d + quad_rot<1>(d);
+        d = r + quad_rot<2>(r);
+    }
+    const double E = mfma4(x.tp, d, 0.0); // d = q_u[a] in every lane of row a;  E[c] = sum_k T'[k][c] q_u[k], V layout
+    const double pn = __builtin_fma(-x.hf, E, q);
+    FRP_SB();
+    // (pn first: the hazard recognizer does not see inside inline asm, and an LDS store that reads an MFMA result needs wait
+    // states after the MFMA; behind the store of pn -- a VALU result computed FROM E -- the MFMA has long retired)
+    lds_st<K * RSB>(p.wp, pn); // p_k for y_k = P_k ds_k + p_k
+    lds_st<K * RSB>(p.wk, E);  // kbar (rows 0..3; the other lanes write the dump slot)
     pv = pn;
 }
 
 __device__ __noinline__ void sweep_backvec(ldouble *recs, ldouble *xs, int N, double smu)
 {
     N = uni(N); smu = uni(smu);
-    const int lane = threadIdx.x & 63;
-    const int idx = 4 * ((lane >> 2) & 3) + (lane >> 4); // V layout: the vector row this lane holds
-    BackTabs t;
-#pragma unroll
-    for (int r = 0; r < 4; r++) t.mo[r] = tab(T4_MTT + r, lane);
-    t.pho = idx <= 12 ? zi_of(idx) : 0;                       // q~ rows [u; x] -> z index
-    t.cbo = (idx >= 4 && idx <= 6) ? R_CB + idx - 4 : R_ZERO;  // corridor parts: pos rows only
-    t.cco = (idx >= 4 && idx <= 6) ? R_CC + idx - 4 : R_ZERO;
-    t.pwo = 4 + (idx & 3);                                    // p_w rows -> z index of w
-    t.pdo = idx <= 12 ? R_PD + idx : R_ZERO;
-    t.kbo = idx < 4 ? R_T + 16 * idx + 13 : R_DUMP;
-    t.pvo = idx <= 12 ? R_PV + idx : R_DUMP;
-    const double fx = idx <= 12 ? 1.0 : 0.0, f0 = idx < 4 ? 1.0 : 0.0;
+    const int lane = threadIdx.x & 63, a = lane >> 4, b = (lane >> 2) & 3;
+    const int idx = 4 * b + a; // V layout: the vector row this lane holds
+    ldouble *base = recs + (N - 2) * RS; // (N >= 2)
+    BackAddr p;
+    p.m0 = lds_addr(base + tab(T4_MTT + 0, lane)); p.m1 = lds_addr(base + tab(T4_MTT + 1, lane));
+    p.m2 = lds_addr(base + tab(T4_MTT + 2, lane)); p.m3 = lds_addr(base + tab(T4_MTT + 3, lane));
+    p.mu = lds_addr(base + tab(T4_MTTU, lane));
+    p.ph = lds_addr(base + R_PHIB + 4 + idx);                                   // z index of q row idx: w (4..7), x (8..16); rows 13..15 read finite junk that meets zero columns
+    p.cb = lds_addr(base + ((idx >= 4 && idx <= 6) ? R_CB + idx - 4 : R_ZERO)); // corridor parts: pos rows only
+    p.pu = lds_addr(base + (b == 0 ? R_PHIB + a : R_ZERO));
+    p.hf = lds_addr(base + (b == 0 ? R_HC : R_ONE));
+    p.tp = lds_addr(base + R_T + lane);
+    p.pd = lds_addr(base + (idx <= 12 ? R_PD + idx : R_ZERO));
+    p.wk = lds_addr(base + (b == 0 ? R_T + 16 * a + 13 : R_DUMP));
+    p.wp = lds_addr(base + (idx <= 12 ? R_PV + idx : R_DUMP));
+    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): nothing of the compiler's own LDS traffic is left in flight
+    // Every step starts by issuing the gather of the NEXT stage into the other operand set and ends with a wait that ties
+    // that set: a load result never crosses a control-flow edge while in flight (the register allocator may copy a value
+    // on an edge, and a copy of a register whose load has not landed copies stale data).
     double pv = 0.0;
     BackOps A, B;
-    back_gather(recs + (N - 1) * RS, t, lane, smu, fx, A);
-    back_gather(recs + (N > 1 ? N - 2 : 0) * RS, t, lane, smu, fx, B);
-    int kk = N - 1;
-    for (; kk >= 1; kk -= 2) {
-        back_step(recs, kk, kk == N - 1, lane, smu, fx, f0, t, A, pv);
-        back_step(recs, kk - 1, false, lane, smu, fx, f0, t, B, pv);
+    back_gather<1>(p, A); // stage N-1
+    back_wait<0>(A);
+    back_gather<0>(p, B); // stage N-2
+    FRP_SB();
+    back_step<1, true>(p, A, smu, pv);
+    back_wait<2>(B);
+    int s_ = N - 2; // B holds stage s_, the addresses sit on it
+    for (; s_ >= 4; s_ -= 4) { // pass: steps at stages s_ .. s_-3, gathers for s_-1 .. s_-4, addresses at s_-4
+        p.step(-4 * RSB);
+        back_gather<3>(p, A); FRP_SB(); back_step<4, false>(p, B, smu, pv); back_wait<2>(A);
+        back_gather<2>(p, B); FRP_SB(); back_step<3, false>(p, A, smu, pv); back_wait<2>(B);
+        back_gather<1>(p, A); FRP_SB(); back_step<2, false>(p, B, smu, pv); back_wait<2>(A);
+        back_gather<0>(p, B); FRP_SB(); back_step<1, false>(p, A, smu, pv); back_wait<2>(B);
     }
-    if (kk == 0) back_step(recs, 0, N == 1, lane, smu, fx, f0, t, A, pv);
+    for (; s_ >= 1; s_--) {
+        p.step(-RSB);
+        back_gather<0>(p, A); FRP_SB(); back_step<1, false>(p, B, smu, pv); back_wait<2>(A);
+        B = A; // (landed values: safe to copy)
+    }
+    back_step<0, false>(p, B, smu, pv); // stage 0
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // p_w[g] sits in the quad-0 lanes of row g; the stage-0 solve wants it in the lanes (g, 13)
     stage0_solve(xs, lane, __shfl(pv, lane & 48));
     WSYNC();
 }
 
-// ---- forward sweep: dz for all stages.  du = -T' [hc dw; dx; 1],  ds+ = Mt [du; dx; 1].
-// WITH_Y (corrector pass): also y+_k = P_k ds_k + p_k (stored in the P d slot of the stage, which is dead by then).
-// Two alternating operand sets as in the backward sweep.
-struct FwdOps {
-    d4 tt, mt, Pk;
-    double hc, pk;
-};
-struct FwdTabs {
-    int mto[4], tto[4], pmo[4], pvo, duo, dso, yo;
-};
-template <bool WITH_Y>
-__device__ __forceinline__ void fwd_gather(cldouble *rn, const FwdTabs &t, FwdOps &o)
-{
-#pragma unroll
-    for (int s = 0; s < 4; s++) { o.tt[s] = rn[t.tto[s]]; o.mt[s] = rn[t.mto[s]]; }
-    o.hc = rn[R_T + 14];
-    if (WITH_Y) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) o.Pk[r] = rn[t.pmo[r]];
-        o.pk = rn[t.pvo];
+// forward sweep: dz for all stages.  du = -T' [hc dw; dx; 1],  ds+ = Mt [du; dx; 1].
+struct FwdAddr {
+    unsigned m0, m1, m2, m3, ts, mu, hf, wu, ws;
+    __device__ __forceinline__ void step(int n)
+    {
+        m0 += n; m1 += n; m2 += n; m3 += n; ts += n; mu += n; hf += n; wu += n; ws += n;
+        asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "+v"(ts), "+v"(mu), "+v"(hf), "+v"(wu), "+v"(ws)); // (see BackAddr::step)
     }
-}
-template <bool WITH_Y>
-__device__ __forceinline__ void fwd_step(ldouble *recs, int N, int kk, double f0, double f13, const FwdTabs &t, FwdOps &o, double &v)
+};
+struct FwdOps {
+    double m0, m1, m2, m3, ts, mu, hf;
+};
+template <int K> // operands of the stage K records above the pass base
+__device__ __forceinline__ void fwd_gather(const FwdAddr &p, FwdOps &x)
 {
-    ldouble *rec = recs + kk * RS;
-    // rows 0..3 (f0): hc dw;  row 13 (f13): the constant 1 that multiplies the kbar / d column;  other rows: v
-    const double hv = o.hc * v;
-    const double v1 = f0 != 0.0 ? hv : (f13 != 0.0 ? 1.0 : v);
-    const double D1 = matvec4s(o.tt, v1, 0.0);
-    double Y = 0.0;
-    if (WITH_Y) Y = matvec4(o.Pk, v, o.pk); // y+_k = P_k ds_k + p_k
-    const double du = -D1;
-    const double v2 = f0 != 0.0 ? du : (f13 != 0.0 ? 1.0 : v);
-    const double D2 = matvec4s(o.mt, v2, 0.0);
-    fwd_gather<WITH_Y>(recs + (kk + 2 < N ? kk + 2 : N - 1) * RS, t, o); // this set's next stage (clamped: unused at the end)
-    // branch-free LDS writes: the four replicas of a row (lane & 3) write the same value to the same slot
-    rec[t.duo] = du;
-    rec[t.dso] = v;
-    if (WITH_Y) rec[t.yo] = Y;
-    v = D2; // rows 13..15 of Mt are zero
+    x.ts = lds_ld<K * RSB>(p.ts);
+    x.hf = lds_ld<K * RSB>(p.hf); // quad 0: hc, other quads: 1
+    x.m0 = lds_ld<K * RSB>(p.m0);
+    x.m1 = lds_ld<K * RSB>(p.m1);
+    x.m2 = lds_ld<K * RSB>(p.m2);
+    x.m3 = lds_ld<K * RSB>(p.m3);
+    x.mu = lds_ld<K * RSB>(p.mu);
+}
+template <int YOUNGER> // wait until at most YOUNGER LDS operations are outstanding; the operand set is usable afterwards
+__device__ __forceinline__ void fwd_wait(FwdOps &x)
+{
+    asm volatile("s_waitcnt lgkmcnt(%7)" : "+v"(x.m0), "+v"(x.m1), "+v"(x.m2), "+v"(x.m3), "+v"(x.ts), "+v"(x.mu), "+v"(x.hf) : "n"(YOUNGER));
+}
+template <int K>
+__device__ __forceinline__ void fwd_step(const FwdAddr &p, const FwdOps &x, double &v)
+{
+    // v = [dw; dx; 1; 0; 0].  Serial path: v -> du -> v+; the x / affine part of Mt [du; dx; 1] is dealt out into the
+    // latency gaps of that path by hand (FRP_SB pins the order: the scheduler does not put the path first).
+    const double vin = v;
+    const double m = x.hf * v;
+    FRP_SB();
+    const double v1 = quad_rot<1>(v);
+    FRP_SB();
+    const double d = mfma4(x.ts, m, 0.0);
+    FRP_SB();
+    const double v2 = quad_rot<2>(v), v3 = quad_rot<3>(v);
+    double acc = mfma4(x.m0, v, 0.0);
+    FRP_SB();
+    const double r = -d - quad_rot<1>(d);
+    FRP_SB();
+    acc = mfma4(x.m1, v1, acc);
+    FRP_SB();
+    const double du = r + quad_rot<2>(r); // du[a] in every lane of row a
+    FRP_SB();
+    acc = mfma4(x.m2, v2, acc);
+    acc = mfma4(x.m3, v3, acc);
+    FRP_SB();
+    v = mfma4(x.mu, du, acc);
+    FRP_SB();
+    lds_st<K * RSB>(p.wu, du);
+    lds_st<K * RSB>(p.ws, vin); // (the stores and the refill that follows them fill the latency of the closing MFMA)
 }
 
-template <bool WITH_Y>
 __device__ __noinline__ void sweep_forward(ldouble *recs, ldouble *xs, int N)
 {
     N = uni(N);
-    const int lane = threadIdx.x & 63;
-    const int idx = 4 * ((lane >> 2) & 3) + (lane >> 4); // V layout: the vector row this lane holds
-    FwdTabs t;
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-        t.mto[s] = tab(T4_MT + s, lane);
-        t.tto[s] = tab(T4_TT + s, lane);
-        t.pmo[s] = tab(T4_P + s, lane);
-    }
-    t.pvo = idx <= 12 ? R_PV + idx : R_ZERO;
-    const bool q0 = idx < 4 && (lane & 12) == 0; // rows 0..3 (quad 0 of every 16-lane row)
-    t.duo = q0 ? R_DZ + idx : R_DUMP; t.dso = idx <= 12 ? R_DZ + 4 + idx : R_DUMP; t.yo = idx <= 12 ? R_PD + idx : R_DUMP;
-    const double f0 = q0 ? 1.0 : 0.0, f13 = idx == 13 ? 1.0 : 0.0;
-    double v = xs[X_DS0 + idx]; // ds_0 (entries 13..15 are zero)
+    const int lane = threadIdx.x & 63, a = lane >> 4, b = (lane >> 2) & 3;
+    const int idx = 4 * b + a; // V layout: the vector row this lane holds
+    FwdAddr p;
+    p.m0 = lds_addr(recs + tab(T4_MT + 0, lane)); p.m1 = lds_addr(recs + tab(T4_MT + 1, lane));
+    p.m2 = lds_addr(recs + tab(T4_MT + 2, lane)); p.m3 = lds_addr(recs + tab(T4_MT + 3, lane));
+    p.ts = lds_addr(recs + tab(T4_TS, lane));
+    p.mu = lds_addr(recs + tab(T4_MU, lane));
+    p.hf = lds_addr(recs + (b == 0 ? R_HC : R_ONE));
+    p.wu = lds_addr(recs + (b == 0 ? R_DZ + a : R_DUMP));
+    p.ws = lds_addr(recs + (idx <= 12 ? R_DZ + 4 + idx : R_DUMP));
+    double v = idx == 13 ? 1.0 : xs[X_DS0 + idx]; // ds_0 (entries 14, 15 are zero), the constant 1 in row 13
+    __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): nothing of the compiler's own LDS traffic is left in flight
     FwdOps A, B;
-    const d4 zero = {0.0, 0.0, 0.0, 0.0};
-    A.Pk = zero; B.Pk = zero; A.pk = 0.0; B.pk = 0.0;
-    fwd_gather<WITH_Y>(recs, t, A);
-    fwd_gather<WITH_Y>(recs + (N > 1 ? 1 : 0) * RS, t, B);
-    int kk = 0;
-    for (; kk + 1 < N; kk += 2) {
-        fwd_step<WITH_Y>(recs, N, kk, f0, f13, t, A, v);
-        fwd_step<WITH_Y>(recs, N, kk + 1, f0, f13, t, B, v);
+    fwd_gather<0>(p, A);
+    fwd_wait<0>(A);
+    int left = N; // stages to go; A holds the operands of the next one, the addresses sit on it
+    for (; left >= 5; left -= 4) { // (see sweep_backvec: the next stage's gather opens a step, the wait that ties it closes it)
+        fwd_gather<1>(p, B); FRP_SB(); fwd_step<0>(p, A, v); fwd_wait<2>(B);
+        fwd_gather<2>(p, A); FRP_SB(); fwd_step<1>(p, B, v); fwd_wait<2>(A);
+        fwd_gather<3>(p, B); FRP_SB(); fwd_step<2>(p, A, v); fwd_wait<2>(B);
+        fwd_gather<4>(p, A); FRP_SB(); fwd_step<3>(p, B, v); fwd_wait<2>(A);
+        p.step(4 * RSB);
     }
-    if (kk < N) fwd_step<WITH_Y>(recs, N, kk, f0, f13, t, A, v);
+    for (; left >= 2; left--) {
+        fwd_gather<1>(p, B); FRP_SB(); fwd_step<0>(p, A, v); fwd_wait<2>(B);
+        A = B; // (landed values: safe to copy)
+        p.step(RSB);
+    }
+    fwd_step<0>(p, A, v); // the last stage
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     WSYNC();
 }
 
@@ -1005,7 +1112,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             xs[X_FEXT + k] = ms.fext[0]; xs[X_FEXT + NP + k] = ms.fext[1]; xs[X_FEXT + 2 * NP + k] = ms.fext[2];
             ldouble *rec = recs + k * RS;
             rec[R_HC] = -2.0 * pk[8]; // (u_i, w_i) cost coupling of this stage (constant)
-            rec[R_ZERO] = 0.0; rec[R_ONE] = 1.0; rec[R_DT] = DT; rec[R_DUMP] = 0.0;
+            rec[R_ZERO] = 0.0; rec[R_ZERO2] = 0.0; rec[R_ONE] = 1.0; rec[R_DT] = DT; rec[R_DUMP] = 0.0;
             if (k == N - 1) { // no dynamics behind the last stage: its M row stays zero
 #pragma unroll
                 for (int i = 0; i < 64; i++) rec[R_LIN + i] = 0.0;
@@ -1168,7 +1275,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             SWEEP_T0();
             const int fr = sweep_factor(recs, xs, N, gn_retry ? 0.0 : theta_h);
             SWEEP_T1(0);
-            if (!fr) sweep_forward<false>(recs, xs, N);
+            if (!fr) sweep_forward(recs, xs, N);
             SWEEP_T1(1);
             if (lane == 0) sh.ctl->fail = fr;
         }
@@ -1257,7 +1364,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             SWEEP_T0();
             sweep_backvec(recs, xs, N, smu);
             SWEEP_T1(2);
-            sweep_forward<false>(recs, xs, N);
+            sweep_forward(recs, xs, N);
             SWEEP_T1(3);
         }
         BAR_P(3); // ------------------------------------------------------------- E
