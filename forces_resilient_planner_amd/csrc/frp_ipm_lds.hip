@@ -1156,7 +1156,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     BAR();
     const int mtot = sh.ctl->mtot;
     if (sh.ctl->bad) { // a stage has more live corridor rows than the caller sized the problem for (MF)
-        if (threadIdx.x == 0) { a.exitflag[b] = FRP_EXIT_PARAM_VALUE; a.iters[b] = 0; }
+        if (wave == 0 && lane == 0) { a.exitflag[b] = FRP_EXIT_PARAM_VALUE; a.iters[b] = 0; }
         if (wave == 1 && kact) {
             double *zo = a.z + ((size_t)b * N + k) * NZ;
 #pragma unroll
@@ -1537,7 +1537,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         l_obj = wave_sum(l_obj);
         if (a.info && lane == 0) a.info[(size_t)b * FRP_INFO_STRIDE + 4] = l_obj;
     }
-    if (threadIdx.x == 0) {
+    if (wave == 0 && lane == 0) {
         a.exitflag[b] = flag;
         a.iters[b] = it;
         if (a.info) {
@@ -1553,14 +1553,14 @@ template <int NP, int FL, bool FREG, int ROLE>
 __device__ __forceinline__ void role_loop(const KernelArgs &a, const Shared &sh)
 {
     // the queue head is pulled one problem ahead (while the current one is being solved), so its latency is never exposed
-    if (ROLE == 0 && threadIdx.x == 0) sh.ctl->next = atomicAdd(a.counter, 1);
+    if (ROLE == 0 && (threadIdx.x & 63) == 0) sh.ctl->next = atomicAdd(a.counter, 1);
     for (;;) {
         BAR();
         int b = sh.ctl->next;
         if (b >= a.B) break;
         if (a.order) b = a.order[b]; // longest-expected-first launch order (see order_keys_kernel)
         BAR(); // everybody has read the index: the slot can take the next one
-        if (ROLE == 0 && threadIdx.x == 0) sh.ctl->next = atomicAdd(a.counter, 1);
+        if (ROLE == 0 && (threadIdx.x & 63) == 0) sh.ctl->next = atomicAdd(a.counter, 1);
         solve_one<NP, FL, FREG, ROLE>(a, b, sh);
     }
 }
@@ -1571,11 +1571,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     __shared__ double s_recs[NP * RS];
     __shared__ double s_xs[X_TOTAL + 3 * NP];
     __shared__ Ctl s_ctl;
+    __shared__ int s_place[5];
     Shared sh;
     sh.recs = (ldouble *)s_recs; sh.xs = (ldouble *)s_xs; sh.ctl = &s_ctl;
     if (threadIdx.x == 0) { s_xs[X_C0] = 0.0; s_xs[X_C1] = 1.0; }
+    // ---- which wave plays which role.  A wavefront stays on the SIMD it was launched on, and one wavefront of every
+    // resident workgroup sits on each SIMD of the CU.  The Riccati role keeps its SIMD busy for ~70 % of an iteration, the
+    // three helper roles for 13-18 % each, so the iteration rate of a CU is set by the SIMD with the most work on it.  With
+    // three workgroups per CU the roles are placed by SIMD: the k-th workgroup to arrive on a CU (a per-CU counter in the
+    // workspace, zeroed by the launcher) runs its Riccati role on SIMD k, every workgroup runs its heaviest helper (the
+    // model) on SIMD 3, which hosts no Riccati wave; the two light helpers share the SIMDs of the other two workgroups'
+    // Riccati waves.  Anything unexpected (SIMDs not distinct, other residency) falls back to role = wave index.
+    const int widx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int role = widx;
+    if (WPE == 3 && a.cu_slots) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID: SIMD_ID [5:4], CU_ID [11:8], SH_ID [12], SE_ID [15:13]
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID [3:0]
+        const int simd = (int)((hw >> 4) & 3u);
+        if ((threadIdx.x & 63) == 0) s_place[widx] = simd;
+        if (threadIdx.x == 0) {
+            const unsigned key = ((xcc & 7u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+            s_place[4] = atomicAdd(a.cu_slots + key, 1);
+        }
+        __syncthreads();
+        const int s0 = s_place[0], s1 = s_place[1], s2 = s_place[2], s3 = s_place[3], arrival = s_place[4];
+        const bool distinct = ((1 << s0) | (1 << s1) | (1 << s2) | (1 << s3)) == 15;
+        if (distinct && arrival < 3) {
+            const int rs = arrival; // SIMD of this workgroup's Riccati wave
+            // the two SIMDs that are neither rs nor 3, in increasing order, take the roles 2 and 3
+            int lo = -1;
+            for (int q = 0; q < 3; q++)
+                if (q != rs && lo < 0) lo = q;
+            role = simd == rs ? 0 : (simd == 3 ? 1 : (simd == lo ? 2 : 3));
+        }
+    }
     // one copy of the solver loop per role: the four waves run different code between the same barriers
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(role);
     if (wave == 0) role_loop<NP, FL, FREG, 0>(a, sh);
     else if (wave == 1) role_loop<NP, FL, FREG, 1>(a, sh);
     else if (wave == 2) role_loop<NP, FL, FREG, 2>(a, sh);

@@ -77,10 +77,12 @@ struct KernelArgs {
     double *info;
     double *ws;
     int *counter;     // work-queue head (set by the launcher)
+    int *cu_slots;    // per-CU arrival counters of the resident workgroups, zeroed by the launcher (frp_ipm_lds.hip: role placement)
     const int *order; // launch order of the problems, or null = index order (set by the launcher)
     const int *models; // per-problem FRP_MODEL_*, or null = `model` for the whole batch
 };
 
+constexpr int CU_SLOT_ENTRIES = 2048; // (XCC, SE, SH, CU) of HW_ID
 size_t ws_bytes(int B, int N, int MF);
 hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream);
 // frp_ipm_lds.hip: the LDS-resident kernel (queue counter / order already set up by launch_ipm)

@@ -1432,9 +1432,10 @@ __global__ __launch_bounds__(256) void order_keys_kernel(int B, int N, int np, i
 // order = the problems sorted by decreasing key, to bucket resolution (also zeroes the work-queue head): one workgroup, a 1024-bin counting sort on the
 // (monotone) bit pattern of the non-negative keys -- i.e. on a log scale -- with the bins spread over the key range of
 // this batch.  The order inside a bin is arbitrary (atomics); order[] is a permutation for any input.
-__global__ __launch_bounds__(1024) void order_bucket_kernel(int B, const double *__restrict__ keys, int *__restrict__ order, int *__restrict__ counter)
+__global__ __launch_bounds__(1024) void order_bucket_kernel(int B, const double *__restrict__ keys, int *__restrict__ order, int *__restrict__ counter, int *__restrict__ cu_slots)
 {
     if (threadIdx.x == 0) *counter = 0; // queue head of the solve that follows on this stream
+    for (int i = threadIdx.x; i < CU_SLOT_ENTRIES; i += 1024) cu_slots[i] = 0;
     __shared__ unsigned long long s_min, s_max;
     __shared__ int hist[1024];
     const int t = threadIdx.x;
@@ -1566,7 +1567,8 @@ static int resident_slots(int B)
     return (B + rounds - 1) / rounds;
 }
 
-// workspace = [solver state of min(B, FRP_MAX_SLOTS) slots][work-queue counter, 256 B][keys: B doubles][order: B ints]
+// workspace = [solver state of min(B, FRP_MAX_SLOTS) slots][work-queue counter, 256 B][per-CU arrival counters, 8 KB][keys: B doubles][order: B ints]
+constexpr int QUEUE_RESERVED = 32 + CU_SLOT_ENTRIES / 2; // doubles
 static size_t queue_offset_doubles(int B, int N, int MF)
 {
     const size_t slots = B < FRP_MAX_SLOTS ? B : FRP_MAX_SLOTS;
@@ -1574,10 +1576,14 @@ static size_t queue_offset_doubles(int B, int N, int MF)
 }
 size_t ws_bytes(int B, int N, int MF)
 {
-    return (queue_offset_doubles(B, N, MF) + 32 + (size_t)B + ((size_t)B + 1) / 2) * sizeof(double);
+    return (queue_offset_doubles(B, N, MF) + QUEUE_RESERVED + (size_t)B + ((size_t)B + 1) / 2) * sizeof(double);
 }
 
-__global__ void reset_counter_kernel(int *counter) { *counter = 0; }
+__global__ void reset_counter_kernel(int *counter, int *cu_slots)
+{
+    if (threadIdx.x == 0) *counter = 0;
+    for (int i = threadIdx.x; i < CU_SLOT_ENTRIES; i += blockDim.x) cu_slots[i] = 0;
+}
 
 // Kernel selection: the LDS-resident four-wave kernel (frp_ipm_lds.hip) is the product path; FRP_KERNEL=r01 selects the
 // round-1 single-wave kernel with its HBM workspace (kept for same-box A/B measurements only).
@@ -1611,19 +1617,20 @@ hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
     const int slots = lds ? lds_resident_slots(a.B, a.N) : resident_slots(a.B);
     double *q = a.ws + queue_offset_doubles(a.B, a.N, a.MF);
     k.counter = reinterpret_cast<int *>(q);
+    k.cu_slots = reinterpret_cast<int *>(q + 32);
     k.order = nullptr;
     if (a.B > slots) { // more problems than resident workgroups: order the queue, longest expected solve first
-        double *keys = q + 32;
+        double *keys = q + QUEUE_RESERVED;
         int *order = reinterpret_cast<int *>(keys + a.B);
         k.order = order;
         hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, stream, a.B, a.N, NPRE + 4 * a.M, a.model,
                            a.models, a.x0, a.params, keys);
-        hipLaunchKernelGGL(order_bucket_kernel, dim3(1), dim3(1024), 0, stream, a.B, keys, order, k.counter);
+        hipLaunchKernelGGL(order_bucket_kernel, dim3(1), dim3(1024), 0, stream, a.B, keys, order, k.counter, k.cu_slots);
     } else {
         // a one-thread kernel rather than hipMemsetAsync: as a node of a captured hipGraph the 4-byte memset was not
         // ordered before the solve on the graph's first launch (ROCm 7.2; tools/graph_tick.py), which left the queue
         // exhausted and the previous outputs in place
-        hipLaunchKernelGGL(reset_counter_kernel, dim3(1), dim3(1), 0, stream, k.counter);
+        hipLaunchKernelGGL(reset_counter_kernel, dim3(1), dim3(256), 0, stream, k.counter, k.cu_slots);
     }
     if (lds) return launch_ipm_lds(k, slots, stream);
     switch (padded_stages(a.N)) {
