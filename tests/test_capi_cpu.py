@@ -107,12 +107,12 @@ int main() {{
 
 
 def test_workspace_size_formula():
-    """Workspace = (resident slots) x (per-problem solver state) + work queue (counter 256 B, one key and one order
-    entry per problem): the solver state grows with the batch only up to the number of slots the library sizes for
-    (4096), and with the horizon and the face count; the queue is 12 B per problem."""
+    """Workspace = (resident slots) x (per-problem solver state) + work queue (counter 256 B, per-CU arrival counters
+    8 KB, one key and one order entry per problem): the solver state grows with the batch only up to the number of slots
+    the library sizes for (4096), and with the horizon and the face count; the queue is 12 B per problem."""
     lib = solver.lib()
     ws = lib.frp_nmpc_workspace_bytes
-    queue = lambda B: 8 * (32 + B + (B + 1) // 2)
+    queue = lambda B: 8 * (32 + 1024 + B + (B + 1) // 2)
     per = ws(1, 20, 6) - queue(1)
     assert per > 20 * 384 * 8
     assert ws(7, 20, 6) == 7 * per + queue(7)
