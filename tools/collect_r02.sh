@@ -20,8 +20,9 @@ python tools/bench_configs.py > $R/bench_configs.txt 2>&1
 if [ -f forces_resilient_planner_amd/lib_prof.so ]; then
   for b in 1 4096; do FRP_LIB=forces_resilient_planner_amd/lib_prof.so python tools/prof_lds.py $b 2 >> $R/wave_phases.txt 2>&1; done
 fi
-tools/ubench/sweep_timing > $R/sweep_timing.txt 2>&1
+timeout 60 tools/ubench/sweep_timing > $R/sweep_timing.txt 2>&1
 tools/ubench/rcp_f64 > $R/rcp_f64.txt 2>&1
+(echo "== chain_lat"; timeout 60 tools/ubench/chain_lat; echo "== issue_rate"; timeout 60 tools/ubench/issue_rate; echo "== fwd_model"; timeout 60 tools/ubench/fwd_model; for n in 4 20; do echo "== sweep_timing N=$n"; tools/ubench/sweep_timing $n; done) > $R/issue_model.txt 2>&1
 python tools/stage_eval_bench.py > $R/stage_eval.json 2>/dev/null
 python tools/full_tick_bench.py 4096 10 20000 > $R/full_tick.json 2> $R/full_tick.err
 python tools/receding_bench.py 65536 20 > $R/configs4_receding.json 2>/dev/null

@@ -40,10 +40,6 @@ __global__ void k(const double *in, double *out, double *sinkp)
     TIME(REP8(MFV6))                                           // 7: 8 x (mfma4 + 6 32-bit VALU)
 #define MFD(j) a[j] = mfma4(c, c, a[j]); a[(j + 4) & 7] = __builtin_fma(a[(j + 4) & 7], c, c);
     TIME(REP8(MFD))                                            // 8: 8 x (mfma4 + 1 v_fma_f64 on another chain)
-#define SAL(j) asm volatile("s_add_u32 s20, s20, 1\n" ::: "s20");
-    TIME(REP8(SAL))                                            // 9: 8 s_add_u32
-#define WR(j) sh[threadIdx.x + 64 * j] = a[j];
-    TIME(REP8(WR))                                             // 10: 8 ds_write_b64
     for (int j = 0; j < 8; j++) s += a[j] + q[j];
     if (s == 1234.5) sinkp[0] = s;
 }
@@ -58,7 +54,7 @@ int main()
     double r[32];
     hipMemcpy(r, o, sizeof r, hipMemcpyDeviceToHost);
     const char *nm[] = {"8 v_fma_f64", "8 v_add_u32", "8 v_mov_b32_dpp", "8 v_cndmask_b32", "8 (v_and + ds_read_b64 + v_add_f64)", "8 mfma_f64_4x4x4",
-                        "8 (mfma4 + 3 32-bit VALU)", "8 (mfma4 + 6 32-bit VALU)", "8 (mfma4 + v_fma_f64)", "8 s_add_u32", "8 ds_write_b64"};
-    for (int i = 0; i < 11; i++) printf("%-40s %7.1f cycles per group = %5.1f per unit\n", nm[i], r[i], r[i] / 8);
+                        "8 (mfma4 + 3 32-bit VALU)", "8 (mfma4 + 6 32-bit VALU)", "8 (mfma4 + v_fma_f64)"};
+    for (int i = 0; i < 9; i++) printf("%-40s %7.1f cycles per group = %5.1f per unit\n", nm[i], r[i], r[i] / 8);
     return 0;
 }
