@@ -326,7 +326,8 @@ __device__ __forceinline__ void gather_tiles(cldouble *rn, const int (&c1)[4], c
 {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        C[r] = rn[c1[r]] + rn[c2[r]] + theta * rn[c3[r]];
+        // (the corridor block and the corridor part of the gradient sit in tile rows 4..6: register 1 only)
+        C[r] = r == 1 ? rn[c1[r]] + rn[c2[r]] + theta * rn[c3[r]] : rn[c1[r]] + theta * rn[c3[r]];
         Mt[r] = rn[mo[r]];
     }
     hc = rn[R_HC];
@@ -576,6 +577,17 @@ __device__ __forceinline__ void back_step(const BackAddr &p, const BackOps &x, d
     pv = pn;
 }
 
+template <int K> // stages K .. 0 above the addresses; X holds the operands of stage K
+__device__ __forceinline__ void back_tail(const BackAddr &p, BackOps &X, BackOps &Y, double smu, double &pv)
+{
+    if constexpr (K > 0) {
+        back_gather<K - 1>(p, Y); FRP_SB(); back_step<K, false>(p, X, smu, pv); back_wait<2>(Y);
+        back_tail<K - 1>(p, Y, X, smu, pv);
+    } else {
+        back_step<0, false>(p, X, smu, pv); // stage 0
+    }
+}
+
 __device__ __noinline__ void sweep_backvec(ldouble *recs, ldouble *xs, int N, double smu)
 {
     N = uni(N); smu = uni(smu);
@@ -614,12 +626,14 @@ __device__ __noinline__ void sweep_backvec(ldouble *recs, ldouble *xs, int N, do
         back_gather<1>(p, A); FRP_SB(); back_step<2, false>(p, B, smu, pv); back_wait<2>(A);
         back_gather<0>(p, B); FRP_SB(); back_step<1, false>(p, A, smu, pv); back_wait<2>(B);
     }
-    for (; s_ >= 1; s_--) {
-        p.step(-RSB);
-        back_gather<0>(p, A); FRP_SB(); back_step<1, false>(p, B, smu, pv); back_wait<2>(A);
-        B = A; // (landed values: safe to copy)
+    // stages s_ .. 0 left (s_ <= 3), B holds stage s_: unrolled by count, addresses moved to stage 0 once
+    p.step(-s_ * RSB);
+    switch (s_) {
+    case 3: back_tail<3>(p, B, A, smu, pv); break;
+    case 2: back_tail<2>(p, B, A, smu, pv); break;
+    case 1: back_tail<1>(p, B, A, smu, pv); break;
+    default: back_tail<0>(p, B, A, smu, pv); break;
     }
-    back_step<0, false>(p, B, smu, pv); // stage 0
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // p_w[g] sits in the quad-0 lanes of row g; the stage-0 solve wants it in the lanes (g, 13)
     stage0_solve(xs, lane, __shfl(pv, lane & 48));
@@ -684,6 +698,17 @@ __device__ __forceinline__ void fwd_step(const FwdAddr &p, const FwdOps &x, doub
     lds_st<K * RSB>(p.ws, vin); // (the stores and the refill that follows them fill the latency of the closing MFMA)
 }
 
+template <int K, int L> // stages K .. L-1 above the addresses; X holds the operands of stage K
+__device__ __forceinline__ void fwd_tail(const FwdAddr &p, FwdOps &X, FwdOps &Y, double &v)
+{
+    if constexpr (K + 1 < L) {
+        fwd_gather<K + 1>(p, Y); FRP_SB(); fwd_step<K>(p, X, v); fwd_wait<2>(Y);
+        fwd_tail<K + 1, L>(p, Y, X, v);
+    } else {
+        fwd_step<K>(p, X, v); // the last stage
+    }
+}
+
 __device__ __noinline__ void sweep_forward(ldouble *recs, ldouble *xs, int N)
 {
     N = uni(N);
@@ -710,12 +735,13 @@ __device__ __noinline__ void sweep_forward(ldouble *recs, ldouble *xs, int N)
         fwd_gather<4>(p, A); FRP_SB(); fwd_step<3>(p, B, v); fwd_wait<2>(A);
         p.step(4 * RSB);
     }
-    for (; left >= 2; left--) {
-        fwd_gather<1>(p, B); FRP_SB(); fwd_step<0>(p, A, v); fwd_wait<2>(B);
-        A = B; // (landed values: safe to copy)
-        p.step(RSB);
+    // one to four stages left: unrolled by count (no operand-set copies, no address stepping)
+    switch (left) {
+    case 4: fwd_tail<0, 4>(p, A, B, v); break;
+    case 3: fwd_tail<0, 3>(p, A, B, v); break;
+    case 2: fwd_tail<0, 2>(p, A, B, v); break;
+    default: fwd_tail<0, 1>(p, A, B, v); break;
     }
-    fwd_step<0>(p, A, v); // the last stage
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     WSYNC();
 }
