@@ -271,6 +271,61 @@ def test_lds_kernel_has_no_spill_behind_a_lane_divergent_loop(tmp_path):
     # (every other loop of that file runs over the wave-uniform horizon length or a compile-time face count: the kernel
     # bodies, which do use scratch, contain no per-lane trip count)
     assert len([n for n in scratch if "nmpc_ipm_lds_kernel" in n]) >= 6
+    _check_asm_lds_loads_land_before_edges(txt)
+
+
+def _check_asm_lds_loads_land_before_edges(txt):
+    """The vector sweeps issue their LDS loads through inline asm and wait for them with hand-counted s_waitcnt: the
+    compiler believes a loaded register is valid at once.  Invariant that keeps this safe (frp_ipm_lds.hip, "the two
+    vector sweeps"): between a ds_read of the sweeps and the s_waitcnt that retires it, no instruction reads the
+    destination registers, and no label / branch is crossed (the register allocator may copy values on an edge).  Checked
+    on the generated code: a linear scan per function with the set of registers whose load is in flight."""
+    import re
+
+    def regs(tok):
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.fullmatch(r"v(\d+)", tok)
+        return {int(m.group(1))} if m else set()
+
+    checked = 0
+    for fn in ("sweep_forward", "sweep_backvec"):
+        m = re.search(r"^(_ZN3frp2lr\d+%s\w*):\s" % fn, txt, flags=re.M)
+        assert m, fn
+        body = txt[m.end():]
+        body = body[:body.index("s_setpc_b64")]
+        inflight = set()
+        in_asm = False
+        for line in body.splitlines():
+            if "#ASMSTART" in line or "#ASMEND" in line:  # (the compiler's own LDS loads are waited for by the compiler)
+                in_asm = "#ASMSTART" in line
+                continue
+            line = line.split(";")[0].strip()
+            if not line or line.startswith("."):
+                if line.startswith(".LBB"):
+                    assert not inflight, (fn, "label reached with loads in flight", line, sorted(inflight))
+                continue
+            op, _, rest = line.partition(" ")
+            toks = [t.strip() for t in rest.replace(" offset", ", offset").split(",")]
+            if op == "s_waitcnt":
+                m2 = re.search(r"lgkmcnt\((\d+)\)", rest)
+                if m2 and int(m2.group(1)) <= 2:  # at most the two stores of the running step stay outstanding
+                    inflight.clear()
+                continue
+            if op.startswith("s_cbranch") or op in ("s_branch", "s_setpc_b64", "s_swappc_b64"):
+                assert not inflight, (fn, "branch with loads in flight", line, sorted(inflight))
+                continue
+            if op == "ds_read_b64" and in_asm:
+                dst = regs(toks[0])
+                src = set().union(*[regs(t) for t in toks[1:]])
+                assert not (src & inflight), (fn, line)
+                inflight |= dst
+                checked += 1
+                continue
+            used = set().union(*[regs(t) for t in toks]) if toks else set()
+            assert not (used & inflight), (fn, "register of a load in flight touched", line, sorted(used & inflight))
+    assert checked > 100
 
 
 def test_header_is_plain_c99(tmp_path):
