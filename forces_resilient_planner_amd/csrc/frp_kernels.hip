@@ -1480,24 +1480,63 @@ __global__ __launch_bounds__(1024) void order_bucket_kernel(int B, const double 
 }
 
 // ------------------------------------------------------------------ batched model callback
-// One thread per (problem, stage): the reference's extfunc for B*N stage points (casadi2forces.c:42-245).
-__global__ __launch_bounds__(256) void stage_eval_kernel(int B, int N, int M, int model, const double *__restrict__ z,
+// One thread per (problem, stage): the reference's extfunc for B*N stage points (casadi2forces.c:42-245).  HBM-bound:
+// 147 doubles in, 282 out per point, 221 of them the dense 13 x 17 Jacobian (column-major, ld 13, as the reference's
+// sparse2fullcopy writes it).  A thread that stored its own Jacobian would touch 64 cache lines per store instruction, so
+// the Jacobian leaves through LDS: every thread parks the 51 entries of its compact linearisation, then the wavefront
+// writes the points' Jacobians one after the other as runs of 64 consecutive doubles (source of each dense entry: a
+// compile-time table into the parked record, whose slots 51 / 52 / 53 hold 0, 1 and dt).
+constexpr int SE_SLOTS = 55; // 51 + constants (0, 1, dt), odd stride
+constexpr int SE_MAXM = 64;  // corridor rows staged per point
+__host__ __device__ constexpr int jc_source(int e) // dense entry e = col * 13 + row  ->  slot of the parked record
+{
+    const int col = e / 13, row = e % 13;
+    if (row >= 9) return col == row - 9 ? 52 : 51;
+    const int bi = row / 3, ii = row % 3;
+    if (col < 4) { // lin_B(row, col)
+        if (col == 3) return bi == 0 ? 36 + ii : (bi == 1 ? 39 + ii : 51);
+        if (bi == 1) return 42 + ii * 3 + col;
+        if (bi == 2) return ii == col ? 53 : 51;
+        return 51;
+    }
+    if (col < 8) return 51;
+    const int j = col - 8, bj = j / 3, jj = j % 3; // lin_A(row, j)
+    if (bi == 0) return bj == 0 ? (ii == jj ? 52 : 51) : (bj == 1 ? 0 : 9) + ii * 3 + jj;
+    if (bi == 1) return bj == 0 ? 51 : (bj == 1 ? 18 : 27) + ii * 3 + jj;
+    return (bj == 2 && ii == jj) ? 52 : 51;
+}
+struct JcTable {
+    unsigned char v[256];
+};
+constexpr JcTable make_jc_table()
+{
+    JcTable t{};
+    for (int e = 0; e < 256; e++) t.v[e] = (unsigned char)(e < 221 ? jc_source(e) : 51);
+    return t;
+}
+__device__ const JcTable g_jc_table = make_jc_table();
+
+__global__ __launch_bounds__(64) void stage_eval_kernel(int B, int N, int M, int model, const double *__restrict__ z,
                                                           const double *__restrict__ params, double *__restrict__ f,
                                                           double *__restrict__ gf, double *__restrict__ c,
                                                           double *__restrict__ Jc, double *__restrict__ h)
 {
+    __shared__ double s_lin[1][64 * SE_SLOTS]; // one wavefront per workgroup: 31 KB of LDS each, five per CU
+    __shared__ double s_pos[64 * 3]; // one point's corridor rows [A (3 M) | b (M)]
+    const size_t total = (size_t)B * N;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)B * N) return;
-    const int k = (int)(t % N);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool act = t < total;
+    const int k = act ? (int)(t % N) : 0;
     const int np = NPRE + 4 * M;
-    const double *zk = z + t * NZ, *pk = params + t * np;
+    const double *zk = z + (act ? t : 0) * NZ, *pk = params + (act ? t : 0) * np;
     double zl[NZ], p10[NPRE];
 #pragma unroll
     for (int i = 0; i < NZ; i++) zl[i] = zk[i];
 #pragma unroll
     for (int i = 0; i < NPRE; i++) p10[i] = pk[i];
     const int sc = stage_class(k, N);
-    if (f || gf) {
+    if (act && (f || gf)) {
         double g[NZ];
         const double cost = stage_cost(zl, p10, sc, model, g);
         if (f) f[t] = cost;
@@ -1506,8 +1545,10 @@ __global__ __launch_bounds__(256) void stage_eval_kernel(int B, int N, int M, in
             for (int i = 0; i < NZ; i++) gf[t * NZ + i] = g[i];
         }
     }
+    double *mine = s_lin[wv] + lane * SE_SLOTS;
+    s_pos[lane * 3] = zl[8]; s_pos[lane * 3 + 1] = zl[9]; s_pos[lane * 3 + 2] = zl[10];
     if (c || Jc) {
-        if (sc != STAGE_LAST) {
+        if (act && sc != STAGE_LAST) {
             Lin L;
             double xn[9];
             rk2<true>(zl + 8, zl, p10 + 3, xn, &L);
@@ -1517,29 +1558,71 @@ __global__ __launch_bounds__(256) void stage_eval_kernel(int B, int N, int M, in
 #pragma unroll
                 for (int i = 0; i < 4; i++) c[t * 13 + 9 + i] = zl[i];
             }
-            if (Jc) {
-                double *J = Jc + t * 221;
-                const double *Lc = reinterpret_cast<const double *>(&L);
-                for (int col = 0; col < 17; col++) {
+            const double *Lc = reinterpret_cast<const double *>(&L);
 #pragma unroll
-                    for (int row = 0; row < 13; row++) {
-                        double v = 0.0;
-                        if (row < 9) {
-                            if (col < 4) v = lin_B(Lc, row, col);
-                            else if (col >= 8) v = lin_A(Lc, row, col - 8);
-                        } else if (col == row - 9) v = 1.0;
-                        J[col * 13 + row] = v;
-                    }
-                }
-            }
+            for (int i = 0; i < 51; i++) mine[i] = Lc[i];
+            mine[51] = 0.0; mine[52] = 1.0; mine[53] = DT;
         } else {
-            if (c) for (int i = 0; i < 13; i++) c[t * 13 + i] = 0.0;
-            if (Jc) for (int i = 0; i < 221; i++) Jc[t * 221 + i] = 0.0;
+            if (act && c) for (int i = 0; i < 13; i++) c[t * 13 + i] = 0.0;
+            for (int i = 0; i < 54; i++) mine[i] = 0.0; // the last stage has no dynamics: a zero Jacobian
         }
     }
-    if (h) {
-        const double *A = pk + NPRE, *bb = pk + NPRE + 3 * M;
-        for (int j = 0; j < M; j++) h[t * M + j] = A[3 * j] * zl[8] + A[3 * j + 1] * zl[9] + A[3 * j + 2] * zl[10] - bb[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const size_t t0 = t - lane; // first point of this wavefront
+    const int npts = t0 < total ? (int)((total - t0) < 64 ? (total - t0) : 64) : 0;
+    if (Jc) {
+        const int src0 = g_jc_table.v[lane], src1 = g_jc_table.v[64 + lane], src2 = g_jc_table.v[128 + lane], src3 = g_jc_table.v[192 + lane];
+        for (int p = 0; p < npts; p++) {
+            const double *rec = s_lin[wv] + p * SE_SLOTS;
+            double *J = Jc + (t0 + p) * 221;
+            J[lane] = rec[src0];
+            J[64 + lane] = rec[src1];
+            J[128 + lane] = rec[src2];
+            if (lane < 221 - 192) J[192 + lane] = rec[src3];
+        }
+    }
+    if (h && M > 0) {
+        // corridor rows h = A pos - b, eight points at a time: the wavefront reads their [A | b] (4 M consecutive doubles each)
+        // with coalesced loads -- sixteen in flight per lane -- into the LDS area the Jacobian pass has just vacated, then
+        // writes the 8 M results, consecutive in memory, with coalesced stores
+        if (M <= SE_MAXM) {
+            constexpr int PB = 8;
+            double *ab = s_lin[0]; // [PB][4 SE_MAXM]
+            static_assert(PB * 4 * SE_MAXM <= 64 * SE_SLOTS, "staging area");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int p0 = 0; p0 < npts; p0 += PB) {
+                const int nb = npts - p0 < PB ? npts - p0 : PB;
+                double r0[PB], r1[PB], r2[PB], r3[PB];
+#pragma unroll
+                for (int q = 0; q < PB; q++) {
+                    const double *src = params + (t0 + p0 + (q < nb ? q : 0)) * np + NPRE;
+                    r0[q] = lane < 4 * M ? src[lane] : 0.0;
+                    r1[q] = lane + 64 < 4 * M ? src[lane + 64] : 0.0;
+                    r2[q] = lane + 128 < 4 * M ? src[lane + 128] : 0.0;
+                    r3[q] = lane + 192 < 4 * M ? src[lane + 192] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < PB; q++) {
+                    double *dst = ab + q * 4 * SE_MAXM;
+                    dst[lane] = r0[q]; dst[lane + 64] = r1[q]; dst[lane + 128] = r2[q]; dst[lane + 192] = r3[q];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                double *out = h + (t0 + p0) * M;
+                for (int o = lane; o < nb * M; o += 64) {
+                    const int q = o / M, j = o - q * M;
+                    const double *a = ab + q * 4 * SE_MAXM, *ps = s_pos + (p0 + q) * 3;
+                    out[o] = a[3 * j] * ps[0] + a[3 * j + 1] * ps[1] + a[3 * j + 2] * ps[2] - a[3 * M + j];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else if (act) {
+            const double *A = pk + NPRE, *bb = pk + NPRE + 3 * M;
+            for (int j = 0; j < M; j++) h[t * M + j] = A[3 * j] * zl[8] + A[3 * j + 1] * zl[9] + A[3 * j + 2] * zl[10] - bb[j];
+        }
     }
 }
 
@@ -1646,8 +1729,8 @@ hipError_t launch_stage_eval(int B, int N, int M, int model, const double *z, co
                              double *gf, double *c, double *Jc, double *h, hipStream_t stream)
 {
     const size_t total = (size_t)B * N;
-    const int blocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(stage_eval_kernel, dim3(blocks), dim3(256), 0, stream, B, N, M, model, z, params, f, gf, c, Jc, h);
+    const int blocks = (int)((total + 63) / 64);
+    hipLaunchKernelGGL(stage_eval_kernel, dim3(blocks), dim3(64), 0, stream, B, N, M, model, z, params, f, gf, c, Jc, h);
     return hipGetLastError();
 }
 

@@ -21,9 +21,19 @@ Jc = torch.zeros((B, N, 221), **f64); h = torch.zeros((B, N, M), **f64)
 lib = solver.lib()
 lib.frp_nmpc_stage_eval.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 8
 s = torch.cuda.current_stream(dev)
-def run():
-    rc = lib.frp_nmpc_stage_eval(B, N, M, 0, z.data_ptr(), p.data_ptr(), f.data_ptr(), gf.data_ptr(), c.data_ptr(), Jc.data_ptr(), h.data_ptr(), s.cuda_stream)
+def run(want="f gf c Jc h"):
+    w_ = want.split()
+    ptr = lambda name, t: t.data_ptr() if name in w_ else None
+    rc = lib.frp_nmpc_stage_eval(B, N, M, 0, z.data_ptr(), p.data_ptr(), ptr("f", f), ptr("gf", gf), ptr("c", c), ptr("Jc", Jc), ptr("h", h), s.cuda_stream)
     assert rc == 0
+def timed(want, reps=20):
+    run(want); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        run(want)
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
 for _ in range(3):
     run()
 torch.cuda.synchronize()
@@ -39,5 +49,6 @@ tot = B * N * (bytes_in + bytes_out)
 out = {"kernel": "stage_eval_kernel", "stage_points": B * N, "ms": ms, "bytes_in_per_point": bytes_in, "bytes_out_per_point": bytes_out,
        "algorithmic_GB": tot / 1e9, "achieved_GBps": tot / (ms * 1e-3) / 1e9, "peak_GBps": 8000.0, "frac": tot / (ms * 1e-3) / 1e9 / 8000.0,
        "stage_points_per_s": B * N / (ms * 1e-3),
-       "note": "one thread per (problem, stage): 147 doubles in, 282 doubles out per point (dense 13 x 17 Jacobian, column-major ld 13, as the reference's sparse2fullcopy writes it); the 221-double Jacobian store of each thread is strided by 3.4 KB across a wave, so the kernel is bound by write transactions, not by bytes"}
+       "ms_by_output": {k: timed(k) for k in ("f gf", "c", "Jc", "h")},
+       "note": "one thread per (problem, stage) computes; 147 doubles in, 282 doubles out per point (dense 13 x 17 Jacobian, column-major ld 13, as the reference's sparse2fullcopy writes it); the Jacobian and the corridor rows leave / enter through LDS so that the wavefront moves runs of consecutive doubles"}
 print(json.dumps(out, indent=1))
