@@ -42,7 +42,10 @@
 
 namespace frp {
 
-constexpr int CR_THREADS = 256, CR_WAVES = 4, CR_UNROLL = 4, CR_BATCH = 2;
+#ifndef FRP_CR_WAVES
+#define FRP_CR_WAVES 4
+#endif
+constexpr int CR_WAVES = FRP_CR_WAVES, CR_THREADS = 64 * CR_WAVES, CR_UNROLL = 4, CR_BATCH = 2;
 constexpr double CR_EPS = 1e-10; // epsilon_, data_type.h:129
 
 struct M3 { double m[9]; };
@@ -166,7 +169,17 @@ struct Scan {             // what a scan iterates over
     int Pn, W;            // positions, 64-position words
 };
 
-constexpr int CR_TILE = 8;    // 64-position words per wave held in registers (CR_TILE * CR_THREADS points per planner)
+#ifndef FRP_CR_TILE
+#define FRP_CR_TILE 5
+#endif
+#ifndef FRP_CR_WPE
+#define FRP_CR_WPE 3
+#endif
+// Register tile of 5 words per wave (1280 points per planner) at three workgroups per CU: a decomposition is a chain of
+// ~20 latency-bound scans (reduction, barrier, thread-0 algebra), so a third resident workgroup per CU is worth more than the
+// 8-word tile that needs 256 VGPRs (full tick, 4096 planners: 1.32 -> 1.09 ms; 4 per CU spills too much: 1.28; two-wave
+// workgroups: 1.27-1.52).
+constexpr int CR_TILE = FRP_CR_TILE; // 64-position words per wave held in registers (CR_TILE * CR_THREADS points per planner)
 constexpr int CR_LIST = 8192; // capacity of the in-box index list (LDS); larger boxes fall back to cloud positions
 
 // Wave-uniform state of the running decomposition.  It lives in LDS and is advanced by thread 0 only, so the 3x3
@@ -488,7 +501,7 @@ __device__ void emit_row(Uni &u, const double q[3], const double n_[3], int F, d
 // with only_flagged = 1 redoes just those planners from the plain cloud.  Two kernels instead of one with both first
 // scans inlined: the combined one needs 256 VGPRs + 100 spilled SGPRs and loses the second resident workgroup per CU.
 template <bool GRID>
-__global__ __launch_bounds__(CR_THREADS) void corridor_kernel(frp_nmpc_corridor c, int only_flagged)
+__global__ __launch_bounds__(CR_THREADS) __attribute__((amdgpu_waves_per_eu(FRP_CR_WPE, FRP_CR_WPE))) void corridor_kernel(frp_nmpc_corridor c, int only_flagged)
 {
 #ifdef FRP_CORRIDOR_PROFILE
     long long tp_check = 0, tp_init = 0, tp_cloud = 0, tp_lead = 0, tp_scan = 0, tp_emit = 0, tp_begin = wall_clock64();
