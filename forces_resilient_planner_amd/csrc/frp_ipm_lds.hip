@@ -1607,7 +1607,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     // three workgroups per CU the roles are placed by SIMD: the k-th workgroup to arrive on a CU (a per-CU counter in the
     // workspace, zeroed by the launcher) runs its Riccati role on SIMD k, every workgroup runs its heaviest helper (the
     // model) on SIMD 3, which hosts no Riccati wave; the two light helpers share the SIMDs of the other two workgroups'
-    // Riccati waves.  Anything unexpected (SIMDs not distinct, other residency) falls back to role = wave index.
+    // Riccati waves.  Anything unexpected (SIMDs not distinct, other residency) falls back to role = wave index.  (With two
+    // workgroups per CU -- Riccati waves on SIMD 0 / 1, model waves on SIMD 2 / 3 -- the same idea LOSES 2.4 % on configs[3]
+    // against the dispatcher's own rotation, so it is applied to the three-per-CU variants only.)
     const int widx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int role = widx;
     if (WPE == 3 && a.cu_slots) {
