@@ -1182,7 +1182,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     BAR();
     const int mtot = sh.ctl->mtot;
     if (sh.ctl->bad) { // a stage has more live corridor rows than the caller sized the problem for (MF)
-        if (wave == 0 && lane == 0) { a.exitflag[b] = FRP_EXIT_PARAM_VALUE; a.iters[b] = 0; }
+        if (wave == 0 && lane == 0) { sh.ctl->next = atomicAdd(a.counter, 1); a.exitflag[b] = FRP_EXIT_PARAM_VALUE; a.iters[b] = 0; }
         if (wave == 1 && kact) {
             double *zo = a.z + ((size_t)b * N + k) * NZ;
 #pragma unroll
@@ -1548,6 +1548,9 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     // ---------------------------------------------------------------- outputs
     PROF_FLUSH(wave, it);
     __builtin_amdgcn_s_setprio(0);
+    // the next problem is claimed only now (its latency hides behind the write-out): a slot that claimed it while it still
+    // had a solve ahead of it would keep it from the slots that go idle at the end of the launch
+    if (wave == 0 && lane == 0) sh.ctl->next = atomicAdd(a.counter, 1);
     if constexpr (wave == 1) {
         // the objective is reported, not iterated on: evaluated once, at the returned iterate
         double l_obj = 0.0;
@@ -1578,15 +1581,14 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 template <int NP, int FL, bool FREG, int ROLE>
 __device__ __forceinline__ void role_loop(const KernelArgs &a, const Shared &sh)
 {
-    // the queue head is pulled one problem ahead (while the current one is being solved), so its latency is never exposed
+    // (solve_one claims the next problem when it leaves its iteration)
     if (ROLE == 0 && (threadIdx.x & 63) == 0) sh.ctl->next = atomicAdd(a.counter, 1);
     for (;;) {
         BAR();
         int b = sh.ctl->next;
         if (b >= a.B) break;
         if (a.order) b = a.order[b]; // longest-expected-first launch order (see order_keys_kernel)
-        BAR(); // everybody has read the index: the slot can take the next one
-        if (ROLE == 0 && (threadIdx.x & 63) == 0) sh.ctl->next = atomicAdd(a.counter, 1);
+        BAR(); // everybody has read the index before solve_one's exit overwrites it
         solve_one<NP, FL, FREG, ROLE>(a, b, sh);
     }
 }
