@@ -318,9 +318,10 @@ def test_receding_horizon_warm_start_matches_oracle():
     assert ig[1:].mean() <= ig[0].mean() + 0.5
 
 
-@pytest.mark.parametrize("N", [8, 12, 20, 25, 33])
+@pytest.mark.parametrize("N", [2, 3, 6, 7, 8, 11, 12, 18, 20, 25, 33, 47, 64])
 def test_horizon_lengths_cover_every_lane_mapping(N):
-    """Stage strides 16 / 20 / 32 / 64 (4, 3, 2, 1 row groups per wavefront) against the oracle."""
+    """Stage strides 20 / 32 / 64 (3, 2, 1 row groups per wavefront) against the oracle, and every shape of the vector
+    sweeps' stage loops: passes of four stages plus a tail of 1..4 (forward) / 0..3 (backward), no pass at all (N < 6)."""
     w = workloads.config3(24, N=N, M=15)
     z, fl, it, info = solver.solve_batch_host(w)
     zo, flo, io = OL.solve_batch(w)
