@@ -7,7 +7,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libfrp_nmpc_amd.so")
-SOURCES = ["frp_kernels.hip", "frp_ipm_lds.hip", "frp_capi.hip", "frp_pack.hip", "frp_tube.hip", "frp_corridor.hip", "frp_reference.hip"]
+SOURCES = ["frp_kernels.hip", "frp_ipm_lds.hip", "frp_ipm_lds_mem.hip", "frp_capi.hip", "frp_pack.hip", "frp_tube.hip", "frp_corridor.hip", "frp_reference.hip"]
 HEADERS = ["frp_kernels.h", "frp_device.hpp", "frp_model.hpp", "frp_adapter.hpp", os.path.join(ROOT, "include", "frp_nmpc.h")]
 
 
@@ -25,17 +25,39 @@ def _stale(target, deps):
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+# Code-generation flags of the solver kernel's main translation unit (the test that inspects its generated code uses the same).
+#   -amdgpu-use-amdgpu-trackers=1: the scheduler tracks register pressure with the AMDGPU-specific trackers; on the solver
+#   variants that keep the corridor rows in registers (168-VGPR cap, role loops full of live state) that is 3.8 % per launch
+#   (1.388 -> 1.335 ms at B = 4096, same box); the variants that re-read them lose 2-10 % with it, so they are a translation
+#   unit of their own (frp_ipm_lds_mem.hip) without it; the other files are indifferent and stay on the defaults.
+CODEGEN_FLAGS = ["-mllvm", "-amdgpu-use-amdgpu-trackers=1"]
+PER_SOURCE_FLAGS = {"frp_ipm_lds.hip": CODEGEN_FLAGS + ["-DFRP_LDS_SPLIT_TU"]}
+OBJDIR = os.path.join(PKG, "_build")
+
+
 def build_native(force=False, verbose=True):
-    """hipcc --offload-arch=gfx950 -> forces_resilient_planner_amd/libfrp_nmpc_amd.so (in-tree)."""
+    """hipcc --offload-arch=gfx950 -> forces_resilient_planner_amd/libfrp_nmpc_amd.so (in-tree): one object per source
+    (compiled in parallel, per-source flags), linked into the shared library."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     if not force and not _stale(LIB, deps):
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-Wall",
-           "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")] + srcs + ["-o", LIB]
+    os.makedirs(OBJDIR, exist_ok=True)
+    common = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")]
+    jobs = []
+    for name, src in zip(SOURCES, srcs):
+        obj = os.path.join(OBJDIR, name + ".o")
+        cmd = common + PER_SOURCE_FLAGS.get(name, []) + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        jobs.append((cmd, obj, subprocess.Popen(cmd)))
+    for cmd, obj, pr in jobs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [j[1] for j in jobs] + ["-o", LIB]
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+        print(" ".join(link), flush=True)
+    subprocess.check_call(link)
     return LIB
 
 
@@ -53,7 +75,7 @@ def build_ubench(verbose=True):
             deps += [os.path.join(c, g) for g in os.listdir(c)]
         if os.path.exists(exe) and os.path.getmtime(exe) >= max(os.path.getmtime(g) for g in deps):
             continue
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-Wno-unused-value", src, "-o", exe]
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-Wno-unused-value"] + (CODEGEN_FLAGS if "csrc/" in open(src).read() else []) + [src, "-o", exe]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -142,7 +142,7 @@ constexpr LaneTables make_tables()
     }
     return t;
 }
-__device__ const LaneTables g_tab = make_tables();
+static __device__ const LaneTables g_tab = make_tables();
 
 __device__ __forceinline__ int tab(int row, int lane) { return (int)g_tab.v[row][lane]; }
 
@@ -156,7 +156,7 @@ typedef __attribute__((address_space(3))) const double cldouble;
 
 // -DFRP_PROFILE: per-wave cycle counts of the work before each of the five barriers of an iteration and of the wait at it
 #ifdef FRP_PROFILE
-__device__ long long g_prof_lds[4][16];
+static __device__ long long g_prof_lds[4][16];
 #define PROF_T0() const long long pinit0_ = clock64()
 #define PROF_DECL() long long pw_[5] = {0, 0, 0, 0, 0}, pb_[5] = {0, 0, 0, 0, 0}, pt_ = clock64(); const long long pinit_ = pt_ - pinit0_
 #define BAR_P(i)                                                    \
@@ -186,7 +186,7 @@ __device__ long long g_prof_lds[4][16];
 #define PROF_FLUSH(wave, its)
 #endif
 #ifdef FRP_PROFILE
-__device__ long long g_prof_seg[32];
+static __device__ long long g_prof_seg[32];
 #endif
 #ifdef FRP_PROFILE_SEG // (each timer read drains lgkmcnt: the segments are serialised, use them for proportions only) // factor sweep: mfma X/G, gather, pivot, tail mfma, P update + stores; then whole sweeps: factor, forward, backvec, forward+y
 #define SEG_DECL() long long sg_[6] = {0, 0, 0, 0, 0, 0}, st_ = clock64()
@@ -1652,6 +1652,18 @@ static hipError_t launch_variant(const KernelArgs &k, int slots, hipStream_t str
 
 } // namespace lr
 
+// Two translation units (build.py): the variants that keep the corridor rows in registers (FREG) are compiled with
+// -amdgpu-use-amdgpu-trackers=1 (-4 % on the (20, 2) variant of the headline workload), the variants that re-read them from
+// the parameters without it (the same flag costs them 2-10 %).  frp_ipm_lds_mem.hip includes this file with FRP_LDS_MEM_TU
+// and contributes launch_ipm_lds_mem only; a build that defines neither macro (probes, experiments) gets everything here.
+#ifdef FRP_LDS_MEM_TU
+hipError_t launch_ipm_lds_mem(const KernelArgs &k, int slots, hipStream_t stream)
+{
+    if (k.N <= 20) return lr::launch_variant<20, 10, false, 3>(k, slots, stream);
+    if (k.N <= 32) return lr::launch_variant<32, 15, false, 2>(k, slots, stream);
+    return lr::launch_variant<64, 30, false, 1>(k, slots, stream);
+}
+#else
 #ifdef FRP_PROFILE
 void debug_read_prof_lds(long long *out)
 {
@@ -1668,6 +1680,17 @@ int lds_workgroups_per_cu(int N) { return N <= 20 ? 3 : (N <= 32 ? 2 : 1); }
 
 bool lds_kernel_supports(int N, int MF) { return N >= 1 && N <= 64 && MF >= 0 && MF <= 30; }
 
+#ifdef FRP_LDS_SPLIT_TU
+hipError_t launch_ipm_lds_mem(const KernelArgs &k, int slots, hipStream_t stream); // frp_ipm_lds_mem.hip
+#else
+static hipError_t launch_ipm_lds_mem(const KernelArgs &k, int slots, hipStream_t stream)
+{
+    if (k.N <= 20) return lr::launch_variant<20, 10, false, 3>(k, slots, stream);
+    if (k.N <= 32) return lr::launch_variant<32, 15, false, 2>(k, slots, stream);
+    return lr::launch_variant<64, 30, false, 1>(k, slots, stream);
+}
+#endif
+
 // counter / order already set up by launch_ipm
 hipError_t launch_ipm_lds(const KernelArgs &k, int slots, hipStream_t stream)
 {
@@ -1675,19 +1698,16 @@ hipError_t launch_ipm_lds(const KernelArgs &k, int slots, hipStream_t stream)
     if (k.N <= 20) {
         if (MF <= 6) return lr::launch_variant<20, 2, true, 3>(k, slots, stream);
         if (MF <= 15) return lr::launch_variant<20, 5, true, 3>(k, slots, stream);
-        return lr::launch_variant<20, 10, false, 3>(k, slots, stream);
-    }
-    if (k.N <= 32) {
+    } else if (k.N <= 32) {
         if (MF <= 6) return lr::launch_variant<32, 3, true, 2>(k, slots, stream);
         if (MF <= 16) return lr::launch_variant<32, 8, true, 2>(k, slots, stream);
-        return lr::launch_variant<32, 15, false, 2>(k, slots, stream);
-    }
-    if (MF <= 8) return lr::launch_variant<64, 8, true, 1>(k, slots, stream);
-    return lr::launch_variant<64, 30, false, 1>(k, slots, stream);
+    } else if (MF <= 8) return lr::launch_variant<64, 8, true, 1>(k, slots, stream);
+    return launch_ipm_lds_mem(k, slots, stream);
 }
+#endif // FRP_LDS_MEM_TU
 
 } // namespace frp
 
-#ifdef FRP_PROFILE
+#if defined(FRP_PROFILE) && !defined(FRP_LDS_MEM_TU)
 extern "C" void frp_debug_read_prof_lds(long long *out) { frp::debug_read_prof_lds(out); }
 #endif
