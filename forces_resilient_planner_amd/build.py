@@ -26,11 +26,20 @@ def _stale(target, deps):
 
 
 # Code-generation flags of the solver kernel's main translation unit (the test that inspects its generated code uses the same).
-#   -amdgpu-use-amdgpu-trackers=1: the scheduler tracks register pressure with the AMDGPU-specific trackers; on the solver
-#   variants that keep the corridor rows in registers (168-VGPR cap, role loops full of live state) that is 3.8 % per launch
-#   (1.388 -> 1.335 ms at B = 4096, same box); the variants that re-read them lose 2-10 % with it, so they are a translation
-#   unit of their own (frp_ipm_lds_mem.hip) without it; the other files are indifferent and stay on the defaults.
-CODEGEN_FLAGS = ["-mllvm", "-amdgpu-use-amdgpu-trackers=1"]
+# The kernel sits at the 168-VGPR cap of three workgroups per CU with role loops full of live state, and what it issues is what
+# it costs: every flag below trades recomputation or code size for fewer live registers / spills.  Measured one after
+# the other on the same box, B = 4096 (tools/ab_variants.sh): 1.388 ms per launch with the defaults,
+#   -amdgpu-use-amdgpu-trackers=1                 1.335   (the scheduler tracks pressure with the AMDGPU-specific trackers)
+#   -disable-machine-licm                         1.310   (no hoisting of loop invariants into registers)
+#   -disable-machine-cse                          1.296
+#   -amdgpu-enable-rewrite-partial-reg-uses=0     1.278
+#   -amdgpu-load-store-vectorizer=0               1.268
+# (not additive beyond this: -greedy-reverse-local-assignment=1 alone 1.273, together with the last one 1.304; max-ilp, O2 / Os,
+# no post-RA scheduler, no machine sinking, no LSR: all slower).  The variants that re-read the corridor rows from the
+# parameters lose 2-10 % with the first flag already, so they are a translation unit of their own (frp_ipm_lds_mem.hip)
+# on the defaults; the other files are indifferent and stay on the defaults too.
+CODEGEN_FLAGS = ["-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-mllvm", "-disable-machine-licm", "-mllvm", "-disable-machine-cse",
+                 "-mllvm", "-amdgpu-enable-rewrite-partial-reg-uses=0", "-mllvm", "-amdgpu-load-store-vectorizer=0"]
 PER_SOURCE_FLAGS = {"frp_ipm_lds.hip": CODEGEN_FLAGS + ["-DFRP_LDS_SPLIT_TU"]}
 OBJDIR = os.path.join(PKG, "_build")
 
