@@ -335,6 +335,29 @@ def test_horizon_lengths_cover_every_lane_mapping(N):
     assert np.max(np.abs(z[ok] - zo[ok])) < 1e-3
 
 
+@pytest.mark.parametrize("N,M,B", [(20, 6, 64), (20, 15, 64), (20, 30, 64), (30, 6, 48), (30, 15, 48), (30, 30, 48), (48, 8, 24), (48, 30, 24)])
+def test_every_kernel_variant_reports_the_oracles_numbers(N, M, B):
+    """One batch per kernel variant of the LDS-resident solver (stage stride 20 / 32 / 64 x corridor rows in registers or
+    re-read from the parameters; the variants are separate template instantiations in two translation units with their own
+    code-generation flags): flags, iteration counts, iterates AND every reported quantity -- residual norms, objective,
+    mu -- against the oracle.  `nfaces` is withheld so that the padding detection runs and MF = M selects the variant."""
+    w = workloads.config3(B, N=N, M=M)
+    wn = dict(w); wn["nfaces"] = None
+    z, fl, it, info = solver.solve_batch_host(wn)
+    zo, flo, io = OL.solve_batch(w)
+    assert np.array_equal(fl, flo)
+    ok = (fl == 1) & (flo == 1) & (it == np.array([i.it for i in io]))
+    assert ok.sum() >= B // 2
+    assert np.max(np.abs(z[ok] - zo[ok])) < 1e-6
+    # residuals of a converged iterate are rounding noise below ~1e-7: absolute; objective and mu: relative
+    for col, name in ((0, "res_eq"), (1, "res_ineq"), (2, "rsnorm"), (3, "rcompnorm")):
+        ref = np.array([getattr(i, name) for i in io])
+        assert np.max(np.abs(info[ok, col] - ref[ok])) < 1e-7, name
+    for col, name in ((4, "pobj"), (5, "mu")):
+        ref = np.array([getattr(i, name) for i in io])
+        assert np.max(np.abs(info[ok, col] - ref[ok]) / (1e-9 + np.abs(ref[ok]))) < 1e-6, name
+
+
 def test_device_packing_matches_the_adapter():
     """frp_nmpc_pack_batch / frp_nmpc_update_batch against the host adapter (adapter.py, itself
     checked against the C++ mirror of forces_normal.cpp): copies bit-exact, the tightened offsets b - ||E a|| to 2 ulp
