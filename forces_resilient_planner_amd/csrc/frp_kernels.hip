@@ -1459,17 +1459,22 @@ __global__ __launch_bounds__(1024) void order_bucket_kernel(int B, const double 
         atomicAdd(&hist[1023 - (int)((u - base) >> shift)], 1); // bin 0 = largest keys
     }
     __syncthreads();
-    { // exclusive prefix sum over the 1024 bins (Hillis-Steele, 10 steps)
-        const int own = hist[t];
-        for (int off = 1; off < 1024; off <<= 1) {
-            const int add = t >= off ? hist[t - off] : 0;
-            __syncthreads();
-            hist[t] += add;
-            __syncthreads();
+    { // exclusive prefix sum over the 1024 bins: a shuffle scan inside every wavefront, then the sixteen wave totals
+      // (two barriers instead of the twenty of a Hillis-Steele scan over the workgroup: the kernel is all latency)
+        __shared__ int wtot[16];
+        const int own = hist[t], lane = t & 63, wv = t >> 6;
+        int v = own;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(v, off);
+            if (lane >= off) v += up;
         }
-        const int incl = hist[t];
+        if (lane == 63) wtot[wv] = v;
         __syncthreads();
-        hist[t] = incl - own;
+        int before = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) before += w < wv ? wtot[w] : 0;
+        hist[t] = before + v - own;
     }
     __syncthreads();
     for (int i = t; i < B; i += 1024) {
