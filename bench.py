@@ -73,18 +73,19 @@ def native_oracle():
         return "-O3 -march=x86-64-v3 (in-tree build)"
 
 
-def cpu_baseline(w, seconds_target=12.0):
+def cpu_baseline(w, seconds_target=12.0, diverge_mu=1e3):
     """The CPU oracle (same algorithm, FP64, OpenMP over problems) timed on a bounded sample of the
     same workload on this box's host cores.  Test infrastructure used only as the reported baseline."""
     import tests.oracle_lib as OL
     flags = native_oracle()
     cores = usable_cores()
     B = w["xinit"].shape[0]
-    OL.solve_batch(w, nthreads=cores)  # warm up threads / page in
+    oopt = OL.default_options(diverge_mu=diverge_mu)
+    OL.solve_batch(w, oopt, nthreads=cores)  # warm up threads / page in
     reps, solved, t0 = 0, 0, time.perf_counter()
     conv = 0
     while True:
-        z, fl, info = OL.solve_batch(w, nthreads=cores)
+        z, fl, info = OL.solve_batch(w, oopt, nthreads=cores)
         reps += 1; solved += B; conv += int((fl == 1).sum())
         dt = time.perf_counter() - t0
         if dt >= seconds_target or reps >= 2000:
@@ -106,7 +107,7 @@ def cpu_baseline(w, seconds_target=12.0):
         anchor = {"error": str(e)}
     n1 = min(B, 512)
     sub = {k: (v[:n1] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in w.items()}
-    t1 = time.perf_counter(); OL.solve_batch(sub, nthreads=1); dt1 = time.perf_counter() - t1
+    t1 = time.perf_counter(); OL.solve_batch(sub, oopt, nthreads=1); dt1 = time.perf_counter() - t1
     cpu_model = ""
     try:
         cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
@@ -135,6 +136,13 @@ def pmc_traffic(batch, kernel):
     return None, None
 
 
+def self_launch_command(n, argv, port=None):
+    """The command line `python bench.py --gpus N ...` re-executes itself with when no launcher set WORLD_SIZE."""
+    port = port or int(os.environ.get("FRP_BENCH_PORT", "0")) or (29500 + os.getpid() % 2000)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,6 +162,12 @@ def main():
                     help="informational: `value` is always the strictly serial single-stream rate; the rate with the steps issued "
                          "round-robin on 2 streams (the tail of one launch overlapping the next) is reported in config.pipelined_*")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` by itself must be an N-rank run: without a launcher around it (no WORLD_SIZE) re-execute under
+    # torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = self_launch_command(args.gpus, sys.argv[1:])
+        os.execv(cmd[0], cmd)
 
     import torch
     from forces_resilient_planner_amd import distributed as D
@@ -236,6 +250,10 @@ def main():
 
             def step():
                 ds.solve(stream)
+        if cfg == 3:
+            # configs[3]'s generator makes (locally) infeasible instances; the benchmark opts into the early infeasibility
+            # exit (frp_nmpc_options.diverge_mu, default 1e3) -- the CPU baseline below runs with the same setting
+            ds.opt.diverge_mu = 10.0
     else:
         # configs[4]: Monte-Carlo f_ext around ONE nominal problem, warm-started receding horizon; a step = one tick
         from forces_resilient_planner_amd.workloads import _bbox_faces, _weights
@@ -304,6 +322,7 @@ def main():
     if cfg in (2, 3) and not strong:
         d2 = solver.DeviceSolver(B, N, M, ds.MF, model, f"cuda:{local_rank}")
         d2.xinit, d2.x0, d2.params, d2.nfaces = ds.xinit, ds.x0, ds.params, ds.nfaces
+        d2.opt = ds.opt
         s2 = torch.cuda.Stream(dev)
         lanes = [(ds, stream), (d2, s2)]
         cnt = [0]
@@ -337,6 +356,10 @@ def main():
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)  # summary statistics, not on the data path
         stats[3] = mx[0]
     conv_frac = float(stats[0] / stats[2]); mean_it = float(stats[1] / stats[2])
+    ranks_solving = torch.tensor([1.0 if B > 0 else 0.0], **f64)  # n_gpus = the ranks that actually solved a shard
+    if dist is not None:
+        dist.all_reduce(ranks_solving, op=dist.ReduceOp.SUM)
+    ranks_solving = int(ranks_solving.item())
 
     # dominant kernel: average duration over the same launches, HIP events on the launch stream
     kernel_ms = ds.time_solve(max(1, args.steps), stream) if B > 0 else 0.0
@@ -351,25 +374,28 @@ def main():
         achieved_tf = B * f_solve / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
         alg_bytes = 8.0 * (9 + 17 * N + N * (10 + 4 * M) + 1) + 8.0 * 17 * N + 136.0  # dense ABI image of one solve: params + output + info (26 456 B at N = 20, M = 30)
         achieved_gbs = B * alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        kname = "nmpc_ipm_kernel" if os.environ.get("FRP_KERNEL", "") == "r01" else "nmpc_ipm_lds_kernel"
+        kname = "nmpc_ipm_lds_kernel"
         traffic, traffic_src = pmc_traffic(B, kname) if cfg == 2 else (None, None)
         names = {2: "BASELINE.json configs[2]: N=20, constant f_ext~U[-3,3]^3, 6-face tightened corridor per stage, cold start, reference 30-row parameter layout",
                  3: "BASELINE.json configs[3]: N=30, time-varying f_ext, per-stage polytopes with <=15 faces, cold start",
                  4: "BASELINE.json configs[4]: Monte-Carlo f_ext~N(fbar,0.5^2 I) around one nominal problem, N=20, warm-started receding horizon, one step = one tick (pack + solve + update on the device)"}
         out = {
             "metric": "NMPC solves/sec, batch=4096 horizons N=20", "value": value, "unit": "solves/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": int(ranks_solving), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": names[cfg] + f"; batch {B} per GPU" + (f" of {B_total} in total, scattered from / gathered to rank 0 every step" if strong and cfg != 4 else ""),
-                       "baseline_config": cfg, "batch_per_gpu": B, "batch_total": B_total, "horizon": int(N), "converged_frac": conv_frac,
+                       "baseline_config": cfg, "world_size": world, "collectives": ("RCCL (torch.distributed nccl backend)" if dist is not None else "none (single process)"),
+                       "batch_per_gpu": B, "batch_total": B_total, "horizon": int(N), "converged_frac": conv_frac,
                        "mean_ipm_iterations": mean_it, "max_ipm_iterations": int(stats[3]), "p95_ipm_iterations": float(np.percentile(it, 95)) if len(it) else 0.0,
                        "timing": f"median of {len(reps)} repeats of the {args.steps}-step region, strictly serial launches on one stream; max over ranks per repeat",
                        "repeat_ms_per_step": [r / args.steps * 1e3 for r in reps],
                        "pipelined_solves_per_s": pipelined,
                        "pipelined_note": "the same steps issued round-robin on 2 HIP streams (the few long solves at the end of a launch overlap the head of the next); informational, never `value`",
                        "tolerances": 1e-4},
-            "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma",
+                         "bound_detail": "fp64-issue: FP64 VALU + MFMA issue slots of in-order wavefronts on the serial stage chain (DESIGN 5); priced against the FP64 matrix == vector peak",
+                         "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "kernel": kname, "kernel_ms": kernel_ms,
@@ -401,7 +427,7 @@ def main():
             out["dropin_latency_ms"] = {"value": float(np.median(lat[5:])) * 1e3, "exitflag": int(flag), "iterations": int(info.it),
                                         "what": "BASELINE configs[0] through FORCESNLPsolver_normal_solve (H2D of the 23.6 KB params, one-problem solve, D2H), warm, median of 20"}
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(wcpu)
+            out["cpu_baseline"] = cpu_baseline(wcpu, diverge_mu=float(ds.opt.diverge_mu))
         elif not args.no_cpu:
             out["cpu_baseline"] = None
         line = json.dumps(out)

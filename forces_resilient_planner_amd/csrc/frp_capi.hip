@@ -50,7 +50,7 @@ struct DevMem {
 
 bool fill_args(const frp_nmpc_batch *b, const frp_nmpc_options *opt_in, void *ws, size_t ws_bytes, frp::KernelArgs *a)
 {
-    if (!b || b->B <= 0 || b->N < 2 || b->N > 64 || b->M < 0 || b->MF < 0 || b->MF > b->M) return false;
+    if (!b || b->B <= 0 || b->N < 2 || b->N > 64 || b->M < 0 || b->MF < 0 || b->MF > b->M || b->MF > frp::FRP_MAX_FACES) return false;
     if (!b->xinit || !b->x0 || !b->params || !b->z || !b->exitflag || !b->iters || !ws) return false;
     if (b->model != FRP_MODEL_NORMAL && b->model != FRP_MODEL_FINAL) return false;
     if (ws_bytes < frp::ws_bytes(b->B, b->N, b->MF)) return false;
@@ -59,6 +59,7 @@ bool fill_args(const frp_nmpc_batch *b, const frp_nmpc_options *opt_in, void *ws
     a->B = b->B; a->N = b->N; a->M = b->M; a->MF = b->MF; a->model = b->model; a->maxit = o.maxit;
     a->tol_stat = o.tol_stat; a->tol_eq = o.tol_eq; a->tol_ineq = o.tol_ineq; a->tol_comp = o.tol_comp;
     a->mu0 = o.mu0; a->ftb = o.ftb; a->hessian = o.hessian;
+    a->diverge_mu = o.diverge_mu > 0.0 ? o.diverge_mu : 1e3;
     a->xinit = b->xinit; a->x0 = b->x0; a->params = b->params; a->nfaces = b->nfaces;
     a->z = b->z; a->exitflag = b->exitflag; a->iters = b->iters; a->info = b->info;
     a->ws = static_cast<double *>(ws);
@@ -216,7 +217,7 @@ int forces_solve(int model, frp_forces_params *params, frp_forces_output *output
 
 extern "C" {
 
-const char *frp_nmpc_version(void) { return "frp_nmpc_amd 0.1 (gfx950, FP64 wave-per-problem IPM)"; }
+const char *frp_nmpc_version(void) { return "frp_nmpc_amd 0.3 (gfx950, FP64 interior point: four wavefronts per problem, stage records in LDS)"; }
 
 int frp_nmpc_device_count(void)
 {
@@ -235,6 +236,7 @@ void frp_nmpc_default_options(frp_nmpc_options *o)
     o->mu0 = 1.0;
     o->ftb = 0.99;
     o->hessian = 1;
+    o->diverge_mu = 1e3;
 }
 
 size_t frp_nmpc_workspace_bytes(int B, int N, int MF) { return frp::ws_bytes(B, N, MF); }
@@ -273,7 +275,7 @@ int frp_nmpc_time_solve(const frp_nmpc_batch *batch, const frp_nmpc_options *opt
 int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *opt)
 {
     // the same checks as fill_args, before anything is sized or copied from the caller's pointers
-    if (!h || h->B <= 0 || h->N < 2 || h->N > 64 || h->M < 0 || h->MF < 0 || h->MF > h->M) return FRP_ERR_ARG;
+    if (!h || h->B <= 0 || h->N < 2 || h->N > 64 || h->M < 0 || h->MF < 0 || h->MF > h->M || h->MF > frp::FRP_MAX_FACES) return FRP_ERR_ARG;
     if (!h->xinit || !h->x0 || !h->params || !h->z || !h->exitflag || !h->iters) return FRP_ERR_ARG;
     if (h->model != FRP_MODEL_NORMAL && h->model != FRP_MODEL_FINAL) return FRP_ERR_ARG;
     int n = 0;

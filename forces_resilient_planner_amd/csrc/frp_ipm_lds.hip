@@ -8,7 +8,7 @@
 // One workgroup = 4 wavefronts = one NMPC problem at a time; persistent workgroups pull problems from a device queue.
 // Nothing of the per-iteration state lives in HBM:
 //   * the per-stage records the Riccati sweeps work on (linearisation, barrier Hessian, T', packed P, rhs vectors,
-//     Newton step) stay in LDS for the whole solve: RS = 307 doubles per stage, 49 KB at N = 20 -> 3 problems per CU;
+//     Newton step) stay in LDS for the whole solve: RS = 309 doubles per stage, 49 KB at N = 20 -> 3 problems per CU;
 //   * slacks, multipliers, second-order terms, corridor faces, the iterate z and the equality multipliers y live in the
 //     REGISTERS of the wave that owns them.
 // Wave roles (wave-uniform control flow, 5 workgroup barriers per interior-point iteration):
@@ -45,12 +45,12 @@ constexpr int R_PD = 232;    // P_{k+1} d_k (13); after the corrector's backward
 constexpr int R_PHIB = 245;  // corrector rhs phi_cc = PHIB + (sigma mu) PHIC (17 + 17), bound rows and cost;
 constexpr int R_CB = 262;    //   corridor part (pos entries) of PHIB; evaluation phase: A' lam (stationarity residual)
 constexpr int R_BC = 21;     // distance from every "B" slot (PHIB, CB) to its "C" twin (PHIC, CC): one ds_read2 fetches both
-constexpr int R_PHIC = R_PHIB + R_BC; // evaluation phase: PHIB = cost gradient + bound multipliers (stationarity residual)
+constexpr int R_PHIC = R_PHIB + R_BC; // evaluation phase: PHIB = cost gradient + bound multipliers, PHIC = M'y part (stationarity residual)
 constexpr int R_CC = R_CB + R_BC;     // corridor part of PHIC; evaluation phase: corridor part of phi_aff
 constexpr int R_HC = 286;    // (u_i, w_i) cost coupling -2 w_rate of this stage
 constexpr int R_ZERO = 287, R_ONE = 288, R_DT = 289; // constants the gathers pick up
 constexpr int R_DUMP = 290;  // target of masked-out writes (never read)
-constexpr int R_DZ = 291;    // Newton step [du(4); ds(13)]; evaluation phase: M'y part of the stationarity residual
+constexpr int R_DZ = 291;    // Newton step [du(4); ds(13)]
 constexpr int R_ZERO2 = R_ZERO + R_BC; // second zero, R_BC behind the first: masked (B, C) pair reads
 constexpr int RS = 309;      // odd stride: lane == stage accesses are conflict-free
 static_assert(R_PHIC + 17 <= R_CC && R_CC + 3 <= R_HC && R_DZ + 17 <= R_ZERO2 && R_ZERO2 < RS, "record tail");
@@ -256,7 +256,7 @@ __device__ __forceinline__ double stationarity_norm(cldouble *recs, int N)
         for (int r = 0; r < R; r++) {
             const int i = r * H + half;
             if (i >= NZ) continue;
-            double g = rec[R_PHIB + i] + rec[R_DZ + i];
+            double g = rec[R_PHIB + i] + rec[R_PHIC + i];
             if (i >= 8 && i < 11) g += rec[R_CB + i - 8];
             rs = fmax(rs, fabs(g));
         }
@@ -923,7 +923,9 @@ __device__ __forceinline__ void model_phase(ldouble *recs, ldouble *xs, ModelSta
                 gm[3] += gT;
             }
 #pragma unroll
-            for (int i = 0; i < NZ; i++) rec[R_DZ + i] = gm[i];
+            // (PHIC is free from the step phase to the affine phase; the Newton step's slots are NOT: wave 0 starts the
+            // predictor's forward sweep, which writes them, while the other waves may still be summing the residual)
+            for (int i = 0; i < NZ; i++) rec[R_PHIC + i] = gm[i];
         }
     }
     SEG(5);
@@ -1293,7 +1295,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             if (!(nm.eq == nm.eq) || !(nm.rs == nm.rs) || !(nm.gap == nm.gap)) { flag = FRP_EXIT_BADFUNCEVAL; break; }
             if (nm.eq <= a.tol_eq && nm.in <= a.tol_ineq && nm.rs <= a.tol_stat && nm.rc <= a.tol_comp) { flag = FRP_EXIT_OPTIMAL; break; }
             if (it >= a.maxit) { flag = FRP_EXIT_MAXIT; break; }
-            if (mu > DIVERGE_MU * fmax(1.0, a.mu0) || nm.rs > DIVERGE_RS) { flag = FRP_EXIT_NOPROGRESS; break; }
+            if (mu > a.diverge_mu * fmax(1.0, a.mu0) || nm.rs > DIVERGE_RS) { flag = FRP_EXIT_NOPROGRESS; break; }
         }
 
         // ============================================================ predictor: factorisation + forward sweep
@@ -1678,7 +1680,7 @@ void debug_read_prof_lds(long long *out)
 // workgroups resident per CU: LDS-bound (3 x 49 KB, 2 x 79 KB, 1 x 157 KB)
 int lds_workgroups_per_cu(int N) { return N <= 20 ? 3 : (N <= 32 ? 2 : 1); }
 
-bool lds_kernel_supports(int N, int MF) { return N >= 1 && N <= 64 && MF >= 0 && MF <= 30; }
+bool lds_kernel_supports(int N, int MF) { return N >= 1 && N <= 64 && MF >= 0 && MF <= FRP_MAX_FACES; }
 
 #ifdef FRP_LDS_SPLIT_TU
 hipError_t launch_ipm_lds_mem(const KernelArgs &k, int slots, hipStream_t stream); // frp_ipm_lds_mem.hip

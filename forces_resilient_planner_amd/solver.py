@@ -23,7 +23,7 @@ c_int_p = ctypes.POINTER(ctypes.c_int)
 class Options(ctypes.Structure):
     _fields_ = [("maxit", ctypes.c_int), ("tol_stat", ctypes.c_double), ("tol_eq", ctypes.c_double),
                 ("tol_ineq", ctypes.c_double), ("tol_comp", ctypes.c_double), ("mu0", ctypes.c_double),
-                ("ftb", ctypes.c_double), ("hessian", ctypes.c_int)]
+                ("ftb", ctypes.c_double), ("hessian", ctypes.c_int), ("diverge_mu", ctypes.c_double)]
 
 
 class Batch(ctypes.Structure):
@@ -408,6 +408,9 @@ class DeviceFleet:
         self.poly_b = torch.zeros((B, self.NPOLY, F), **f64)
         self.poly_nfaces = torch.zeros((B, self.NPOLY), dtype=torch.int32, device=dev)
         self.poly_index = None
+        # per planner: polytopes produced by the last corridor() (>= 1), negated when one of them needed more than F rows and
+        # was truncated (getSikangConst tests all rows; callers that size F below FRP_CORRIDOR_MAX_F should check overflowed())
+        self.poly_count = torch.zeros((B,), dtype=torch.int32, device=dev)
         self.weights_final = None if weights_final is None else tuple(float(x) for x in weights_final)
         self.mode = None
         if self.weights_final is not None:
@@ -465,15 +468,12 @@ class DeviceFleet:
         assert self.NPOLY == self.N
         if self.poly_index is None:
             self.poly_index = t.zeros((self.B, self.N), dtype=t.int32, device=self.solver.device)
-        if getattr(self, "poly_count", None) is None:
-            # per planner: polytopes produced, negative when one of them needed more than F rows and was truncated
-            # (getSikangConst tests all rows; callers that size F below FRP_CORRIDOR_MAX_F should check overflowed())
-            self.poly_count = t.zeros((self.B,), dtype=t.int32, device=self.solver.device)
         corridor_batch_device(cloud, ref_pos, ref_yaw, self.ellipsoid, self.poly_A, self.poly_b, self.poly_nfaces,
                               self.poly_index, self.poly_count, cloud_count, consts, stream, grid)
 
     def overflowed(self):
-        """Planners whose last corridor() truncated a polytope to F rows (device tensor of bool)."""
+        """Planners whose last corridor() truncated a polytope to F rows (device tensor of bool; all False before the first
+        corridor() call)."""
         return self.poly_count < 0
 
     def coldstart(self, state=None, only_failed=True, thrust=7.3, stream=None):

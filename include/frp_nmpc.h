@@ -69,13 +69,19 @@ typedef struct frp_nmpc_options {
     double ftb;       /* fraction to boundary, 0.99 (normal.h:89)          */
     int hessian;      /* 1 (default): exact Lagrangian Hessian of the RK2 dynamics with Gauss-Newton
                          fallback when the reduced Hessian is indefinite; 0: Gauss-Newton only   */
+    double diverge_mu;/* 1e3: exit -7 (NOPROGRESS) once the average complementarity exceeds
+                         diverge_mu * max(1, mu0) -- multipliers growing without bound = a (locally)
+                         infeasible instance.  Converging solves of the BASELINE workloads stay below 10;
+                         10 is the early-exit setting of the configs[3] benchmark (bench.py)          */
 } frp_nmpc_options;
 
 typedef struct frp_nmpc_batch {
     int B;      /* problems                                                             */
     int N;      /* horizon (stages); 20 in the reference (setup.m:36), <= 64 here       */
     int M;      /* corridor rows in the parameter layout (30 in the reference, setup.m:42) */
-    int MF;     /* max LIVE corridor rows of any stage (<= M); sizes the workspace       */
+    int MF;     /* max LIVE corridor rows of any stage (<= M, <= 30 = the reference's
+                   num_const: its adapter drops rows beyond 30, forces_normal.cpp:114);
+                   selects the kernel variant; a larger value is FRP_ERR_ARG               */
     int model;  /* FRP_MODEL_NORMAL / FRP_MODEL_FINAL                                    */
     const double *xinit;  /* [B][9]            params.xinit            (normal.h:156)  */
     const double *x0;     /* [B][N][17]        params.x0, initial guess (normal.h:159)  */

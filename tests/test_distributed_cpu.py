@@ -122,3 +122,29 @@ def test_shard_ranges_cover_batch_exactly():
                 lo, hi = D.shard_range(B, r, world)
                 got += list(range(lo, hi))
             assert got == list(range(B))
+
+
+def test_bench_gpus_n_relaunches_itself_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` without a launcher around it re-executes under torch.distributed.run with N ranks on
+    127.0.0.1, keeping its own arguments (both --scaling modes); with WORLD_SIZE set (the driver's torchrun form) it does not."""
+    import sys
+    import bench
+    cmd = bench.self_launch_command(8, ["--gpus", "8", "--steps", "5", "--warmup", "1", "--scaling", "strong"], port=29999)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    i = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "1", "--scaling", "strong"]
+    # main() takes that path exactly when --gpus > 1 and no launcher set WORLD_SIZE
+    calls = []
+    monkeypatch.setattr(os, "execv", lambda exe, argv: (calls.append(argv), (_ for _ in ()).throw(SystemExit(0))))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--scaling", "weak"])
+    with pytest.raises(SystemExit):
+        bench.main()
+    assert len(calls) == 1 and "--nproc-per-node=4" in calls[0] and calls[0][-4:] == ["--gpus", "4", "--scaling", "weak"]
+    calls.clear()
+    monkeypatch.setenv("WORLD_SIZE", "4")  # under a launcher: no re-exec (here it then stops at "needs an MI355X")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert not calls and "MI355X" in str(e.value)
