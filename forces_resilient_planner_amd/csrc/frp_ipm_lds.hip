@@ -864,14 +864,14 @@ __device__ __forceinline__ void model_phase(ldouble *recs, ldouble *xs, ModelSta
         for (int i = 0; i < 4; i++) {
             const double zn = dpp_move<0x130>(st.z[4 + i]); // wave_shl:1, lane k <- lane k+1
             const double d = zk[i] - zn;
-            if (dyn) rec[R_D + i] = d;
+            if (k < N) rec[R_D + i] = dyn ? d : 0.0; // (the last stage has no successor: d = 0; the slots carried y+ through the step phase)
             dmax = fmax(dmax, fabs(d));
         }
 #pragma unroll
         for (int i = 0; i < 9; i++) {
             const double zn = dpp_move<0x130>(st.z[8 + i]);
             const double d = xn[i] - zn;
-            if (dyn) rec[R_D + 4 + i] = d;
+            if (k < N) rec[R_D + 4 + i] = dyn ? d : 0.0;
             dmax = fmax(dmax, fabs(d));
         }
         if (dyn) l_eq = fmax(l_eq, dmax);
@@ -955,6 +955,305 @@ __device__ __forceinline__ void hessian_phase(ldouble *rec, const HessState &hs,
     }
 }
 
+// ================================================================== three lanes per stage (NP = 20)
+// The evaluation phase is the part of an iteration in which the Riccati wave waits for the helpers, and with lane ==
+// stage the model and the Hessian are 1.5-2 k instructions each on 20 of 64 lanes.  With NP = 20 three lanes share a stage
+// (lane = sub * NP + k, like the bound rows): every lane keeps a copy of the stage's state and evaluates the part of the
+// Jacobian / Hessian that belongs to ONE attitude angle -- column `sub` of the blocks d(.)/d(v, e) and of the products with
+// them -- with the same instruction stream for the three angles:
+//   d/d(angle j) of a product of sines / cosines that contains the angle once = the product with (s_j, c_j) -> (c_j, -s_j),
+// so a lane differentiates by substituting ITS angle in the trig set (six selects) and evaluating zB again (TrigK).  What a lane
+// needs of the other two (their sine / cosine, s_j and a_j of the Hessian, a column of Ke) goes through a dozen scratch
+// slots of the stage record that are dead in this phase.  Products with J = d acc / d v use its structure,
+// J c = d (zB (zB . c) - c), instead of nine multiply-adds per column.
+__device__ __forceinline__ double pick3(int sub, double a0, double a1, double a2) { return sub == 0 ? a0 : (sub == 1 ? a1 : a2); }
+// zB = (cy sp cr + sy sr, sy sp cr - cy sr, cp cr) and its derivatives.  A derivative by one angle replaces that angle's
+// (sin, cos) by (cos, -sin) in the terms that contain it and removes the terms that do not: the "sr" terms carry no pitch
+// (factor kB), the "cp cr" term no yaw (factor kC).  The rule composes, so second derivatives are two substitutions.
+struct TrigK {
+    double sr, cr, sp, cp, sy, cy, kB, kC;
+};
+__device__ __forceinline__ TrigK trigk(const Trig &t)
+{
+    TrigK d;
+    d.sr = t.sr; d.cr = t.cr; d.sp = t.sp; d.cp = t.cp; d.sy = t.sy; d.cy = t.cy; d.kB = 1.0; d.kC = 1.0;
+    return d;
+}
+__device__ __forceinline__ void zb_of(const TrigK &t, double z[3])
+{
+    const double spcr = t.sp * t.cr;
+    z[0] = t.cy * spcr + t.kB * (t.sy * t.sr);
+    z[1] = t.sy * spcr - t.kB * (t.cy * t.sr);
+    z[2] = t.kC * (t.cp * t.cr);
+}
+__device__ __forceinline__ void zb_of(const Trig &t, double z[3])
+{
+    z[0] = t.cy * t.sp * t.cr + t.sy * t.sr;
+    z[1] = t.sy * t.sp * t.cr - t.cy * t.sr;
+    z[2] = t.cp * t.cr;
+}
+__device__ __forceinline__ double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ TrigK dtrig_lane(const TrigK &t, int sub) // derivative with respect to the lane's own angle
+{
+    TrigK d;
+    d.sr = sub == 0 ? t.cr : t.sr; d.cr = sub == 0 ? -t.sr : t.cr;
+    d.sp = sub == 1 ? t.cp : t.sp; d.cp = sub == 1 ? -t.sp : t.cp;
+    d.sy = sub == 2 ? t.cy : t.sy; d.cy = sub == 2 ? -t.sy : t.cy;
+    d.kB = sub == 1 ? 0.0 : t.kB; d.kC = sub == 2 ? 0.0 : t.kC;
+    return d;
+}
+template <int L>
+__device__ __forceinline__ TrigK dtrig(const TrigK &t) // derivative with respect to angle L (roll, pitch, yaw)
+{
+    TrigK d = t;
+    if (L == 0) { d.sr = t.cr; d.cr = -t.sr; }
+    if (L == 1) { d.sp = t.cp; d.cp = -t.sp; d.kB = 0.0; }
+    if (L == 2) { d.sy = t.cy; d.cy = -t.sy; d.kC = 0.0; }
+    return d;
+}
+// sines / cosines of e and e + dt rates: every lane evaluates its own angle of both, the stage's three lanes swap them
+// through 12 scratch slots (layout [s1(3) c1(3) s2(3) c2(3)])
+__device__ __forceinline__ void trig_shared(ldouble *sc, int sub, const double e[3], const double et[3], Trig &t1, Trig &t2)
+{
+    double s1, c1, s2, c2;
+    sincos_bounded(pick3(sub, e[0], e[1], e[2]), &s1, &c1);
+    sincos_bounded(pick3(sub, et[0], et[1], et[2]), &s2, &c2);
+    sc[sub] = s1; sc[3 + sub] = c1; sc[6 + sub] = s2; sc[9 + sub] = c2;
+    WSYNC();
+    t1.sr = sc[0]; t1.sp = sc[1]; t1.sy = sc[2]; t1.cr = sc[3]; t1.cp = sc[4]; t1.cy = sc[5];
+    t2.sr = sc[6]; t2.sp = sc[7]; t2.sy = sc[8]; t2.cr = sc[9]; t2.cp = sc[10]; t2.cy = sc[11];
+    WSYNC();
+}
+
+// wave 1, three lanes per stage: Heun step, column `sub` of the compact linearisation, d, M'y (see model_phase).
+// Register budget: z and y are this wave's persistent state (60 VGPRs); y waits in the record for the whole phase (the
+// neighbour stage and the lane-dependent entries are read from there anyway), and every block below ends with the stores of
+// what it produced, so that little more than the trig sets and the step itself is live from block to block.
+template <int NP>
+__device__ __forceinline__ void model_phase3(ldouble *recs, ldouble *xs, ModelState &st, int N, double &l_eq)
+{
+    const int lane = threadIdx.x & 63, k = lane % NP, sub = lane / NP;
+    const bool act = k < N && sub < 3, dyn = act && k < N - 1;
+    const double *z = st.z;
+    l_eq = 0.0;
+    ldouble *rec = recs + (act ? k : 0) * RS;
+    if (act && sub == 0) {
+#pragma unroll
+        for (int i = 0; i < NS; i++) rec[RT_Y + i] = st.y[i];
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const double dx = xs[X_XINIT + i] - z[8 + i];
+            xs[X_DX0 + i] = dx;
+            l_eq = fmax(l_eq, fabs(dx));
+        }
+    }
+    WSYNC();
+    // ---- block 1: the step
+    Trig t1, t2;
+    double zb1[3], zb2[3], vt[3], xn[9], a1s = 0.0, a2s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) xn[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) zb1[i] = zb2[i] = vt[i] = 0.0;
+    t1.sr = t1.cr = t1.sp = t1.cp = t1.sy = t1.cy = 0.0; t2 = t1;
+    if (dyn) {
+        const double *w = z, T = z[3], *pp = z + 8, *v = z + 11, *e = z + 14;
+        double et[3], a1[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) et[i] = e[i] + DT * w[i];
+        trig_shared(rec + R_PV, sub, e, et, t1, t2);
+        zb_of(t1, zb1); zb_of(t2, zb2);
+        a1s = T * (1.0 / MASS) + DRAG * dot3(zb1, v);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            a1[i] = a1s * zb1[i] - DRAG * v[i] + st.fext[i] - (i == 2 ? GRAV : 0.0);
+            vt[i] = v[i] + DT * a1[i];
+        }
+        a2s = T * (1.0 / MASS) + DRAG * dot3(zb2, vt);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const double a2 = a2s * zb2[i] - DRAG * vt[i] + st.fext[i] - (i == 2 ? GRAV : 0.0);
+            xn[i] = pp[i] + 0.5 * DT * (v[i] + vt[i]);
+            xn[3 + i] = v[i] + 0.5 * DT * (a1[i] + a2);
+            xn[6 + i] = et[i];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- block 2: d = prev(z_k) - s_{k+1}: the next stage's [w; x] comes from lane + 1 (same sub); stored by sub 0
+    {
+        double dmax = 0.0, dv[NS];
+#pragma unroll
+        for (int i = 0; i < 4; i++) dv[i] = z[i] - dpp_move<0x130>(st.z[4 + i]); // wave_shl:1
+#pragma unroll
+        for (int i = 0; i < 9; i++) dv[4 + i] = xn[i] - dpp_move<0x130>(st.z[8 + i]);
+#pragma unroll
+        for (int i = 0; i < NS; i++) dmax = fmax(dmax, fabs(dv[i]));
+        if (dyn) l_eq = fmax(l_eq, dmax);
+        if (act && sub == 0) { // (the last stage has no successor: d = 0; the slots carried y+ through the step phase)
+#pragma unroll
+            for (int i = 0; i < NS; i++) rec[R_D + i] = dyn ? dv[i] : 0.0;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- block 3: column `sub` of the linearisation and the entries (sub, 4 + sub, 8 + sub, 11 + sub, 14 + sub) of
+    // gm = M' y_{k+1} - [0; y_k] (3 and 7 on sub 0)
+    if (act) {
+        cldouble *yk = rec + RT_Y, *yn = rec + RS + RT_Y;
+        double g_u = 0.0, g_T = 0.0;
+        double g_w = -yk[sub], g_p = -yk[4 + sub], g_v = -yk[7 + sub], g_e = -yk[10 + sub];
+        const double g_w3 = -yk[3];
+        if (dyn) {
+            const double *v = z + 11;
+            // column `sub` of F_ve = d acc / d e and of F_vv = d acc / d v = d (zB zB' - I) at both points
+            double d1[3], d2[3], fe1[3], fe2[3], fv1[3], fv2[3];
+            zb_of(dtrig_lane(trigk(t1), sub), d1); zb_of(dtrig_lane(trigk(t2), sub), d2);
+            const double dzv1 = dot3(d1, v), dzv2 = dot3(d2, vt);
+            const double zb1j = pick3(sub, zb1[0], zb1[1], zb1[2]), zb2j = pick3(sub, zb2[0], zb2[1], zb2[2]);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                fe1[i] = a1s * d1[i] + DRAG * zb1[i] * dzv1;
+                fe2[i] = a2s * d2[i] + DRAG * zb2[i] * dzv2;
+                fv1[i] = DRAG * zb1[i] * zb1j - (sub == i ? DRAG : 0.0);
+                fv2[i] = DRAG * zb2[i] * zb2j - (sub == i ? DRAG : 0.0);
+            }
+            const double q1 = dot3(zb2, fv1), q2 = dot3(zb2, fe1), q3 = dot3(zb2, zb1) * (1.0 / MASS);
+            const double yp[3] = {yn[4], yn[5], yn[6]}, yv[3] = {yn[7], yn[8], yn[9]};
+            const double ywj = yn[sub], yej = yn[10 + sub], ypj = yn[4 + sub];
+            ldouble *lc = rec + R_LIN + sub;
+            g_u = ywj + DT * yej;
+            g_p += ypj;
+            g_e += yej;
+            g_T = yn[3];
+            double bptj = 0.0, bvtj = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const double sv = fv2[i] + DT * DRAG * (zb2[i] * q1 - fv1[i]); // (F_vv2 (I + dt F_vv1))[i][sub]
+                const double se = fe2[i] + DT * DRAG * (zb2[i] * q2 - fe1[i]); // (F_ve2 + dt F_vv2 F_ve1)[i][sub]
+                const double apv = (sub == i ? DT : 0.0) + 0.5 * DT * DT * fv1[i];
+                const double ape = 0.5 * DT * DT * fe1[i];
+                const double avv = (sub == i ? 1.0 : 0.0) + 0.5 * DT * (fv1[i] + sv);
+                const double ave = 0.5 * DT * (fe1[i] + se);
+                const double bvw = 0.5 * DT * DT * fe2[i];
+                lc[0 + 3 * i] = apv; lc[9 + 3 * i] = ape; lc[18 + 3 * i] = avv; lc[27 + 3 * i] = ave; lc[42 + 3 * i] = bvw;
+                const double g1 = zb1[i] * (1.0 / MASS), g2 = zb2[i] * (1.0 / MASS);
+                const double bpt = 0.5 * DT * DT * g1, bvt = 0.5 * DT * (g1 + g2 + DT * DRAG * (zb2[i] * q3 - g1));
+                bptj = sub == i ? bpt : bptj; bvtj = sub == i ? bvt : bvtj;
+                g_u += bvw * yv[i];
+                g_v += apv * yp[i] + avv * yv[i];
+                g_e += ape * yp[i] + ave * yv[i];
+                g_T += bpt * yp[i] + bvt * yv[i];
+            }
+            rec[R_LIN + 36 + sub] = bptj;
+            rec[R_LIN + 39 + sub] = bvtj;
+        }
+        rec[R_PHIC + sub] = g_u; rec[R_PHIC + 4 + sub] = g_w; rec[R_PHIC + 8 + sub] = g_p;
+        rec[R_PHIC + 11 + sub] = g_v; rec[R_PHIC + 14 + sub] = g_e;
+        if (sub == 0) { rec[R_PHIC + 3] = g_T; rec[R_PHIC + 7] = g_w3; }
+#pragma unroll
+        for (int i = 0; i < NS; i++) st.y[i] = yk[i];
+    }
+}
+
+// wave 0, three lanes per stage: exact Hessian of y_{k+1}' c(z_k), rows / columns of angle `sub` (see rk2_hessian_core)
+static_assert(hd_pack(0, 0) == 0 && hd_pack(1, 1) == 10 && hd_pack(2, 2) == 19 && hd_pack(3, 7) == 27 && hd_pack(4, 7) == 30 &&
+              hd_pack(5, 7) == 33 && hd_pack(6, 7) == 36 && hd_pack(7, 7) == 39 && hd_pack(8, 8) == 42 && hd_pack(9, 9) == 44, "packed Hessian rows");
+__device__ __forceinline__ void hessian_phase3(ldouble *rec, const HessState &hs, int sub, bool dyn, int hess)
+{
+    if (dyn && hess) {
+        const double *w = hs.u, T = hs.u[3], *v = hs.ve, *e = hs.ve + 3, *yp = hs.y6, *yv = hs.y6 + 3;
+        double et[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) et[i] = e[i] + DT * w[i];
+        ldouble *sc = rec + R_PD;
+        Trig t1, t2;
+        trig_shared(sc, sub, e, et, t1, t2);
+        double zb1[3], zb2[3], vt[3], beta[3], gam1[3];
+        zb_of(t1, zb1); zb_of(t2, zb2);
+        const double a1s = T * (1.0 / MASS) + DRAG * dot3(zb1, v);
+#pragma unroll
+        for (int i = 0; i < 3; i++) vt[i] = v[i] + DT * (a1s * zb1[i] - DRAG * v[i] + hs.fext[i] - (i == 2 ? GRAV : 0.0));
+        const double a2s = T * (1.0 / MASS) + DRAG * dot3(zb2, vt);
+#pragma unroll
+        for (int i = 0; i < 3; i++) beta[i] = 0.5 * DT * yv[i];
+        const double s2 = dot3(beta, zb2);
+#pragma unroll
+        for (int i = 0; i < 3; i++) gam1[i] = (0.5 * DT * DT * yp[i] + 0.5 * DT * yv[i]) + DT * (DRAG * zb2[i] * s2 - DRAG * beta[i]);
+        const double s1 = dot3(gam1, zb1);
+        // first derivatives of zB: all three directions at the first point (the Jacobian of acc1 enters K in full), the own one at the second
+        double D1a[3][3], d1[3], d2[3], dzv1[3];
+        zb_of(dtrig<0>(trigk(t1)), D1a[0]); zb_of(dtrig<1>(trigk(t1)), D1a[1]); zb_of(dtrig<2>(trigk(t1)), D1a[2]);
+#pragma unroll
+        for (int c = 0; c < 3; c++) d1[c] = pick3(sub, D1a[0][c], D1a[1][c], D1a[2][c]);
+#pragma unroll
+        for (int l = 0; l < 3; l++) dzv1[l] = dot3(D1a[l], v);
+        const TrigK t1j = dtrig_lane(trigk(t1), sub), t2j = dtrig_lane(trigk(t2), sub);
+        zb_of(t2j, d2);
+        const double sj1 = dot3(gam1, d1), aj1 = DRAG * pick3(sub, dzv1[0], dzv1[1], dzv1[2]);
+        const double sj2 = dot3(beta, d2), aj2 = DRAG * dot3(d2, vt);
+        sc[sub] = sj1; sc[3 + sub] = aj1; sc[6 + sub] = sj2; sc[9 + sub] = aj2;
+        WSYNC();
+        double sj1v[3], aj1v[3], sj2v[3], aj2v[3];
+#pragma unroll
+        for (int l = 0; l < 3; l++) { sj1v[l] = sc[l]; aj1v[l] = sc[3 + l]; sj2v[l] = sc[6 + l]; aj2v[l] = sc[9 + l]; }
+        WSYNC();
+        // row `sub` of the two (e, e) blocks
+        double hee1[3], hee2[3];
+        {
+            double dd[3];
+            zb_of(dtrig<0>(t1j), dd); hee1[0] = DRAG * dot3(dd, v) * s1 + aj1 * sj1v[0] + aj1v[0] * sj1 + a1s * dot3(gam1, dd);
+            zb_of(dtrig<1>(t1j), dd); hee1[1] = DRAG * dot3(dd, v) * s1 + aj1 * sj1v[1] + aj1v[1] * sj1 + a1s * dot3(gam1, dd);
+            zb_of(dtrig<2>(t1j), dd); hee1[2] = DRAG * dot3(dd, v) * s1 + aj1 * sj1v[2] + aj1v[2] * sj1 + a1s * dot3(gam1, dd);
+            zb_of(dtrig<0>(t2j), dd); hee2[0] = DRAG * dot3(dd, vt) * s2 + aj2 * sj2v[0] + aj2v[0] * sj2 + a2s * dot3(beta, dd);
+            zb_of(dtrig<1>(t2j), dd); hee2[1] = DRAG * dot3(dd, vt) * s2 + aj2 * sj2v[1] + aj2v[1] * sj2 + a2s * dot3(beta, dd);
+            zb_of(dtrig<2>(t2j), dd); hee2[2] = DRAG * dot3(dd, vt) * s2 + aj2 * sj2v[2] + aj2v[2] * sj2 + a2s * dot3(beta, dd);
+        }
+        const double hTe1 = sj1 * (1.0 / MASS), hTe2 = sj2 * (1.0 / MASS);
+        double hve1[3], hve2[3], Kv[3], Ke[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            hve1[i] = DRAG * (d1[i] * s1 + zb1[i] * sj1);
+            hve2[i] = DRAG * (d2[i] * s2 + zb2[i] * sj2);
+        }
+        // K = J1' H2ve (+ h2Te on the T row), column `sub`: J1 = [F_vv1 F_ve1 g_T1] of the first acceleration
+        const double zh = dot3(zb1, hve2);
+        const double KT = hTe2 + DT * (1.0 / MASS) * zh;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            Kv[i] = hve2[i] + DT * DRAG * (zb1[i] * zh - hve2[i]);
+            Ke[i] = DT * (a1s * dot3(D1a[i], hve2) + DRAG * zh * dzv1[i]);
+        }
+        sc[3 * sub] = Ke[0]; sc[3 * sub + 1] = Ke[1]; sc[3 * sub + 2] = Ke[2];
+        WSYNC();
+        double Ker[3]; // Ke[sub][l]: entry `sub` of the columns of the three lanes
+#pragma unroll
+        for (int l = 0; l < 3; l++) Ker[l] = sc[3 * l + sub];
+        WSYNC();
+        // packed upper triangle over (w 0..2, T 3, v 4..6, e 7..9): row a < 3 starts at {0, 10, 19}[a] for column a, row 3 + i at
+        // 27 + 3 i for column 7, row 7 + a at {39, 42, 44}[a] for column 7 + a
+        ldouble *hd = rec + R_HD;
+        ldouble *hw = hd + (sub == 0 ? 0 : (sub == 1 ? 9 : 17));  // + column index
+        ldouble *he = hd + (sub == 0 ? 39 : (sub == 1 ? 41 : 42)); // + l
+        ldouble *dump = rec + R_DUMP;
+#pragma unroll
+        for (int l = 0; l < 3; l++) {
+            ldouble *pw = l >= sub ? hw + l : dump, *pe = l >= sub ? he + l : dump;
+            *pw = DT * DT * hee2[l];                             // (w_sub, w_l)
+            *pe = hee1[l] + Ker[l] + Ke[l] + hee2[l];            // (e_sub, e_l)
+            hw[7 + l] = DT * (Ke[l] + hee2[l]);                  // (w_sub, e_l)
+            hw[4 + l] = DT * Kv[l];                              // (w_sub, v_l)
+            hd[30 + 3 * l + sub] = hve1[l] + Kv[l];              // (v_l, e_sub)
+        }
+        hw[3] = DT * KT;                                         // (w_sub, T)
+        hd[27 + sub] = hTe1 + KT;                                // (T, e_sub)
+    } else if (sub < 3) {
+        // the Hessian slots are overwritten by P every iteration: stages without a dynamics Hessian clear them again
+#pragma unroll
+        for (int i = 0; i < REC_HD_SIZE / 3; i++) rec[R_HD + 15 * sub + i] = 0.0;
+    }
+}
+
 // Live corridor rows of a stage when the caller gives no face counts: trailing all-zero rows are padding
 // (forces_normal.cpp:127-135).  The loop is lane-divergent (face counts differ per stage), so it lives in a function of its
 // own that must compile WITHOUT scratch: the gfx950 backend can place a VGPR spill at the exit of a lane-divergent loop,
@@ -990,8 +1289,12 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     const int lane = threadIdx.x & 63;
     const int N = a.N, M = a.M, MF = a.MF, np = NPRE + 4 * M;
     ldouble *recs = sh.recs, *xs = sh.xs;
-    const int k = (wave == 1) ? lane : lane % NP, half = lane / NP; // stage of this lane; row / face group
-    const bool kact = k < N && (wave == 1 || half < H);
+    // three lanes per stage (H == 3: NP = 20) also on the Riccati wave's Hessian and on the model wave (model_phase3, hessian_phase3)
+    constexpr bool H3 = (H == 3);
+    const int k = (wave == 1 && !H3) ? lane : lane % NP, half = lane / NP; // stage of this lane; row / face group
+    const bool kact = k < N && ((wave == 1 && !H3) || half < H);
+    const bool hact = kact && (H3 || half == 0); // lanes that carry a copy of the stage's model state (waves 0, 1)
+    const bool own0 = kact && half == 0;         // one lane per stage: writes that must happen once
     const double *pk = a.params + ((size_t)b * N + (k < N ? k : 0)) * np;
     const int hess = a.hessian ? 1 : 0;
     const int model = a.models ? a.models[b] : a.model; // normal / final objective of THIS problem (switch_to_final, nmpc_solver.cpp:381)
@@ -1009,12 +1312,14 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 #pragma unroll
     for (int i = 0; i < NPRE; i++) pc[i] = 0.0;
     ms.fext[0] = ms.fext[1] = ms.fext[2] = 0.0;
-    HessState hs; // wave 0, lanes of row group 0 (lane == stage)
+    // wave 0: what its Hessian lanes carry from the step phase to the next evaluation -- the Newton step of (rates, T), (v, e) and
+    // y+ (p, v rows) of the next stage; the values before the step come from the model wave through the record (RT_HZ, RT_HY),
+    // so that nothing of the Hessian's inputs is live across the sweeps
+    double hdz[10], hyp[6], hap = 0.0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) hs.u[i] = 0.0;
+    for (int i = 0; i < 10; i++) hdz[i] = 0.0;
 #pragma unroll
-    for (int i = 0; i < 6; i++) { hs.ve[i] = 0.0; hs.y6[i] = 0.0; }
-    hs.fext[0] = hs.fext[1] = hs.fext[2] = 0.0;
+    for (int i = 0; i < 6; i++) hyp[i] = 0.0;
 #pragma unroll
     for (int r = 0; r < R; r++) { bz[r] = bzp[r] = 0.0; bsl[r] = bsu[r] = bll[r] = blu[r] = 1.0; bcl[r] = bcu[r] = 0.0; }
 #pragma unroll
@@ -1123,13 +1428,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         }
     };
     if constexpr (wave == 0) {
-        if (kact && half == 0) { // this wave is idle in the evaluation phase: it evaluates the dynamics Hessian there
-            const double *z0 = a.x0 + ((size_t)b * N + k) * NZ;
-#pragma unroll
-            for (int i = 0; i < 4; i++) hs.u[i] = z0[i];
-#pragma unroll
-            for (int i = 0; i < 6; i++) hs.ve[i] = z0[11 + i];
-        }
+        // (this wave is idle in the evaluation phase: it evaluates the dynamics Hessian there, from what wave 1 publishes)
     } else if constexpr (wave == 1) {
         if (lane < 9) xs[X_XINIT + lane] = a.xinit[(size_t)b * 9 + lane];
         if (kact) {
@@ -1137,16 +1436,22 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 #pragma unroll
             for (int i = 0; i < NZ; i++) ms.z[i] = z0[i];
             ms.fext[0] = pk[3]; ms.fext[1] = pk[4]; ms.fext[2] = pk[5];
-            xs[X_FEXT + k] = ms.fext[0]; xs[X_FEXT + NP + k] = ms.fext[1]; xs[X_FEXT + 2 * NP + k] = ms.fext[2];
-            ldouble *rec = recs + k * RS;
-            rec[R_HC] = -2.0 * pk[8]; // (u_i, w_i) cost coupling of this stage (constant)
-            rec[R_ZERO] = 0.0; rec[R_ZERO2] = 0.0; rec[R_ONE] = 1.0; rec[R_DT] = DT; rec[R_DUMP] = 0.0;
-            if (k == N - 1) { // no dynamics behind the last stage: its M row stays zero
+            if (half == 0) {
+                xs[X_FEXT + k] = ms.fext[0]; xs[X_FEXT + NP + k] = ms.fext[1]; xs[X_FEXT + 2 * NP + k] = ms.fext[2];
+                ldouble *rec = recs + k * RS;
+                rec[R_HC] = -2.0 * pk[8]; // (u_i, w_i) cost coupling of this stage (constant)
+                rec[R_ZERO] = 0.0; rec[R_ZERO2] = 0.0; rec[R_ONE] = 1.0; rec[R_DT] = DT; rec[R_DUMP] = 0.0;
+                if (k == N - 1) { // no dynamics behind the last stage: its M row stays zero
 #pragma unroll
-                for (int i = 0; i < 64; i++) rec[R_LIN + i] = 0.0;
+                    for (int i = 0; i < 64; i++) rec[R_LIN + i] = 0.0;
+                }
+                rec[R_CB + 0] = rec[R_CB + 1] = rec[R_CB + 2] = 0.0;
+                rec[R_CC + 0] = rec[R_CC + 1] = rec[R_CC + 2] = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) rec[RT_HZ + i] = ms.z[i]; // the Hessian's inputs of the first iteration (y = 0)
+#pragma unroll
+                for (int i = 0; i < 6; i++) { rec[RT_HZ + 4 + i] = ms.z[11 + i]; rec[RT_HY + i] = 0.0; }
             }
-            rec[R_CB + 0] = rec[R_CB + 1] = rec[R_CB + 2] = 0.0;
-            rec[R_CC + 0] = rec[R_CC + 1] = rec[R_CC + 2] = 0.0;
         }
     } else if constexpr (wave == 2) {
         bounds_init();
@@ -1185,7 +1490,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     const int mtot = sh.ctl->mtot;
     if (sh.ctl->bad) { // a stage has more live corridor rows than the caller sized the problem for (MF)
         if (wave == 0 && lane == 0) { sh.ctl->next = atomicAdd(a.counter, 1); a.exitflag[b] = FRP_EXIT_PARAM_VALUE; a.iters[b] = 0; }
-        if (wave == 1 && kact) {
+        if (wave == 1 && own0) {
             double *zo = a.z + ((size_t)b * N + k) * NZ;
 #pragma unroll
             for (int i = 0; i < NZ; i++) zo[i] = ms.z[i];
@@ -1232,13 +1537,27 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     for (it = 0;;) {
         // ============================================================ evaluation phase
         if constexpr (wave == 0) {
-            if (kact && half == 0) {
+            if (hact) {
+                HessState hs; // the model wave's values before the last step + the step
+                cldouble *rec = recs + k * RS;
+#pragma unroll
+                for (int i = 0; i < 4; i++) hs.u[i] = rec[RT_HZ + i] + hap * hdz[i];
+#pragma unroll
+                for (int i = 0; i < 6; i++) hs.ve[i] = rec[RT_HZ + 4 + i] + hap * hdz[4 + i];
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const double yo = (k < N - 1) ? rec[RS + RT_HY + i] : 0.0;
+                    hs.y6[i] = yo + hap * (hyp[i] - yo);
+                }
                 hs.fext[0] = xs[X_FEXT + k]; hs.fext[1] = xs[X_FEXT + NP + k]; hs.fext[2] = xs[X_FEXT + 2 * NP + k];
-                hessian_phase(recs + k * RS, hs, k < N - 1, hess);
+                WSYNC(); // (the neighbour lane's reads of this stage's RT_HY slots come before the scratch use of the record below)
+                if constexpr (H3) hessian_phase3(recs + k * RS, hs, half, k < N - 1, hess);
+                else hessian_phase(recs + k * RS, hs, k < N - 1, hess);
             }
         } else if constexpr (wave == 1) {
             double l_eq;
-            model_phase<NP>(recs, xs, ms, N, l_eq);
+            if constexpr (H3) model_phase3<NP>(recs, xs, ms, N, l_eq);
+            else model_phase<NP>(recs, xs, ms, N, l_eq);
             publish(xs, 1, lane, 0, wave_max(l_eq));
         } else if constexpr (wave == 2) {
             double l_in = 0.0, l_rc = 0.0, l_gap = 0.0;
@@ -1316,6 +1635,19 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 nfallback++;
                 theta_h *= THETA_DOWN;
                 gn_retry = true;
+                // the factorisation has overwritten the T' slots: the model wave hands the Hessian's inputs over again (no step
+                // in between), behind a barrier of its own (0.05 % of solves come here)
+                if constexpr (wave == 1) {
+                    if (own0) {
+                        ldouble *rec = recs + k * RS;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) rec[RT_HZ + i] = ms.z[i];
+#pragma unroll
+                        for (int i = 0; i < 6; i++) { rec[RT_HZ + 4 + i] = ms.z[11 + i]; rec[RT_HY + i] = ms.y[4 + i]; }
+                    }
+                }
+                hap = 0.0;
+                BAR();
                 continue;
             }
             if (fr) { flag = FRP_EXIT_FACTORIZATION; break; }
@@ -1399,7 +1731,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 
         // ============================================================ step: pass A (ratios), pass B (commit)
         double m_p = 0.0, m_d = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0; // q: sums of ds l, s dl, ds dl
-        double dzr[NZ], ypl[NS], dzb[R], dzp[R], dzf[3];            // waves 0, 1: Newton step / y+ of their copies; waves 2, 3: dz of their bound rows and of the (u, w) partners; wave 3: dz of pos
+        double dzb[R], dzp[R], dzf[3];            // waves 2, 3: dz of their bound rows and of the (u, w) partners; wave 3: dz of pos
         // one constraint of the corrector step
         auto cstep = [&](double s, double l, double corr, double gdz, double viol, double &ds, double &dl) {
             const double u = fast_rcp(s * l);
@@ -1420,23 +1752,31 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             return acc;
         };
         if constexpr (wave == 0) {
-            if (kact && half == 0) { // Newton step of the Hessian lanes' copies: (rates, T), (v, e), (y_p, y_v)+ of the next stage
-                cldouble *rec = recs + k * RS;
-#pragma unroll
-                for (int i = 0; i < 4; i++) dzr[i] = rec[R_DZ + i];
-#pragma unroll
-                for (int i = 0; i < 6; i++) dzr[4 + i] = rec[R_DZ + 11 + i];
-#pragma unroll
-                for (int i = 0; i < 6; i++) ypl[i] = (k < N - 1) ? y_plus(rec + RS, 4 + i) : 0.0;
-            }
-        } else if constexpr (wave == 1) {
-            if (kact) {
+            // Newton step of the Hessian's inputs, and y+ of the whole stage for the model wave's commit: it goes to the d slots of
+            // the record, which are dead from the last sweep to the next model phase (the model wave has 60 registers of
+            // persistent state; this wave has none)
+            if (hact) {
                 ldouble *rec = recs + k * RS;
 #pragma unroll
-                for (int i = 0; i < NZ; i++) dzr[i] = rec[R_DZ + i];
+                for (int i = 0; i < 4; i++) hdz[i] = rec[R_DZ + i];
 #pragma unroll
-                for (int i = 0; i < NS; i++) ypl[i] = y_plus(rec, i);
-                // (T' is dead from here to the next factorisation)
+                for (int i = 0; i < 6; i++) hdz[4 + i] = rec[R_DZ + 11 + i];
+                double yall[NS];
+#pragma unroll
+                for (int i = 0; i < NS; i++) yall[i] = y_plus(rec, i);
+                if (half == 0) {
+#pragma unroll
+                    for (int i = 0; i < NS; i++) rec[R_D + i] = yall[i];
+                }
+            }
+            WSYNC();
+            if (hact) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) hyp[i] = (k < N - 1) ? recs[(k + 1) * RS + R_D + 4 + i] : 0.0;
+            }
+        } else if constexpr (wave == 1) {
+            if (own0) { // the values before the step, for the Hessian lanes (T' is dead from here to the next factorisation)
+                ldouble *rec = recs + k * RS;
 #pragma unroll
                 for (int i = 0; i < 4; i++) rec[RT_HZ + i] = ms.z[i];
 #pragma unroll
@@ -1499,24 +1839,15 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 if (ln * sn < fprod) ln = fprod * fast_rcp(sn);
                 s = sn; l = ln;
             };
-            if constexpr (wave == 0) {
-                if (kact && half == 0) { // the Hessian inputs of the next iteration: the owners' values before the step + the step
+            hap = ap;
+            if constexpr (wave == 1) {
+                if (kact) { // (the Newton step is valid until the next predictor's forward sweep, y+ until this wave's next model phase)
                     cldouble *rec = recs + k * RS;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) hs.u[i] = rec[RT_HZ + i] + ap * dzr[i];
+                    for (int i = 0; i < NZ; i++) ms.z[i] += ap * rec[R_DZ + i];
 #pragma unroll
-                    for (int i = 0; i < 6; i++) hs.ve[i] = rec[RT_HZ + 4 + i] + ap * dzr[4 + i];
-#pragma unroll
-                    for (int i = 0; i < 6; i++) {
-                        const double yo = (k < N - 1) ? rec[RS + RT_HY + i] : 0.0;
-                        hs.y6[i] = yo + ap * (ypl[i] - yo);
-                    }
+                    for (int i = 0; i < NS; i++) ms.y[i] += ap * (rec[R_D + i] - ms.y[i]); // y <- y + ap (y+ - y)
                 }
-            } else if constexpr (wave == 1) {
-#pragma unroll
-                for (int i = 0; i < NZ; i++) ms.z[i] += ap * dzr[i];
-#pragma unroll
-                for (int i = 0; i < NS; i++) ms.y[i] += ap * (ypl[i] - ms.y[i]); // y <- y + ap (y+ - y)
             }
             if constexpr (wave >= 2) {
 #pragma unroll
@@ -1556,7 +1887,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     if constexpr (wave == 1) {
         // the objective is reported, not iterated on: evaluated once, at the returned iterate
         double l_obj = 0.0;
-        if (kact) {
+        if (own0) {
             double *zo = a.z + ((size_t)b * N + k) * NZ;
 #pragma unroll
             for (int i = 0; i < NZ; i++) zo[i] = ms.z[i];
@@ -1616,7 +1947,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     // against the dispatcher's own rotation, so it is applied to the three-per-CU variants only.)
     const int widx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int role = widx;
-    if (WPE == 3 && a.cu_slots) {
+    if (WPE >= 3 && a.cu_slots) {
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID: SIMD_ID [5:4], CU_ID [11:8], SH_ID [12], SE_ID [15:13]
         const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID [3:0]
         const int simd = (int)((hw >> 4) & 3u);
@@ -1693,13 +2024,16 @@ static hipError_t launch_ipm_lds_mem(const KernelArgs &k, int slots, hipStream_t
 }
 #endif
 
+#ifndef FRP_WPE20 // experiment knob: register budget of the N <= 20 variants (3 waves per SIMD = 168 VGPRs; 4 = 128)
+#define FRP_WPE20 3
+#endif
 // counter / order already set up by launch_ipm
 hipError_t launch_ipm_lds(const KernelArgs &k, int slots, hipStream_t stream)
 {
     const int MF = k.MF;
     if (k.N <= 20) {
-        if (MF <= 6) return lr::launch_variant<20, 2, true, 3>(k, slots, stream);
-        if (MF <= 15) return lr::launch_variant<20, 5, true, 3>(k, slots, stream);
+        if (MF <= 6) return lr::launch_variant<20, 2, true, FRP_WPE20>(k, slots, stream);
+        if (MF <= 15) return lr::launch_variant<20, 5, true, FRP_WPE20>(k, slots, stream);
     } else if (k.N <= 32) {
         if (MF <= 6) return lr::launch_variant<32, 3, true, 2>(k, slots, stream);
         if (MF <= 16) return lr::launch_variant<32, 8, true, 2>(k, slots, stream);
