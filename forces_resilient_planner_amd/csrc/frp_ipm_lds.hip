@@ -1338,7 +1338,11 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     // The 17 bound pairs of a stage are shared by waves 2 and 3: rounds [RB0, RB1) of the row mapping each (wave 3 also
     // owns the corridor rows), so that neither is the long pole of the element-wise phases.
     // (measured: a corridor row costs about as much as 1.5 bound pairs because of its cross-lane sums)
-    constexpr int RSPLIT = R - (FL <= 2 ? R / 3 : (FL <= 5 ? R / 6 : 0));
+#ifndef FRP_RSPLIT_ADJ // experiment knob: bound rounds moved from the faces wave to the bounds wave
+#define FRP_RSPLIT_ADJ 0
+#endif
+    constexpr int RSPLIT0 = R - (FL <= 2 ? R / 3 : (FL <= 5 ? R / 6 : 0));
+    constexpr int RSPLIT = RSPLIT0 + FRP_RSPLIT_ADJ <= R ? RSPLIT0 + FRP_RSPLIT_ADJ : R;
     constexpr int RB0 = wave == 3 ? RSPLIT : 0, RB1 = wave == 2 ? RSPLIT : R;
     // evaluation: residuals, barrier Hessian / predictor rhs of this wave's bound rows -> record; norms
     auto bounds_eval = [&](double &l_in, double &l_rc, double &l_gap) {
@@ -1761,6 +1765,8 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 for (int i = 0; i < 4; i++) hdz[i] = rec[R_DZ + i];
 #pragma unroll
                 for (int i = 0; i < 6; i++) hdz[4 + i] = rec[R_DZ + 11 + i];
+                // (split over the three lanes of a stage by rows -- lane-dependent addresses into the packed triangle -- this measured
+                // no faster: 5.4 k vs 4.7 k cycles for the phase on this wave, the launch time unchanged)
                 double yall[NS];
 #pragma unroll
                 for (int i = 0; i < NS; i++) yall[i] = y_plus(rec, i);
