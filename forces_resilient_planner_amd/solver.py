@@ -72,6 +72,23 @@ class Reference(ctypes.Structure):  # frp_nmpc_reference (include/frp_nmpc.h)
                 ("ref_pos", ctypes.c_void_p), ("ref_yaw", ctypes.c_void_p), ("replan", ctypes.c_void_p)]
 
 
+class Astar(ctypes.Structure):  # frp_nmpc_astar (include/frp_nmpc.h)
+    _fields_ = [("B", ctypes.c_int), ("occ", ctypes.c_void_p), ("grid", ctypes.c_int * 3), ("origin", ctypes.c_double * 3),
+                ("map_size", ctypes.c_double * 3), ("resolution", ctypes.c_double), ("local_box", ctypes.c_void_p),
+                ("ego_r", ctypes.c_double), ("ego_h", ctypes.c_double),
+                ("max_tau", ctypes.c_double), ("init_max_tau", ctypes.c_double), ("max_vel", ctypes.c_double), ("max_acc", ctypes.c_double),
+                ("w_time", ctypes.c_double), ("horizon", ctypes.c_double), ("lambda_heu", ctypes.c_double), ("tie_breaker", ctypes.c_double),
+                ("allocate_num", ctypes.c_int), ("check_num", ctypes.c_int),
+                ("start_pt", ctypes.c_void_p), ("start_vel", ctypes.c_void_p), ("start_acc", ctypes.c_void_p), ("end_pt", ctypes.c_void_p),
+                ("end_vel", ctypes.c_void_p), ("external_acc", ctypes.c_void_p), ("active", ctypes.c_void_p), ("init_search", ctypes.c_int),
+                ("Ts", ctypes.c_double), ("K", ctypes.c_int),
+                ("kino_path", ctypes.c_void_p), ("kino_size", ctypes.c_void_p), ("status", ctypes.c_void_p), ("stats", ctypes.c_void_p),
+                ("path_nodes", ctypes.c_void_p)]
+
+
+ASTAR_MAX_PATH = 256
+ASTAR_REACH_HORIZON, ASTAR_REACH_END, ASTAR_NO_PATH, ASTAR_REACH_END_BUT_SHOT_FAILS = 1, 2, 3, 4
+
 REFERENCE_PI = 3.1415926  # nmpc_solver.cpp:3
 
 # getSikangConst's constants (nmpc_solver.cpp:302, :318, :323)
@@ -107,7 +124,7 @@ EXPORTS = ["frp_nmpc_default_options", "frp_nmpc_workspace_bytes", "frp_nmpc_sol
            "FORCESNLPsolver_final_solve", "frp_nmpc_pack_batch", "frp_nmpc_update_batch", "frp_nmpc_tube_batch",
            "frp_nmpc_corridor_batch", "frp_nmpc_reference_batch",
            "frp_nmpc_coldstart_batch", "frp_nmpc_cloud_grid_build",
-           "frp_nmpc_mode_batch"]
+           "frp_nmpc_mode_batch", "frp_nmpc_astar_batch", "frp_nmpc_astar_workspace_bytes"]
 
 _lib = None
 
@@ -148,6 +165,9 @@ def lib():
                                           ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
         l.frp_nmpc_coldstart_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
                                                ctypes.c_void_p, ctypes.c_void_p]
+        l.frp_nmpc_astar_workspace_bytes.restype = ctypes.c_size_t
+        l.frp_nmpc_astar_workspace_bytes.argtypes = [ctypes.POINTER(Astar)]
+        l.frp_nmpc_astar_batch.argtypes = [ctypes.POINTER(Astar), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         _lib = l
     return _lib
 
@@ -296,6 +316,65 @@ def reference_batch_host(kino_path, time_offset, mpc_output, kino_size=None, Ts=
     reference_batch_device(dev(kino_path), dev(time_offset), dev(mpc_output), rp, ry, fl, ks, Ts)
     torch.cuda.synchronize(device)
     return rp.cpu().numpy(), ry.cpu().numpy(), fl.cpu().numpy()
+
+
+class AstarPlanner:
+    """SURVEY 8f row f-4 (second half): the kinodynamic A* of NMPCSolver::getKinoPath for B planners on the device
+    (frp_nmpc_astar_batch).  `world`: occupancy grid occ[x][y][z] (uint8) + the map / search constants of the reference's launch
+    files (forces_resilient_planner_amd.workloads.astar_world).  Outputs stay in HBM: kino_path [B,K,3] / kino_size [B] are what
+    DeviceFleet.references() takes as a per-planner path."""
+
+    def __init__(self, world, B, K=1024, Ts=0.05, device="cuda:0", want_path_nodes=False, allocate_num=None):
+        import torch
+        lib()
+        self.torch = torch
+        self.B, self.K, self.Ts = B, K, Ts
+        self.device = torch.device(device)
+        self.world = world
+        f64 = dict(dtype=torch.float64, device=self.device)
+        i32 = dict(dtype=torch.int32, device=self.device)
+        self.occ = torch.from_numpy(np.ascontiguousarray(world["occ"], dtype=np.uint8)).to(self.device)
+        self.kino_path = torch.zeros((B, K, 3), **f64)
+        self.kino_size = torch.zeros((B,), **i32)
+        self.status = torch.zeros((B,), **i32)
+        self.stats = torch.zeros((B, 4), **i32)
+        self.path_nodes = torch.zeros((B, ASTAR_MAX_PATH, 11), **f64) if want_path_nodes else None
+        self.allocate_num = int(allocate_num or world["allocate_num"])
+        self._q = [torch.zeros((B, 3), **f64) for _ in range(6)]
+        a = self._args()
+        self.ws_bytes = int(lib().frp_nmpc_astar_workspace_bytes(ctypes.byref(a)))
+        self.ws = torch.empty((self.ws_bytes // 8 + 1,), **f64)
+
+    def _args(self, init=True, local_box=None, active=None):
+        w = self.world
+        a = Astar()
+        a.B = self.B; a.occ = self.occ.data_ptr(); a.grid[:] = tuple(self.occ.shape); a.origin[:] = w["origin"]; a.map_size[:] = w["map_size"]
+        a.resolution = w["resolution"]; a.local_box = local_box.data_ptr() if local_box is not None else None
+        a.ego_r = w["ego_r"]; a.ego_h = w["ego_h"]
+        for k in ("max_tau", "init_max_tau", "max_vel", "max_acc", "w_time", "horizon", "lambda_heu", "tie_breaker", "check_num"):
+            setattr(a, k, w[k])
+        a.allocate_num = self.allocate_num
+        a.start_pt, a.start_vel, a.start_acc, a.end_pt, a.end_vel, a.external_acc = (t.data_ptr() for t in self._q)
+        a.active = active.data_ptr() if active is not None else None
+        a.init_search = 1 if init else 0
+        a.Ts = self.Ts; a.K = self.K
+        a.kino_path = self.kino_path.data_ptr(); a.kino_size = self.kino_size.data_ptr(); a.status = self.status.data_ptr()
+        a.stats = self.stats.data_ptr(); a.path_nodes = self.path_nodes.data_ptr() if self.path_nodes is not None else None
+        return a
+
+    def upload(self, start_pt, start_v, start_a, end_pt, end_v, f_ext):
+        t = self.torch
+        for dst, src in zip(self._q, (start_pt, start_v, start_a, end_pt, end_v, f_ext)):
+            dst.copy_(src if t.is_tensor(src) else t.from_numpy(np.ascontiguousarray(src, dtype=np.float64)))
+
+    def plan(self, init=True, local_box=None, stream=None, active=None):
+        """Asynchronous on `stream` (or torch's current stream): every planner's search + retry + getKinoTraj.
+        active: int32 [B] device tensor -- only planners with a non-zero entry search (the others keep their path);
+        a planner whose search ends in NO_PATH keeps its previous path as well."""
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        a = self._args(init, local_box, active)
+        _check(lib().frp_nmpc_astar_batch(ctypes.byref(a), ctypes.c_void_p(self.ws.data_ptr()), self.ws_bytes, ctypes.c_void_p(s.cuda_stream)),
+               "frp_nmpc_astar_batch")
 
 
 class CloudGrid:
@@ -489,6 +568,31 @@ class DeviceFleet:
         """SURVEY 8f row f-4 (first half): ref_total_pos_ / ref_total_yaw_ of all B planners from the kinodynamic
         path (getCurTraj + calculate_yaw, nmpc_solver.cpp:109-142, 834-862), on the device."""
         reference_batch_device(kino_path, time_offset, self.mpc_output, ref_pos, ref_yaw, replan, kino_size, Ts, stream)
+
+    def replan(self, planner, end_pt, external_acc, replan, time_offset=None, end_vel=None, init=True, mass=0.74, g=9.81, stream=None):
+        """The FSM's REPLAN_TRAJ step (nmpc_manage.cpp:215-235 -> NMPCSolver::getKinoPath, nmpc_solver.cpp:145-223) for the planners
+        whose tick raised kino_replan_ (`replan` [B] int32, as written by references() / full_tick): a kinodynamic A* from the
+        plan's next state -- position, velocity and the acceleration the planned thrust produces (:169-181) -- to end_pt [B,3]
+        with external_acc [B,3] in the primitives, on the device (AstarPlanner = frp_nmpc_astar_batch).  The planner object owns
+        the per-planner paths (planner.kino_path / kino_size): pass them to references() / full_tick as the path.  Planners
+        that found a path get time_offset = 0 (kino_start_time_ = now, :219) and go back to the normal solver (:218).
+        Returns the mask (bool [B]) of planners that received a new path.  Asynchronous on torch's current stream."""
+        t = self.torch
+        mo = self.mpc_output[:, 1]
+        e = mo[:, 14:17]
+        sr, cr, sp, cp, sy, cy = t.sin(e[:, 0]), t.cos(e[:, 0]), t.sin(e[:, 1]), t.cos(e[:, 1]), t.sin(e[:, 2]), t.cos(e[:, 2])
+        zb = t.stack([cy * sp * cr + sy * sr, sy * sp * cr - cy * sr, cp * cr], 1)  # eulerToRot(e) [0 0 1]'
+        acc = zb * (mo[:, 3:4] / mass)
+        acc[:, 2] -= g
+        ev = end_vel if end_vel is not None else t.zeros_like(end_pt)
+        planner.upload(mo[:, 8:11].contiguous(), mo[:, 11:14].contiguous(), acc.contiguous(), end_pt, ev, external_acc)
+        planner.plan(init=init, active=replan, stream=stream)
+        ok = (replan != 0) & (planner.status != ASTAR_NO_PATH)
+        if time_offset is not None:
+            time_offset.masked_fill_(ok, 0.0)
+        if self.mode is not None:
+            self.mode.masked_fill_(ok, L.MODEL_NORMAL)
+        return ok
 
     def full_tick(self, external_acc, kino_path, time_offset, cloud, ref_pos, ref_yaw, stream=None, replan=None,
                   kino_size=None, tube_consts=None, corridor_consts=None, Ts=0.05, coldstart=True, state=None, grid=None):

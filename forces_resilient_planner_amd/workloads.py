@@ -177,3 +177,53 @@ def config4_nominal(B=65536, seed=SEED0 + 5, model=L.MODEL_NORMAL, M=L.NH_REF, t
 
 
 CONFIGS = {0: config0, 1: config1, 2: config2, 3: config3, 4: config4_nominal}
+
+
+# ------------------------------------------------------------------ kinodynamic A* worlds (second half)
+# search/* and occ_map/* values of plan_manage/launch/advanced_param.xml:56-66, 97-109 and rotors_sim.launch:4-6, 47-48, 67-68
+ASTAR_DEFAULTS = dict(max_tau=0.5, init_max_tau=0.5, max_vel=2.0, max_acc=3.0, w_time=10.0, horizon=7.5, lambda_heu=5.0,
+                      allocate_num=100000, check_num=15, tie_breaker=1.0 + 1.0 / 10000, resolution=0.1, ego_r=0.27, ego_h=0.0425)
+
+
+def astar_world(seed=0, kind="pillars", map_size=(20.0, 20.0, 4.0), origin=(-10.0, -10.0, -1.0), n_obstacles=40, **overrides):
+    """An occupancy grid occ[x][y][z] (uint8, 1 = occupied) plus the map / search constants of the reference's launch files.
+    The A* bounds its states by (origin, map_size / 2) in x, y and (0.1, map_size_z / 2) in z (kinodynamic_astar.cpp:152-154), so
+    the map is centred on the origin like the reference's (origin -20, size 40).
+    kind: "empty" | "pillars" (random vertical boxes) | "wall_gap" (a wall across x = 0 with one gap)."""
+    w = dict(ASTAR_DEFAULTS)
+    w.update(overrides)
+    res = w["resolution"]
+    grid = tuple(int(np.ceil(m / res)) for m in map_size)
+    occ = np.zeros(grid, dtype=np.uint8)
+    rng = np.random.default_rng(SEED0 + 77 + seed)
+    to_idx = lambda p, i: int(np.floor((p - origin[i]) / res))
+    if kind == "pillars":
+        for _ in range(n_obstacles):
+            cx, cy = rng.uniform(-4.5, 4.5), rng.uniform(-7.0, 7.0)
+            hx, hy = rng.uniform(0.15, 0.6), rng.uniform(0.15, 0.6)
+            z1 = rng.uniform(1.2, 3.0) if rng.random() < 0.3 else 3.0
+            occ[max(0, to_idx(cx - hx, 0)):to_idx(cx + hx, 0) + 1, max(0, to_idx(cy - hy, 1)):to_idx(cy + hy, 1) + 1, 0:to_idx(z1, 2)] = 1
+    elif kind == "wall_gap":
+        gap_y = rng.uniform(-4.0, 4.0); gap_w = rng.uniform(1.2, 2.0)
+        occ[to_idx(-0.2, 0):to_idx(0.2, 0) + 1, :, :] = 1
+        occ[to_idx(-0.2, 0):to_idx(0.2, 0) + 1, to_idx(gap_y - gap_w / 2, 1):to_idx(gap_y + gap_w / 2, 1) + 1, :] = 0
+        w["gap_y"] = gap_y
+    elif kind != "empty":
+        raise ValueError(kind)
+    w.update(occ=occ, origin=tuple(origin), map_size=tuple(map_size), kind=kind)
+    return w
+
+
+def astar_queries(B, seed=0, goal_dist=(4.0, 12.0), f_scale=1.5):
+    """B planner queries for a world of astar_world's default size: start on the -x side (in free space by construction of the
+    worlds: |x| > 5), goal on the +x side, small initial velocity, external acceleration ~ U[-f_scale, f_scale]^3."""
+    rng = np.random.default_rng(SEED0 + 99 + seed)
+    start = np.stack([rng.uniform(-8.5, -5.5, B), rng.uniform(-6.0, 6.0, B), rng.uniform(0.6, 1.6, B)], 1)
+    d = rng.uniform(goal_dist[0], goal_dist[1], B)
+    ang = rng.uniform(-0.5, 0.5, B)
+    end = start + np.stack([d * np.cos(ang), d * np.sin(ang), rng.uniform(-0.3, 0.3, B)], 1)
+    end[:, 0] = np.clip(end[:, 0], -9.0, 9.0); end[:, 1] = np.clip(end[:, 1], -9.0, 9.0); end[:, 2] = np.clip(end[:, 2], 0.5, 1.8)
+    v0 = rng.uniform(-0.5, 0.5, (B, 3)) * np.array([1.0, 1.0, 0.2])
+    a0 = np.zeros((B, 3))
+    f = rng.uniform(-f_scale, f_scale, (B, 3)) * np.array([1.0, 1.0, 0.3])
+    return dict(start_pt=start, start_v=v0, start_a=a0, end_pt=end, end_v=np.zeros((B, 3)), f_ext=f)

@@ -263,6 +263,58 @@ int frp_nmpc_mode_batch(int B, int N, const double *mpc_output, const double *ti
 int frp_nmpc_coldstart_batch(int B, int N, const double *state, const int *exitflag, double thrust, double *mpc_output,
                              void *stream);
 
+/* ---- (7) SURVEY 8f row f-4 (second half): the kinodynamic A* front end on the device ---- */
+/* KinodynamicAstar::search return values (path_searching/include/path_searching/kinodynamic_astar.h:169) */
+#define FRP_ASTAR_REACH_HORIZON 1
+#define FRP_ASTAR_REACH_END 2
+#define FRP_ASTAR_NO_PATH 3
+#define FRP_ASTAR_REACH_END_BUT_SHOT_FAILS 4
+#define FRP_ASTAR_MAX_PATH 256 /* path nodes reported per planner (a node per max_tau seconds of path) */
+typedef struct frp_nmpc_astar {
+    int B;                     /* planners                                                                              */
+    /* the occupancy map all planners search (OccMap, occ_grid/src/occ_map.cpp)                                          */
+    const unsigned char *occ;  /* [gx][gy][gz], != 0 <=> occupancy_buffer_ > min_occupancy_log_ (occ_map.cpp:105)        */
+    int grid[3];               /* grid_size_ = ceil(map_size_ / resolution_) (occ_map.cpp:789)                           */
+    double origin[3];          /* occ_map/origin_*                                                                       */
+    double map_size[3];        /* occ_map/map_size_*: states are bounded by (origin, map_size / 2), z by (0.1, map_size_z / 2)
+                                  (kinodynamic_astar.cpp:152-154)                                                        */
+    double resolution;         /* occ_map/resolution = the A* voxel size (intialGridMap, kinodynamic_astar.cpp:511)       */
+    const int *local_box;      /* [B][6] min_id(3), max_id(3) of OccMap::isInLocalMap (voxels outside read as free,
+                                  occ_map.cpp:45-57, 101-102), or NULL: the whole map is local                           */
+    double ego_r, ego_h;       /* nmpc/ego_r, nmpc/ego_h: the swept cross of checkState (occ_map.cpp:645-684)             */
+    /* search parameters (setParam, kinodynamic_astar.cpp:290-305)                                                     */
+    double max_tau, init_max_tau, max_vel, max_acc, w_time, horizon, lambda_heu;
+    double tie_breaker;        /* 1 + 1 / 10000 (kinodynamic_astar.h:139)                                                */
+    int allocate_num;          /* node pool per planner (search/allocate_num; "run out of memory" -> NO_PATH, :255-259)   */
+    int check_num;             /* collision samples per primitive (search/check_num)                                     */
+    /* the arguments of KinodynamicAstar::search (kinodynamic_astar.cpp:17-19), per planner                              */
+    const double *start_pt, *start_vel, *start_acc, *end_pt, *end_vel; /* [B][3] each                                     */
+    const double *external_acc; /* [B][3] updateExternalAcc: added to every primitive's input (stateTransit, :838)        */
+    const int *active;         /* [B] or NULL: planners with active[b] == 0 are skipped and keep their path (kino_replan_ of
+                                  frp_nmpc_reference.replan selects who replans, nmpc_solver.cpp:475-479)                  */
+    int init_search;           /* `init`: the first expansion keeps start_acc for init_max_tau / 8 .. init_max_tau; when it
+                                  ends in NO_PATH the search is repeated with init = false (nmpc_solver.cpp:190-207)      */
+    double Ts;                 /* sampling step of getKinoTraj (nmpc_utils.h:189)                                        */
+    int K;                     /* samples stored per path                                                                */
+    /* outputs                                                                                                           */
+    double *kino_path;         /* [B][K][3] kino_path_ = getKinoTraj(Ts) (nmpc_solver.cpp:209) = frp_nmpc_reference.kino_path
+                                  with path_per_planner != 0                                                             */
+    int *kino_size;            /* [B] kino_size_; a planner whose search ends in NO_PATH keeps its previous path and size
+                                  (getKinoPath returns before assigning them, nmpc_solver.cpp:195-198)                     */
+    int *status;               /* [B] FRP_ASTAR_*                                                                        */
+    int *stats;                /* [B][4] or NULL: nodes used, expansions, 1 if the search was repeated, path nodes (negated
+                                  when the path had more than K samples and lost its tail)                               */
+    double *path_nodes;        /* [B][FRP_ASTAR_MAX_PATH][11] or NULL: state(6), input(3), duration, pool index of every
+                                  path node (path_nodes_, :308-320)                                                      */
+} frp_nmpc_astar;
+
+/* Bytes of device workspace for (B, grid, allocate_num): bit-packed map + per planner node pool, open-set heap, voxel hash. */
+size_t frp_nmpc_astar_workspace_bytes(const frp_nmpc_astar *p);
+
+/* NMPCSolver::getKinoPath's search (plan_manage/src/nmpc_solver.cpp:154-215) for B planners: KinodynamicAstar::search with
+ * the external acceleration in the primitives, the retry on NO_PATH, getKinoTraj(Ts).  Asynchronous on `stream`. */
+int frp_nmpc_astar_batch(const frp_nmpc_astar *p, void *workspace, size_t workspace_bytes, void *stream);
+
 const char *frp_nmpc_version(void);
 int frp_nmpc_device_count(void);
 
