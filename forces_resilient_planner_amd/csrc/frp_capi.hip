@@ -11,7 +11,10 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include "../../include/frp_nmpc.h"
 #include "frp_kernels.h"
@@ -71,11 +74,14 @@ bool fill_args(const frp_nmpc_batch *b, const frp_nmpc_options *opt_in, void *ws
 // ---- single-problem context of the drop-in ABI: created lazily on first call, freed at unload
 // (the reference has no init/teardown call; SURVEY 8b "Ownership"). Serialised by a mutex: the
 // reference library is not re-entrant either (static work arrays).
+// One call = ONE host-to-device copy and ONE device-to-host copy, both through pinned staging blocks:
+//   in  (doubles): xinit(9) | x0(340) | all_parameters(2600) | nfaces(20 ints)
+//   out (doubles): z(340) | info(FRP_INFO_STRIDE) | exitflag, iterations (2 ints)
+constexpr int DI_IN_DOUBLES = 9 + 340 + 2600 + 10, DI_OUT_DOUBLES = 340 + FRP_INFO_STRIDE + 1;
 struct DropInCtx {
     bool ready = false;
     hipStream_t stream = nullptr;
-    double *d_xinit = nullptr, *d_x0 = nullptr, *d_par = nullptr, *d_z = nullptr, *d_info = nullptr, *d_ws = nullptr;
-    int *d_flag = nullptr, *d_it = nullptr;
+    double *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr, *d_ws = nullptr;
     size_t ws_bytes = 0;
     frp_forces_extfunc probed[2] = {nullptr, nullptr}; // the callback last probed per model (a different pointer is probed again)
     bool probe_ok[2] = {false, false};
@@ -83,8 +89,8 @@ struct DropInCtx {
     ~DropInCtx()
     {
         if (!ready) return;
-        (void)hipFree(d_xinit); (void)hipFree(d_x0); (void)hipFree(d_par); (void)hipFree(d_z); (void)hipFree(d_info); (void)hipFree(d_ws);
-        (void)hipFree(d_flag); (void)hipFree(d_it);
+        (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_ws);
+        (void)hipHostFree(h_in); (void)hipHostFree(h_out);
         (void)hipStreamDestroy(stream);
     }
 };
@@ -97,13 +103,10 @@ int ctx_init()
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FRP_ERR_NO_DEVICE;
     FRP_HIP(hipStreamCreate(&g_ctx.stream));
     g_ctx.ws_bytes = frp::ws_bytes(1, FRP_N_REF, FRP_NH_REF);
-    FRP_HIP(hipMalloc(&g_ctx.d_xinit, 9 * sizeof(double)));
-    FRP_HIP(hipMalloc(&g_ctx.d_x0, 340 * sizeof(double)));
-    FRP_HIP(hipMalloc(&g_ctx.d_par, 2600 * sizeof(double)));
-    FRP_HIP(hipMalloc(&g_ctx.d_z, 340 * sizeof(double)));
-    FRP_HIP(hipMalloc(&g_ctx.d_info, FRP_INFO_STRIDE * sizeof(double)));
-    FRP_HIP(hipMalloc(&g_ctx.d_flag, sizeof(int)));
-    FRP_HIP(hipMalloc(&g_ctx.d_it, sizeof(int)));
+    FRP_HIP(hipMalloc(&g_ctx.d_in, DI_IN_DOUBLES * sizeof(double)));
+    FRP_HIP(hipMalloc(&g_ctx.d_out, DI_OUT_DOUBLES * sizeof(double)));
+    FRP_HIP(hipHostMalloc(&g_ctx.h_in, DI_IN_DOUBLES * sizeof(double), hipHostMallocDefault));
+    FRP_HIP(hipHostMalloc(&g_ctx.h_out, DI_OUT_DOUBLES * sizeof(double), hipHostMallocDefault));
     FRP_HIP(hipMalloc(&g_ctx.d_ws, g_ctx.ws_bytes));
     g_ctx.ready = true;
     return FRP_OK;
@@ -172,26 +175,42 @@ int forces_solve(int model, frp_forces_params *params, frp_forces_output *output
     }
     for (int i = 0; i < 9; i++) if (!std::isfinite(params->xinit[i])) return FRP_EXIT_PARAM_VALUE;
     hipStream_t st = g_ctx.stream;
-    if (hipMemcpyAsync(g_ctx.d_xinit, params->xinit, 9 * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(g_ctx.d_x0, params->x0, 340 * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(g_ctx.d_par, params->all_parameters, 2600 * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
-        return FRP_EXIT_PARAM_VALUE;
+    // stage the inputs; count the live corridor rows here (600 rows): trailing all-zero rows are the padding
+    // forces_normal.cpp:127-135 writes -- with the counts the kernel variant that keeps the rows in registers runs
+    double *hin = g_ctx.h_in;
+    std::memcpy(hin, params->xinit, 9 * sizeof(double));
+    std::memcpy(hin + 9, params->x0, 340 * sizeof(double));
+    std::memcpy(hin + 349, params->all_parameters, 2600 * sizeof(double));
+    int *hnf = reinterpret_cast<int *>(hin + 2949);
+    int mf = 0;
+    for (int k = 0; k < FRP_N_REF; k++) {
+        const double *pk = params->all_parameters + (size_t)k * FRP_NPAR(FRP_NH_REF);
+        int nf = FRP_NH_REF;
+        while (nf > 0) {
+            const double *r = pk + FRP_NPRE + 3 * (nf - 1);
+            if (r[0] == 0.0 && r[1] == 0.0 && r[2] == 0.0 && pk[FRP_NPRE + 3 * FRP_NH_REF + nf - 1] >= -frp::HU) nf--;
+            else break;
+        }
+        hnf[k] = nf;
+        mf = nf > mf ? nf : mf;
+    }
+    if (hipMemcpyAsync(g_ctx.d_in, hin, DI_IN_DOUBLES * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return FRP_EXIT_PARAM_VALUE;
     frp_nmpc_batch b;
     std::memset(&b, 0, sizeof b);
-    b.B = 1; b.N = FRP_N_REF; b.M = FRP_NH_REF; b.MF = FRP_NH_REF; b.model = model;
-    b.xinit = g_ctx.d_xinit; b.x0 = g_ctx.d_x0; b.params = g_ctx.d_par; b.nfaces = nullptr;
-    b.z = g_ctx.d_z; b.exitflag = g_ctx.d_flag; b.iters = g_ctx.d_it; b.info = g_ctx.d_info;
+    b.B = 1; b.N = FRP_N_REF; b.M = FRP_NH_REF; b.MF = mf; b.model = model;
+    b.xinit = g_ctx.d_in; b.x0 = g_ctx.d_in + 9; b.params = g_ctx.d_in + 349; b.nfaces = reinterpret_cast<const int *>(g_ctx.d_in + 2949);
+    b.z = g_ctx.d_out; b.info = g_ctx.d_out + 340;
+    b.exitflag = reinterpret_cast<int *>(g_ctx.d_out + 340 + FRP_INFO_STRIDE); b.iters = b.exitflag + 1;
     frp::KernelArgs a;
     if (!fill_args(&b, nullptr, g_ctx.d_ws, g_ctx.ws_bytes, &a)) return FRP_EXIT_PARAM_VALUE;
     if (frp::launch_ipm(a, st) != hipSuccess) return FRP_EXIT_PARAM_VALUE;
-    int flag = FRP_EXIT_PARAM_VALUE, it = 0;
-    double inf[FRP_INFO_STRIDE];
-    if (hipMemcpyAsync(output->x, g_ctx.d_z, 340 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(&flag, g_ctx.d_flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(&it, g_ctx.d_it, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(inf, g_ctx.d_info, sizeof inf, hipMemcpyDeviceToHost, st) != hipSuccess ||
+    if (hipMemcpyAsync(g_ctx.h_out, g_ctx.d_out, DI_OUT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
         return FRP_EXIT_PARAM_VALUE;
+    std::memcpy(output->x, g_ctx.h_out, 340 * sizeof(double));
+    const double *inf = g_ctx.h_out + 340;
+    const int *fi = reinterpret_cast<const int *>(g_ctx.h_out + 340 + FRP_INFO_STRIDE);
+    const int flag = fi[0], it = fi[1];
     info->it = it; info->it2opt = it;
     info->res_eq = inf[0]; info->res_ineq = inf[1]; info->rsnorm = inf[2]; info->rcompnorm = inf[3];
     info->pobj = inf[4]; info->mu = inf[5]; info->step_cc = inf[6]; info->sigma = 0.0;
@@ -213,6 +232,111 @@ int forces_solve(int model, frp_forces_params *params, frp_forces_output *output
     return flag;
 }
 
+} // namespace
+
+// Host-buffer batch: persistent device buffers and pinned staging (grown on demand, freed at unload), the batch cut into chunks
+// whose copies and solves overlap on three streams: chunk c + 1 is staged and copied in while chunk c solves and chunk c - 1
+// copies out.  Serialised by a mutex (one pipeline per process).
+namespace {
+// A few persistent worker threads for the staging copies (user buffer <-> pinned block): one thread moves ~10-15 GB/s, the PCIe
+// link 50; without them the host copy is the bottleneck of the whole path.
+class CopyPool {
+public:
+    explicit CopyPool(int n) { for (int i = 0; i < n; i++) workers_.emplace_back([this] { run(); }); }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    void copy(void *dst, const void *src, size_t bytes)
+    {
+        const size_t parts = workers_.size() + 1, slice = ((bytes + parts - 1) / parts + 4095) / 4096 * 4096;
+        if (bytes < (1u << 20) || workers_.empty()) { std::memcpy(dst, src, bytes); return; }
+        size_t off = slice; // the caller's thread takes the first slice
+        int queued = 0;
+        {
+            std::lock_guard<std::mutex> l(m_);
+            for (; off < bytes; off += slice) { jobs_.push_back({static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, std::min(slice, bytes - off)}); queued++; }
+            pending_ += queued;
+        }
+        cv_.notify_all();
+        std::memcpy(dst, src, std::min(slice, bytes));
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [this] { return pending_ == 0; });
+    }
+private:
+    struct Job { char *d; const char *s; size_t n; };
+    void run()
+    {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [this] { return stop_ || !jobs_.empty(); });
+                if (stop_ && jobs_.empty()) return;
+                j = jobs_.back(); jobs_.pop_back();
+            }
+            std::memcpy(j.d, j.s, j.n);
+            { std::lock_guard<std::mutex> l(m_); if (--pending_ == 0) done_.notify_all(); }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::vector<Job> jobs_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    int pending_ = 0;
+    bool stop_ = false;
+};
+CopyPool &copy_pool()
+{
+    static CopyPool pool([] { const unsigned hc = std::thread::hardware_concurrency(); return (int)std::min(7u, hc > 2 ? hc / 2 - 1 : 0u); }());
+    return pool;
+}
+
+struct HostPipe {
+    std::mutex mtx;
+    bool ready = false;
+    hipStream_t s_in = nullptr, s_solve = nullptr, s_out = nullptr;
+    static constexpr int NSLOT = 3;
+    struct Slot {
+        double *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr, *d_ws = nullptr;
+        size_t in_bytes = 0, out_bytes = 0, ws_bytes = 0;
+        hipEvent_t e_in = nullptr, e_solve = nullptr, e_out = nullptr;
+    } slot[NSLOT];
+    ~HostPipe()
+    {
+        if (!ready) return;
+        for (auto &s : slot) {
+            (void)hipFree(s.d_in); (void)hipFree(s.d_out); (void)hipFree(s.d_ws); (void)hipHostFree(s.h_in); (void)hipHostFree(s.h_out);
+            (void)hipEventDestroy(s.e_in); (void)hipEventDestroy(s.e_solve); (void)hipEventDestroy(s.e_out);
+        }
+        (void)hipStreamDestroy(s_in); (void)hipStreamDestroy(s_solve); (void)hipStreamDestroy(s_out);
+    }
+};
+HostPipe g_pipe;
+
+int pipe_reserve(HostPipe::Slot &s, size_t in_bytes, size_t out_bytes, size_t ws_bytes)
+{
+    if (in_bytes > s.in_bytes) {
+        (void)hipFree(s.d_in); (void)hipHostFree(s.h_in); s.d_in = s.h_in = nullptr; s.in_bytes = 0;
+        FRP_HIP(hipMalloc(&s.d_in, in_bytes));
+        FRP_HIP(hipHostMalloc(&s.h_in, in_bytes, hipHostMallocDefault));
+        s.in_bytes = in_bytes;
+    }
+    if (out_bytes > s.out_bytes) {
+        (void)hipFree(s.d_out); (void)hipHostFree(s.h_out); s.d_out = s.h_out = nullptr; s.out_bytes = 0;
+        FRP_HIP(hipMalloc(&s.d_out, out_bytes));
+        FRP_HIP(hipHostMalloc(&s.h_out, out_bytes, hipHostMallocDefault));
+        s.out_bytes = out_bytes;
+    }
+    if (ws_bytes > s.ws_bytes) {
+        (void)hipFree(s.d_ws); s.d_ws = nullptr; s.ws_bytes = 0;
+        FRP_HIP(hipMalloc(&s.d_ws, ws_bytes));
+        s.ws_bytes = ws_bytes;
+    }
+    return FRP_OK;
+}
 } // namespace
 
 extern "C" {
@@ -280,39 +404,83 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
     if (h->model != FRP_MODEL_NORMAL && h->model != FRP_MODEL_FINAL) return FRP_ERR_ARG;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FRP_ERR_NO_DEVICE;
-    const size_t B = h->B, N = h->N, np = FRP_NPAR(h->M);
-    DevMem xinit, x0, par, z, info, nf, flag, it, ws, models;
-    const size_t wsb = frp::ws_bytes(h->B, h->N, h->MF);
-    FRP_HIP(xinit.alloc(B * 9 * sizeof(double)));
-    FRP_HIP(x0.alloc(B * N * 17 * sizeof(double)));
-    FRP_HIP(par.alloc(B * N * np * sizeof(double)));
-    FRP_HIP(z.alloc(B * N * 17 * sizeof(double)));
-    FRP_HIP(info.alloc(B * FRP_INFO_STRIDE * sizeof(double)));
-    FRP_HIP(flag.alloc(B * sizeof(int)));
-    FRP_HIP(it.alloc(B * sizeof(int)));
-    FRP_HIP(ws.alloc(wsb));
-    FRP_HIP(hipMemcpy(xinit.p, h->xinit, B * 9 * sizeof(double), hipMemcpyHostToDevice));
-    FRP_HIP(hipMemcpy(x0.p, h->x0, B * N * 17 * sizeof(double), hipMemcpyHostToDevice));
-    FRP_HIP(hipMemcpy(par.p, h->params, B * N * np * sizeof(double), hipMemcpyHostToDevice));
-    if (h->nfaces) {
-        FRP_HIP(nf.alloc(B * N * sizeof(int)));
-        FRP_HIP(hipMemcpy(nf.p, h->nfaces, B * N * sizeof(int), hipMemcpyHostToDevice));
+    std::lock_guard<std::mutex> lock(g_pipe.mtx);
+    if (!g_pipe.ready) {
+        FRP_HIP(hipStreamCreateWithFlags(&g_pipe.s_in, hipStreamNonBlocking));
+        FRP_HIP(hipStreamCreateWithFlags(&g_pipe.s_solve, hipStreamNonBlocking));
+        FRP_HIP(hipStreamCreateWithFlags(&g_pipe.s_out, hipStreamNonBlocking));
+        for (auto &s : g_pipe.slot) {
+            FRP_HIP(hipEventCreateWithFlags(&s.e_in, hipEventDisableTiming));
+            FRP_HIP(hipEventCreateWithFlags(&s.e_solve, hipEventDisableTiming));
+            FRP_HIP(hipEventCreateWithFlags(&s.e_out, hipEventDisableTiming));
+        }
+        g_pipe.ready = true;
     }
-    if (h->model_per_problem) {
-        FRP_HIP(models.alloc(B * sizeof(int)));
-        FRP_HIP(hipMemcpy(models.p, h->model_per_problem, B * sizeof(int), hipMemcpyHostToDevice));
+    const size_t N = h->N, np = FRP_NPAR(h->M);
+    // per-problem doubles in a chunk's input block: xinit | x0 | params, then nfaces / models (ints, padded to doubles)
+    const size_t in_d = 9 + N * 17 + N * np, nf_d = h->nfaces ? (N + 1) / 2 : 0, md_d = h->model_per_problem ? 1 : 0;
+    const size_t out_d = N * 17 + (h->info ? FRP_INFO_STRIDE : 0) + 1; // z | info | (exitflag, iterations)
+    // chunks of >= 1024 problems keep every resident workgroup busy; at most 8 chunks per call
+    size_t chunk = (size_t)h->B;
+    if (h->B >= 4096) { // >= 3 chunks of <= 4096 problems (measured on the dense 4096-problem batch: 1 chunk 5.1 ms, 2: 4.4, 3: 3.7, 4: 4.6)
+        size_t nc = ((size_t)h->B + 4095) / 4096;
+        if (nc < 3) nc = 3;
+        chunk = ((size_t)h->B + nc - 1) / nc;
     }
-    frp_nmpc_batch d = *h;
-    d.model_per_problem = h->model_per_problem ? models.as<int>() : nullptr;
-    d.xinit = xinit.as<double>(); d.x0 = x0.as<double>(); d.params = par.as<double>(); d.nfaces = h->nfaces ? nf.as<int>() : nullptr;
-    d.z = z.as<double>(); d.exitflag = flag.as<int>(); d.iters = it.as<int>(); d.info = info.as<double>();
-    const int rc = frp_nmpc_solve_batch(&d, opt, ws.p, wsb, nullptr);
-    if (rc != FRP_OK) return rc;
-    FRP_HIP(hipDeviceSynchronize());
-    FRP_HIP(hipMemcpy(h->z, z.p, B * N * 17 * sizeof(double), hipMemcpyDeviceToHost));
-    FRP_HIP(hipMemcpy(h->exitflag, flag.p, B * sizeof(int), hipMemcpyDeviceToHost));
-    FRP_HIP(hipMemcpy(h->iters, it.p, B * sizeof(int), hipMemcpyDeviceToHost));
-    if (h->info) FRP_HIP(hipMemcpy(h->info, info.p, B * FRP_INFO_STRIDE * sizeof(double), hipMemcpyDeviceToHost));
+    if (const char *e = getenv("FRP_HOST_CHUNK")) { const long v = atol(e); if (v > 0) chunk = (size_t)v; } // tuning knob
+    const size_t nchunk = ((size_t)h->B + chunk - 1) / chunk;
+    for (auto &s : g_pipe.slot) {
+        const int rc = pipe_reserve(s, chunk * (in_d + nf_d + md_d) * sizeof(double), chunk * out_d * sizeof(double), frp::ws_bytes((int)chunk, h->N, h->MF));
+        if (rc != FRP_OK) return rc;
+    }
+    auto drain = [&](size_t c) -> int { // chunk c's results: wait for its copy-out, unpack from the pinned block
+        HostPipe::Slot &s = g_pipe.slot[c % HostPipe::NSLOT];
+        FRP_HIP(hipEventSynchronize(s.e_out));
+        const size_t b0 = c * chunk, nb = std::min(chunk, (size_t)h->B - b0);
+        const double *o = s.h_out;
+        copy_pool().copy(h->z + b0 * N * 17, o, nb * N * 17 * sizeof(double)); o += nb * N * 17;
+        if (h->info) { std::memcpy(h->info + b0 * FRP_INFO_STRIDE, o, nb * FRP_INFO_STRIDE * sizeof(double)); o += nb * FRP_INFO_STRIDE; }
+        const int *fi = reinterpret_cast<const int *>(o);
+        std::memcpy(h->exitflag + b0, fi, nb * sizeof(int));
+        std::memcpy(h->iters + b0, fi + nb, nb * sizeof(int));
+        return FRP_OK;
+    };
+    for (size_t c = 0; c < nchunk; c++) {
+        HostPipe::Slot &s = g_pipe.slot[c % HostPipe::NSLOT];
+        if (c >= HostPipe::NSLOT) { const int rc = drain(c - HostPipe::NSLOT); if (rc != FRP_OK) return rc; } // the slot's previous chunk has left it
+        const size_t b0 = c * chunk, nb = std::min(chunk, (size_t)h->B - b0);
+        double *hi = s.h_in;
+        std::memcpy(hi, h->xinit + b0 * 9, nb * 9 * sizeof(double)); double *h_x0 = hi + nb * 9;
+        copy_pool().copy(h_x0, h->x0 + b0 * N * 17, nb * N * 17 * sizeof(double)); double *h_par = h_x0 + nb * N * 17;
+        copy_pool().copy(h_par, h->params + b0 * N * np, nb * N * np * sizeof(double));
+        int *h_nf = reinterpret_cast<int *>(h_par + nb * N * np);
+        if (h->nfaces) std::memcpy(h_nf, h->nfaces + b0 * N, nb * N * sizeof(int));
+        int *h_md = reinterpret_cast<int *>(reinterpret_cast<double *>(h_nf) + nb * nf_d);
+        if (h->model_per_problem) std::memcpy(h_md, h->model_per_problem + b0, nb * sizeof(int));
+        const size_t in_bytes = (nb * (in_d + nf_d) + (md_d ? (nb + 1) / 2 : 0)) * sizeof(double);
+        FRP_HIP(hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, g_pipe.s_in));
+        FRP_HIP(hipEventRecord(s.e_in, g_pipe.s_in));
+        frp_nmpc_batch d = *h;
+        d.B = (int)nb;
+        d.xinit = s.d_in; d.x0 = s.d_in + nb * 9; d.params = s.d_in + nb * 9 + nb * N * 17;
+        const double *d_tail = s.d_in + nb * in_d;
+        d.nfaces = h->nfaces ? reinterpret_cast<const int *>(d_tail) : nullptr;
+        d.model_per_problem = h->model_per_problem ? reinterpret_cast<const int *>(d_tail + nb * nf_d) : nullptr;
+        d.z = s.d_out; d.info = h->info ? s.d_out + nb * N * 17 : nullptr;
+        d.exitflag = reinterpret_cast<int *>(s.d_out + nb * N * 17 + (h->info ? nb * FRP_INFO_STRIDE : 0)); d.iters = d.exitflag + nb;
+        FRP_HIP(hipStreamWaitEvent(g_pipe.s_solve, s.e_in, 0));
+        const int rc = frp_nmpc_solve_batch(&d, opt, s.d_ws, s.ws_bytes, g_pipe.s_solve);
+        if (rc != FRP_OK) return rc;
+        FRP_HIP(hipEventRecord(s.e_solve, g_pipe.s_solve));
+        FRP_HIP(hipStreamWaitEvent(g_pipe.s_out, s.e_solve, 0));
+        const size_t out_bytes = (nb * N * 17 + (h->info ? nb * FRP_INFO_STRIDE : 0) + nb) * sizeof(double);
+        FRP_HIP(hipMemcpyAsync(s.h_out, s.d_out, out_bytes, hipMemcpyDeviceToHost, g_pipe.s_out));
+        FRP_HIP(hipEventRecord(s.e_out, g_pipe.s_out));
+    }
+    for (size_t c = nchunk > HostPipe::NSLOT ? nchunk - HostPipe::NSLOT : 0; c < nchunk; c++) {
+        const int rc = drain(c);
+        if (rc != FRP_OK) return rc;
+    }
     return FRP_OK;
 }
 

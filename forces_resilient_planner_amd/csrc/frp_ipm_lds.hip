@@ -57,7 +57,6 @@ static_assert(R_PHIC + 17 <= R_CC && R_CC + 3 <= R_HC && R_DZ + 17 <= R_ZERO2 &&
 static_assert(R_HD + REC_HD_SIZE <= R_PV && R_PV + 13 <= R_PD, "overlay region");
 
 // workgroup-shared scratch (doubles)
-constexpr int X_MI = 0, X_DI = 6;     // pivot block handed from uniform registers to lanes: m = L^-1 (6), D^-1 (4)
 constexpr int X_RW = 16;              // stage-0 solve: Pww^-1 (16)
 constexpr int X_PWX = 32;             // stage-0 solve: Pwx (4 x 9)
 constexpr int X_DS0 = 68;             // ds_0 = [dw_0; dx_0] (16)

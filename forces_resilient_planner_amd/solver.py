@@ -186,8 +186,9 @@ def _check(rc, what):
                            "this library has no CPU path)")
 
 
-def solve_batch_host(w, opt: Options | None = None, MF: int | None = None, x0=None):
-    """Solve a workload dict (host numpy arrays) on the GPU through frp_nmpc_solve_batch_host."""
+def solve_batch_host(w, opt: Options | None = None, MF: int | None = None, x0=None, out=None):
+    """Solve a workload dict (host numpy arrays) on the GPU through frp_nmpc_solve_batch_host.
+    out: (z, flag, iters, info) arrays of an earlier call to write into (a caller in a loop does not re-allocate)."""
     B, N, M = int(w["xinit"].shape[0]), int(w["N"]), int(w["M"])
     xinit = np.ascontiguousarray(w["xinit"], dtype=np.float64)
     z0 = np.ascontiguousarray(w["x0"] if x0 is None else x0, dtype=np.float64)
@@ -195,8 +196,11 @@ def solve_batch_host(w, opt: Options | None = None, MF: int | None = None, x0=No
     nf = None if w.get("nfaces") is None else np.ascontiguousarray(w["nfaces"], dtype=np.int32)
     if MF is None:
         MF = int(nf.max()) if nf is not None and nf.size else M
-    z = np.zeros((B, N, L.NZ)); flag = np.zeros(B, dtype=np.int32); iters = np.zeros(B, dtype=np.int32)
-    info = np.zeros((B, INFO_STRIDE))
+    if out is not None:
+        z, flag, iters, info = out
+    else:
+        z = np.zeros((B, N, L.NZ)); flag = np.zeros(B, dtype=np.int32); iters = np.zeros(B, dtype=np.int32)
+        info = np.zeros((B, INFO_STRIDE))
     models = None if w.get("models") is None else np.ascontiguousarray(w["models"], dtype=np.int32)  # per-problem normal / final
     b = Batch(B, N, M, MF, int(w["model"]), xinit.ctypes.data, z0.ctypes.data, params.ctypes.data,
               nf.ctypes.data if nf is not None else None, z.ctypes.data, flag.ctypes.data, iters.ctypes.data,
