@@ -1900,6 +1900,9 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 #pragma unroll
             for (int i = 0; i < NPRE; i++) p10[i] = pk[i];
             l_obj = stage_cost(ms.z, p10, stage_class(k, N), model, nullptr);
+#ifdef FRP_DEBUG_OBJ // per-stage cost instead of the yaw in the returned plan (diagnosis of code-generation variants)
+            zo[16] = l_obj;
+#endif
         }
         l_obj = wave_sum(l_obj);
         if (a.info && lane == 0) a.info[(size_t)b * FRP_INFO_STRIDE + 4] = l_obj;

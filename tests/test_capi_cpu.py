@@ -345,3 +345,24 @@ def test_widened_entry_points_reject_bad_arguments_before_touching_a_device():
     d3, i3 = (ctypes.c_double * 3)(0, 0, 0), (ctypes.c_int * 3)(1 << 11, 1 << 11, 2)   # 2^23 cells > FRP_CORRIDOR_MAX_CELLS
     assert l.frp_nmpc_cloud_grid_build(one, 10, d3, 0.5, i3, one, one, one, one, None) == ERR
     assert l.frp_nmpc_cloud_grid_build(one, 10, d3, 0.0, (ctypes.c_int * 3)(4, 4, 4), one, one, one, one, None) == ERR
+
+
+def test_product_objects_hold_no_truncated_scalar_immediates(monkeypatch):
+    """Guard against the miscompile behind round 2's "wrong objective" build: with -disable-machine-licm -disable-machine-cse alone
+    this compiler emits s_mov_b64 with a 64-bit FP immediate, gfx9 encodes the low dword only, and 12.0 / 10.0 / 20.0 become 0.0
+    (build.py has the whole story).  Every object of the product library is disassembled and checked; and the code-generation
+    switches are dropped when hipcc is not the release they were checked on."""
+    from forces_resilient_planner_amd import build
+    build.build_native(force=False, verbose=False)
+    checked = 0
+    for n in build.SOURCES:
+        obj = os.path.join(build.OBJDIR, n + ".o")
+        if os.path.exists(obj):
+            checked += build.check_device_code(obj)
+    assert checked > 500
+    import subprocess
+    real = subprocess.run
+    monkeypatch.setattr(build.subprocess, "run", lambda *a, **k: type("R", (), {"stdout": "HIP version: 9.9\nAMD clang version 99 (roc-9.9.0)", "returncode": 0})())
+    assert not build.codegen_flags_trusted()
+    monkeypatch.setattr(build.subprocess, "run", real)
+    assert build.codegen_flags_trusted()

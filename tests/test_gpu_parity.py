@@ -1013,3 +1013,18 @@ def test_fleet_with_per_planner_mode_switch():
         assert np.max(np.abs(z[sel] - res[m][0][sel])) < 1e-9
     fleet.reset_mode()
     assert int((fleet.mode != L.MODEL_NORMAL).sum()) == 0
+
+
+def test_default_code_generation_build_passes_the_variant_and_horizon_tests():
+    """The product compiles the solver kernel with internal code-generation switches of one compiler release (build.py:
+    CODEGEN_FLAGS, +5 % speed).  No result may depend on them: the library built with the compiler's defaults
+    (lib_defaultflags.so, made by __graft_entry__.build()) passes the same per-variant and per-horizon parity tests."""
+    import subprocess
+    import sys
+    from forces_resilient_planner_amd import build
+    lib = build.DEFAULT_FLAGS_LIB
+    assert os.path.exists(lib), "run __graft_entry__.build()"
+    env = dict(os.environ, FRP_LIB=lib)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "every_kernel_variant or horizon_lengths"], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,9 +1,7 @@
 #!/bin/bash
-# tools/build_variant.sh <name> [extra hipcc flags...]  ->  forces_resilient_planner_amd/lib_<name>.so  (experiments only)
+# tools/build_variant.sh <name> [--solver-flags="..."] [extra hipcc flags...]  ->  forces_resilient_planner_amd/lib_<name>.so  (experiments only)
+# The product sources with their per-source flags plus the extra flags; --solver-flags="" compiles the solver kernel's translation
+# unit with the compiler's default code generation instead of build.py's CODEGEN_FLAGS.
 set -e
 cd "$(dirname "$0")/.."
-name=$1; shift
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -c forces_resilient_planner_amd/csrc/frp_astar.hip -o forces_resilient_planner_amd/csrc/frp_astar.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -Iinclude "$@" \
-  forces_resilient_planner_amd/csrc/frp_kernels.hip forces_resilient_planner_amd/csrc/frp_ipm_lds.hip forces_resilient_planner_amd/csrc/frp_capi.hip forces_resilient_planner_amd/csrc/frp_pack.hip forces_resilient_planner_amd/csrc/frp_tube.hip forces_resilient_planner_amd/csrc/frp_corridor.hip forces_resilient_planner_amd/csrc/frp_reference.hip forces_resilient_planner_amd/csrc/frp_astar.o \
-  -o forces_resilient_planner_amd/lib_$name.so
+python -m forces_resilient_planner_amd.build variant "$@"
