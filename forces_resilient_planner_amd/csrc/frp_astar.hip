@@ -7,16 +7,17 @@
 //   KinodynamicAstar::getKinoTraj(Ts)   :648-695  -> kino_path_, exactly the input of frp_nmpc_reference_batch
 // and the occupancy queries of OccMap::checkState (occ_grid/src/occ_map.cpp:645-718, raycast.cpp:263-365).
 //
-// One wavefront = one planner.  A search is a chain of expansions; inside an expansion
-//   * lane 0 pops the open set: a binary heap of (f, node) pairs in HBM that reproduces std::priority_queue's
+// One workgroup of four wavefronts = one planner.  A search is a chain of expansions; inside an expansion
+//   * thread 0 pops the open set: a binary heap of (f, node) pairs in HBM that reproduces std::priority_queue's
 //     __push_heap / __adjust_heap step by step -- the reference changes keys in place without re-heapifying
 //     (kinodynamic_astar.cpp:220-226, :263-272), so the pop order is defined by those algorithms and nothing else;
 //   * all lanes stage the occupancy columns around the node in LDS: the map is bit-packed once per call, one 64-bit word per
 //     (x, y) column (z = bit), and a 64 x 64-column window (32 KB) covers every cell a primitive of this node can touch;
-//   * lane = primitive (125 inputs x 1 duration; 1 x 8 for the first expansion of a continuous start): state transit, range /
-//     closed-set / velocity / same-voxel tests, check_num collision samples through the staged window, cost and the
-//     quartic heuristic; then every survivor finds the first survivor of its voxel;
-//   * lane 0 commits the survivors in input order -- node creation, in-place updates, heap pushes -- which is where the
+//   * thread = primitive (125 inputs x 1 duration; 1 x 8 for the first expansion of a continuous start): state transit, range /
+//     closed-set / velocity / same-voxel tests; thread = (primitive, collision sample) for the check_num samples through the
+//     staged window; thread = surviving primitive for the cost and the quartic heuristic; then every survivor finds the first
+//     survivor of its voxel;
+//   * thread 0 commits the survivors in input order -- node creation, in-place updates, heap pushes -- which is where the
 //     reference's sequential semantics live.
 // The closed / expanded set is an open-addressing hash from the voxel index to the node (exact map semantics).  Arithmetic
 // follows oracle/astar_oracle.c operation by operation (this file is compiled with -ffp-contract=off; cbrt / acos / cos are
@@ -33,6 +34,7 @@ namespace astar {
 constexpr int MAX_CAND = 128;    // primitives per expansion (125 in the reference's configuration)
 constexpr int MAX_PATH = FRP_ASTAR_MAX_PATH;
 constexpr int WIN = 64;          // window of staged occupancy columns: WIN x WIN words
+constexpr int NT = 256;          // threads per planner (four wavefronts): the collision samples of an expansion are spread over them
 constexpr char IN_CLOSE_SET = 'a', IN_OPEN_SET = 'b';
 
 struct Node { // 128 bytes
@@ -395,7 +397,7 @@ __device__ void heap_pop(HeapEnt *heap, Node *nodes, int &size) // std::pop_heap
 }
 
 #ifdef FRP_ASTAR_PROFILE // cycles per phase of a search, written into the last path_nodes row of the planner
-#define APROF(i) do { const long long tn_ = clock64(); if ((threadIdx.x & 63) == 0) sh.prof[i] += tn_ - pt_; pt_ = tn_; } while (0)
+#define APROF(i) do { const long long tn_ = clock64(); if (threadIdx.x == 0) sh.prof[i] += tn_ - pt_; pt_ = tn_; } while (0)
 #define APROF_DECL() long long pt_ = clock64()
 #else
 #define APROF(i)
@@ -406,7 +408,7 @@ struct Shared {
     unsigned long long win[WIN * WIN];
     double c_state[MAX_CAND][6], c_g[MAX_CAND], c_f[MAX_CAND], c_um[MAX_CAND][3], c_tau[MAX_CAND], grp_val[MAX_CAND];
     long long c_key[MAX_CAND];
-    int c_pre[MAX_CAND], c_surv[MAX_CAND], c_leader[MAX_CAND], c_created[MAX_CAND];
+    int c_pre[MAX_CAND], c_surv[MAX_CAND], c_leader[MAX_CAND], c_created[MAX_CAND], c_winner[MAX_CAND];
     double cur_state[6], cur_g, end_state[6], coef_shot[12], t_shot;
     int cur, cur_index[3], cur_parent, heap_size, use_node_num, iter_num, status, terminate, n_cand, shot_ok, shot_fail, is_shot_succ;
     int path_ids[MAX_PATH], n_path, n_in, n_dur_init;
@@ -417,7 +419,7 @@ struct Shared {
 __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, int b, bool init)
 {
     const frp_nmpc_astar *P = &a.p;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x;
     const int A = P->allocate_num;
     Node *nodes = a.nodes + (size_t)b * A;
     HeapEnt *heap = a.heap + (size_t)b * A;
@@ -425,7 +427,7 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
     const double *start_pt = P->start_pt + 3 * b, *start_v = P->start_vel + 3 * b, *start_a = P->start_acc + 3 * b;
     const double *end_pt = P->end_pt + 3 * b, *end_v = P->end_vel + 3 * b;
     // reset(): expanded_nodes_.clear(), open set emptied, counters zeroed
-    for (int i = lane; i < a.hcap; i += 64) hash[i].val = -1;
+    for (int i = lane; i < a.hcap; i += NT) hash[i].val = -1;
     __syncthreads();
     if (lane == 0) {
         sh.heap_size = 0; sh.use_node_num = 0; sh.iter_num = 0; sh.is_shot_succ = 0; sh.status = FRP_ASTAR_NO_PATH; sh.terminate = -1;
@@ -472,7 +474,7 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
         // ---- stage the occupancy columns around the node (also used by the one-shot check below)
         if (ctx.packed) {
             const int wx0 = sh.cur_index[0] - WIN / 2, wy0 = sh.cur_index[1] - WIN / 2;
-            for (int i = lane; i < WIN * WIN; i += 64) {
+            for (int i = lane; i < WIN * WIN; i += NT) {
                 const int gx = wx0 + i / WIN, gy = wy0 + (i % WIN);
                 sh.win[i] = (gx >= 0 && gx < P->grid[0] && gy >= 0 && gy < P->grid[1]) ? ctx.packed[(size_t)gx * P->grid[1] + gy] : 0ull;
             }
@@ -500,7 +502,7 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
                 const double t_delta = t_d / 10;
                 double time = t_delta;
                 int nsamp = 0;
-                for (double tt = t_delta; tt <= t_d && nsamp < 64; tt += t_delta) { if (nsamp == lane) time = tt; nsamp++; }
+                for (double tt = t_delta; tt <= t_d && nsamp < NT; tt += t_delta) { if (nsamp == lane) time = tt; nsamp++; }
                 if (lane < nsamp) {
                     const double t[4] = {1.0, time, time * time, time * time * time};
                     double coord[3], vel[3];
@@ -551,10 +553,11 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
         const int n_cand = use_init ? sh.n_dur_init : sh.n_in;
         __syncthreads();
         APROF(2);
-        for (int c = lane; c < MAX_CAND; c += 64) {
+        // phase 1, thread = primitive: state transit and the tests that need no map
+        for (int c = lane; c < MAX_CAND; c += NT) {
             int surv = 0, pre = -1;
             long long key = 0;
-            double pro[6], g = 0.0, f = 0.0, um[3] = {0.0, 0.0, 0.0}, tau = 0.0;
+            double pro[6], um[3] = {0.0, 0.0, 0.0}, tau = 0.0;
 #pragma unroll
             for (int i = 0; i < 6; i++) pro[i] = 0.0;
             if (c < n_cand) {
@@ -574,29 +577,44 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
                 }
                 if (surv && (fabs(pro[3]) > P->max_vel || fabs(pro[4]) > P->max_vel || fabs(pro[5]) > P->max_vel)) surv = 0;
                 if (surv && i0 == sh.cur_index[0] && i1 == sh.cur_index[1] && i2 == sh.cur_index[2]) surv = 0;
-                if (surv) {
-                    for (int k = 1; k <= P->check_num; ++k) {
-                        const double dt = tau * (double)k / (double)P->check_num;
-                        double xt[6];
-                        state_transit(ctx, sh.cur_state, xt, um, dt);
-                        if (!check_state(ctx, xt, xt + 3, 1.5)) { surv = 0; break; }
-                    }
-                }
-                if (surv) {
-                    double ttg;
-                    g = ((um[0] * um[0] + um[1] * um[1] + um[2] * um[2]) + P->w_time) * tau + sh.cur_g;
-                    f = g + P->lambda_heu * estimate_heuristic(P, pro, sh.end_state, &ttg);
-                }
             }
-            sh.c_surv[c] = surv; sh.c_pre[c] = pre; sh.c_key[c] = key; sh.c_g[c] = g; sh.c_f[c] = f; sh.c_tau[c] = tau;
+            sh.c_surv[c] = surv; sh.c_pre[c] = pre; sh.c_key[c] = key; sh.c_tau[c] = tau; sh.c_g[c] = 0.0; sh.c_f[c] = 0.0; sh.c_leader[c] = c;
 #pragma unroll
             for (int i = 0; i < 6; i++) sh.c_state[c][i] = pro[i];
             sh.c_um[c][0] = um[0]; sh.c_um[c][1] = um[1]; sh.c_um[c][2] = um[2];
         }
         __syncthreads();
-        APROF(3);
+        // phase 2, thread = (primitive, collision sample): check_num samples per surviving primitive (kinodynamic_astar.cpp:190-199;
+        // the reference stops at the first colliding sample -- the verdict of a primitive is the same)
+        for (int t = lane; t < n_cand * P->check_num; t += NT) {
+            const int c = t / P->check_num, k = t - c * P->check_num + 1;
+            if (!sh.c_surv[c]) continue;
+            const double um[3] = {sh.c_um[c][0], sh.c_um[c][1], sh.c_um[c][2]};
+            const double dt = sh.c_tau[c] * (double)k / (double)P->check_num;
+            double xt[6];
+            state_transit(ctx, sh.cur_state, xt, um, dt);
+            if (!check_state(ctx, xt, xt + 3, 1.5)) sh.c_leader[c] = -1; // (c_leader doubles as the collision flag until phase 3 has read it)
+        }
+        __syncthreads();
+        // phase 3, thread = primitive: cost and heuristic of the survivors
+        for (int c = lane; c < n_cand; c += NT) {
+            int surv = sh.c_surv[c];
+            if (surv && sh.c_leader[c] == -1) surv = 0;
+            if (surv) {
+                double ttg;
+                const double um0 = sh.c_um[c][0], um1 = sh.c_um[c][1], um2 = sh.c_um[c][2];
+                const double g = ((um0 * um0 + um1 * um1 + um2 * um2) + P->w_time) * sh.c_tau[c] + sh.cur_g;
+                double pro[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) pro[i] = sh.c_state[c][i];
+                sh.c_g[c] = g;
+                sh.c_f[c] = g + P->lambda_heu * estimate_heuristic(P, pro, sh.end_state, &ttg);
+            }
+            sh.c_surv[c] = surv;
+        }
+        __syncthreads();
         // ---- the first survivor of every voxel (tmp_expand_nodes' lookup, kinodynamic_astar.cpp:210-230)
-        for (int c = lane; c < n_cand; c += 64) {
+        for (int c = lane; c < n_cand; c += NT) {
             int leader = c;
             if (sh.c_surv[c]) {
                 const long long key = sh.c_key[c];
@@ -607,7 +625,9 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
         }
         __syncthreads();
         APROF(4);
-        // ---- commit in input order (kinodynamic_astar.cpp:232-278)
+        // ---- commit in input order (kinodynamic_astar.cpp:232-278).  Thread 0 walks the survivors and takes the decisions that
+        // depend on their order -- which primitive a node keeps, node numbers, heap pushes, keys changed in place --; the node
+        // records themselves are written afterwards, one thread per touched node, from the winning primitive.
         if (lane == 0) {
             int use = sh.use_node_num, hs = sh.heap_size;
             bool out_of_memory = false;
@@ -615,49 +635,43 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
                 if (!sh.c_surv[c]) continue;
                 const int L = sh.c_leader[c];
                 const double g = sh.c_g[c], f = sh.c_f[c];
+                if (L == c) sh.c_winner[c] = -1; // (winner of the voxel's group: the primitive whose values the node ends up with)
                 if (sh.c_pre[c] >= 0) { // a node of this voxel is in the open set: keep the cheaper way to it
                     const int nid = sh.c_pre[c];
-                    const double gcur = (L == c) ? nodes[nid].g : sh.grp_val[L];
-                    if (L == c) sh.grp_val[c] = gcur;
-                    if (g < gcur) {
-                        for (int i = 0; i < 6; i++) nodes[nid].state[i] = sh.c_state[c][i];
-                        nodes[nid].f = f; nodes[nid].g = g;
-                        for (int i = 0; i < 3; i++) nodes[nid].input[i] = sh.c_um[c][i];
-                        nodes[nid].duration = sh.c_tau[c];
-                        nodes[nid].parent = cur;
+                    if (L == c) { sh.grp_val[c] = nodes[nid].g; sh.c_created[c] = nid; }
+                    if (g < sh.grp_val[L]) {
                         heap[nodes[nid].heap_pos].f = f; // the key changes in place: no re-heapify (as in the reference)
-                        sh.grp_val[L] = g;
+                        sh.grp_val[L] = g; sh.c_winner[L] = c;
                     }
                 } else if (L == c) { // new node
                     const int nid = use;
-                    for (int i = 0; i < 6; i++) nodes[nid].state[i] = sh.c_state[c][i];
-                    nodes[nid].f = f; nodes[nid].g = g;
-                    for (int i = 0; i < 3; i++) nodes[nid].input[i] = sh.c_um[c][i];
-                    nodes[nid].duration = sh.c_tau[c];
-                    nodes[nid].key = sh.c_key[c];
-                    nodes[nid].parent = cur;
-                    nodes[nid].node_state = IN_OPEN_SET;
                     hs++;
                     heap_push_hole(heap, nodes, hs - 1, 0, f, nid);
                     hash_insert(hash, a.hcap, sh.c_key[c], nid);
-                    sh.c_created[c] = nid;
-                    sh.grp_val[c] = f;
+                    sh.c_created[c] = nid; sh.grp_val[c] = f; sh.c_winner[c] = c;
                     use++;
                     if (use == A) out_of_memory = true; // "run out of memory", kinodynamic_astar.cpp:255-259
-                } else { // a node of this voxel was created earlier in this expansion: keep the lower f
-                    const int nid = sh.c_created[L];
-                    if (f < sh.grp_val[L]) {
-                        nodes[nid].f = f; nodes[nid].g = g;
-                        for (int i = 0; i < 6; i++) nodes[nid].state[i] = sh.c_state[c][i];
-                        for (int i = 0; i < 3; i++) nodes[nid].input[i] = sh.c_um[c][i];
-                        nodes[nid].duration = sh.c_tau[c];
-                        heap[nodes[nid].heap_pos].f = f;
-                        sh.grp_val[L] = f;
-                    }
+                } else if (f < sh.grp_val[L]) { // a node of this voxel was created earlier in this expansion: keep the lower f
+                    heap[nodes[sh.c_created[L]].heap_pos].f = f;
+                    sh.grp_val[L] = f; sh.c_winner[L] = c;
                 }
             }
             sh.use_node_num = use; sh.heap_size = hs;
             if (out_of_memory) { sh.status = FRP_ASTAR_NO_PATH; sh.terminate = -1; sh.heap_size = -1; }
+        }
+        __syncthreads();
+        for (int c = lane; c < n_cand; c += NT) {
+            if (!sh.c_surv[c] || sh.c_leader[c] != c || sh.c_winner[c] < 0) continue;
+            const int w = sh.c_winner[c], nid = sh.c_created[c];
+            Node *nd = nodes + nid;
+#pragma unroll
+            for (int i = 0; i < 6; i++) nd->state[i] = sh.c_state[w][i];
+            nd->g = sh.c_g[w]; nd->f = sh.c_f[w];
+#pragma unroll
+            for (int i = 0; i < 3; i++) nd->input[i] = sh.c_um[w][i];
+            nd->duration = sh.c_tau[w];
+            if (sh.c_pre[c] < 0) { nd->key = sh.c_key[c]; nd->node_state = IN_OPEN_SET; nd->parent = cur; }
+            else nd->parent = cur; // (an open node that found a cheaper parent, :263-272)
         }
         // (the planner's pool, heap and hash are touched by this wavefront only: the lanes of one CU share its L1, so the
         //  workgroup-scope ordering of the barrier is all the other lanes need to see lane 0's stores)
@@ -678,11 +692,11 @@ __global__ __launch_bounds__(64) void pack_map_kernel(const unsigned char *occ, 
     packed[col] = w;
 }
 
-__global__ __launch_bounds__(64) void astar_kernel(Args a)
+__global__ __launch_bounds__(NT) void astar_kernel(Args a)
 {
     __shared__ Shared sh;
     const frp_nmpc_astar *P = &a.p;
-    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const int b = blockIdx.x, lane = threadIdx.x;
     const int A = P->allocate_num;
     if (P->active && !P->active[b]) return; // this planner keeps its path (no replan requested)
     Ctx ctx;
@@ -738,7 +752,7 @@ __global__ __launch_bounds__(64) void astar_kernel(Args a)
     const int n_path = sh.n_path;
     if (P->path_nodes) {
         double *o = P->path_nodes + (size_t)b * MAX_PATH * 11;
-        for (int q = lane; q < n_path; q += 64) {
+        for (int q = lane; q < n_path; q += NT) {
             const int c = sh.path_ids[q];
             for (int i = 0; i < 6; i++) o[q * 11 + i] = nodes[c].state[i];
             for (int i = 0; i < 3; i++) o[q * 11 + 6 + i] = nodes[c].input[i];
@@ -863,7 +877,7 @@ int frp_nmpc_astar_batch(const frp_nmpc_astar *p, void *workspace, size_t worksp
         hipLaunchKernelGGL(pack_map_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(64), 0, st, p->occ, p->grid[0], p->grid[1], p->grid[2], packed);
         a.packed = packed;
     }
-    hipLaunchKernelGGL(astar_kernel, dim3(p->B), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(astar_kernel, dim3(p->B), dim3(NT), 0, st, a);
     return hipGetLastError() == hipSuccess ? FRP_OK : FRP_ERR_HIP;
 }
 

@@ -1955,7 +1955,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     // against the dispatcher's own rotation, so it is applied to the three-per-CU variants only.)
     const int widx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int role = widx;
-    if (WPE >= 3 && a.cu_slots) {
+#ifndef FRP_NO_PLACE
+#define FRP_NO_PLACE 0
+#endif
+    if (WPE >= 3 && a.cu_slots && !FRP_NO_PLACE) {
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID: SIMD_ID [5:4], CU_ID [11:8], SH_ID [12], SE_ID [15:13]
         const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID [3:0]
         const int simd = (int)((hw >> 4) & 3u);

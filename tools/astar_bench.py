@@ -1,0 +1,33 @@
+"""Batch throughput of the device kinodynamic A* (frp_nmpc_astar_batch) against the CPU oracle (OpenMP over planners).
+   python tools/astar_bench.py [B] [kind] [allocate_num] -> one JSON line"""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from forces_resilient_planner_amd import solver, workloads
+import tests.astar_lib as AL
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+kind = sys.argv[2] if len(sys.argv) > 2 else "pillars"
+alloc = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
+w = workloads.astar_world(5, kind, allocate_num=alloc, n_obstacles=40)
+q = workloads.astar_queries(B, 5)
+pl = solver.AstarPlanner(w, B, K=1024)
+pl.upload(q["start_pt"], q["start_v"], q["start_a"], q["end_pt"], q["end_v"], q["f_ext"])
+pl.plan(); torch.cuda.synchronize()
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter(); pl.plan(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+stats = pl.stats.cpu().numpy(); st = pl.status.cpu().numpy()
+nthr = len(os.sched_getaffinity(0))
+nb = min(B, 256)
+t0 = time.perf_counter()
+o = AL.plan_batch(w, q["start_pt"][:nb], q["start_v"][:nb], q["start_a"][:nb], q["end_pt"][:nb], q["end_v"][:nb], q["f_ext"][:nb], cap=1024, nthreads=nthr)
+t_cpu = time.perf_counter() - t0
+same = bool(np.array_equal(st[:nb], o["status"]) and np.array_equal(pl.kino_size.cpu().numpy()[:nb][st[:nb] != 3], o["kino_size"][st[:nb] != 3]))
+print(json.dumps({"what": "frp_nmpc_astar_batch: searches/s, whole batch (one 256-thread workgroup per planner)", "B": B, "world": kind, "allocate_num": alloc,
+                  "gpu_ms": float(np.median(ts)) * 1e3, "gpu_searches_per_s": B / float(np.median(ts)),
+                  "expansions_total": int(stats[:, 1].sum()), "expansions_max": int(stats[:, 1].max()), "nodes_mean": float(stats[:, 0].mean()),
+                  "gpu_us_per_expansion_of_the_longest_search": float(np.median(ts)) * 1e6 / max(1, int(stats[:, 1].max())),
+                  "status_counts[1..4]": np.bincount(st, minlength=5)[1:].tolist(), "retried": int(stats[:, 2].sum()),
+                  "cpu_oracle": {"planners": nb, "threads": nthr, "seconds": t_cpu, "searches_per_s": nb / t_cpu}, "same_results_on_the_cpu_sample": same}))
