@@ -150,6 +150,39 @@ def build_variant(name, extra_flags=(), solver_flags=None, verbose=False, check=
                         solver_flags=solver_flags, objdir=os.path.join(OBJDIR, "variant_" + name), check=check)
 
 
+DROPIN_DIR = os.path.join(PKG, "dropin", "lib")
+
+
+def build_dropin_archives(verbose=False):
+    """libFORCESNLPsolver_normal.a / libFORCESNLPsolver_final.a: the file names plan_manage links (CMakeLists.txt:64-65, 82-83:
+    link_directories(.../lib) + target_link_libraries(... libFORCESNLPsolver_normal.a libFORCESNLPsolver_final.a)).  Both hold
+    the same objects (either one resolves both solve symbols; the linker takes every member once); the consumer adds the HIP
+    runtime to its link line (-L/opt/rocm/lib -lamdhip64), see INTEGRATION.md."""
+    objs = [os.path.join(OBJDIR, n + ".o") for n in SOURCES]
+    os.makedirs(DROPIN_DIR, exist_ok=True)
+    out = []
+    for name in ("libFORCESNLPsolver_normal.a", "libFORCESNLPsolver_final.a"):
+        dst = os.path.join(DROPIN_DIR, name)
+        if _stale(dst, objs):
+            if os.path.exists(dst):
+                os.remove(dst)
+            cmd = ["ar", "rcs", dst] + objs
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        out.append(dst)
+    # when the reference tree is here (build container): a stand-in for plan_manage's link line -- a program compiled against the
+    # REFERENCE's generated headers, linked by plain g++ against the two archives + the HIP runtime; -m gpu tests run it on the box
+    ref_inc = ["/root/reference/src/resilient_planner/plan_manage/solver/%s/FORCESNLPsolver_%s/include" % (m, m) for m in ("normal", "final")]
+    stub_src = os.path.join(ROOT, "tests", "cpp", "static_dropin_stub.cpp")
+    stub = os.path.join(os.path.dirname(DROPIN_DIR), "planner_stub")
+    if all(os.path.isdir(d) for d in ref_inc) and os.path.exists(stub_src) and _stale(stub, out + [stub_src]):
+        rocm = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc()))), "lib")
+        subprocess.check_call(["g++", "-O1", "-I" + ref_inc[0], "-I" + ref_inc[1], stub_src, "-L" + DROPIN_DIR, "-l:libFORCESNLPsolver_normal.a",
+                               "-l:libFORCESNLPsolver_final.a", "-L" + rocm, "-lamdhip64", "-lpthread", "-Wl,-rpath," + rocm, "-o", stub])
+    return out
+
+
 DEFAULT_FLAGS_LIB = os.path.join(PKG, "lib_defaultflags.so")
 
 

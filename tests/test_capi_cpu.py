@@ -366,3 +366,31 @@ def test_product_objects_hold_no_truncated_scalar_immediates(monkeypatch):
     assert not build.codegen_flags_trusted()
     monkeypatch.setattr(build.subprocess, "run", real)
     assert build.codegen_flags_trusted()
+
+
+def _build_static_dropin_program(tmp_path):
+    """A C++ program compiled against the REFERENCE's generated headers and linked, by plain g++, against static archives with
+    the reference's file names (plan_manage/CMakeLists.txt:64-65, 82-83) + the HIP runtime."""
+    import subprocess
+    from forces_resilient_planner_amd import build
+    build.build_native(force=False, verbose=False)
+    build.build_dropin_archives()
+    inc = [REF_INC.format(m=m) for m in ("normal", "final")]
+    if not all(os.path.isdir(d) for d in inc):
+        pytest.skip("reference headers absent (GPU box)")
+    src = os.path.join(ROOT, "tests", "cpp", "static_dropin_stub.cpp")
+    exe = tmp_path / "planner_stub"
+    rocm = "/opt/rocm/lib"
+    r = subprocess.run(["g++", "-O1", "-I" + inc[0], "-I" + inc[1], str(src), "-L" + build.DROPIN_DIR, "-l:libFORCESNLPsolver_normal.a",
+                        "-l:libFORCESNLPsolver_final.a", "-L" + rocm, "-lamdhip64", "-lpthread", "-Wl,-rpath," + rocm, "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-device behaviour of the statically linked stub")
+def test_static_archives_with_the_references_file_names_link_and_fail_loudly_without_a_device(tmp_path):
+    import subprocess
+    exe = _build_static_dropin_program(tmp_path)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.split()[:2] == ["-11", "-11"], r.stdout + r.stderr

@@ -1028,3 +1028,23 @@ def test_default_code_generation_build_passes_the_variant_and_horizon_tests():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         "-k", "every_kernel_variant or horizon_lengths"], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_statically_linked_planner_stub_solves_config0(tmp_path):
+    """The reference links libFORCESNLPsolver_normal.a / libFORCESNLPsolver_final.a by file name (plan_manage/CMakeLists.txt:64-65,
+    82-83).  build() makes archives with those names and, in the build container, a stub compiled against the reference's own
+    headers and linked against them by plain g++; here it solves BASELINE configs[0] with both solvers."""
+    import subprocess
+    from forces_resilient_planner_amd import build
+    stub = os.path.join(os.path.dirname(build.DROPIN_DIR), "planner_stub")
+    if not os.path.exists(stub):
+        pytest.skip("planner_stub is built where the reference headers are (build container)")
+    w0 = workloads.config0()
+    p = solver.ForcesParams()
+    p.xinit[:] = w0["xinit"][0]; p.x0[:] = w0["x0"][0].ravel(); p.all_parameters[:] = w0["params"][0].ravel(); p.num_of_threads = 1
+    f = tmp_path / "params.bin"
+    f.write_bytes(bytes(p))
+    r = subprocess.run([stub, str(f)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    f1, f2, obj_n, obj_f, it = r.stdout.split()
+    assert f1 == "1" and f2 == "1" and abs(float(obj_n) - 23.1594329641) < 1e-4 and abs(float(obj_f) - 48.4610568794) < 2e-4
