@@ -317,11 +317,20 @@ __device__ __forceinline__ double matvec4s(const d4 &A, double x, double c)
 //   T = L^-T D^-1 K (Kbar, kbar),  S = G - K' D^-1 K,  P <- [Phi_w - hc^2 R, -hc Kbar_x; -hc Kbar_x', S_xx].
 // The tiles of stage k-1 are gathered from its LDS record as soon as the MFMAs that read the tiles of stage k have
 // been issued: the gathers land while those MFMAs and the pivot-block factorisation execute.  The rank-4 products
-// around the pivot block (K, R, T, T') run on the 4x4x4 MFMA (24 cycles instead of 64), whose block layout coincides
+// around the pivot block (K, R, T) run on the 4x4x4 MFMA (24 cycles instead of 64), whose block layout coincides
 // with register 0 of the 16x16 tiles: A[i][k] in lane 16k+4b+i, B[k][j] in lane 16k+4b+j, D[i][j] in lane 16i+4b+j.
+// Written for instruction count (round 3: 288 -> ~240 per stage):
+//   * rows 4.. of P come out of ONE MFMA: S' = G - (D^-1 K)' [K + hc m e_u'] has S_xx in the x columns and, in the u columns,
+//     G_xu - K_x' D^-1 K_u (= 0 up to rounding: K_u = D L') - hc K_x' D^-1 m = -hc Kbar_x', the (x, w) block of P -- no
+//     transposed product, no row shifts, no selects;
+//   * column 13 of the P tile simply carries p (its partner row of M is zero, so it does not enter X = P M); the affine part of
+//     X is X += (column-13 mask) * P;  rows 13..15 of the tiles hold finite junk that meets zero rows of M;
+//   * the w rows of P are one multiply-add on a gathered value: P_w = pq - hc (hc4 * [R | T]), pq = Phi_w on the diagonal lanes
+//     and phi_w in column 13 (masks in the gather address), hc4 = hc in the u columns and 1 elsewhere;
+//   * one select chain hands m = L^-1 to the lanes (entry (max, min) of the pair (g, c & 3)); its two uses mask it.
 // Returns 1 when a pivot block is not positive definite.
 __device__ __forceinline__ void gather_tiles(cldouble *rn, const int (&c1)[4], const int (&c2)[4], const int (&c3)[4],
-                                             const int (&mo)[4], int g, double theta, d4 &C, d4 &Mt, double &hc, double &PhiDw, double &phiw)
+                                             const int (&mo)[4], int pqo, double theta, d4 &C, d4 &Mt, double &hc, double &pq)
 {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -330,8 +339,7 @@ __device__ __forceinline__ void gather_tiles(cldouble *rn, const int (&c1)[4], c
         Mt[r] = rn[mo[r]];
     }
     hc = rn[R_HC];
-    PhiDw = rn[R_PHID + 4 + g];
-    phiw = rn[R_PHI + 4 + g];
+    pq = rn[pqo];
 }
 
 __device__ __noinline__ int sweep_factor(ldouble *recs, ldouble *xs, int N, double theta)
@@ -344,28 +352,30 @@ __device__ __noinline__ int sweep_factor(ldouble *recs, ldouble *xs, int N, doub
         mo[r] = tab(T_M + r, lane); c1[r] = tab(T_C1 + r, lane); c2[r] = tab(T_C2 + r, lane);
         c3[r] = tab(T_C3 + r, lane); ppo[r] = tab(T_PP + r, lane); pdo[r] = tab(T_PD + r, lane);
     }
-    // which entry of m = L^-1 of the pivot block this lane needs as m[g][c & 3] / m[c & 3][g]: index into the strictly
-    // lower triangle (1,0) (2,0) (2,1) (3,0) (3,1) (3,2), 6 = unit diagonal, 7 = zero
-    const int mgs = c3_ < g ? g * (g - 1) / 2 + c3_ : (c3_ == g ? 6 : 7);
-    const int mcs = g < c3_ ? c3_ * (c3_ - 1) / 2 + g : (c3_ == g ? 6 : 7);
-    const bool row3 = g == 0; // tile rows 12..15: only row 12 is a state row
+    // Phi_w[g] on the diagonal lanes of the w block, phi_w[g] in column 13, zero elsewhere
+    const int pqo = (c < 4 && g == c) ? R_PHID + 4 + g : (c == 13 ? R_PHI + 4 + g : R_ZERO);
+    // the entry of m = L^-1 of the pivot block this lane needs, as m[g][c & 3] (c & 3 <= g) and / or m[c & 3][g] (g <= c & 3):
+    // index into the strictly lower triangle (1,0) (2,0) (2,1) (3,0) (3,1) (3,2), 6 = unit diagonal
+    const int mhi = g > c3_ ? g : c3_, mlo = g > c3_ ? c3_ : g;
+    const int msel = mhi == mlo ? 6 : mhi * (mhi - 1) / 2 + mlo;
+    const bool m_lower = c3_ <= g, m_upper = g <= c3_;
+    const double m4 = c < 4 ? 1.0 : 0.0, m13 = c == 13 ? 1.0 : 0.0; // lane masks as factors
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
-    d4 P = zero, pv = zero, C, Mt;
-    double hcn, PhiDwn, phiwn;
-    gather_tiles(recs + (N - 1) * RS, c1, c2, c3, mo, g, theta, C, Mt, hcn, PhiDwn, phiwn);
+    d4 P = zero, C, Mt;
+    double hcn, pqn;
+    gather_tiles(recs + (N - 1) * RS, c1, c2, c3, mo, pqo, theta, C, Mt, hcn, pqn);
     d4 G = C; // the last stage has no successor: G = C~
     bool ok = true;
     SEG_DECL();
     // Loop body in the order of the dependency chain, rotated so that independent work sits next to the MFMA chains:
     //   gather(k-1) [while the G MFMAs of stage k, issued at the end of the previous pass, execute] -> pivot block of G
-    //   -> rank-4 products -> P_k -> X = P_k M_{k-1} [its MFMAs interleave with the assembly of P_k's rows 4..15 and
-    //   the packed-P stores] -> G of stage k-1.
+    //   -> rank-4 products -> P_k -> X = P_k M_{k-1} -> G of stage k-1.
     for (int kk = N - 1;; kk--) {
         SEG(5);
         ldouble *rec = recs + kk * RS;
-        const double hc = hcn, PhiDw = PhiDwn, phiw = phiwn; // of stage kk
+        const double hc = hcn, pq = pqn; // of stage kk
         // the tiles of stage kk are consumed: gather those of stage kk-1 (clamped at 0: unused after the last step)
-        gather_tiles(recs + (kk > 0 ? kk - 1 : 0) * RS, c1, c2, c3, mo, g, theta, C, Mt, hcn, PhiDwn, phiwn);
+        gather_tiles(recs + (kk > 0 ? kk - 1 : 0) * RS, c1, c2, c3, mo, pqo, theta, C, Mt, hcn, pqn);
         SEG(1);
         // ---- pivot block Guu = L D L' (4 x 4): lower triangle to uniform registers, factored redundantly
         double q[16], Mi[6], Di[4];
@@ -376,14 +386,11 @@ __device__ __noinline__ int sweep_factor(ldouble *recs, ldouble *xs, int N, doub
         ok &= ldl4(q, Mi, Di); // (a failed pivot poisons the rest of the sweep, which is discarded: no branch in the loop)
         // the uniform factors reach the lanes through selects on lane-constant predicates (an LDS round trip costs ~250 cycles
         // of the dependency chain)
-        auto pick = [&](int sel) {
-            double v = sel == 6 ? 1.0 : 0.0;
+        double me = msel == 6 ? 1.0 : Mi[0];
 #pragma unroll
-            for (int i = 0; i < 6; i++) v = sel == i ? Mi[i] : v;
-            return v;
-        };
+        for (int i = 1; i < 6; i++) me = msel == i ? Mi[i] : me;
         // elimination in factored form: an explicit inverse of Guu cancels O(1e10) barrier terms against cond(Guu) eps errors
-        const double m_gc = pick(mgs), m_cg = pick(mcs); // m[g][c & 3], m[c & 3][g]
+        const double m_gc = m_lower ? me : 0.0, m_cg = m_upper ? me : 0.0; // m[g][c & 3], m[c & 3][g]
         const double dg = g == 0 ? Di[0] : (g == 1 ? Di[1] : (g == 2 ? Di[2] : Di[3]));
         const double md = dg * m_gc;
         SEG(2);
@@ -391,38 +398,25 @@ __device__ __noinline__ int sweep_factor(ldouble *recs, ldouble *xs, int N, doub
         const double rt = mfma4(m_gc, md, 0.0);    // R = m' D^-1 m      (replicated in every column block)
         const double Kd = dg * K0;
         const double T0 = mfma4(m_gc, Kd, 0.0);    // T = m' D^-1 K = R G_u
-        const double TTb = mfma4(K0, md, 0.0);     // (K' D^-1 m)[4b + i][j] in lane (i, 4b + j)
+        const double hcm = hc * m4;
+        const double Kb = __builtin_fma(hcm, m_gc, K0); // K + hc m in the u columns
         d4 S = G;
-        S = __builtin_amdgcn_mfma_f64_16x16x4f64(-Kd, K0, S, 0, 0, 0); // S = G - K' D^-1 K
+        S = __builtin_amdgcn_mfma_f64_16x16x4f64(-Kd, Kb, S, 0, 0, 0); // [-hc Kbar_x' | S_xx | p_x] in rows 4..12
         SEG(3);
-        // (every candidate is computed first and then selected: expressions inside nested selects compile to exec-mask branches)
-        const double hT = hc * T0, hhr = hc * hc * rt, pdiag = PhiDw - hhr, pw = phiw - hT, hc14 = lane == 14 ? hc : 0.0;
-        rec[R_T + lane] = c < 4 ? rt : (c <= 13 ? T0 : hc14);
-        P[0] = c < 4 ? (g == c ? pdiag : -hhr) : (c <= 12 ? -hT : 0.0);
-        pv[0] = c == 13 ? pw : 0.0;
-        // rows 4..15, columns 0..3: -hc Kbar_x' = -hc (K' D^-1 m) moved from column block r to column block 0
-        const double tt1 = -hc * row_shl<4>(TTb), tt2 = -hc * row_shl<8>(TTb), tt3 = -hc * row_shl<12>(TTb);
+        const double tsel = c < 4 ? rt : T0;       // [R | Kbar_x | kbar] (T' of the sweeps; its columns 14, 15 are zero)
+        rec[R_T + lane] = tsel;
+        const double hc4 = __builtin_fma(hc, m4, 1.0 - m4);
+        P[0] = __builtin_fma(-hc, hc4 * tsel, pq); // [Phi_w - hc^2 R | -hc Kbar_x | phi_w - hc kbar]
+        P[1] = S[1]; P[2] = S[2]; P[3] = S[3];
         if (kk == 0) {
-            P[1] = c < 4 ? tt1 : (c <= 12 ? S[1] : 0.0);
-            P[2] = c < 4 ? tt2 : (c <= 12 ? S[2] : 0.0);
-            P[3] = row3 ? (c < 4 ? tt3 : (c <= 12 ? S[3] : 0.0)) : 0.0;
-            pv[1] = c == 13 ? S[1] : 0.0;
-            pv[2] = c == 13 ? S[2] : 0.0;
-            pv[3] = (row3 && c == 13) ? S[3] : 0.0;
 #pragma unroll
             for (int r = 0; r < 4; r++) rec[ppo[r]] = P[r];
             break;
         }
-        // ---- X = P_k M_{k-1} (col 13: P d), register by register as the rows of P_k become available
+        // ---- X = P_k M_{k-1} (col 13: P d)
         d4 X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[0], Mt[0], zero, 0, 0, 0);
-        P[1] = c < 4 ? tt1 : (c <= 12 ? S[1] : 0.0);
-        pv[1] = c == 13 ? S[1] : 0.0;
         X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[1], Mt[1], X, 0, 0, 0);
-        P[2] = c < 4 ? tt2 : (c <= 12 ? S[2] : 0.0);
-        pv[2] = c == 13 ? S[2] : 0.0;
         X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[2], Mt[2], X, 0, 0, 0);
-        P[3] = row3 ? (c < 4 ? tt3 : (c <= 12 ? S[3] : 0.0)) : 0.0;
-        pv[3] = (row3 && c == 13) ? S[3] : 0.0;
         X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[3], Mt[3], X, 0, 0, 0);
         // P_k (packed lower triangle) for the multiplier recovery y_k = P_k ds_k + p_k; it overwrites the Hessian part
         // of this stage's record, which was gathered one step ago
@@ -433,8 +427,8 @@ __device__ __noinline__ int sweep_factor(ldouble *recs, ldouble *xs, int N, doub
         ldouble *recn = rec - RS;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            recn[pdo[r]] = X[r]; // P d (column 13; every other lane writes the dump slot)
-            X[r] += pv[r];       // pv is zero outside column 13
+            recn[pdo[r]] = X[r];                      // P d (column 13; every other lane writes the dump slot)
+            X[r] = __builtin_fma(m13, P[r], X[r]);    // + p in column 13
         }
         // the rows w+ of M (tile rows 0..3) are [I 0 | d_w], so their slice adds X[w+_j][.] to G[u_j][.] (and something to
         // the unused row 13): one vector add instead of an MFMA
@@ -460,7 +454,7 @@ __device__ __noinline__ int sweep_factor(ldouble *recs, ldouble *xs, int N, doub
 #pragma unroll
             for (int i = 0; i < 16; i++) xs[X_RW + i] = Rw[i];
             if (c >= 4 && c <= 12) xs[X_PWX + g * 9 + c - 4] = P[0];
-            stage0_solve(xs, lane, pv[0]);
+            stage0_solve(xs, lane, P[0]); // (p_w sits in column 13 of the w rows)
         }
     }
     WSYNC();
