@@ -320,9 +320,8 @@ __device__ __forceinline__ double matvec4s(const d4 &A, double x, double c)
 // around the pivot block (K, R, T) run on the 4x4x4 MFMA (24 cycles instead of 64), whose block layout coincides
 // with register 0 of the 16x16 tiles: A[i][k] in lane 16k+4b+i, B[k][j] in lane 16k+4b+j, D[i][j] in lane 16i+4b+j.
 // Written for instruction count (round 3: 288 -> ~240 per stage):
-//   * rows 4.. of P come out of ONE MFMA: S' = G - (D^-1 K)' [K + hc m e_u'] has S_xx in the x columns and, in the u columns,
-//     G_xu - K_x' D^-1 K_u (= 0 up to rounding: K_u = D L') - hc K_x' D^-1 m = -hc Kbar_x', the (x, w) block of P -- no
-//     transposed product, no row shifts, no selects;
+//   * rows 4.. of P come out of ONE MFMA: S' = [0 | G_x.] - (D^-1 K)' [hc m | K_x.] has S_xx (and p_x) in the x columns and
+//     -hc K_x' D^-1 m = -hc Kbar_x', the (x, w) block of P, in the u columns -- no transposed product, no row shifts, no selects;
 //   * column 13 of the P tile simply carries p (its partner row of M is zero, so it does not enter X = P M); the affine part of
 //     X is X += (column-13 mask) * P;  rows 13..15 of the tiles hold finite junk that meets zero rows of M;
 //   * the w rows of P are one multiply-add on a gathered value: P_w = pq - hc (hc4 * [R | T]), pq = Phi_w on the diagonal lanes
@@ -359,7 +358,7 @@ __device__ __noinline__ int sweep_factor(ldouble *recs, ldouble *xs, int N, doub
     const int mhi = g > c3_ ? g : c3_, mlo = g > c3_ ? c3_ : g;
     const int msel = mhi == mlo ? 6 : mhi * (mhi - 1) / 2 + mlo;
     const bool m_lower = c3_ <= g, m_upper = g <= c3_;
-    const double m4 = c < 4 ? 1.0 : 0.0, m13 = c == 13 ? 1.0 : 0.0; // lane masks as factors
+    const double m4 = c < 4 ? 1.0 : 0.0, m4c = 1.0 - m4, m13 = c == 13 ? 1.0 : 0.0; // lane masks as factors
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     d4 P = zero, C, Mt;
     double hcn, pqn;
@@ -398,14 +397,17 @@ __device__ __noinline__ int sweep_factor(ldouble *recs, ldouble *xs, int N, doub
         const double rt = mfma4(m_gc, md, 0.0);    // R = m' D^-1 m      (replicated in every column block)
         const double Kd = dg * K0;
         const double T0 = mfma4(m_gc, Kd, 0.0);    // T = m' D^-1 K = R G_u
+        // (the u columns of rows 4.. would come out as G_xu - K_x' D^-1 K_u, zero only up to rounding RELATIVE TO G_xu, which carries
+        //  barrier terms: they are taken out of both operands instead -- three multiplies -- and the block is exactly -hc K_x' D^-1 m)
         const double hcm = hc * m4;
-        const double Kb = __builtin_fma(hcm, m_gc, K0); // K + hc m in the u columns
+        const double Kb = __builtin_fma(hcm, m_gc, K0 * m4c); // [hc m | K_x | k]
         d4 S = G;
+        S[1] *= m4c; S[2] *= m4c; S[3] *= m4c;
         S = __builtin_amdgcn_mfma_f64_16x16x4f64(-Kd, Kb, S, 0, 0, 0); // [-hc Kbar_x' | S_xx | p_x] in rows 4..12
         SEG(3);
         const double tsel = c < 4 ? rt : T0;       // [R | Kbar_x | kbar] (T' of the sweeps; its columns 14, 15 are zero)
         rec[R_T + lane] = tsel;
-        const double hc4 = __builtin_fma(hc, m4, 1.0 - m4);
+        const double hc4 = __builtin_fma(hc, m4, m4c);
         P[0] = __builtin_fma(-hc, hc4 * tsel, pq); // [Phi_w - hc^2 R | -hc Kbar_x | phi_w - hc kbar]
         P[1] = S[1]; P[2] = S[2]; P[3] = S[3];
         if (kk == 0) {
@@ -432,9 +434,8 @@ __device__ __noinline__ int sweep_factor(ldouble *recs, ldouble *xs, int N, doub
         }
         // the rows w+ of M (tile rows 0..3) are [I 0 | d_w], so their slice adds X[w+_j][.] to G[u_j][.] (and something to
         // the unused row 13): one vector add instead of an MFMA
-        G = C;
-        G[0] += X[0];
-        G = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[1], X[1], G, 0, 0, 0);
+        C[0] += X[0];
+        G = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[1], X[1], C, 0, 0, 0);
         G = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[2], X[2], G, 0, 0, 0);
         G = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[3], X[3], G, 0, 0, 0);
         SEG(0);
