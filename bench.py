@@ -157,6 +157,7 @@ def main():
                          "HBM; every step scatters the shards (grouped RCCL send/recv), solves, gathers the plans back (SURVEY 8e); "
                          "configs[4]: one nominal problem is broadcast, the samples are drawn on every rank's device")
     ap.add_argument("--repeats", type=int, default=5, help="the K-step region is timed this many times; the MEDIAN is reported")
+    ap.add_argument("--no-order-hint", action="store_true", help="configs[4]: queue the problems by the cost of the initial guess instead of by the previous tick's iteration counts")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / end-to-end / drop-in latency legs")
     ap.add_argument("--streams", type=int, default=1,
                     help="informational: `value` is always the strictly serial single-stream rate; the rate with the steps issued "
@@ -273,6 +274,7 @@ def main():
             D.broadcast_nominal(nominal + [fbar], sdist)
         fleet = solver.DeviceFleet(max(B, 1), N, M, 6, model, _weights(model), f"cuda:{local_rank}")
         ds = fleet.solver
+        ds.order_by_last_iters = not args.no_order_hint  # queue order = the previous tick's iteration counts
         fleet.mpc_output.copy_(nominal[0].expand(max(B, 1), N + 1, L.NZ))
         fleet.ellipsoid.copy_(nominal[1].expand(max(B, 1), N, 3, 3))
         fleet.poly_nfaces.fill_(6)

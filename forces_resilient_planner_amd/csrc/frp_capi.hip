@@ -67,6 +67,7 @@ bool fill_args(const frp_nmpc_batch *b, const frp_nmpc_options *opt_in, void *ws
     a->z = b->z; a->exitflag = b->exitflag; a->iters = b->iters; a->info = b->info;
     a->ws = static_cast<double *>(ws);
     a->models = b->model_per_problem;
+    a->order_hint = b->order_hint;
     a->counter = nullptr; a->order = nullptr;
     return true;
 }
@@ -466,6 +467,7 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
         const double *d_tail = s.d_in + nb * in_d;
         d.nfaces = h->nfaces ? reinterpret_cast<const int *>(d_tail) : nullptr;
         d.model_per_problem = h->model_per_problem ? reinterpret_cast<const int *>(d_tail + nb * nf_d) : nullptr;
+        d.order_hint = nullptr; // (a queue-order hint is not worth a copy here: the chunks are at most two rounds of resident workgroups)
         d.z = s.d_out; d.info = h->info ? s.d_out + nb * N * 17 : nullptr;
         d.exitflag = reinterpret_cast<int *>(s.d_out + nb * N * 17 + (h->info ? nb * FRP_INFO_STRIDE : 0)); d.iters = d.exitflag + nb;
         FRP_HIP(hipStreamWaitEvent(g_pipe.s_solve, s.e_in, 0));

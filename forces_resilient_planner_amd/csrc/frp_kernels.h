@@ -57,6 +57,7 @@ struct KernelArgs {
     int *cu_slots;    // per-CU arrival counters of the resident workgroups, zeroed by the launcher (frp_ipm_lds.hip: role placement)
     const int *order; // launch order of the problems, or null = index order (set by the launcher)
     const int *models; // per-problem FRP_MODEL_*, or null = `model` for the whole batch
+    const int *order_hint; // per-problem expected work (last tick's iteration count), or null = order by the cost of the initial guess
 };
 
 constexpr int CU_SLOT_ENTRIES = 2048; // (XCC, SE, SH, CU) of HW_ID

@@ -44,6 +44,13 @@ __global__ __launch_bounds__(256) void order_keys_kernel(int B, int N, int np, i
     c = wave_sum(c);
     if (k == 0) keys[b] = (c == c && c < 1e300) ? c : 0.0;
 }
+// The caller knows better: a receding-horizon tick re-solves yesterday's problem shifted by one stage, and the iteration
+// count of the previous tick predicts this one's (frp_nmpc_batch.order_hint).  Unknown (<= 0) sorts with the typical solve.
+__global__ __launch_bounds__(256) void order_hint_kernel(int B, const int *__restrict__ hint, double *__restrict__ keys)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < B) keys[b] = hint[b] > 0 ? (double)hint[b] : 4.0;
+}
 // order = the problems sorted by decreasing key, to bucket resolution (also zeroes the work-queue head): one workgroup, a 1024-bin counting sort on the
 // (monotone) bit pattern of the non-negative keys -- i.e. on a log scale -- with the bins spread over the key range of
 // this batch.  The order inside a bin is arbitrary (atomics); order[] is a permutation for any input.
@@ -289,8 +296,11 @@ hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
         double *keys = q + QUEUE_RESERVED;
         int *order = reinterpret_cast<int *>(keys + a.B);
         k.order = order;
-        hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, stream, a.B, a.N, NPRE + 4 * a.M, a.model,
-                           a.models, a.x0, a.params, keys);
+        if (a.order_hint)
+            hipLaunchKernelGGL(order_hint_kernel, dim3((unsigned)((a.B + 255) / 256)), dim3(256), 0, stream, a.B, a.order_hint, keys);
+        else
+            hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, stream, a.B, a.N, NPRE + 4 * a.M, a.model,
+                               a.models, a.x0, a.params, keys);
         hipLaunchKernelGGL(order_bucket_kernel, dim3(1), dim3(1024), 0, stream, a.B, keys, order, k.counter, k.cu_slots);
     } else {
         // a one-thread kernel rather than hipMemsetAsync: as a node of a captured hipGraph the 4-byte memset was not

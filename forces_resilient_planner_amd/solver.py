@@ -31,7 +31,8 @@ class Batch(ctypes.Structure):
                 ("model", ctypes.c_int),
                 ("xinit", ctypes.c_void_p), ("x0", ctypes.c_void_p), ("params", ctypes.c_void_p),
                 ("nfaces", ctypes.c_void_p), ("z", ctypes.c_void_p), ("exitflag", ctypes.c_void_p),
-                ("iters", ctypes.c_void_p), ("info", ctypes.c_void_p), ("model_per_problem", ctypes.c_void_p)]
+                ("iters", ctypes.c_void_p), ("info", ctypes.c_void_p), ("model_per_problem", ctypes.c_void_p),
+                ("order_hint", ctypes.c_void_p)]
 
 
 class Pack(ctypes.Structure):  # frp_nmpc_pack (include/frp_nmpc.h)
@@ -243,6 +244,9 @@ class DeviceSolver:
         self.ws_bytes = int(lib().frp_nmpc_workspace_bytes(B, N, MF))
         self.ws = torch.empty((self.ws_bytes // 8 + 1,), **f64)
         self.use_nfaces = True
+        # receding-horizon callers: queue the problems by the PREVIOUS solve's iteration counts (frp_nmpc_batch.order_hint);
+        # off = by the objective of the initial guess
+        self.order_by_last_iters = False
         self.opt = default_options()
 
     def upload(self, w):
@@ -256,7 +260,8 @@ class DeviceSolver:
         return Batch(self.B, self.N, self.M, self.MF, self.model, self.xinit.data_ptr(), self.x0.data_ptr(),
                      self.params.data_ptr(), self.nfaces.data_ptr() if self.use_nfaces else None, self.z.data_ptr(),
                      self.exitflag.data_ptr(), self.iters.data_ptr(), self.info.data_ptr(),
-                     self.models.data_ptr() if getattr(self, "models", None) is not None else None)
+                     self.models.data_ptr() if getattr(self, "models", None) is not None else None,
+                     self.iters.data_ptr() if self.order_by_last_iters else None)
 
     def solve(self, stream=None):
         """Asynchronous launch on `stream` (a torch.cuda.Stream) or torch's current stream."""

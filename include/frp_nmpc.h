@@ -98,6 +98,11 @@ typedef struct frp_nmpc_batch {
     const int *model_per_problem; /* [B] FRP_MODEL_* of each problem, or NULL: `model` for all.  A fleet whose
                              planners switch to the final solver one by one (switch_to_final,
                              nmpc_solver.cpp:381, 446-447) stays one batch.                    */
+    const int *order_hint; /* [B] expected work of each problem, or NULL.  Only the ORDER in which the solver's
+                             persistent workgroups take problems off the queue depends on it (largest first), never a
+                             result.  A receding-horizon caller passes the PREVIOUS tick's `iters` -- the same buffer
+                             as `iters` is fine, it is read before the solve writes it; values <= 0 = unknown.
+                             NULL: ordered by the objective of the initial guess.                               */
 } frp_nmpc_batch;
 
 void frp_nmpc_default_options(frp_nmpc_options *opt);

@@ -464,6 +464,25 @@ def test_launch_order_is_a_permutation_for_hostile_keys():
     assert np.all(np.isfinite(z[clean]))
 
 
+def test_queue_order_hint_changes_the_order_and_nothing_else():
+    """frp_nmpc_batch.order_hint (a receding-horizon caller's previous iteration counts): any hint -- the previous counts,
+    garbage, negative, all equal -- gives bit-identical plans, flags and iteration counts; the hint may alias `iters`."""
+    import torch
+    B = 3000  # more problems than resident workgroups: the queue is ordered
+    w = workloads.config2(B, seed=78)
+    ds = solver.DeviceSolver(B, w["N"], w["M"], 6, w["model"])
+    ds.upload(w)
+    ds.solve(); torch.cuda.synchronize()
+    z0, f0, i0 = ds.z.cpu().numpy().copy(), ds.exitflag.cpu().numpy().copy(), ds.iters.cpu().numpy().copy()
+    ds.order_by_last_iters = True   # hint = ds.iters, the buffer the solve writes its counts to
+    rng = np.random.default_rng(5)
+    for hint in (i0, rng.integers(-(2 ** 31), 2 ** 31 - 1, B), np.zeros(B), np.full(B, 7)):
+        ds.iters.copy_(torch.from_numpy(np.asarray(hint, dtype=np.int32)))
+        ds.solve(); torch.cuda.synchronize()
+        assert np.array_equal(ds.exitflag.cpu().numpy(), f0) and np.array_equal(ds.iters.cpu().numpy(), i0)
+        assert np.max(np.abs(ds.z.cpu().numpy() - z0)) == 0.0
+
+
 @pytest.mark.skipif(not OL.ref_model_available(), reason="oracle/_ref not built (reference tree absent)")
 def test_gpu_plans_satisfy_reference_kkt_measured_with_reference_callbacks():
     """The HIP path's plans are KKT points of the REFERENCE NLP as measured with the reference's own CasADi
