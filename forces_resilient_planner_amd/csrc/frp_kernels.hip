@@ -15,34 +15,72 @@
 #include "frp_kernels.h"
 #include "frp_device.hpp"
 #include <cstdlib>
+#include <cstdio>
 
 namespace frp {
 
 
 // ------------------------------------------------------------------ launch order: longest expected solve first
-// The launch ends when its slowest problem does, and a problem that needs 3-5x the typical iteration count should not
-// be the last one to start.  Proxy for the work of a solve: the objective of the caller's initial guess (a plan that
-// starts far from its reference / corridor costs more and takes more interior-point iterations; rank correlation with
-// the iteration count ~0.45 on the BASELINE workloads, and the hardest problems are reliably in the upper half, i.e.
-// in the first wave of resident workgroups).  Only the ORDER in which the persistent workgroups pull problems
+// The launch ends when its slowest problem does: at the BASELINE batch of 4096 the typical solve takes 5 interior-point
+// iterations, one in a hundred takes 10..25, and a 25-iteration solve that starts in the second round of resident
+// workgroups ends after everybody else has gone home.  Only the ORDER in which the persistent workgroups pull problems
 // changes; every problem is solved exactly as before.
-__global__ __launch_bounds__(256) void order_keys_kernel(int B, int N, int np, int model, const int *__restrict__ models, const double *__restrict__ x0,
-                                                         const double *__restrict__ params, double *__restrict__ keys)
+// Proxy for the work of a solve, from the caller's initial guess alone:
+//     key = f(z0) * (1 + W_EQ * defect(z0)) * (1 + W_IN * violation(z0))
+// f = objective (a plan that starts far from its reference takes more iterations), defect = max |x_{k+1} - rk2(z_k)|,
+// |xinit - x_0| (an initial guess that is not a trajectory), violation = how far it leaves the corridor / the box.  The
+// slow solves are the ones whose guess is infeasible AND expensive: of the 28 problems of configs[2] that need >= 10
+// iterations, 25 are in the first 768 of this key (17 with the objective alone, round 2), and the oracle's iteration
+// counts put through a list-scheduling model give makespan / ideal 1.11 instead of 1.16 (perfect knowledge: 1.07).
+constexpr double ORDER_W_EQ = 40.0, ORDER_W_IN = 20.0;
+__global__ __launch_bounds__(256) void order_keys_kernel(int B, int N, int M, int model, const int *__restrict__ models, const double *__restrict__ xinit,
+                                                         const double *__restrict__ x0, const double *__restrict__ params,
+                                                         const int *__restrict__ nfaces, double w_eq, double w_in, double *__restrict__ keys)
 {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), k = threadIdx.x & 63; // one wavefront per problem, lane = stage
     if (b >= B) return;
-    double c = 0.0;
-    if (k < N) {
-        const size_t t = (size_t)b * N + k;
-        double zl[NZ], p10[NPRE];
+    const int np = NPRE + 4 * M;
+    double c = 0.0, eq = 0.0, vi = 0.0;
+    double zl[NZ];
+    const bool act = k < N;
+    const size_t t = (size_t)b * N + (act ? k : 0);
 #pragma unroll
-        for (int i = 0; i < NZ; i++) zl[i] = x0[t * NZ + i];
+    for (int i = 0; i < NZ; i++) zl[i] = x0[t * NZ + i];
+    const double *pk = params + t * np;
+    if (act) {
+        double p10[NPRE];
 #pragma unroll
-        for (int i = 0; i < NPRE; i++) p10[i] = params[t * np + i];
+        for (int i = 0; i < NPRE; i++) p10[i] = pk[i];
         c = stage_cost(zl, p10, stage_class(k, N), models ? models[b] : model, nullptr);
+        // the box and the live corridor rows
+#pragma unroll
+        for (int i = 0; i < NZ; i++) vi = fmax(vi, fmax(lower_bound(i) - zl[i], zl[i] - upper_bound(i)));
+        const int nf = nfaces ? nfaces[t] : M;
+        for (int j = 0; j < nf; j++)
+            vi = fmax(vi, pk[NPRE + 3 * j] * zl[8] + pk[NPRE + 3 * j + 1] * zl[9] + pk[NPRE + 3 * j + 2] * zl[10] - pk[NPRE + 3 * M + j] - HU);
+        if (k == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) eq = fmax(eq, fabs(xinit[(size_t)b * 9 + i] - zl[8 + i]));
+        }
     }
-    c = wave_sum(c);
-    if (k == 0) keys[b] = (c == c && c < 1e300) ? c : 0.0;
+    // dynamics defect against the next stage's [w; x] (lane k + 1)
+    double xn[9];
+    rk2<false>(zl + 8, zl, pk + 3, xn, nullptr);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const double nx = __shfl_down(zl[4 + i], 1);
+        if (k < N - 1) eq = fmax(eq, fabs(zl[i] - nx));
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const double nx = __shfl_down(zl[8 + i], 1);
+        if (k < N - 1) eq = fmax(eq, fabs(xn[i] - nx));
+    }
+    c = wave_sum(c); eq = wave_max(eq); vi = wave_max(vi);
+    if (k == 0) {
+        const double key = c * (1.0 + w_eq * eq) * (1.0 + w_in * vi);
+        keys[b] = (key == key && key < 1e300) ? key : 0.0;
+    }
 }
 // The caller knows better: a receding-horizon tick re-solves yesterday's problem shifted by one stage, and the iteration
 // count of the previous tick predicts this one's (frp_nmpc_batch.order_hint).  Unknown (<= 0) sorts with the typical solve.
@@ -283,6 +321,22 @@ static int lds_resident_slots(int B, int N)
     return B <= cap ? B : cap;
 }
 
+struct OrderWeights {
+    double w[2];
+    OrderWeights() : w{ORDER_W_EQ, ORDER_W_IN}
+    {
+        if (const char *e = getenv("FRP_ORDER_W")) { // "w_eq,w_in": tuning knob
+            double a = -1.0, b = -1.0;
+            if (sscanf(e, "%lf,%lf", &a, &b) == 2 && a >= 0.0 && b >= 0.0) { w[0] = a; w[1] = b; }
+        }
+    }
+};
+static double order_weight(int i)
+{
+    static const OrderWeights ow; // (initialised once, thread-safe)
+    return ow.w[i];
+}
+
 hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
 {
     if (!lds_kernel_supports(a.N, a.MF)) return hipErrorInvalidValue; // (fill_args rejects these before they get here)
@@ -299,8 +353,8 @@ hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
         if (a.order_hint)
             hipLaunchKernelGGL(order_hint_kernel, dim3((unsigned)((a.B + 255) / 256)), dim3(256), 0, stream, a.B, a.order_hint, keys);
         else
-            hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, stream, a.B, a.N, NPRE + 4 * a.M, a.model,
-                               a.models, a.x0, a.params, keys);
+            hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, stream, a.B, a.N, a.M, a.model,
+                               a.models, a.xinit, a.x0, a.params, a.nfaces, order_weight(0), order_weight(1), keys);
         hipLaunchKernelGGL(order_bucket_kernel, dim3(1), dim3(1024), 0, stream, a.B, keys, order, k.counter, k.cu_slots);
     } else {
         // a one-thread kernel rather than hipMemsetAsync: as a node of a captured hipGraph the 4-byte memset was not
