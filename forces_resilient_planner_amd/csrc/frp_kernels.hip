@@ -33,17 +33,29 @@ namespace frp {
 // iterations, 25 are in the first 768 of this key (17 with the objective alone, round 2), and the oracle's iteration
 // counts put through a list-scheduling model give makespan / ideal 1.11 instead of 1.16 (perfect knowledge: 1.07).
 constexpr double ORDER_W_EQ = 40.0, ORDER_W_IN = 20.0;
+// One wavefront holds as many problems as fit (lane = (problem, stage): three at the reference's N = 20); the per-problem
+// sums / maxima are segmented shuffle reductions.
+template <bool MAX>
+__device__ __forceinline__ double segment_reduce(double v, int k, int N)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_down(v, off);
+        if (k + off < N) v = MAX ? fmax(v, o) : v + o;
+    }
+    return v; // complete in the segment's first lane
+}
 __global__ __launch_bounds__(256) void order_keys_kernel(int B, int N, int M, int model, const int *__restrict__ models, const double *__restrict__ xinit,
                                                          const double *__restrict__ x0, const double *__restrict__ params,
                                                          const int *__restrict__ nfaces, double w_eq, double w_in, double *__restrict__ keys)
 {
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), k = threadIdx.x & 63; // one wavefront per problem, lane = stage
-    if (b >= B) return;
+    const int per = 64 / N, lane = threadIdx.x & 63, seg = lane / N, k = lane - seg * N; // problems per wavefront; stage of this lane
+    const int b = (blockIdx.x * 4 + (threadIdx.x >> 6)) * per + seg;
+    const bool act = seg < per && b < B;
     const int np = NPRE + 4 * M;
     double c = 0.0, eq = 0.0, vi = 0.0;
     double zl[NZ];
-    const bool act = k < N;
-    const size_t t = (size_t)b * N + (act ? k : 0);
+    const size_t t = act ? (size_t)b * N + k : 0;
 #pragma unroll
     for (int i = 0; i < NZ; i++) zl[i] = x0[t * NZ + i];
     const double *pk = params + t * np;
@@ -55,29 +67,39 @@ __global__ __launch_bounds__(256) void order_keys_kernel(int B, int N, int M, in
         // the box and the live corridor rows
 #pragma unroll
         for (int i = 0; i < NZ; i++) vi = fmax(vi, fmax(lower_bound(i) - zl[i], zl[i] - upper_bound(i)));
+        // (six rows per pass with clamped indices: the 24 loads of a pass are independent and in flight together)
         const int nf = nfaces ? nfaces[t] : M;
-        for (int j = 0; j < nf; j++)
-            vi = fmax(vi, pk[NPRE + 3 * j] * zl[8] + pk[NPRE + 3 * j + 1] * zl[9] + pk[NPRE + 3 * j + 2] * zl[10] - pk[NPRE + 3 * M + j] - HU);
+        for (int j0 = 0; j0 < nf; j0 += 6) {
+            double ar[6][3], br[6];
+#pragma unroll
+            for (int jj = 0; jj < 6; jj++) {
+                const int j = j0 + jj < nf ? j0 + jj : nf - 1;
+                ar[jj][0] = pk[NPRE + 3 * j]; ar[jj][1] = pk[NPRE + 3 * j + 1]; ar[jj][2] = pk[NPRE + 3 * j + 2];
+                br[jj] = pk[NPRE + 3 * M + j];
+            }
+#pragma unroll
+            for (int jj = 0; jj < 6; jj++) vi = fmax(vi, ar[jj][0] * zl[8] + ar[jj][1] * zl[9] + ar[jj][2] * zl[10] - br[jj] - HU);
+        }
         if (k == 0) {
 #pragma unroll
             for (int i = 0; i < 9; i++) eq = fmax(eq, fabs(xinit[(size_t)b * 9 + i] - zl[8 + i]));
         }
     }
-    // dynamics defect against the next stage's [w; x] (lane k + 1)
+    // dynamics defect against the next stage's [w; x] (lane + 1)
     double xn[9];
     rk2<false>(zl + 8, zl, pk + 3, xn, nullptr);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const double nx = __shfl_down(zl[4 + i], 1);
-        if (k < N - 1) eq = fmax(eq, fabs(zl[i] - nx));
+        if (act && k < N - 1) eq = fmax(eq, fabs(zl[i] - nx));
     }
 #pragma unroll
     for (int i = 0; i < 9; i++) {
         const double nx = __shfl_down(zl[8 + i], 1);
-        if (k < N - 1) eq = fmax(eq, fabs(xn[i] - nx));
+        if (act && k < N - 1) eq = fmax(eq, fabs(xn[i] - nx));
     }
-    c = wave_sum(c); eq = wave_max(eq); vi = wave_max(vi);
-    if (k == 0) {
+    c = segment_reduce<false>(c, k, N); eq = segment_reduce<true>(eq, k, N); vi = segment_reduce<true>(vi, k, N);
+    if (act && k == 0) {
         const double key = c * (1.0 + w_eq * eq) * (1.0 + w_in * vi);
         keys[b] = (key == key && key < 1e300) ? key : 0.0;
     }
@@ -94,35 +116,46 @@ __global__ __launch_bounds__(256) void order_hint_kernel(int B, const int *__res
 // this batch.  The order inside a bin is arbitrary (atomics); order[] is a permutation for any input.
 __global__ __launch_bounds__(1024) void order_bucket_kernel(int B, const double *__restrict__ keys, int *__restrict__ order, int *__restrict__ counter, int *__restrict__ cu_slots)
 {
-    if (threadIdx.x == 0) *counter = 0; // queue head of the solve that follows on this stream
-    for (int i = threadIdx.x; i < CU_SLOT_ENTRIES; i += 1024) cu_slots[i] = 0;
-    __shared__ unsigned long long s_min, s_max;
-    __shared__ int hist[1024];
-    const int t = threadIdx.x;
-    if (t == 0) { s_min = ~0ull; s_max = 0ull; }
+    // (the kernel is all latency: the keys of a batch of up to 4096 are read once and stay in registers, the extrema
+    // go through one shuffle reduction per wavefront, and the prefix sum is a shuffle scan plus sixteen wave totals)
+    __shared__ unsigned long long w_lo[16], w_hi[16];
+    __shared__ int hist[1024], wtot[16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) *counter = 0; // queue head of the solve that follows on this stream
+    for (int i = t; i < CU_SLOT_ENTRIES; i += 1024) cu_slots[i] = 0;
     hist[t] = 0;
-    __syncthreads();
+    constexpr int KR = 4; // keys per thread held in registers
+    auto bits = [](double k) { return (unsigned long long)__double_as_longlong(k > 0.0 ? k : 0.0); };
+    unsigned long long kr[KR];
+#pragma unroll
+    for (int j = 0; j < KR; j++) kr[j] = (t + j * 1024 < B) ? bits(keys[t + j * 1024]) : ~0ull;
     unsigned long long lo = ~0ull, hi = 0ull;
-    for (int i = t; i < B; i += 1024) {
-        const double k = keys[i];
-        const unsigned long long u = (unsigned long long)__double_as_longlong(k > 0.0 ? k : 0.0);
+#pragma unroll
+    for (int j = 0; j < KR; j++)
+        if (t + j * 1024 < B) { lo = kr[j] < lo ? kr[j] : lo; hi = kr[j] > hi ? kr[j] : hi; }
+    for (int i = t + KR * 1024; i < B; i += 1024) {
+        const unsigned long long u = bits(keys[i]);
         lo = u < lo ? u : lo; hi = u > hi ? u : hi;
     }
-    atomicMin(&s_min, lo); atomicMax(&s_max, hi);
-    __syncthreads();
-    const unsigned long long base = s_min, span = s_max - s_min;
-    int shift = 0;
-    while ((span >> shift) >= 1024ull) shift++;
-    for (int i = t; i < B; i += 1024) {
-        const double k = keys[i];
-        const unsigned long long u = (unsigned long long)__double_as_longlong(k > 0.0 ? k : 0.0);
-        atomicAdd(&hist[1023 - (int)((u - base) >> shift)], 1); // bin 0 = largest keys
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long ol = __shfl_xor(lo, off), oh = __shfl_xor(hi, off);
+        lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi;
     }
+    if (lane == 0) { w_lo[wv] = lo; w_hi[wv] = hi; }
     __syncthreads();
-    { // exclusive prefix sum over the 1024 bins: a shuffle scan inside every wavefront, then the sixteen wave totals
-      // (two barriers instead of the twenty of a Hillis-Steele scan over the workgroup: the kernel is all latency)
-        __shared__ int wtot[16];
-        const int own = hist[t], lane = t & 63, wv = t >> 6;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { lo = w_lo[w] < lo ? w_lo[w] : lo; hi = w_hi[w] > hi ? w_hi[w] : hi; }
+    const unsigned long long base = lo, span = hi - lo;
+    const int shift = span < 1024ull ? 0 : 54 - __builtin_clzll(span); // smallest shift with (span >> shift) < 1024
+    auto bin = [&](unsigned long long u) { return 1023 - (int)((u - base) >> shift); }; // bin 0 = largest keys
+#pragma unroll
+    for (int j = 0; j < KR; j++)
+        if (t + j * 1024 < B) atomicAdd(&hist[bin(kr[j])], 1);
+    for (int i = t + KR * 1024; i < B; i += 1024) atomicAdd(&hist[bin(bits(keys[i]))], 1);
+    __syncthreads();
+    { // exclusive prefix sum over the 1024 bins
+        const int own = hist[t];
         int v = own;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -137,11 +170,10 @@ __global__ __launch_bounds__(1024) void order_bucket_kernel(int B, const double 
         hist[t] = before + v - own;
     }
     __syncthreads();
-    for (int i = t; i < B; i += 1024) {
-        const double k = keys[i];
-        const unsigned long long u = (unsigned long long)__double_as_longlong(k > 0.0 ? k : 0.0);
-        order[atomicAdd(&hist[1023 - (int)((u - base) >> shift)], 1)] = i;
-    }
+#pragma unroll
+    for (int j = 0; j < KR; j++)
+        if (t + j * 1024 < B) order[atomicAdd(&hist[bin(kr[j])], 1)] = t + j * 1024;
+    for (int i = t + KR * 1024; i < B; i += 1024) order[atomicAdd(&hist[bin(bits(keys[i]))], 1)] = i;
 }
 
 // ------------------------------------------------------------------ batched model callback
@@ -353,7 +385,7 @@ hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
         if (a.order_hint)
             hipLaunchKernelGGL(order_hint_kernel, dim3((unsigned)((a.B + 255) / 256)), dim3(256), 0, stream, a.B, a.order_hint, keys);
         else
-            hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)((a.B + 3) / 4)), dim3(256), 0, stream, a.B, a.N, a.M, a.model,
+            hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)((a.B + 4 * (64 / a.N) - 1) / (4 * (64 / a.N)))), dim3(256), 0, stream, a.B, a.N, a.M, a.model,
                                a.models, a.xinit, a.x0, a.params, a.nfaces, order_weight(0), order_weight(1), keys);
         hipLaunchKernelGGL(order_bucket_kernel, dim3(1), dim3(1024), 0, stream, a.B, keys, order, k.counter, k.cu_slots);
     } else {
