@@ -62,10 +62,10 @@ constexpr int X_PWX = 32;             // stage-0 solve: Pwx (4 x 9)
 constexpr int X_DS0 = 68;             // ds_0 = [dw_0; dx_0] (16)
 constexpr int X_XINIT = 84;           // xinit (9)
 constexpr int X_DX0 = 96;             // xinit - x_0 (9)
-constexpr int X_C0 = 106, X_C1 = 107; // constants 0, 1
-constexpr int X_RED = 108;            // per-wave partial results: [4][16] (evaluation 0..2, affine 3..7, step 8..12: no slot is reused inside an iteration)
-constexpr int X_FEXT = 172;           // external-force acceleration of every stage: [3][NP]
-constexpr int X_TOTAL = 172;          // (+ 3 NP)
+constexpr int X_C0 = 93, X_C1 = 94;   // constants 0, 1
+constexpr int X_RED = 106;            // per-wave partial results: [4][16] (evaluation 0..2, affine 3..7, step 8..12: no slot is reused inside an iteration)
+constexpr int X_FEXT = 170;           // external-force acceleration of every stage: [3][NP]
+constexpr int X_TOTAL = 170;          // (+ 3 NP)
 
 // ------------------------------------------------------------------ per-lane gather tables (record offsets)
 // 16x16 register tiles (factorisation sweep): lane (g, c), register r <-> element (4r+g, c).
@@ -198,6 +198,13 @@ static __device__ long long g_prof_seg[32];
 #define SEG_FLUSH()
 #define SEGM_FLUSH()
 #endif
+#ifdef FRP_PROFILE_F3 // faces wave, step phase: bound rows, corridor rows, reductions (slots of the model-phase segments)
+#define F3_T0() long long f3_ = clock64()
+#define F3(i) do { if (wave == 3) { const long long tn_ = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&g_prof_seg[16 + (i)], (unsigned long long)(tn_ - f3_)); f3_ = tn_; } } while (0)
+#else
+#define F3_T0()
+#define F3(i)
+#endif
 #ifdef FRP_PROFILE
 #define SWEEP_T0() const long long sw0_ = clock64()
 #define SWEEP_T1(i) do { if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&g_prof_seg[8 + (i)], (unsigned long long)(clock64() - sw0_)); } while (0)
@@ -218,13 +225,17 @@ struct RowMap {
     static constexpr int R = (NZ + H - 1) / H;
 };
 
-// value of a per-row constant for row i = ib + half, chosen among the H compile-time candidates of round r
+// value of a per-row constant for row i = ib + half, chosen among the H compile-time candidates of round r.
+// `halfp` = a copy of `half` made opaque once per phase (opq below): the selects are loop invariant, and hoisted out of the
+// interior-point loop they cost two VGPRs per constant for the whole solve in waves that are at the register cap -- where the
+// allocator then spills them, an L2 round trip to save two v_cndmask
+__device__ __forceinline__ int opq(int v) { asm volatile("" : "+v"(v)); return v; }
 #define ROW_PICK(expr_of_i)                                                                          \
     ([&]() {                                                                                           \
         double v_ = [&](int i) { return (double)(expr_of_i); }(ib < NZ ? ib : NZ - 1);                  \
-        if (H > 1 && half == 1) v_ = [&](int i) { return (double)(expr_of_i); }(ib + 1 < NZ ? ib + 1 : NZ - 1); \
-        if (H > 2 && half == 2) v_ = [&](int i) { return (double)(expr_of_i); }(ib + 2 < NZ ? ib + 2 : NZ - 1); \
-        if (H > 3 && half == 3) v_ = [&](int i) { return (double)(expr_of_i); }(ib + 3 < NZ ? ib + 3 : NZ - 1); \
+        if (H > 1 && halfp == 1) v_ = [&](int i) { return (double)(expr_of_i); }(ib + 1 < NZ ? ib + 1 : NZ - 1); \
+        if (H > 2 && halfp == 2) v_ = [&](int i) { return (double)(expr_of_i); }(ib + 2 < NZ ? ib + 2 : NZ - 1); \
+        if (H > 3 && halfp == 3) v_ = [&](int i) { return (double)(expr_of_i); }(ib + 3 < NZ ? ib + 3 : NZ - 1); \
         return v_;                                                                                     \
     }())
 
@@ -1343,6 +1354,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         if (!kact) return;
         const CostQ cq = make_cost(pc, stage_class(k, N), model);
         ldouble *rec = recs + k * RS;
+        const int halfp = opq(half);
 #pragma unroll
         for (int r = RB0; r < RB1; r++) {
             const int ib = r * H, i = ib + half;
@@ -1371,6 +1383,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         if (!kact) return;
         const CostQ cq = make_cost(pc, stage_class(k, N), model);
         ldouble *rec = recs + k * RS;
+        const int halfp = opq(half);
 #pragma unroll
         for (int r = RB0; r < RB1; r++) {
             const int ib = r * H, i = ib + half;
@@ -1412,6 +1425,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         if (!kact) return;
         const double *z0 = a.x0 + ((size_t)b * N + k) * NZ;
         pc[0] = pk[0]; pc[1] = pk[1]; pc[2] = pk[2]; pc[6] = pk[6]; pc[7] = pk[7]; pc[8] = pk[8]; pc[9] = pk[9];
+        const int halfp = opq(half);
 #pragma unroll
         for (int r = RB0; r < RB1; r++) {
             const int ib = r * H, i = ib + half;
@@ -1501,7 +1515,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         const double shift = (smin >= S_MIN) ? 0.0 : (S_MIN - smin) + fmax(0.0, -smin);
         if constexpr (wave >= 2) {
 #pragma unroll
-            for (int r = RB0; r < RB1; r++) {
+for (int r = RB0; r < RB1; r++) {
                 bsl[r] += shift; bsu[r] += shift;
                 bll[r] = a.mu0 / bsl[r]; blu[r] = a.mu0 / bsu[r];
             }
@@ -1602,12 +1616,14 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             publish(xs, 3, lane, 0, wave_max(l_in)); publish(xs, 3, lane, 1, wave_max(l_rc)); publish(xs, 3, lane, 2, wave_sum(l_gap));
         }
         BAR_P(0); // ------------------------------------------------------------- A
-        nm.eq = red(xs, 1, 0);
-        nm.in = fmax(red(xs, 2, 0), red(xs, 3, 0));
-        nm.rc = fmax(red(xs, 2, 1), red(xs, 3, 1));
-        nm.gap = red(xs, 2, 2) + red(xs, 3, 2);
-        nm.rs = stationarity_norm<NP>(recs, N);
-        mu = nm.gap * (KAPPA_LAM * inv_kmtot);
+        // (workgroup-uniform scalars that live across phases go to scalar registers: the element-wise roles are at the
+        // 168-VGPR cap of three workgroups per CU, and every spilled value is an L2 round trip on an in-order wavefront)
+        nm.eq = uni(red(xs, 1, 0));
+        nm.in = uni(fmax(red(xs, 2, 0), red(xs, 3, 0)));
+        nm.rc = uni(fmax(red(xs, 2, 1), red(xs, 3, 1)));
+        nm.gap = uni(red(xs, 2, 2) + red(xs, 3, 2));
+        nm.rs = uni(stationarity_norm<NP>(recs, N));
+        mu = uni(nm.gap * (KAPPA_LAM * inv_kmtot));
         if (!gn_retry) {
             if (!(nm.eq == nm.eq) || !(nm.rs == nm.rs) || !(nm.gap == nm.gap)) { flag = FRP_EXIT_BADFUNCEVAL; break; }
             if (nm.eq <= a.tol_eq && nm.in <= a.tol_ineq && nm.rs <= a.tol_stat && nm.rc <= a.tol_comp) { flag = FRP_EXIT_OPTIMAL; break; }
@@ -1715,6 +1731,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             if (sigma > 1.0) sigma = 1.0;
             smu = sigma * mu;
             if (smu < MU_FLOOR_FRAC * a.tol_comp) smu = MU_FLOOR_FRAC * a.tol_comp;
+            smu = uni(smu);
         }
 
         // ============================================================ corrector: vector backward sweep + forward sweep with y+
@@ -1761,12 +1778,14 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 for (int i = 0; i < 6; i++) hdz[4 + i] = rec[R_DZ + 11 + i];
                 // (split over the three lanes of a stage by rows -- lane-dependent addresses into the packed triangle -- this measured
                 // no faster: 5.4 k vs 4.7 k cycles for the phase on this wave, the launch time unchanged)
-                double yall[NS];
+                // This wave forms the rows its own Hessian lanes read back (p, v: 4..9), the model wave -- idle until the commit --
+                // the other seven.
+                double yall[6];
 #pragma unroll
-                for (int i = 0; i < NS; i++) yall[i] = y_plus(rec, i);
+                for (int i = 0; i < 6; i++) yall[i] = y_plus(rec, 4 + i);
                 if (half == 0) {
 #pragma unroll
-                    for (int i = 0; i < NS; i++) rec[R_D + i] = yall[i];
+                    for (int i = 0; i < 6; i++) rec[R_D + 4 + i] = yall[i];
                 }
             }
             WSYNC();
@@ -1781,13 +1800,20 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 for (int i = 0; i < 4; i++) rec[RT_HZ + i] = ms.z[i];
 #pragma unroll
                 for (int i = 0; i < 6; i++) { rec[RT_HZ + 4 + i] = ms.z[11 + i]; rec[RT_HY + i] = ms.y[4 + i]; }
+                // y+ rows 0..3 (w) and 10..12 (e) for the commit below; rows 4..9: the Riccati wave
+#pragma unroll
+                for (int i = 0; i < 4; i++) rec[R_D + i] = y_plus(rec, i);
+#pragma unroll
+                for (int i = 10; i < NS; i++) rec[R_D + i] = y_plus(rec, i);
             }
         }
+        F3_T0();
         if constexpr (wave >= 2) { // bound rows of this wave
             if (kact) {
                 cldouble *rec = recs + k * RS;
+        const int halfp = opq(half);
 #pragma unroll
-                for (int r = RB0; r < RB1; r++) {
+        for (int r = RB0; r < RB1; r++) {
                     const int ib = r * H, i = ib + half;
                     if (i >= NZ) continue;
                     const double lb = ROW_PICK(lower_bound(i));
@@ -1801,6 +1827,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 }
             }
         }
+        F3(0);
         if constexpr (wave == 3) { // corridor rows
             if (kact) {
                 cldouble *rec = recs + k * RS;
@@ -1816,18 +1843,20 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 }
             }
         }
+        F3(1);
         if constexpr (wave >= 2) {
             publish(xs, wave, lane, 8, wave_max(m_p)); publish(xs, wave, lane, 9, wave_max(m_d));
             publish(xs, wave, lane, 10, wave_sum(q1)); publish(xs, wave, lane, 11, wave_sum(q2)); publish(xs, wave, lane, 12, wave_sum(q3));
         }
+        F3(2);
         BAR_P(4); // ------------------------------------------------------------- F
         {
             const double mp = fmax(red(xs, 2, 8), red(xs, 3, 8)), md = fmax(red(xs, 2, 9), red(xs, 3, 9));
-            const double ap = (mp > a.ftb) ? a.ftb * fast_rcp(mp) : 1.0;
-            const double ad = (md > a.ftb) ? a.ftb * fast_rcp(md) : 1.0;
+            const double ap = uni((mp > a.ftb) ? a.ftb * fast_rcp(mp) : 1.0);
+            const double ad = uni((md > a.ftb) ? a.ftb * fast_rcp(md) : 1.0);
             // multiplier safeguard: s_i lam_i >= mu_new / KAPPA_LAM for every pair after the step
-            const double fprod = (mu * (double)mtot + ap * (red(xs, 2, 10) + red(xs, 3, 10)) +
-                                  ad * ((red(xs, 2, 11) + red(xs, 3, 11)) + ap * (red(xs, 2, 12) + red(xs, 3, 12)))) * inv_kmtot;
+            const double fprod = uni((mu * (double)mtot + ap * (red(xs, 2, 10) + red(xs, 3, 10)) +
+                                      ad * ((red(xs, 2, 11) + red(xs, 3, 11)) + ap * (red(xs, 2, 12) + red(xs, 3, 12)))) * inv_kmtot);
             step_cc = ap;
             auto commit = [&](double &s, double &l, double corr, double gdz, double viol) {
                 const double sinv = fast_rcp(s);
@@ -1850,8 +1879,9 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 }
             }
             if constexpr (wave >= 2) {
+        const int halfp = opq(half);
 #pragma unroll
-                for (int r = RB0; r < RB1; r++) {
+        for (int r = RB0; r < RB1; r++) {
                     const int ib = r * H, i = ib + half;
                     if (i >= NZ) continue;
                     const double lb = ROW_PICK(lower_bound(i));
@@ -1971,7 +2001,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             int lo = -1;
             for (int q = 0; q < 3; q++)
                 if (q != rs && lo < 0) lo = q;
-            role = simd == rs ? 0 : (simd == 3 ? 1 : (simd == lo ? 2 : 3));
+#ifndef FRP_PLACE_CYCLIC
+#define FRP_PLACE_CYCLIC 1
+#endif
+            // SIMD 3 hosts no Riccati wave: it takes the heaviest helper (the faces wave); model and bounds go to the other two
+            // SIMDs, cyclically, so that every Riccati wave shares its SIMD with one of each
+            const int s_model = FRP_PLACE_CYCLIC ? (rs + 1) % 3 : lo;
+            role = simd == rs ? 0 : (simd == 3 ? 3 : (simd == s_model ? 1 : 2));
         }
     }
     // one copy of the solver loop per role: the four waves run different code between the same barriers
