@@ -198,13 +198,6 @@ static __device__ long long g_prof_seg[32];
 #define SEG_FLUSH()
 #define SEGM_FLUSH()
 #endif
-#ifdef FRP_PROFILE_F3 // faces wave, step phase: bound rows, corridor rows, reductions (slots of the model-phase segments)
-#define F3_T0() long long f3_ = clock64()
-#define F3(i) do { if (wave == 3) { const long long tn_ = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&g_prof_seg[16 + (i)], (unsigned long long)(tn_ - f3_)); f3_ = tn_; } } while (0)
-#else
-#define F3_T0()
-#define F3(i)
-#endif
 #ifdef FRP_PROFILE
 #define SWEEP_T0() const long long sw0_ = clock64()
 #define SWEEP_T1(i) do { if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&g_prof_seg[8 + (i)], (unsigned long long)(clock64() - sw0_)); } while (0)
@@ -1280,6 +1273,15 @@ struct Shared {
     Ctl *ctl;
 };
 
+// The next problem of this workgroup: queue position from the device counter, mapped through the launch order (longest
+// expected solve first, see order_keys_kernel) by the one lane that claims it; a.B = the queue is exhausted.
+__device__ __forceinline__ int claim_next(const KernelArgs &a)
+{
+    const int p = atomicAdd(a.counter, 1);
+    if (p >= a.B) return a.B;
+    return a.order ? a.order[p] : p;
+}
+
 __device__ __forceinline__ void publish(ldouble *xs, int wave, int lane, int slot, double v)
 {
     if (lane == 0) xs[X_RED + wave * 16 + slot] = v;
@@ -1501,7 +1503,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     BAR();
     const int mtot = sh.ctl->mtot;
     if (sh.ctl->bad) { // a stage has more live corridor rows than the caller sized the problem for (MF)
-        if (wave == 0 && lane == 0) { sh.ctl->next = atomicAdd(a.counter, 1); a.exitflag[b] = FRP_EXIT_PARAM_VALUE; a.iters[b] = 0; }
+        if (wave == 0 && lane == 0) { sh.ctl->next = claim_next(a); a.exitflag[b] = FRP_EXIT_PARAM_VALUE; a.iters[b] = 0; }
         if (wave == 1 && own0) {
             double *zo = a.z + ((size_t)b * N + k) * NZ;
 #pragma unroll
@@ -1807,7 +1809,6 @@ for (int r = RB0; r < RB1; r++) {
                 for (int i = 10; i < NS; i++) rec[R_D + i] = y_plus(rec, i);
             }
         }
-        F3_T0();
         if constexpr (wave >= 2) { // bound rows of this wave
             if (kact) {
                 cldouble *rec = recs + k * RS;
@@ -1827,7 +1828,6 @@ for (int r = RB0; r < RB1; r++) {
                 }
             }
         }
-        F3(0);
         if constexpr (wave == 3) { // corridor rows
             if (kact) {
                 cldouble *rec = recs + k * RS;
@@ -1843,12 +1843,10 @@ for (int r = RB0; r < RB1; r++) {
                 }
             }
         }
-        F3(1);
         if constexpr (wave >= 2) {
             publish(xs, wave, lane, 8, wave_max(m_p)); publish(xs, wave, lane, 9, wave_max(m_d));
             publish(xs, wave, lane, 10, wave_sum(q1)); publish(xs, wave, lane, 11, wave_sum(q2)); publish(xs, wave, lane, 12, wave_sum(q3));
         }
-        F3(2);
         BAR_P(4); // ------------------------------------------------------------- F
         {
             const double mp = fmax(red(xs, 2, 8), red(xs, 3, 8)), md = fmax(red(xs, 2, 9), red(xs, 3, 9));
@@ -1913,7 +1911,7 @@ for (int r = RB0; r < RB1; r++) {
     __builtin_amdgcn_s_setprio(0);
     // the next problem is claimed only now (its latency hides behind the write-out): a slot that claimed it while it still
     // had a solve ahead of it would keep it from the slots that go idle at the end of the launch
-    if (wave == 0 && lane == 0) sh.ctl->next = atomicAdd(a.counter, 1);
+    if (wave == 0 && lane == 0) sh.ctl->next = claim_next(a); // (two dependent global round trips, under the model wave's write-out)
     if constexpr (wave == 1) {
         // the objective is reported, not iterated on: evaluated once, at the returned iterate
         double l_obj = 0.0;
@@ -1948,12 +1946,11 @@ template <int NP, int FL, bool FREG, int ROLE>
 __device__ __forceinline__ void role_loop(const KernelArgs &a, const Shared &sh)
 {
     // (solve_one claims the next problem when it leaves its iteration)
-    if (ROLE == 0 && (threadIdx.x & 63) == 0) sh.ctl->next = atomicAdd(a.counter, 1);
+    if (ROLE == 0 && (threadIdx.x & 63) == 0) sh.ctl->next = claim_next(a);
     for (;;) {
         BAR();
-        int b = sh.ctl->next;
+        const int b = sh.ctl->next;
         if (b >= a.B) break;
-        if (a.order) b = a.order[b]; // longest-expected-first launch order (see order_keys_kernel)
         BAR(); // everybody has read the index before solve_one's exit overwrites it
         solve_one<NP, FL, FREG, ROLE>(a, b, sh);
     }
