@@ -584,6 +584,7 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
             sh.c_um[c][0] = um[0]; sh.c_um[c][1] = um[1]; sh.c_um[c][2] = um[2];
         }
         __syncthreads();
+        APROF(3);
         // phase 2, thread = (primitive, collision sample): check_num samples per surviving primitive (kinodynamic_astar.cpp:190-199;
         // the reference stops at the first colliding sample -- the verdict of a primitive is the same)
         for (int t = lane; t < n_cand * P->check_num; t += NT) {
@@ -596,6 +597,7 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
             if (!check_state(ctx, xt, xt + 3, 1.5)) sh.c_leader[c] = -1; // (c_leader doubles as the collision flag until phase 3 has read it)
         }
         __syncthreads();
+        APROF(4);
         // phase 3, thread = primitive: cost and heuristic of the survivors
         for (int c = lane; c < n_cand; c += NT) {
             int surv = sh.c_surv[c];
@@ -613,6 +615,7 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
             sh.c_surv[c] = surv;
         }
         __syncthreads();
+        APROF(5);
         // ---- the first survivor of every voxel (tmp_expand_nodes' lookup, kinodynamic_astar.cpp:210-230)
         for (int c = lane; c < n_cand; c += NT) {
             int leader = c;
@@ -624,7 +627,7 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
             sh.c_leader[c] = leader;
         }
         __syncthreads();
-        APROF(4);
+        APROF(6);
         // ---- commit in input order (kinodynamic_astar.cpp:232-278).  Thread 0 walks the survivors and takes the decisions that
         // depend on their order -- which primitive a node keeps, node numbers, heap pushes, keys changed in place --; the node
         // records themselves are written afterwards, one thread per touched node, from the winning primitive.
@@ -676,7 +679,7 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
         // (the planner's pool, heap and hash are touched by this wavefront only: the lanes of one CU share its L1, so the
         //  workgroup-scope ordering of the barrier is all the other lanes need to see lane 0's stores)
         __syncthreads();
-        APROF(5);
+        APROF(7);
         if (sh.heap_size < 0) break;
     }
     __syncthreads();

@@ -1,5 +1,5 @@
 import os, sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from forces_resilient_planner_amd import solver, workloads
 w = workloads.astar_world(1, "pillars", allocate_num=40000)
@@ -12,7 +12,7 @@ t0 = time.time(); pl.plan(); torch.cuda.synchronize(); print("gpu ms", (time.tim
 stats = pl.stats.cpu().numpy(); pn = pl.path_nodes.cpu().numpy()
 it = stats[:, 1].astype(float)
 prof = pn[:, -1, :8]
-names = ["top", "window", "pop", "cand", "leader", "commit"]
-tot = prof[:, :6].sum(0); its = it.sum()
+names = ["top", "window", "pop", "transit+hash", "collision", "heuristic", "leader", "commit"]
+tot = prof[:, :8].sum(0); its = it.sum()
 print("expansions", its, "cycles per expansion:", {n: round(tot[i] / its) for i, n in enumerate(names)}, "total/exp", round(tot.sum() / its))
 b = int(np.argmax(it)); print("longest: it", it[b], {n: round(prof[b, i] / it[b]) for i, n in enumerate(names)})
