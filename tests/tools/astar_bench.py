@@ -1,8 +1,8 @@
 """Batch throughput of the device kinodynamic A* (frp_nmpc_astar_batch) against the CPU oracle (OpenMP over planners).
-   python tools/astar_bench.py [B] [kind] [allocate_num] -> one JSON line"""
+   python tests/tools/astar_bench.py [B] [kind] [allocate_num] -> one JSON line"""
 import json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from forces_resilient_planner_amd import solver, workloads
 import tests.astar_lib as AL

@@ -1,6 +1,6 @@
-"""End-to-end rate of frp_nmpc_solve_batch_host (host buffers in and out): the reference's dense 30-row parameter layout and the\ncompact 6-row layout of the same problems.  python tools/e2e_bench.py"""
-import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+"""End-to-end rate of frp_nmpc_solve_batch_host (host buffers in and out): the reference's dense 30-row parameter layout and the\ncompact 6-row layout of the same problems.  python tests/tools/e2e_bench.py"""
+import os, sys, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from forces_resilient_planner_amd import solver, workloads
 import tests.oracle_lib as OL
 w = workloads.config2(4096, seed=workloads.SEED0 + 3)

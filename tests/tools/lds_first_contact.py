@@ -1,8 +1,8 @@
 """First contact of a solver kernel with the hardware: per-maxit agreement with the oracle on a few problems, then
-batch agreement on configs[1..3].  FRP_KERNEL=r01 selects the round-1 kernel.  python tools/lds_first_contact.py [B]"""
+batch agreement on configs[1..3].  FRP_KERNEL=r01 selects the round-1 kernel.  python tests/tools/lds_first_contact.py [B]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from forces_resilient_planner_amd import solver, workloads
 import tests.oracle_lib as OL
 

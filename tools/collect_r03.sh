@@ -16,14 +16,14 @@ if [ -f forces_resilient_planner_amd/lib_prof.so ]; then
   for b in 1 4096; do FRP_LIB=$PWD/forces_resilient_planner_amd/lib_prof.so python tools/prof_lds.py $b 2 >> $R/wave_phases.txt 2>&1; done
 fi
 timeout 60 tools/ubench/sweep_timing > $R/sweep_timing.txt 2>&1
-python tools/e2e_bench.py > $R/e2e.txt 2>/dev/null
+python tests/tools/e2e_bench.py > $R/e2e.txt 2>/dev/null
 python tools/order_ceiling.py 4096 > $R/order_ceiling.jsonl 2>/dev/null; python tools/order_ceiling.py 16384 >> $R/order_ceiling.jsonl 2>/dev/null
 bash tools/ab_order.sh > $R/order_weights.txt 2>&1
 python tools/full_tick_bench.py 4096 10 20000 > $R/full_tick.json 2> $R/full_tick.err
 python tools/receding_bench.py 65536 20 > $R/configs4_receding.json 2>/dev/null
-python tools/astar_bench.py 1024 pillars 20000 2>/dev/null | tail -1 > $R/astar_bench.jsonl
-python tools/astar_bench.py 4096 empty 4000 2>/dev/null | tail -1 >> $R/astar_bench.jsonl
-python tools/astar_bench.py 1024 wall_gap 20000 2>/dev/null | tail -1 >> $R/astar_bench.jsonl
+python tests/tools/astar_bench.py 1024 pillars 20000 2>/dev/null | tail -1 > $R/astar_bench.jsonl
+python tests/tools/astar_bench.py 4096 empty 4000 2>/dev/null | tail -1 >> $R/astar_bench.jsonl
+python tests/tools/astar_bench.py 1024 wall_gap 20000 2>/dev/null | tail -1 >> $R/astar_bench.jsonl
 python tests/tools/astar_check.py 12 16 > $R/astar_check.txt 2>&1
 if [ "$1" != "quick" ]; then
   python tests/tools/sweep_check.py > $R/sweep_check.txt 2>&1
