@@ -216,6 +216,19 @@ __device__ __forceinline__ double quad_rot(double v) // result in quad q <- quad
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 __device__ __forceinline__ double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+// Sum over the 64 lanes on the matrix pipe: with B = 1 the 4x4x4 product sums the four lanes 16 k + 4 b + i over k, a second
+// one the four partial sums of a block over i, and two quad rotations add the four blocks -- 2 MFMAs + 6 VALU instructions
+// instead of the 23 of the DPP / readlane reduction, and the MFMAs cost the SIMD's VALU nothing (the element-wise waves
+// share their SIMDs with Riccati waves that are short of exactly that).  The result is in every lane.  Summation order:
+// ((x_l + x_{l+16}) + x_{l+32}) + x_{l+48} per lane column, then rows of four, then blocks -- fixed, like the DPP order.
+__device__ __forceinline__ double wave_sum_mx(double x)
+{
+    double d = mfma4(x, 1.0, 0.0);
+    d = mfma4(d, 1.0, 0.0);
+    d += quad_rot<1>(d);
+    d += quad_rot<2>(d);
+    return d;
+}
 __device__ __forceinline__ double matvec4(const d4 &A, double x, double c)
 {
     const double x1 = quad_rot<1>(x), x2 = quad_rot<2>(x), x3 = quad_rot<3>(x);

@@ -1576,7 +1576,7 @@ for (int r = RB0; r < RB1; r++) {
         } else if constexpr (wave == 2) {
             double l_in = 0.0, l_rc = 0.0, l_gap = 0.0;
             bounds_eval(l_in, l_rc, l_gap);
-            publish(xs, 2, lane, 0, wave_max(l_in)); publish(xs, 2, lane, 1, wave_max(l_rc)); publish(xs, 2, lane, 2, wave_sum(l_gap));
+            publish(xs, 2, lane, 0, wave_max(l_in)); publish(xs, 2, lane, 1, wave_max(l_rc)); publish(xs, 2, lane, 2, wave_sum_mx(l_gap));
         } else if constexpr (wave == 3) {
             double l_in = 0.0, l_rc = 0.0, l_gap = 0.0;
             bounds_eval(l_in, l_rc, l_gap);
@@ -1615,7 +1615,7 @@ for (int r = RB0; r < RB1; r++) {
                 rec[R_CB + 0] = gp0; rec[R_CB + 1] = gp1; rec[R_CB + 2] = gp2;
                 rec[R_CC + 0] = fp0; rec[R_CC + 1] = fp1; rec[R_CC + 2] = fp2;
             }
-            publish(xs, 3, lane, 0, wave_max(l_in)); publish(xs, 3, lane, 1, wave_max(l_rc)); publish(xs, 3, lane, 2, wave_sum(l_gap));
+            publish(xs, 3, lane, 0, wave_max(l_in)); publish(xs, 3, lane, 1, wave_max(l_rc)); publish(xs, 3, lane, 2, wave_sum_mx(l_gap));
         }
         BAR_P(0); // ------------------------------------------------------------- A
         // (workgroup-uniform scalars that live across phases go to scalar registers: the element-wise roles are at the
@@ -1676,7 +1676,7 @@ for (int r = RB0; r < RB1; r++) {
             double m_p = 0.0, m_d = 0.0, s_sdl = 0.0, s_lds = 0.0, s_dsdl = 0.0;
             bounds_affine(m_p, m_d, s_sdl, s_lds, s_dsdl);
             publish(xs, 2, lane, 3, wave_max(m_p)); publish(xs, 2, lane, 4, wave_max(m_d));
-            publish(xs, 2, lane, 5, wave_sum(s_sdl)); publish(xs, 2, lane, 6, wave_sum(s_lds)); publish(xs, 2, lane, 7, wave_sum(s_dsdl));
+            publish(xs, 2, lane, 5, wave_sum_mx(s_sdl)); publish(xs, 2, lane, 6, wave_sum_mx(s_lds)); publish(xs, 2, lane, 7, wave_sum_mx(s_dsdl));
         } else if constexpr (wave == 3) {
             double m_p = 0.0, m_d = 0.0, s_sdl = 0.0, s_lds = 0.0, s_dsdl = 0.0;
             bounds_affine(m_p, m_d, s_sdl, s_lds, s_dsdl);
@@ -1718,7 +1718,7 @@ for (int r = RB0; r < RB1; r++) {
                 rec[R_CC + 0] = c0; rec[R_CC + 1] = c1; rec[R_CC + 2] = c2;
             }
             publish(xs, 3, lane, 3, wave_max(m_p)); publish(xs, 3, lane, 4, wave_max(m_d));
-            publish(xs, 3, lane, 5, wave_sum(s_sdl)); publish(xs, 3, lane, 6, wave_sum(s_lds)); publish(xs, 3, lane, 7, wave_sum(s_dsdl));
+            publish(xs, 3, lane, 5, wave_sum_mx(s_sdl)); publish(xs, 3, lane, 6, wave_sum_mx(s_lds)); publish(xs, 3, lane, 7, wave_sum_mx(s_dsdl));
         }
         BAR_P(2); // ------------------------------------------------------------- D
         double smu;
@@ -1845,7 +1845,7 @@ for (int r = RB0; r < RB1; r++) {
         }
         if constexpr (wave >= 2) {
             publish(xs, wave, lane, 8, wave_max(m_p)); publish(xs, wave, lane, 9, wave_max(m_d));
-            publish(xs, wave, lane, 10, wave_sum(q1)); publish(xs, wave, lane, 11, wave_sum(q2)); publish(xs, wave, lane, 12, wave_sum(q3));
+            publish(xs, wave, lane, 10, wave_sum_mx(q1)); publish(xs, wave, lane, 11, wave_sum_mx(q2)); publish(xs, wave, lane, 12, wave_sum_mx(q3));
         }
         BAR_P(4); // ------------------------------------------------------------- F
         {
