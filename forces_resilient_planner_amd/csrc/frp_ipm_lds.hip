@@ -20,6 +20,7 @@
 // Norms, step lengths and the centring parameter are combined from per-wave partial results in LDS by every wave
 // redundantly (bitwise identical), so all four waves take the same branches without a second barrier.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <math.h>
 #include "frp_model.hpp"
 #include "../../include/frp_nmpc.h"
@@ -370,16 +371,42 @@ __device__ __noinline__ int sweep_factor(ldouble *recs, ldouble *xs, int N, doub
     d4 G = C; // the last stage has no successor: G = C~
     bool ok = true;
     SEG_DECL();
-    // Loop body in the order of the dependency chain, rotated so that independent work sits next to the MFMA chains:
-    //   gather(k-1) [while the G MFMAs of stage k, issued at the end of the previous pass, execute] -> pivot block of G
-    //   -> rank-4 products -> P_k -> X = P_k M_{k-1} -> G of stage k-1.
-    for (int kk = N - 1;; kk--) {
-        SEG(5);
-        ldouble *rec = recs + kk * RS;
-        const double hc = hcn, pq = pqn; // of stage kk
-        // the tiles of stage kk are consumed: gather those of stage kk-1 (clamped at 0: unused after the last step)
-        gather_tiles(recs + (kk > 0 ? kk - 1 : 0) * RS, c1, c2, c3, mo, pqo, theta, C, Mt, hcn, pqn);
-        SEG(1);
+    // Every LDS operand of a stage is (per-lane pointer) + (compile-time offset): the pointers sit on the record of the lowest
+    // stage a step touches and move once per step -- per PASS OF FOUR STAGES while at least five are left (offsets 4 RS .. 0),
+    // then per stage (offsets RS, 0) -- instead of ~25 address computations per stage from the table indices.
+    ldouble *base = recs + (N - 1) * RS;
+    ldouble *p_c1[4], *p_c3[4], *p_mo[4], *p_pp[4], *p_pd[4];
+    ldouble *p_c2 = base + c2[1], *p_pq = base + pqo, *p_t = base + lane;
+#pragma unroll
+    for (int r = 0; r < 4; r++) { p_c1[r] = base + c1[r]; p_c3[r] = base + c3[r]; p_mo[r] = base + mo[r]; p_pp[r] = base + ppo[r]; p_pd[r] = base + pdo[r]; }
+    // (laundered through an empty asm: left to itself the optimiser turns every pointer back into base + 8 * index and
+    // recomputes it at each use -- 28 address instructions per stage, which is what this is here to remove)
+    auto opaque = [](ldouble *&q) { unsigned v = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void *)q; asm volatile("" : "+v"(v)); q = (ldouble *)(unsigned long long)v; };
+    auto move = [&](int by) {
+        base -= by; p_c2 -= by; p_pq -= by; p_t -= by;
+        opaque(base); opaque(p_c2); opaque(p_pq); opaque(p_t);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            p_c1[r] -= by; p_c3[r] -= by; p_mo[r] -= by; p_pp[r] -= by; p_pd[r] -= by;
+            opaque(p_c1[r]); opaque(p_c3[r]); opaque(p_mo[r]); opaque(p_pp[r]); opaque(p_pd[r]);
+        }
+    };
+    // one stage: OR / OG = offsets of its record and of the record below it from the pointers; LAST = stage 0 (nothing below)
+    auto stage = [&](auto orc, auto lastc) {
+        constexpr int OR = decltype(orc)::value, OG = OR - RS;
+        constexpr bool LAST = decltype(lastc)::value;
+        const double hc = hcn, pq = pqn; // of this stage
+        if constexpr (!LAST) {
+            // the tiles of this stage are consumed: gather those of the stage below while the pivot block is factored
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                // (the corridor block and the corridor part of the gradient sit in tile rows 4..6: register 1 only)
+                C[r] = r == 1 ? p_c1[r][OG] + p_c2[OG] + theta * p_c3[r][OG] : p_c1[r][OG] + theta * p_c3[r][OG];
+                Mt[r] = p_mo[r][OG];
+            }
+            hcn = base[OG + R_HC];
+            pqn = p_pq[OG];
+        }
         // ---- pivot block Guu = L D L' (4 x 4): lower triangle to uniform registers, factored redundantly
         double q[16], Mi[6], Di[4];
 #pragma unroll
@@ -396,7 +423,6 @@ __device__ __noinline__ int sweep_factor(ldouble *recs, ldouble *xs, int N, doub
         const double m_gc = m_lower ? me : 0.0, m_cg = m_upper ? me : 0.0; // m[g][c & 3], m[c & 3][g]
         const double dg = g == 0 ? Di[0] : (g == 1 ? Di[1] : (g == 2 ? Di[2] : Di[3]));
         const double md = dg * m_gc;
-        SEG(2);
         const double K0 = mfma4(m_cg, G[0], 0.0);  // K = m G_u          (4 x 16, register-0 layout)
         const double rt = mfma4(m_gc, md, 0.0);    // R = m' D^-1 m      (replicated in every column block)
         const double Kd = dg * K0;
@@ -408,42 +434,52 @@ __device__ __noinline__ int sweep_factor(ldouble *recs, ldouble *xs, int N, doub
         d4 S = G;
         S[1] *= m4c; S[2] *= m4c; S[3] *= m4c;
         S = __builtin_amdgcn_mfma_f64_16x16x4f64(-Kd, Kb, S, 0, 0, 0); // [-hc Kbar_x' | S_xx | p_x] in rows 4..12
-        SEG(3);
         const double tsel = c < 4 ? rt : T0;       // [R | Kbar_x | kbar] (T' of the sweeps; its columns 14, 15 are zero)
-        rec[R_T + lane] = tsel;
+        p_t[OR + R_T] = tsel;
         const double hc4 = __builtin_fma(hc, m4, m4c);
         P[0] = __builtin_fma(-hc, hc4 * tsel, pq); // [Phi_w - hc^2 R | -hc Kbar_x | phi_w - hc kbar]
         P[1] = S[1]; P[2] = S[2]; P[3] = S[3];
-        if (kk == 0) {
+        if constexpr (LAST) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) rec[ppo[r]] = P[r];
-            break;
+            for (int r = 0; r < 4; r++) p_pp[r][OR] = P[r];
+        } else {
+            // ---- X = P_k M_{k-1} (col 13: P d)
+            d4 X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[0], Mt[0], zero, 0, 0, 0);
+            X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[1], Mt[1], X, 0, 0, 0);
+            X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[2], Mt[2], X, 0, 0, 0);
+            X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[3], Mt[3], X, 0, 0, 0);
+            // P_k (packed lower triangle) for the multiplier recovery y_k = P_k ds_k + p_k; it overwrites the Hessian part
+            // of this stage's record, which was gathered one step ago
+#pragma unroll
+            for (int r = 0; r < 4; r++) p_pp[r][OR] = P[r];
+            // ---- G of the stage below = M'X + C~ (col 13: q~)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                p_pd[r][OG] = X[r];                       // P d (column 13; every other lane writes the dump slot)
+                X[r] = __builtin_fma(m13, P[r], X[r]);    // + p in column 13
+            }
+            // the rows w+ of M (tile rows 0..3) are [I 0 | d_w], so their slice adds X[w+_j][.] to G[u_j][.] (and something to
+            // the unused row 13): one vector add instead of an MFMA
+            C[0] += X[0];
+            G = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[1], X[1], C, 0, 0, 0);
+            G = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[2], X[2], G, 0, 0, 0);
+            G = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[3], X[3], G, 0, 0, 0);
         }
-        // ---- X = P_k M_{k-1} (col 13: P d)
-        d4 X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[0], Mt[0], zero, 0, 0, 0);
-        X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[1], Mt[1], X, 0, 0, 0);
-        X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[2], Mt[2], X, 0, 0, 0);
-        X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[3], Mt[3], X, 0, 0, 0);
-        // P_k (packed lower triangle) for the multiplier recovery y_k = P_k ds_k + p_k; it overwrites the Hessian part
-        // of this stage's record, which was gathered one step ago
-#pragma unroll
-        for (int r = 0; r < 4; r++) rec[ppo[r]] = P[r];
-        SEG(4);
-        // ---- G of stage kk-1 = M'X + C~ (col 13: q~)
-        ldouble *recn = rec - RS;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            recn[pdo[r]] = X[r];                      // P d (column 13; every other lane writes the dump slot)
-            X[r] = __builtin_fma(m13, P[r], X[r]);    // + p in column 13
-        }
-        // the rows w+ of M (tile rows 0..3) are [I 0 | d_w], so their slice adds X[w+_j][.] to G[u_j][.] (and something to
-        // the unused row 13): one vector add instead of an MFMA
-        C[0] += X[0];
-        G = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[1], X[1], C, 0, 0, 0);
-        G = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[2], X[2], G, 0, 0, 0);
-        G = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[3], X[3], G, 0, 0, 0);
-        SEG(0);
+    };
+    using std::integral_constant;
+    int kk = N - 1;
+    for (; kk >= 4; kk -= 4) {
+        move(4 * RS); // pointers on stage kk - 4
+        stage(integral_constant<int, 4 * RS>{}, std::false_type{});
+        stage(integral_constant<int, 3 * RS>{}, std::false_type{});
+        stage(integral_constant<int, 2 * RS>{}, std::false_type{});
+        stage(integral_constant<int, 1 * RS>{}, std::false_type{});
     }
+    for (; kk >= 1; kk--) {
+        move(RS);
+        stage(integral_constant<int, RS>{}, std::false_type{});
+    }
+    stage(integral_constant<int, 0>{}, std::true_type{}); // stage 0
     SEG_FLUSH();
     int fail = ok ? 0 : 1;
     if (!fail) {
