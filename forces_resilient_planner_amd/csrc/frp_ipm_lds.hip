@@ -475,9 +475,16 @@ __device__ __noinline__ int sweep_factor(ldouble *recs, ldouble *xs, int N, doub
         stage(integral_constant<int, 2 * RS>{}, std::false_type{});
         stage(integral_constant<int, 1 * RS>{}, std::false_type{});
     }
-    for (; kk >= 1; kk--) {
-        move(RS);
-        stage(integral_constant<int, RS>{}, std::false_type{});
+    if (kk == 3) { // (N = 4 m: the reference's 20) the last four stages as one pass on stage 0's record
+        move(3 * RS);
+        stage(integral_constant<int, 3 * RS>{}, std::false_type{});
+        stage(integral_constant<int, 2 * RS>{}, std::false_type{});
+        stage(integral_constant<int, 1 * RS>{}, std::false_type{});
+    } else {
+        for (; kk >= 1; kk--) {
+            move(RS);
+            stage(integral_constant<int, RS>{}, std::false_type{});
+        }
     }
     stage(integral_constant<int, 0>{}, std::true_type{}); // stage 0
     SEG_FLUSH();
