@@ -150,7 +150,10 @@ __device__ __forceinline__ bool ldl4(const double *a, double *m6, double *dinv)
     const double t32 = a32 - l30 * a20 - l31 * t21;
     const double l32 = t32 * i2;
     const double d3 = a33 - l30 * a30 - l31 * t31 - l32 * t32;
-    const double i3 = fast_rcp(d3);
+    double i3 = fast_rcp(d3);
+    // (i3 is only read by the lanes of row group 3: left alone, the compiler sinks the reciprocal into an EXEC-masked region --
+    // a dozen scalar instructions and a branch on the serial path of every stage to save four VALU instructions)
+    asm volatile("" : "+v"(i3));
     const double m10 = -l10, m21 = -l21, m32 = -l32;
     const double m20 = -l20 - l21 * m10;
     const double m31 = -l31 - l32 * m21;

@@ -421,7 +421,8 @@ __device__ __noinline__ int sweep_factor(ldouble *recs, ldouble *xs, int N, doub
         for (int i = 1; i < 6; i++) me = msel == i ? Mi[i] : me;
         // elimination in factored form: an explicit inverse of Guu cancels O(1e10) barrier terms against cond(Guu) eps errors
         const double m_gc = m_lower ? me : 0.0, m_cg = m_upper ? me : 0.0; // m[g][c & 3], m[c & 3][g]
-        const double dg = g == 0 ? Di[0] : (g == 1 ? Di[1] : (g == 2 ? Di[2] : Di[3]));
+        double dg = Di[3]; // (a chain, not a nested conditional: the nested form compiles to EXEC-masked regions)
+        dg = g == 2 ? Di[2] : dg; dg = g == 1 ? Di[1] : dg; dg = g == 0 ? Di[0] : dg;
         const double md = dg * m_gc;
         const double K0 = mfma4(m_cg, G[0], 0.0);  // K = m G_u          (4 x 16, register-0 layout)
         const double rt = mfma4(m_gc, md, 0.0);    // R = m' D^-1 m      (replicated in every column block)
