@@ -425,9 +425,10 @@ __device__ __noinline__ int sweep_factor(ldouble *recs, ldouble *xs, int N, doub
         dg = g == 2 ? Di[2] : dg; dg = g == 1 ? Di[1] : dg; dg = g == 0 ? Di[0] : dg;
         const double md = dg * m_gc;
         const double K0 = mfma4(m_cg, G[0], 0.0);  // K = m G_u          (4 x 16, register-0 layout)
-        const double rt = mfma4(m_gc, md, 0.0);    // R = m' D^-1 m      (replicated in every column block)
         const double Kd = dg * K0;
-        const double T0 = mfma4(m_gc, Kd, 0.0);    // T = m' D^-1 K = R G_u
+        // [R | Kbar_x | kbar] = m' D^-1 [m | K_x | k] in one 4x4x4 product: column block 0 of the B operand carries D^-1 m
+        // instead of D^-1 K_u (which is not needed: K_u = D L')
+        const double tsel = mfma4(m_gc, c < 4 ? md : Kd, 0.0); // T' of the sweeps; its columns 14, 15 are zero
         // (the u columns of rows 4.. would come out as G_xu - K_x' D^-1 K_u, zero only up to rounding RELATIVE TO G_xu, which carries
         //  barrier terms: they are taken out of both operands instead -- three multiplies -- and the block is exactly -hc K_x' D^-1 m)
         const double hcm = hc * m4;
@@ -435,7 +436,6 @@ __device__ __noinline__ int sweep_factor(ldouble *recs, ldouble *xs, int N, doub
         d4 S = G;
         S[1] *= m4c; S[2] *= m4c; S[3] *= m4c;
         S = __builtin_amdgcn_mfma_f64_16x16x4f64(-Kd, Kb, S, 0, 0, 0); // [-hc Kbar_x' | S_xx | p_x] in rows 4..12
-        const double tsel = c < 4 ? rt : T0;       // [R | Kbar_x | kbar] (T' of the sweeps; its columns 14, 15 are zero)
         p_t[OR + R_T] = tsel;
         const double hc4 = __builtin_fma(hc, m4, m4c);
         P[0] = __builtin_fma(-hc, hc4 * tsel, pq); // [Phi_w - hc^2 R | -hc Kbar_x | phi_w - hc kbar]
