@@ -346,7 +346,12 @@ __device__ __forceinline__ void gather_tiles(cldouble *rn, const int (&c1)[4], c
     pq = rn[pqo];
 }
 
-__device__ __noinline__ int sweep_factor(ldouble *recs, ldouble *xs, int N, double theta)
+#ifdef FRP_INLINE_FACTOR
+#define FRP_FACTOR_LINKAGE __forceinline__
+#else
+#define FRP_FACTOR_LINKAGE __noinline__
+#endif
+__device__ FRP_FACTOR_LINKAGE int sweep_factor(ldouble *recs, ldouble *xs, int N, double theta)
 {
     N = uni(N); theta = uni(theta);
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15, c3_ = c & 3;
