@@ -708,7 +708,7 @@ __global__ __launch_bounds__(CR_THREADS) __attribute__((amdgpu_waves_per_eu(FRP_
 #endif
     if (tid == 0) {
         for (int k = npoly; k < c.N; ++k) c.poly_nfaces[(size_t)b * c.N + k] = 0;
-        if (c.poly_count) c.poly_count[b] = u.overflow ? -npoly : npoly;
+        if (c.poly_count) c.poly_count[b] = u.overflow ? -npoly : npoly; // (overflow = a polytope was truncated, so npoly >= 1 and the sign is never lost)
     }
 }
 
