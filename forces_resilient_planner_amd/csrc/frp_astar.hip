@@ -257,6 +257,18 @@ __device__ int check_state(const Ctx &c, const double pos[3], const double vel[3
     return 1;
 }
 
+// position of the n-th (0-based) set bit of m, n < popcount(m)
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, int n)
+{
+    int pos = 0;
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+        const int cnt = __popcll(m & (((1ull << w) - 1ull) << pos));
+        if (n >= cnt) { n -= cnt; pos += w; }
+    }
+    return pos;
+}
+
 __device__ __forceinline__ void state_transit(const Ctx &c, const double s0[6], double s1[6], const double um[3], double tau)
 {
     const double t2 = tau * tau;
@@ -405,6 +417,7 @@ __device__ void heap_pop(HeapEnt *heap, Node *nodes, int &size) // std::pop_heap
 #endif
 struct Shared {
     long long prof[8];
+    unsigned long long alive[2]; // survivors of phase 1 as bit masks over the primitives 0..63, 64..127
     unsigned long long win[WIN * WIN];
     double c_state[MAX_CAND][6], c_g[MAX_CAND], c_f[MAX_CAND], c_um[MAX_CAND][3], c_tau[MAX_CAND], grp_val[MAX_CAND];
     long long c_key[MAX_CAND];
@@ -579,6 +592,9 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
                 if (surv && i0 == sh.cur_index[0] && i1 == sh.cur_index[1] && i2 == sh.cur_index[2]) surv = 0;
             }
             sh.c_surv[c] = surv; sh.c_pre[c] = pre; sh.c_key[c] = key; sh.c_tau[c] = tau; sh.c_g[c] = 0.0; sh.c_f[c] = 0.0; sh.c_leader[c] = c;
+            static_assert(MAX_CAND == 128 && NT >= MAX_CAND, "one primitive per thread of the first two wavefronts");
+            const unsigned long long bal = __ballot(surv != 0); // (c = lane: wavefront w holds the primitives 64 w .. 64 w + 63)
+            if ((c & 63) == 0) sh.alive[c >> 6] = bal;
 #pragma unroll
             for (int i = 0; i < 6; i++) sh.c_state[c][i] = pro[i];
             sh.c_um[c][0] = um[0]; sh.c_um[c][1] = um[1]; sh.c_um[c][2] = um[2];
@@ -587,9 +603,13 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
         APROF(3);
         // phase 2, thread = (primitive, collision sample): check_num samples per surviving primitive (kinodynamic_astar.cpp:190-199;
         // the reference stops at the first colliding sample -- the verdict of a primitive is the same)
-        for (int t = lane; t < n_cand * P->check_num; t += NT) {
-            const int c = t / P->check_num, k = t - c * P->check_num + 1;
-            if (!sh.c_surv[c]) continue;
+        // The samples of the SURVIVING primitives only are dealt over the threads (the a-th survivor = the a-th set bit of the
+        // masks): a dead primitive would hold check_num lanes idle through the longest ray cast of its wavefront.
+        const unsigned long long al0 = sh.alive[0], al1 = sh.alive[1];
+        const int n_al0 = __popcll(al0), n_alive = n_al0 + __popcll(al1);
+        for (int t = lane; t < n_alive * P->check_num; t += NT) {
+            const int ai = t / P->check_num, k = t - ai * P->check_num + 1;
+            const int c = ai < n_al0 ? nth_set_bit(al0, ai) : 64 + nth_set_bit(al1, ai - n_al0);
             const double um[3] = {sh.c_um[c][0], sh.c_um[c][1], sh.c_um[c][2]};
             const double dt = sh.c_tau[c] * (double)k / (double)P->check_num;
             double xt[6];
