@@ -258,7 +258,7 @@ public:
         int queued = 0;
         {
             std::lock_guard<std::mutex> l(m_);
-            for (; off < bytes; off += slice) { jobs_.push_back({static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, std::min(slice, bytes - off)}); queued++; }
+            for (; off < bytes; off += slice) { jobs_.push_back({static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, std::min(slice, bytes - off), 0, 0, 0, 0, 0, 0}); queued++; }
             pending_ += queued;
         }
         cv_.notify_all();
@@ -266,8 +266,34 @@ public:
         std::unique_lock<std::mutex> l(m_);
         done_.wait(l, [this] { return pending_ == 0; });
     }
+    // `rows` parameter rows [10 | A (M x 3) | b (M)] -> [10 | A (MF x 3) | b (MF)]: the live corridor rows only (two segments per row)
+    void pack_rows(double *dst, const double *src, size_t rows, int M, int MF)
+    {
+        const size_t parts = workers_.size() + 1, slice = (rows + parts - 1) / parts;
+        Job proto{nullptr, nullptr, 0, 0, (10 + 3 * (size_t)MF) * 8, (size_t)MF * 8, (10 + 4 * (size_t)M) * 8, (10 + 4 * (size_t)MF) * 8, (10 + 3 * (size_t)M) * 8};
+        auto make = [&](size_t r0, size_t n) { Job j = proto; j.d = reinterpret_cast<char *>(dst) + r0 * j.d_row; j.s = reinterpret_cast<const char *>(src) + r0 * j.s_row; j.rows = n; return j; };
+        if (rows < 4096 || workers_.empty()) { run_job(make(0, rows)); return; }
+        int queued = 0;
+        {
+            std::lock_guard<std::mutex> l(m_);
+            for (size_t r0 = slice; r0 < rows; r0 += slice) { jobs_.push_back(make(r0, std::min(slice, rows - r0))); queued++; }
+            pending_ += queued;
+        }
+        cv_.notify_all();
+        run_job(make(0, std::min(slice, rows)));
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [this] { return pending_ == 0; });
+    }
 private:
-    struct Job { char *d; const char *s; size_t n; };
+    struct Job { char *d; const char *s; size_t n; size_t rows, a_bytes, b_bytes, s_row, d_row, s_boff; }; // rows == 0: one plain copy of n bytes
+    static void run_job(const Job &j)
+    {
+        if (j.rows == 0) { std::memcpy(j.d, j.s, j.n); return; }
+        for (size_t r = 0; r < j.rows; r++) {
+            std::memcpy(j.d + r * j.d_row, j.s + r * j.s_row, j.a_bytes);
+            std::memcpy(j.d + r * j.d_row + j.a_bytes, j.s + r * j.s_row + j.s_boff, j.b_bytes);
+        }
+    }
     void run()
     {
         for (;;) {
@@ -278,7 +304,7 @@ private:
                 if (stop_ && jobs_.empty()) return;
                 j = jobs_.back(); jobs_.pop_back();
             }
-            std::memcpy(j.d, j.s, j.n);
+            run_job(j);
             { std::lock_guard<std::mutex> l(m_); if (--pending_ == 0) done_.notify_all(); }
         }
     }
@@ -417,7 +443,12 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
         }
         g_pipe.ready = true;
     }
-    const size_t N = h->N, np = FRP_NPAR(h->M);
+    // With explicit face counts only the first MF corridor rows of a stage can be live (a larger count is a parameter error the
+    // kernel reports either way): the staging copy packs the parameters to MF rows -- 26.4 -> 8.9 KB per problem over PCIe at
+    // the reference's 30-row layout with 6-face corridors -- and the device solves the same problems in the compact layout.
+    const bool compact = h->nfaces && h->MF < h->M;
+    const int Md = compact ? h->MF : h->M; // corridor rows of the device-side layout
+    const size_t N = h->N, np_h = FRP_NPAR(h->M), np = FRP_NPAR(Md);
     // per-problem doubles in a chunk's input block: xinit | x0 | params, then nfaces / models (ints, padded to doubles)
     const size_t in_d = 9 + N * 17 + N * np, nf_d = h->nfaces ? (N + 1) / 2 : 0, md_d = h->model_per_problem ? 1 : 0;
     const size_t out_d = N * 17 + (h->info ? FRP_INFO_STRIDE : 0) + 1; // z | info | (exitflag, iterations)
@@ -453,7 +484,8 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
         double *hi = s.h_in;
         std::memcpy(hi, h->xinit + b0 * 9, nb * 9 * sizeof(double)); double *h_x0 = hi + nb * 9;
         copy_pool().copy(h_x0, h->x0 + b0 * N * 17, nb * N * 17 * sizeof(double)); double *h_par = h_x0 + nb * N * 17;
-        copy_pool().copy(h_par, h->params + b0 * N * np, nb * N * np * sizeof(double));
+        if (compact) copy_pool().pack_rows(h_par, h->params + b0 * N * np_h, nb * N, h->M, Md);
+        else copy_pool().copy(h_par, h->params + b0 * N * np, nb * N * np * sizeof(double));
         int *h_nf = reinterpret_cast<int *>(h_par + nb * N * np);
         if (h->nfaces) std::memcpy(h_nf, h->nfaces + b0 * N, nb * N * sizeof(int));
         int *h_md = reinterpret_cast<int *>(reinterpret_cast<double *>(h_nf) + nb * nf_d);
@@ -462,7 +494,7 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
         FRP_HIP(hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, g_pipe.s_in));
         FRP_HIP(hipEventRecord(s.e_in, g_pipe.s_in));
         frp_nmpc_batch d = *h;
-        d.B = (int)nb;
+        d.B = (int)nb; d.M = Md;
         d.xinit = s.d_in; d.x0 = s.d_in + nb * 9; d.params = s.d_in + nb * 9 + nb * N * 17;
         const double *d_tail = s.d_in + nb * in_d;
         d.nfaces = h->nfaces ? reinterpret_cast<const int *>(d_tail) : nullptr;
