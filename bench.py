@@ -427,7 +427,8 @@ def main():
                                  "same_plans": bool(np.array_equal(outs[0], outc[0])),
                                  "what": "frp_nmpc_solve_batch_host, pageable host buffers in and out (PCIe-inclusive, median of 7): persistent device buffers, "
                                          "pinned staging filled by a few copy threads, three chunks whose copies and solves overlap; dense = the reference's "
-                                         "30-row parameter layout (26.4 KB per problem over PCIe), compact = the same problems with M = 6 rows (8.9 KB)"}
+                                         "30-row parameter layout in the caller's buffers (face counts given: the staging copy packs the 6 live rows, "
+                                         "8.9 of 26.4 KB per problem cross PCIe), compact = the same problems handed over with M = 6 rows"}
             import ctypes
             w0 = workloads.config0()
             p = solver.ForcesParams(); o = solver.ForcesOutput(); info = solver.ForcesInfo()
