@@ -418,6 +418,8 @@ __device__ void heap_pop(HeapEnt *heap, Node *nodes, int &size) // std::pop_heap
 struct Shared {
     long long prof[8];
     unsigned long long alive[2]; // survivors of phase 1 as bit masks over the primitives 0..63, 64..127
+    unsigned long long vx_key[256]; // first-survivor-of-a-voxel search: open-addressing table voxel key -> lowest candidate index
+    int vx_min[256];
     unsigned long long win[WIN * WIN];
     double c_state[MAX_CAND][6], c_g[MAX_CAND], c_f[MAX_CAND], c_um[MAX_CAND][3], c_tau[MAX_CAND], grp_val[MAX_CAND];
     long long c_key[MAX_CAND];
@@ -636,24 +638,40 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
         }
         __syncthreads();
         APROF(5);
-        // ---- the first survivor of every voxel (tmp_expand_nodes' lookup, kinodynamic_astar.cpp:210-230)
+        // ---- the first survivor of every voxel (tmp_expand_nodes' lookup, kinodynamic_astar.cpp:210-230): every survivor enters
+        // its voxel into a 256-slot table in LDS (compare-and-swap on the key, minimum on the candidate index) and reads the
+        // minimum back -- instead of scanning the candidates before it (~64 LDS reads and compares per thread)
+        int vslot = -1;
         for (int c = lane; c < n_cand; c += NT) {
-            int leader = c;
-            if (sh.c_surv[c]) {
-                const long long key = sh.c_key[c];
-                for (int q = 0; q < c; q++)
-                    if (sh.c_surv[q] && sh.c_key[q] == key) { leader = q; break; }
+            if (!sh.c_surv[c]) continue;
+            const unsigned long long key = (unsigned long long)sh.c_key[c];
+            for (unsigned h = (unsigned)mix64(key) & 255u;; h = (h + 1) & 255u) {
+                const unsigned long long old = atomicCAS(&sh.vx_key[h], ~0ull, key);
+                if (old == ~0ull || old == key) { atomicMin(&sh.vx_min[h], c); vslot = (int)h; break; }
             }
-            sh.c_leader[c] = leader;
         }
         __syncthreads();
+        for (int c = lane; c < n_cand; c += NT) sh.c_leader[c] = vslot >= 0 ? sh.vx_min[vslot] : c;
+        __syncthreads();
+        if (vslot >= 0) { sh.vx_key[vslot] = ~0ull; sh.vx_min[vslot] = 0x7fffffff; } // (cleared by its users for the next expansion; ordered by the barriers of the commit)
         APROF(6);
         // ---- commit in input order (kinodynamic_astar.cpp:232-278).  Thread 0 walks the survivors and takes the decisions that
         // depend on their order -- which primitive a node keeps, node numbers, heap pushes, keys changed in place --; the node
         // records themselves are written afterwards, one thread per touched node, from the winning primitive.
+        // The voxel hash is only read in phase 1, so its inserts -- a chain of dependent probes in HBM per new node, like the heap
+        // pushes -- run beside thread 0's loop on the first lane of the second wavefront (node numbers are the running count).
+        int use_new = 0, hs_new = 0;
+        bool out_of_memory = false;
+        if (lane == 64) {
+            int use = sh.use_node_num;
+            for (int c = 0; c < n_cand; c++) {
+                if (!sh.c_surv[c] || sh.c_pre[c] >= 0 || sh.c_leader[c] != c) continue;
+                hash_insert(hash, a.hcap, sh.c_key[c], use);
+                if (++use == A) break;
+            }
+        }
         if (lane == 0) {
             int use = sh.use_node_num, hs = sh.heap_size;
-            bool out_of_memory = false;
             for (int c = 0; c < n_cand && !out_of_memory; c++) {
                 if (!sh.c_surv[c]) continue;
                 const int L = sh.c_leader[c];
@@ -670,7 +688,6 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
                     const int nid = use;
                     hs++;
                     heap_push_hole(heap, nodes, hs - 1, 0, f, nid);
-                    hash_insert(hash, a.hcap, sh.c_key[c], nid);
                     sh.c_created[c] = nid; sh.grp_val[c] = f; sh.c_winner[c] = c;
                     use++;
                     if (use == A) out_of_memory = true; // "run out of memory", kinodynamic_astar.cpp:255-259
@@ -679,10 +696,13 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
                     sh.grp_val[L] = f; sh.c_winner[L] = c;
                 }
             }
-            sh.use_node_num = use; sh.heap_size = hs;
-            if (out_of_memory) { sh.status = FRP_ASTAR_NO_PATH; sh.terminate = -1; sh.heap_size = -1; }
+            use_new = use; hs_new = hs;
         }
         __syncthreads();
+        if (lane == 0) { // (written back behind the barrier: the other lane reads the node count while this one loops)
+            sh.use_node_num = use_new; sh.heap_size = hs_new;
+            if (out_of_memory) { sh.status = FRP_ASTAR_NO_PATH; sh.terminate = -1; sh.heap_size = -1; }
+        }
         for (int c = lane; c < n_cand; c += NT) {
             if (!sh.c_surv[c] || sh.c_leader[c] != c || sh.c_winner[c] < 0) continue;
             const int w = sh.c_winner[c], nid = sh.c_created[c];
@@ -733,6 +753,7 @@ __global__ __launch_bounds__(NT) void astar_kernel(Args a)
         ctx.ext[i] = P->external_acc[3 * b + i];
     }
     if (lane < 8) sh.prof[lane] = 0;
+    for (int i = lane; i < 256; i += NT) { sh.vx_key[i] = ~0ull; sh.vx_min[i] = 0x7fffffff; } // (every expansion leaves the table empty again)
     if (lane == 0) {
         // the primitive lists, by the reference's own loops (kinodynamic_astar.cpp:119-137): repeated addition, the same comparisons
         const double res = 1 / 2.0, time_res = 1 / 1.0, time_res_init = 1 / 8.0;
