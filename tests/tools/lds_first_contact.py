@@ -1,5 +1,5 @@
 """First contact of a solver kernel with the hardware: per-maxit agreement with the oracle on a few problems, then
-batch agreement on configs[1..3].  FRP_KERNEL=r01 selects the round-1 kernel.  python tests/tools/lds_first_contact.py [B]"""
+batch agreement on configs[1..3].  python tests/tools/lds_first_contact.py [B]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -32,7 +32,7 @@ def batch(name, w):
     for b in bad[:5]:
         print("   ", b, "gpu", fl[b], it[b], info[b, :4], "orc", flo[b], ito[b], io[b].res_eq, io[b].rsnorm)
 
-print(solver.lib().frp_nmpc_version(), "FRP_KERNEL =", os.environ.get("FRP_KERNEL"))
+print(solver.lib().frp_nmpc_version())
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 w2 = workloads.config2(B)
 per_maxit("cfg2", w2, B, 0, 7)
