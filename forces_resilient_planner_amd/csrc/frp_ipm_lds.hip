@@ -157,7 +157,7 @@ typedef __attribute__((address_space(3))) const double cldouble;
 // -DFRP_PROFILE: per-wave cycle counts of the work before each of the five barriers of an iteration and of the wait at it
 #ifdef FRP_PROFILE
 static __device__ long long g_prof_lds[4][16];
-#define PROF_T0() const long long pinit0_ = clock64()
+#define PROF_T0() const long long pinit0_ = clock64(); const long long pwall0_ = wall_clock64()
 #define PROF_DECL() long long pw_[5] = {0, 0, 0, 0, 0}, pb_[5] = {0, 0, 0, 0, 0}, pt_ = clock64(); const long long pinit_ = pt_ - pinit0_
 #define BAR_P(i)                                                    \
     do {                                                            \
@@ -1985,6 +1985,9 @@ for (int r = RB0; r < RB1; r++) {
         if (a.info) {
             double *o = a.info + (size_t)b * FRP_INFO_STRIDE;
             o[0] = nm.eq; o[1] = nm.in; o[2] = nm.rs; o[3] = nm.rc; o[5] = mu; o[6] = step_cc; o[7] = (double)nfallback; // o[4] = objective: wave 1
+#ifdef FRP_PROFILE // tools/timeline.py: start and end of this solve on the 100 MHz wall clock instead of the last two fields
+            o[6] = (double)pwall0_; o[7] = (double)wall_clock64();
+#endif
         }
     }
 }
