@@ -452,15 +452,32 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
     // per-problem doubles in a chunk's input block: xinit | x0 | params, then nfaces / models (ints, padded to doubles)
     const size_t in_d = 9 + N * 17 + N * np, nf_d = h->nfaces ? (N + 1) / 2 : 0, md_d = h->model_per_problem ? 1 : 0;
     const size_t out_d = N * 17 + (h->info ? FRP_INFO_STRIDE : 0) + 1; // z | info | (exitflag, iterations)
-    // chunks of >= 1024 problems keep every resident workgroup busy; at most 8 chunks per call
+    // Chunks whose copies and solves overlap.  A small first chunk gets the GPU going while the rest is still being staged, the
+    // later ones are large because a launch of fewer problems than two rounds of resident workgroups is inefficient: B / 16,
+    // B / 4, then the rest in pieces of at most 4096 (measured on the 4096-problem batch, ms end to end: one chunk 2.54, three
+    // equal ones 2.56, 256 + 1024 + 2816 2.09).
     size_t chunk = (size_t)h->B;
-    if (h->B >= 4096) { // >= 3 chunks of <= 4096 problems (measured on the dense 4096-problem batch: 1 chunk 5.1 ms, 2: 4.4, 3: 3.7, 4: 4.6)
-        size_t nc = ((size_t)h->B + 4095) / 4096;
-        if (nc < 3) nc = 3;
-        chunk = ((size_t)h->B + nc - 1) / nc;
+    std::vector<size_t> cb{0};
+    if (h->B >= 4096) {
+        cb.push_back((size_t)h->B / 16);
+        cb.push_back(cb.back() + (size_t)h->B / 4);
+        const size_t rest = (size_t)h->B - cb.back(), nc = (rest + 4095) / 4096;
+        chunk = (rest + nc - 1) / nc;
     }
     if (const char *e = getenv("FRP_HOST_CHUNK")) { const long v = atol(e); if (v > 0) chunk = (size_t)v; } // tuning knob
-    const size_t nchunk = ((size_t)h->B + chunk - 1) / chunk;
+    // chunk c covers the problems [cb[c], cb[c + 1]); FRP_HOST_SPLIT="n0,n1,..." (tuning knob) gives explicit sizes, the rest uniform
+    if (const char *e = getenv("FRP_HOST_SPLIT")) {
+        cb.assign(1, 0);
+        for (const char *q = e; *q && cb.back() < (size_t)h->B;) {
+            char *end = nullptr; const long v = strtol(q, &end, 10);
+            if (end == q || v <= 0) break;
+            cb.push_back(std::min((size_t)h->B, cb.back() + (size_t)v));
+            q = (*end == ',') ? end + 1 : end;
+        }
+    }
+    while (cb.back() < (size_t)h->B) cb.push_back(std::min((size_t)h->B, cb.back() + chunk));
+    const size_t nchunk = cb.size() - 1;
+    for (size_t c = 0; c < nchunk; c++) chunk = std::max(chunk, cb[c + 1] - cb[c]); // (buffers are sized for the largest)
     for (auto &s : g_pipe.slot) {
         const int rc = pipe_reserve(s, chunk * (in_d + nf_d + md_d) * sizeof(double), chunk * out_d * sizeof(double), frp::ws_bytes((int)chunk, h->N, h->MF));
         if (rc != FRP_OK) return rc;
@@ -468,7 +485,7 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
     auto drain = [&](size_t c) -> int { // chunk c's results: wait for its copy-out, unpack from the pinned block
         HostPipe::Slot &s = g_pipe.slot[c % HostPipe::NSLOT];
         FRP_HIP(hipEventSynchronize(s.e_out));
-        const size_t b0 = c * chunk, nb = std::min(chunk, (size_t)h->B - b0);
+        const size_t b0 = cb[c], nb = cb[c + 1] - cb[c];
         const double *o = s.h_out;
         copy_pool().copy(h->z + b0 * N * 17, o, nb * N * 17 * sizeof(double)); o += nb * N * 17;
         if (h->info) { std::memcpy(h->info + b0 * FRP_INFO_STRIDE, o, nb * FRP_INFO_STRIDE * sizeof(double)); o += nb * FRP_INFO_STRIDE; }
@@ -480,7 +497,7 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
     for (size_t c = 0; c < nchunk; c++) {
         HostPipe::Slot &s = g_pipe.slot[c % HostPipe::NSLOT];
         if (c >= HostPipe::NSLOT) { const int rc = drain(c - HostPipe::NSLOT); if (rc != FRP_OK) return rc; } // the slot's previous chunk has left it
-        const size_t b0 = c * chunk, nb = std::min(chunk, (size_t)h->B - b0);
+        const size_t b0 = cb[c], nb = cb[c + 1] - cb[c];
         double *hi = s.h_in;
         std::memcpy(hi, h->xinit + b0 * 9, nb * 9 * sizeof(double)); double *h_x0 = hi + nb * 9;
         copy_pool().copy(h_x0, h->x0 + b0 * N * 17, nb * N * 17 * sizeof(double)); double *h_par = h_x0 + nb * N * 17;
