@@ -426,7 +426,7 @@ def main():
                                  "compact_layout_solves_per_s": B / float(np.median(e2c)), "compact_layout_ms_per_batch": float(np.median(e2c)) * 1e3,
                                  "same_plans": bool(np.array_equal(outs[0], outc[0])),
                                  "what": "frp_nmpc_solve_batch_host, pageable host buffers in and out (PCIe-inclusive, median of 7): persistent device buffers, "
-                                         "pinned staging filled by a few copy threads, three chunks whose copies and solves overlap; dense = the reference's "
+                                         "pinned staging filled by a few copy threads, chunks of B/16, B/4 and the rest whose copies and solves overlap; dense = the reference's "
                                          "30-row parameter layout in the caller's buffers (face counts given: the staging copy packs the 6 live rows, "
                                          "8.9 of 26.4 KB per problem cross PCIe), compact = the same problems handed over with M = 6 rows"}
             import ctypes
