@@ -480,6 +480,26 @@ def test_launch_order_without_face_counts_and_at_other_horizons():
         assert np.max(np.abs(z - np.concatenate(zs))) == 0.0
 
 
+def test_host_path_packs_live_rows_and_chunks_without_changing_a_plan():
+    """frp_nmpc_solve_batch_host with explicit face counts packs the parameters to the live corridor rows while staging them and
+    solves in growing chunks (B/16, B/4, rest): the plans are those of ONE launch on the caller's 30-row layout resident in HBM,
+    bit for bit, also with another chunk split and with the chunking switched off."""
+    import torch
+    B = 4500
+    w = workloads.config2(B, seed=11)
+    ds = solver.DeviceSolver(B, w["N"], w["M"], int(w["nfaces"].max()), w["model"])
+    ds.upload(w)
+    ds.solve(); torch.cuda.synchronize()
+    z0, f0, i0 = ds.z.cpu().numpy(), ds.exitflag.cpu().numpy(), ds.iters.cpu().numpy()
+    for split in (None, "100,4400", "4500"):
+        if split: os.environ["FRP_HOST_SPLIT"] = split
+        try:
+            z, fl, it, _ = solver.solve_batch_host(w)
+        finally:
+            os.environ.pop("FRP_HOST_SPLIT", None)
+        assert np.array_equal(fl, f0) and np.array_equal(it, i0) and np.max(np.abs(z - z0)) == 0.0, split
+
+
 def test_queue_order_hint_changes_the_order_and_nothing_else():
     """frp_nmpc_batch.order_hint (a receding-horizon caller's previous iteration counts): any hint -- the previous counts,
     garbage, negative, all equal -- gives bit-identical plans, flags and iteration counts; the hint may alias `iters`."""
