@@ -87,8 +87,15 @@ __device__ __forceinline__ double fast_rcp(double x)
 __device__ __forceinline__ bool spd4_inverse(const double *a /*row-major 4x4, lower part used*/, double *r /*16*/,
                                              double *mout = nullptr /*16*/, double *dinv = nullptr /*4*/)
 {
-    const double a00 = a[0], a10 = a[4], a11 = a[5], a20 = a[8], a21 = a[9], a22 = a[10];
-    const double a30 = a[12], a31 = a[13], a32 = a[14], a33 = a[15];
+    const double a00 = a[0], a11 = a[5], a21 = a[9], a22 = a[10];
+    const double a31 = a[13], a32 = a[14], a33 = a[15];
+    // The inputs are wave-uniform (v_readlane results, scalar registers) and a VALU instruction reads at most one scalar
+    // operand: the first column enters every product below, so it is copied to vector registers ONCE -- left alone the
+    // compiler copies an operand per instruction (12 copies per call instead of 3).
+    double a10 = a[4], a20 = a[8], a30 = a[12];
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(a10), "+v"(a20), "+v"(a30));
+#endif
     const double d0 = a00;
     const double i0 = fast_rcp(d0);
     const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
@@ -136,8 +143,12 @@ __device__ __forceinline__ bool spd4_inverse(const double *a /*row-major 4x4, lo
 // false if a pivot is not positive (results then undefined).
 __device__ __forceinline__ bool ldl4(const double *a, double *m6, double *dinv)
 {
-    const double a00 = a[0], a10 = a[4], a11 = a[5], a20 = a[8], a21 = a[9], a22 = a[10];
-    const double a30 = a[12], a31 = a[13], a32 = a[14], a33 = a[15];
+    const double a00 = a[0], a11 = a[5], a21 = a[9], a22 = a[10];
+    const double a31 = a[13], a32 = a[14], a33 = a[15];
+    double a10 = a[4], a20 = a[8], a30 = a[12]; // (one copy to vector registers each: see spd4_inverse)
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(a10), "+v"(a20), "+v"(a30));
+#endif
     const double d0 = a00;
     const double i0 = fast_rcp(d0);
     const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
