@@ -1371,9 +1371,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     // wave 0: what its Hessian lanes carry from the step phase to the next evaluation -- the Newton step of (rates, T), (v, e) and
     // y+ (p, v rows) of the next stage; the values before the step come from the model wave through the record (RT_HZ, RT_HY),
     // so that nothing of the Hessian's inputs is live across the sweeps
-    double hdz[10], hyp[6], hap = 0.0;
-#pragma unroll
-    for (int i = 0; i < 10; i++) hdz[i] = 0.0;
+    double hyp[6], hap = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; i++) hyp[i] = 0.0;
 #pragma unroll
@@ -1511,6 +1509,8 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 rec[R_CB + 0] = rec[R_CB + 1] = rec[R_CB + 2] = 0.0;
                 rec[R_CC + 0] = rec[R_CC + 1] = rec[R_CC + 2] = 0.0;
 #pragma unroll
+                for (int i = 0; i < NZ; i++) rec[R_DZ + i] = 0.0; // (the first evaluation reads 0 * step: not a predecessor's NaN)
+#pragma unroll
                 for (int i = 0; i < 4; i++) rec[RT_HZ + i] = ms.z[i]; // the Hessian's inputs of the first iteration (y = 0)
 #pragma unroll
                 for (int i = 0; i < 6; i++) { rec[RT_HZ + 4 + i] = ms.z[11 + i]; rec[RT_HY + i] = 0.0; }
@@ -1604,9 +1604,9 @@ for (int r = RB0; r < RB1; r++) {
                 HessState hs; // the model wave's values before the last step + the step
                 cldouble *rec = recs + k * RS;
 #pragma unroll
-                for (int i = 0; i < 4; i++) hs.u[i] = rec[RT_HZ + i] + hap * hdz[i];
+                for (int i = 0; i < 4; i++) hs.u[i] = rec[RT_HZ + i] + hap * rec[R_DZ + i]; // (the step is in the record until the next forward sweep)
 #pragma unroll
-                for (int i = 0; i < 6; i++) hs.ve[i] = rec[RT_HZ + 4 + i] + hap * hdz[4 + i];
+                for (int i = 0; i < 6; i++) hs.ve[i] = rec[RT_HZ + 4 + i] + hap * rec[R_DZ + 11 + i];
 #pragma unroll
                 for (int i = 0; i < 6; i++) {
                     const double yo = (k < N - 1) ? rec[RS + RT_HY + i] : 0.0;
@@ -1818,15 +1818,12 @@ for (int r = RB0; r < RB1; r++) {
             return acc;
         };
         if constexpr (wave == 0) {
-            // Newton step of the Hessian's inputs, and y+ of the whole stage for the model wave's commit: it goes to the d slots of
+            // (the Newton step of the Hessian's inputs stays in the record: the next evaluation reads it there, before the forward
+            // sweep that overwrites it)  y+ of the stage for the model wave's commit: it goes to the d slots of
             // the record, which are dead from the last sweep to the next model phase (the model wave has 60 registers of
             // persistent state; this wave has none)
             if (hact) {
                 ldouble *rec = recs + k * RS;
-#pragma unroll
-                for (int i = 0; i < 4; i++) hdz[i] = rec[R_DZ + i];
-#pragma unroll
-                for (int i = 0; i < 6; i++) hdz[4 + i] = rec[R_DZ + 11 + i];
                 // (split over the three lanes of a stage by rows -- lane-dependent addresses into the packed triangle -- this measured
                 // no faster: 5.4 k vs 4.7 k cycles for the phase on this wave, the launch time unchanged)
                 // This wave forms the rows its own Hessian lanes read back (p, v: 4..9), the model wave -- idle until the commit --
