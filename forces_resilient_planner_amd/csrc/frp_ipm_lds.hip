@@ -1079,7 +1079,9 @@ __device__ __forceinline__ void trig_shared(ldouble *sc, int sub, const double e
 template <int NP>
 __device__ __forceinline__ void model_phase3(ldouble *recs, ldouble *xs, ModelState &st, int N, double &l_eq)
 {
-    const int lane = threadIdx.x & 63, k = lane % NP, sub = lane / NP;
+    // (`sub` opaque per call: what is derived from it -- masks, factors, addresses -- is loop invariant, and hoisted out of the
+    // interior-point loop it is spilled and reloaded on this wave's critical phase; see ROW_PICK)
+    const int lane = threadIdx.x & 63, k = lane % NP, sub = opq(lane / NP);
     const bool act = k < N && sub < 3, dyn = act && k < N - 1;
     const double *z = st.z;
     l_eq = 0.0;
@@ -1208,6 +1210,7 @@ static_assert(hd_pack(0, 0) == 0 && hd_pack(1, 1) == 10 && hd_pack(2, 2) == 19 &
               hd_pack(5, 7) == 33 && hd_pack(6, 7) == 36 && hd_pack(7, 7) == 39 && hd_pack(8, 8) == 42 && hd_pack(9, 9) == 44, "packed Hessian rows");
 __device__ __forceinline__ void hessian_phase3(ldouble *rec, const HessState &hs, int sub, bool dyn, int hess)
 {
+    sub = opq(sub); // (see model_phase3)
     if (dyn && hess) {
         const double *w = hs.u, T = hs.u[3], *v = hs.ve, *e = hs.ve + 3, *yp = hs.y6, *yv = hs.y6 + 3;
         double et[3];
