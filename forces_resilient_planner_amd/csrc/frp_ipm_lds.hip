@@ -1800,7 +1800,7 @@ for (int r = RB0; r < RB1; r++) {
 
         // ============================================================ step: pass A (ratios), pass B (commit)
         double m_p = 0.0, m_d = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0; // q: sums of ds l, s dl, ds dl
-        double dzb[R], dzp[R], dzf[3];            // waves 2, 3: dz of their bound rows and of the (u, w) partners; wave 3: dz of pos
+        double dzf[3];                            // wave 3: dz of pos (the commit reads every dz from the record again: nothing is carried across barrier F)
         // one constraint of the corrector step
         auto cstep = [&](double s, double l, double corr, double gdz, double viol, double &ds, double &dl) {
             const double u = fast_rcp(s * l);
@@ -1869,8 +1869,6 @@ for (int r = RB0; r < RB1; r++) {
                     const double lb = ROW_PICK(lower_bound(i));
                     const double ub = ROW_PICK(upper_bound(i));
                     const double zi = bz[r], dzi = rec[R_DZ + i];
-                    dzb[r] = dzi;
-                    if (ib < 8) dzp[r] = rec[R_DZ + (i < 4 ? i + 4 : (i < 8 ? i - 4 : i))];
                     double ds, dl;
                     cstep(bsl[r], bll[r], bcl[r], -dzi, lb - zi, ds, dl);
                     cstep(bsu[r], blu[r], bcu[r], dzi, zi - ub, ds, dl);
@@ -1933,14 +1931,19 @@ for (int r = RB0; r < RB1; r++) {
                     if (i >= NZ) continue;
                     const double lb = ROW_PICK(lower_bound(i));
                     const double ub = ROW_PICK(upper_bound(i));
-                    const double zi = bz[r], dzi = dzb[r];
+                    cldouble *rec = recs + k * RS; // (the step stays in the record until the next forward sweep)
+                    const double zi = bz[r], dzi = rec[R_DZ + i];
                     commit(bsl[r], bll[r], bcl[r], -dzi, lb - zi);
                     commit(bsu[r], blu[r], bcu[r], dzi, zi - ub);
                     bz[r] = zi + ap * dzi;
-                    if (ib < 8) bzp[r] += ap * dzp[r];
+                    if (ib < 8) bzp[r] += ap * rec[R_DZ + (i < 4 ? i + 4 : (i < 8 ? i - 4 : i))];
                 }
             }
             if constexpr (wave == 3) {
+                {
+                    cldouble *rec = recs + k * RS;
+                    dzf[0] = rec[R_DZ + 8]; dzf[1] = rec[R_DZ + 9]; dzf[2] = rec[R_DZ + 10];
+                }
 #pragma unroll
                 for (int t = 0; t < FL; t++) {
                     if (t * H + half < nfk) {
