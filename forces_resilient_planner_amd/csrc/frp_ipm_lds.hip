@@ -1384,12 +1384,19 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     fpos[0] = fpos[1] = fpos[2] = 0.0;
 
     // face t of this lane is row j = t * H + half of its stage; its constants come from registers or from the parameters
+    // (re-reading variants: two per-lane base pointers -- row `half` of A and of b -- made opaque once per phase by face_bases(),
+    // every row of the lane then an immediate offset from them.  Left to itself the compiler keeps a 64-bit address per
+    // row for the whole solve: 40 registers at ten rows per lane, i.e. 40 spills)
+    const double *pkA = pk + NPRE + 3 * half, *pkB = pk + NPRE + 3 * M + half;
+    auto face_bases = [&]() {
+        if constexpr (!FREG) {
+            pkA = pk + NPRE + 3 * half; pkB = pk + NPRE + 3 * M + half;
+            asm volatile("" : "+v"(pkA), "+v"(pkB));
+        }
+    };
     auto face_consts = [&](int t, double &a0, double &a1, double &a2, double &bb) {
         if (FREG) { a0 = fa0[t]; a1 = fa1[t]; a2 = fa2[t]; bb = fbb[t]; }
-        else {
-            const int j = t * H + half;
-            a0 = pk[NPRE + 3 * j]; a1 = pk[NPRE + 3 * j + 1]; a2 = pk[NPRE + 3 * j + 2]; bb = pk[NPRE + 3 * M + j] + HU;
-        }
+        else { a0 = pkA[3 * H * t]; a1 = pkA[3 * H * t + 1]; a2 = pkA[3 * H * t + 2]; bb = pkB[H * t] + HU; }
     };
 
     // The 17 bound pairs of a stage are shared by waves 2 and 3: rounds [RB0, RB1) of the row mapping each (wave 3 also
@@ -1634,6 +1641,7 @@ for (int r = RB0; r < RB1; r++) {
             bounds_eval(l_in, l_rc, l_gap);
             double gp0 = 0, gp1 = 0, gp2 = 0, fp0 = 0, fp1 = 0, fp2 = 0, p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0;
             if (kact) {
+                face_bases();
 #pragma unroll
                 for (int t = 0; t < FL; t++) {
                     if (t * H + half < nfk) {
@@ -1736,6 +1744,7 @@ for (int r = RB0; r < RB1; r++) {
             if (kact) {
                 cldouble *rec = recs + k * RS;
                 const double d8 = rec[R_DZ + 8], d9 = rec[R_DZ + 9], d10 = rec[R_DZ + 10];
+                face_bases();
 #pragma unroll
                 for (int t = 0; t < FL; t++) {
                     if (t * H + half < nfk) {
@@ -1879,6 +1888,7 @@ for (int r = RB0; r < RB1; r++) {
             if (kact) {
                 cldouble *rec = recs + k * RS;
                 dzf[0] = rec[R_DZ + 8]; dzf[1] = rec[R_DZ + 9]; dzf[2] = rec[R_DZ + 10];
+                face_bases();
 #pragma unroll
                 for (int t = 0; t < FL; t++) {
                     if (t * H + half < nfk) {
@@ -1944,6 +1954,7 @@ for (int r = RB0; r < RB1; r++) {
                     cldouble *rec = recs + k * RS;
                     dzf[0] = rec[R_DZ + 8]; dzf[1] = rec[R_DZ + 9]; dzf[2] = rec[R_DZ + 10];
                 }
+                face_bases();
 #pragma unroll
                 for (int t = 0; t < FL; t++) {
                     if (t * H + half < nfk) {
