@@ -87,28 +87,43 @@ struct DropInCtx {
     frp_forces_extfunc probed[2] = {nullptr, nullptr}; // the callback last probed per model (a different pointer is probed again)
     bool probe_ok[2] = {false, false};
     std::mutex mtx;
-    ~DropInCtx()
-    {
-        if (!ready) return;
-        (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_ws);
-        (void)hipHostFree(h_in); (void)hipHostFree(h_out);
-        (void)hipStreamDestroy(stream);
-    }
+    ~DropInCtx();
 };
 DropInCtx g_ctx;
+void ctx_release();
+DropInCtx::~DropInCtx() { if (ready) ctx_release(); }
+
+void ctx_release()
+{
+    if (g_ctx.d_in) (void)hipFree(g_ctx.d_in);
+    if (g_ctx.d_out) (void)hipFree(g_ctx.d_out);
+    if (g_ctx.d_ws) (void)hipFree(g_ctx.d_ws);
+    if (g_ctx.h_in) (void)hipHostFree(g_ctx.h_in);
+    if (g_ctx.h_out) (void)hipHostFree(g_ctx.h_out);
+    if (g_ctx.stream) (void)hipStreamDestroy(g_ctx.stream);
+    g_ctx.d_in = g_ctx.d_out = g_ctx.d_ws = g_ctx.h_in = g_ctx.h_out = nullptr;
+    g_ctx.stream = nullptr;
+    g_ctx.ready = false;
+}
 
 int ctx_init()
 {
     if (g_ctx.ready) return FRP_OK;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FRP_ERR_NO_DEVICE;
-    FRP_HIP(hipStreamCreate(&g_ctx.stream));
     g_ctx.ws_bytes = frp::ws_bytes(1, FRP_N_REF, FRP_NH_REF);
-    FRP_HIP(hipMalloc(&g_ctx.d_in, DI_IN_DOUBLES * sizeof(double)));
-    FRP_HIP(hipMalloc(&g_ctx.d_out, DI_OUT_DOUBLES * sizeof(double)));
-    FRP_HIP(hipHostMalloc(&g_ctx.h_in, DI_IN_DOUBLES * sizeof(double), hipHostMallocDefault));
-    FRP_HIP(hipHostMalloc(&g_ctx.h_out, DI_OUT_DOUBLES * sizeof(double), hipHostMallocDefault));
-    FRP_HIP(hipMalloc(&g_ctx.d_ws, g_ctx.ws_bytes));
+    // (a failure half way leaves nothing behind: the next call starts from scratch)
+    const bool ok = hipStreamCreate(&g_ctx.stream) == hipSuccess &&
+                    hipMalloc(&g_ctx.d_in, DI_IN_DOUBLES * sizeof(double)) == hipSuccess &&
+                    hipMalloc(&g_ctx.d_out, DI_OUT_DOUBLES * sizeof(double)) == hipSuccess &&
+                    hipHostMalloc(&g_ctx.h_in, DI_IN_DOUBLES * sizeof(double), hipHostMallocDefault) == hipSuccess &&
+                    hipHostMalloc(&g_ctx.h_out, DI_OUT_DOUBLES * sizeof(double), hipHostMallocDefault) == hipSuccess &&
+                    hipMalloc(&g_ctx.d_ws, g_ctx.ws_bytes) == hipSuccess;
+    if (!ok) {
+        fprintf(stderr, "[frp_nmpc] HIP error %s while creating the drop-in context\n", hipGetErrorString(hipGetLastError()));
+        ctx_release();
+        return FRP_ERR_HIP;
+    }
     g_ctx.ready = true;
     return FRP_OK;
 }
@@ -160,9 +175,11 @@ int forces_solve(int model, frp_forces_params *params, frp_forces_output *output
     if (!params || !output || !info) return FRP_EXIT_PARAM_VALUE;
     std::lock_guard<std::mutex> lock(g_ctx.mtx);
     std::memset(info, 0, sizeof *info);
-    if (ctx_init() != FRP_OK) {
-        if (fs) fprintf(fs, "frp_nmpc: no usable HIP device -- this library has no CPU path\n");
-        return FRP_EXIT_PARAM_VALUE;
+    if (const int rc = ctx_init(); rc != FRP_OK) {
+        // not a parameter error: "solver not valid on this machine" (the reference's -100) or a failed runtime call (-101)
+        if (fs) fprintf(fs, rc == FRP_ERR_NO_DEVICE ? "frp_nmpc: no usable HIP device -- this library has no CPU path\n"
+                                                      : "frp_nmpc: the HIP runtime failed while creating the solver context\n");
+        return rc == FRP_ERR_NO_DEVICE ? FRP_EXIT_NO_DEVICE : FRP_EXIT_DEVICE_FAULT;
     }
     if (fn) {
         if (g_ctx.probed[model] != fn) {
@@ -195,7 +212,14 @@ int forces_solve(int model, frp_forces_params *params, frp_forces_output *output
         hnf[k] = nf;
         mf = nf > mf ? nf : mf;
     }
-    if (hipMemcpyAsync(g_ctx.d_in, hin, DI_IN_DOUBLES * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return FRP_EXIT_PARAM_VALUE;
+    auto device_fault = [&](const char *what) { // a runtime failure is not the caller's parameters: its own code, the context rebuilt on the next call
+        fprintf(stderr, "[frp_nmpc] HIP error %s in the drop-in solve (%s)\n", hipGetErrorString(hipGetLastError()), what);
+        if (fs) fprintf(fs, "frp_nmpc: HIP runtime failure during the solve (%s)\n", what);
+        (void)hipStreamSynchronize(st);
+        ctx_release();
+        return FRP_EXIT_DEVICE_FAULT;
+    };
+    if (hipMemcpyAsync(g_ctx.d_in, hin, DI_IN_DOUBLES * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return device_fault("copy in");
     frp_nmpc_batch b;
     std::memset(&b, 0, sizeof b);
     b.B = 1; b.N = FRP_N_REF; b.M = FRP_NH_REF; b.MF = mf; b.model = model;
@@ -204,20 +228,24 @@ int forces_solve(int model, frp_forces_params *params, frp_forces_output *output
     b.exitflag = reinterpret_cast<int *>(g_ctx.d_out + 340 + FRP_INFO_STRIDE); b.iters = b.exitflag + 1;
     frp::KernelArgs a;
     if (!fill_args(&b, nullptr, g_ctx.d_ws, g_ctx.ws_bytes, &a)) return FRP_EXIT_PARAM_VALUE;
-    if (frp::launch_ipm(a, st) != hipSuccess) return FRP_EXIT_PARAM_VALUE;
+    if (frp::launch_ipm(a, st) != hipSuccess) return device_fault("launch");
     if (hipMemcpyAsync(g_ctx.h_out, g_ctx.d_out, DI_OUT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
-        return FRP_EXIT_PARAM_VALUE;
+        return device_fault("copy out / synchronise");
     std::memcpy(output->x, g_ctx.h_out, 340 * sizeof(double));
     const double *inf = g_ctx.h_out + 340;
     const int *fi = reinterpret_cast<const int *>(g_ctx.h_out + 340 + FRP_INFO_STRIDE);
     const int flag = fi[0], it = fi[1];
     info->it = it; info->it2opt = it;
     info->res_eq = inf[0]; info->res_ineq = inf[1]; info->rsnorm = inf[2]; info->rcompnorm = inf[3];
-    info->pobj = inf[4]; info->mu = inf[5]; info->step_cc = inf[6]; info->sigma = 0.0;
-    // not computed by this solver (plan_manage never reads them, nmpc_solver.cpp:398-429): the dual objective is reported equal
-    // to the primal one, the gaps and sigma as zero
-    info->dobj = inf[4]; info->dgap = 0.0; info->rdgap = 0.0;
+    info->pobj = inf[4]; info->mu = inf[5]; info->step_cc = inf[6];
+    // affine-step quantities of the last iteration taken (FORCESNLPsolver_normal.h:275-289); no line search exists, so the two
+    // backtracking counters stay 0
+    info->mu_aff = inf[8]; info->sigma = inf[9]; info->step_aff = inf[10];
+    // duality gap of the local QP model at the returned point = sum of slack * multiplier over all inequalities (what an
+    // interior-point method drives to zero; mu is its mean); dobj = pobj - dgap (:262-270)
+    info->dgap = inf[11]; info->dobj = inf[4] - inf[11];
+    info->rdgap = std::fabs(inf[11]) / std::fmax(std::fabs(inf[4]), 1e-300);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     info->solvetime = secs;
     info->fevalstime = 0.0; /* model evaluation is fused into the device kernel */
@@ -328,6 +356,8 @@ CopyPool &copy_pool()
 struct HostPipe {
     std::mutex mtx;
     bool ready = false;
+    int device = -1;    // the device the streams, events and buffers below belong to (the one current at their creation)
+    bool dirty = false; // an error return left work in flight on the shared slots: drained before they are reused
     hipStream_t s_in = nullptr, s_solve = nullptr, s_out = nullptr;
     static constexpr int NSLOT = 3;
     struct Slot {
@@ -335,15 +365,30 @@ struct HostPipe {
         size_t in_bytes = 0, out_bytes = 0, ws_bytes = 0;
         hipEvent_t e_in = nullptr, e_solve = nullptr, e_out = nullptr;
     } slot[NSLOT];
-    ~HostPipe()
+    void release()
     {
         if (!ready) return;
         for (auto &s : slot) {
             (void)hipFree(s.d_in); (void)hipFree(s.d_out); (void)hipFree(s.d_ws); (void)hipHostFree(s.h_in); (void)hipHostFree(s.h_out);
-            (void)hipEventDestroy(s.e_in); (void)hipEventDestroy(s.e_solve); (void)hipEventDestroy(s.e_out);
+            if (s.e_in) (void)hipEventDestroy(s.e_in);
+            if (s.e_solve) (void)hipEventDestroy(s.e_solve);
+            if (s.e_out) (void)hipEventDestroy(s.e_out);
+            s = Slot();
         }
-        (void)hipStreamDestroy(s_in); (void)hipStreamDestroy(s_solve); (void)hipStreamDestroy(s_out);
+        if (s_in) (void)hipStreamDestroy(s_in);
+        if (s_solve) (void)hipStreamDestroy(s_solve);
+        if (s_out) (void)hipStreamDestroy(s_out);
+        s_in = s_solve = s_out = nullptr;
+        ready = false; dirty = false; device = -1;
     }
+    void drain_all()
+    {
+        if (s_in) (void)hipStreamSynchronize(s_in);
+        if (s_solve) (void)hipStreamSynchronize(s_solve);
+        if (s_out) (void)hipStreamSynchronize(s_out);
+        dirty = false;
+    }
+    ~HostPipe() { release(); }
 };
 HostPipe g_pipe;
 
@@ -372,7 +417,7 @@ int pipe_reserve(HostPipe::Slot &s, size_t in_bytes, size_t out_bytes, size_t ws
 
 extern "C" {
 
-const char *frp_nmpc_version(void) { return "frp_nmpc_amd 0.3 (gfx950, FP64 interior point: four wavefronts per problem, stage records in LDS)"; }
+const char *frp_nmpc_version(void) { return "frp_nmpc_amd 0.4 (gfx950, FP64 interior point: four wavefronts per problem, stage records in LDS)"; }
 
 int frp_nmpc_device_count(void)
 {
@@ -436,16 +481,37 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FRP_ERR_NO_DEVICE;
     std::lock_guard<std::mutex> lock(g_pipe.mtx);
+    // The pipeline (streams, events, device and pinned buffers) belongs to ONE device: the one current when it was built.  A call
+    // made with another device current rebuilds it there (the per-call allocation it replaced worked on any device).
+    int dev = 0;
+    FRP_HIP(hipGetDevice(&dev));
+    if (g_pipe.ready && g_pipe.device != dev) {
+        const int prev = g_pipe.device;
+        (void)hipSetDevice(prev);
+        g_pipe.drain_all();
+        g_pipe.release();
+        FRP_HIP(hipSetDevice(dev));
+    }
+    if (g_pipe.ready && g_pipe.dirty) g_pipe.drain_all(); // an earlier call returned an error with copies / solves still in flight
+    struct DirtyOnError { // every early return below leaves the slots in use: mark them, the next call (or the check above) drains
+        int rc = FRP_ERR_HIP;
+        ~DirtyOnError() { if (rc != FRP_OK && g_pipe.ready) { g_pipe.drain_all(); } }
+    } guard;
     if (!g_pipe.ready) {
-        FRP_HIP(hipStreamCreateWithFlags(&g_pipe.s_in, hipStreamNonBlocking));
-        FRP_HIP(hipStreamCreateWithFlags(&g_pipe.s_solve, hipStreamNonBlocking));
-        FRP_HIP(hipStreamCreateWithFlags(&g_pipe.s_out, hipStreamNonBlocking));
-        for (auto &s : g_pipe.slot) {
-            FRP_HIP(hipEventCreateWithFlags(&s.e_in, hipEventDisableTiming));
-            FRP_HIP(hipEventCreateWithFlags(&s.e_solve, hipEventDisableTiming));
-            FRP_HIP(hipEventCreateWithFlags(&s.e_out, hipEventDisableTiming));
+        g_pipe.device = dev;
+        g_pipe.ready = true; // (from here on release() owns whatever was created; a failure half way releases it again)
+        bool ok = hipStreamCreateWithFlags(&g_pipe.s_in, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&g_pipe.s_solve, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&g_pipe.s_out, hipStreamNonBlocking) == hipSuccess;
+        for (auto &s : g_pipe.slot)
+            ok = ok && hipEventCreateWithFlags(&s.e_in, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&s.e_solve, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&s.e_out, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            fprintf(stderr, "[frp_nmpc] HIP error %s while creating the host-batch pipeline\n", hipGetErrorString(hipGetLastError()));
+            g_pipe.release();
+            return FRP_ERR_HIP;
         }
-        g_pipe.ready = true;
     }
     // With explicit face counts only the first MF corridor rows of a stage can be live (a larger count is a parameter error the
     // kernel reports either way): the staging copy packs the parameters to MF rows -- 26.4 -> 8.9 KB per problem over PCIe at
@@ -536,6 +602,7 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
         const int rc = drain(c);
         if (rc != FRP_OK) return rc;
     }
+    guard.rc = FRP_OK;
     return FRP_OK;
 }
 

@@ -1593,6 +1593,7 @@ for (int r = RB0; r < RB1; r++) {
     bool gn_retry = false;              // this iteration is being redone with the Gauss-Newton Hessian
     Norms nm = {0, 0, 0, 0, 0, 0};
     double mu = 0.0, step_cc = 0.0;
+    double i_muaff = 0.0, i_sigma = 0.0, i_stepaff = 0.0; // wave 0: the last iteration's affine-step quantities for the info block
 #ifndef FRP_R_PRIO
 #define FRP_R_PRIO 0
 #endif
@@ -1606,6 +1607,16 @@ for (int r = RB0; r < RB1; r++) {
     if constexpr (wave == 0) __builtin_amdgcn_s_setprio(FRP_R_PRIO);
     else __builtin_amdgcn_s_setprio(FRP_H_PRIO);
 
+    // Which wave runs the forward sweeps (experiment knobs; 0 = the Riccati wave itself).  With three workgroups per CU the
+    // roles are placed by SIMD and SIMD 3 hosts no Riccati wave: a sweep handed to the wave that sits there (role 3) takes
+    // its issue cycles off the SIMD the Riccati wave shares with two helpers of the other resident problems.
+#ifndef FRP_FWD_WAVE_P
+#define FRP_FWD_WAVE_P 0
+#endif
+#ifndef FRP_FWD_WAVE_C
+#define FRP_FWD_WAVE_C 0
+#endif
+    constexpr int FWD_P = NP == 20 ? FRP_FWD_WAVE_P : 0, FWD_C = NP == 20 ? FRP_FWD_WAVE_C : 0;
     PROF_DECL();
     for (it = 0;;) {
         // ============================================================ evaluation phase
@@ -1698,9 +1709,15 @@ for (int r = RB0; r < RB1; r++) {
             SWEEP_T0();
             const int fr = sweep_factor(recs, xs, N, gn_retry ? 0.0 : theta_h);
             SWEEP_T1(0);
-            if (!fr) sweep_forward(recs, xs, N);
+            if (FWD_P == 0 && !fr) sweep_forward(recs, xs, N);
             SWEEP_T1(1);
             if (lane == 0) sh.ctl->fail = fr;
+        }
+        if constexpr (FWD_P != 0) { // the forward sweep works from the records alone: it runs on the wave whose SIMD has room
+            BAR();
+            if constexpr (wave == FWD_P) {
+                if (!sh.ctl->fail) sweep_forward(recs, xs, N);
+            }
         }
         BAR_P(1); // ------------------------------------------------------------- C
         {
@@ -1795,6 +1812,9 @@ for (int r = RB0; r < RB1; r++) {
             smu = sigma * mu;
             if (smu < MU_FLOOR_FRAC * a.tol_comp) smu = MU_FLOOR_FRAC * a.tol_comp;
             smu = uni(smu);
+            if constexpr (wave == 0) { // reported, not iterated on (info.mu_aff / sigma / step_aff, FORCESNLPsolver_normal.h:275-289)
+                i_muaff = uni(gap_aff * fast_rcp((double)mtot)); i_sigma = uni(sigma); i_stepaff = uni(ap);
+            }
         }
 
         // ============================================================ corrector: vector backward sweep + forward sweep with y+
@@ -1802,8 +1822,12 @@ for (int r = RB0; r < RB1; r++) {
             SWEEP_T0();
             sweep_backvec(recs, xs, N, smu);
             SWEEP_T1(2);
-            sweep_forward(recs, xs, N);
+            if (FWD_C == 0) sweep_forward(recs, xs, N);
             SWEEP_T1(3);
+        }
+        if constexpr (FWD_C != 0) {
+            BAR();
+            if constexpr (wave == FWD_C) sweep_forward(recs, xs, N);
         }
         BAR_P(3); // ------------------------------------------------------------- E
 
@@ -1999,6 +2023,7 @@ for (int r = RB0; r < RB1; r++) {
         if (a.info) {
             double *o = a.info + (size_t)b * FRP_INFO_STRIDE;
             o[0] = nm.eq; o[1] = nm.in; o[2] = nm.rs; o[3] = nm.rc; o[5] = mu; o[6] = step_cc; o[7] = (double)nfallback; // o[4] = objective: wave 1
+            o[8] = i_muaff; o[9] = i_sigma; o[10] = i_stepaff; o[11] = nm.gap;
 #ifdef FRP_PROFILE // tools/timeline.py: start and end of this solve on the 100 MHz wall clock instead of the last two fields
             o[6] = (double)pwall0_; o[7] = (double)wall_clock64();
 #endif

@@ -68,7 +68,10 @@ __global__ __launch_bounds__(256) void order_keys_kernel(int B, int N, int M, in
 #pragma unroll
         for (int i = 0; i < NZ; i++) vi = fmax(vi, fmax(lower_bound(i) - zl[i], zl[i] - upper_bound(i)));
         // (six rows per pass with clamped indices: the 24 loads of a pass are independent and in flight together)
-        const int nf = nfaces ? nfaces[t] : M;
+        // (clamped to the rows the parameter block holds: a count beyond M is the solver kernel's PARAM_VALUE exit, and this
+        // kernel runs before it -- it must not read past the stage's block on the way there)
+        int nf = nfaces ? nfaces[t] : M;
+        nf = nf < 0 ? 0 : (nf > M ? M : nf);
         for (int j0 = 0; j0 < nf; j0 += 6) {
             double ar[6][3], br[6];
 #pragma unroll

@@ -14,7 +14,7 @@ from . import layout as L
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRP_LIB") or os.path.join(_PKG, "libfrp_nmpc_amd.so")  # FRP_LIB: an experiment build (tools/build_variant.sh)
-INFO_STRIDE = 8
+INFO_STRIDE = 12
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int_p = ctypes.POINTER(ctypes.c_int)

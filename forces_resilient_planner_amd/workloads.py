@@ -176,6 +176,112 @@ def config4_nominal(B=65536, seed=SEED0 + 5, model=L.MODEL_NORMAL, M=L.NH_REF, t
     return out
 
 
+def _box_corridor(origin, heading, along, lateral, vertical):
+    """One box polytope per problem in the frame of `heading` about `origin` [B,3]: along = (lo, hi) extents [B] each,
+    lateral / vertical = half widths [B].  Returns A [B,6,3], b [B,6] with a_j.x <= b_j."""
+    h = np.stack([np.cos(heading), np.sin(heading), np.zeros_like(heading)], -1)
+    l = np.stack([-np.sin(heading), np.cos(heading), np.zeros_like(heading)], -1)
+    e3 = np.zeros_like(h); e3[..., 2] = 1.0
+    A = np.stack([h, -h, l, -l, e3, -e3], -2)
+    b = np.stack([(h * origin).sum(-1) + along[1], -(h * origin).sum(-1) + along[0],
+                  (l * origin).sum(-1) + lateral, -(l * origin).sum(-1) + lateral,
+                  origin[..., 2] + vertical, -origin[..., 2] + vertical], -1)
+    return A, b
+
+
+HARD_KINDS = ("far", "force", "tight", "replan")
+
+
+def config_hard(B=128, seed=SEED0 + 41, model=L.MODEL_NORMAL, M=L.NH_REF, replan_solver=None):
+    """Hard-but-feasible instances of the configs[2] problem class (N = 20, 6 corridor faces per stage), the family
+    VERDICT r03 asked for: what the solver meets when the planner is in trouble rather than cruising.  Problem b is of kind
+    HARD_KINDS[b % 4]:
+      far     cold start (hover at the state) with the reference line starting 3..5 m away from the state: the velocity
+              box (+-2 m/s, mpc_generator_normal.m:39) is active over most of the horizon, the corridor is one long box;
+      force   |f_ext| horizontal 6..9 m/s^2 (the planner aborts at 10, nmpc_manage.cpp:404), vertical +-2: 40-degree tilt;
+      tight   lateral and vertical corridor faces 5..10 cm beyond the tightening ||E a|| (forces_normal.cpp:124) of the
+              reference line, lateral initial velocity and a lateral push;
+      replan  a poor warm start: x0 is the converged plan for ANOTHER reference (heading 0.6..1.2 rad away) from the same state,
+              as after a replan (nmpc_solver.cpp:154-215).  `replan_solver(w) -> z [B,N,17]` solves the old problems (tests pass
+              the oracle, bench tools the device solver); without it the old plan is the hover guess shifted along the old line.
+    Feasible by construction in the sense that a trajectory inside the boxes exists; that SLSQP on the reference callbacks
+    solves an instance is recorded per instance in tests/golden/solutions_hard.npz (tests/tools/gen_golden.py)."""
+    N = L.N_REF
+    rng = np.random.default_rng(seed)
+    st = _random_states(rng, B)
+    kind = np.arange(B) % 4
+    heading = st[:, 8] + rng.uniform(-0.3, 0.3, B)
+    speed = rng.uniform(0.5, 2.0, B)
+    t = (np.arange(N) + 1) * L.DT
+    d = np.stack([np.cos(heading), np.sin(heading), np.zeros(B)], -1)
+    lat = np.stack([-np.sin(heading), np.cos(heading), np.zeros(B)], -1)
+    start = st[:, 0:3].copy()
+    # far: the line starts 3..5 m away (random horizontal direction, +-0.4 m in z)
+    far = kind == 0
+    off_dir = rng.uniform(-math.pi, math.pi, B)
+    off_len = rng.uniform(3.0, 5.0, B)
+    off = np.stack([off_len * np.cos(off_dir), off_len * np.sin(off_dir), rng.uniform(-0.4, 0.4, B)], -1)
+    start[far] += off[far]
+    start[:, 2] = np.clip(start[:, 2], 0.6, 4.4)
+    ref_pos = start[:, None, :] + speed[:, None, None] * t[None, :, None] * d[:, None, :]
+    ref_yaw = np.repeat(heading[:, None], N, 1)
+    f_ext = rng.uniform(-3, 3, (B, 3))
+    # force: 6..9 m/s^2 horizontally
+    frc = kind == 1
+    fa = rng.uniform(-math.pi, math.pi, B); fm = rng.uniform(6.0, 9.0, B)
+    f_ext[frc] = np.stack([fm * np.cos(fa), fm * np.sin(fa), rng.uniform(-2, 2, B)], -1)[frc]
+    # tight: velocity mostly along the line, a lateral component, a lateral push
+    tgt = kind == 2
+    vlat = rng.uniform(-0.3, 0.3, B); valong = rng.uniform(0.0, 1.0, B)
+    st[tgt, 3:6] = (valong[:, None] * d + vlat[:, None] * lat)[tgt]
+    st[tgt, 5] = rng.uniform(-0.1, 0.1, B)[tgt]
+    f_ext[tgt] = (rng.uniform(1.0, 3.0, B)[:, None] * np.sign(rng.uniform(-1, 1, B))[:, None] * lat + rng.uniform(-1, 1, (B, 1)) * d)[tgt]
+    # corridors
+    A, b = _bbox_faces(ref_pos, np.repeat(heading[:, None], N, 1))
+    R = _rot(st[:, 6:9])
+    E1 = R @ (EGO[None, :, None] * np.swapaxes(R, -1, -2))
+    E = np.repeat(E1[:, None], N, 1)
+    if far.any():  # one long box from 2 m behind the state to 2 m beyond the end of the line, in the frame of the state -> line direction
+        to = ref_pos[:, -1, :] - st[:, 0:3]
+        hd = np.arctan2(to[:, 1], to[:, 0]); ln = np.hypot(to[:, 0], to[:, 1])
+        Af, bf = _box_corridor(st[:, 0:3], hd, (np.full(B, 2.0), ln + 2.0), np.full(B, 2.5), np.full(B, 1.2))
+        A[far] = Af[far, None]; b[far] = bf[far, None]
+    if tgt.any():
+        slack = rng.uniform(0.05, 0.10, (B, 2))
+        Ea = np.linalg.norm(np.einsum('bij,bfj->bfi', E1, A[:, 0]), axis=-1)  # tightening per face [B,6]
+        for k in range(N):
+            # lateral faces 2, 3 and vertical faces 4, 5: tightening + 5..10 cm about the line point of the stage
+            b[tgt, k, 2] = ((lat * ref_pos[:, k]).sum(-1) + Ea[:, 2] + slack[:, 0])[tgt]
+            b[tgt, k, 3] = (-(lat * ref_pos[:, k]).sum(-1) + Ea[:, 3] + slack[:, 0])[tgt]
+            b[tgt, k, 4] = (ref_pos[:, k, 2] + Ea[:, 4] + slack[:, 1])[tgt]
+            b[tgt, k, 5] = (-ref_pos[:, k, 2] + Ea[:, 5] + slack[:, 1])[tgt]
+    nf = np.full((B, N), 6, dtype=np.int32)
+    mpc = init_mpc_output(st, N)
+    # replan: the warm start is the plan for the OLD reference (heading 0.6..1.2 rad away, another speed)
+    rep = kind == 3
+    if rep.any():
+        turn = rng.uniform(0.6, 1.2, B) * np.sign(rng.uniform(-1, 1, B))
+        h_old = heading - turn; s_old = rng.uniform(0.5, 2.0, B)
+        d_old = np.stack([np.cos(h_old), np.sin(h_old), np.zeros(B)], -1)
+        ref_old = st[:, None, 0:3] + s_old[:, None, None] * t[None, :, None] * d_old[:, None, :]
+        Ao, bo = _bbox_faces(ref_old, np.repeat(h_old[:, None], N, 1))
+        ad_o = ForcesAdapter(B, model, N, M)
+        w_old = _finish(ad_o, init_mpc_output(st, N), f_ext, ref_old, np.repeat(h_old[:, None], N, 1), E, Ao, bo, nf, model)
+        if replan_solver is not None:
+            z_old = replan_solver(w_old)
+        else:
+            z_old = w_old["x0"].copy()
+            z_old[:, :, 8:11] = ref_old
+            z_old[:, :, 11:14] = (s_old[:, None] * d_old)[:, None, :]
+        # the plan deque after the solve (update + duplicate the last row, nmpc_solver.cpp:524-543): row 1.. = the old plan
+        mpc[rep, 1:N + 1, :] = z_old[rep]
+        mpc[rep, 1, 8:17] = st[rep]  # stage 0 of a plan IS the state (x_0 = xinit)
+    ad = ForcesAdapter(B, model, N, M)
+    out = _finish(ad, mpc, f_ext, ref_pos, ref_yaw, E, A, b, nf, model)
+    out["kind"] = kind
+    return out
+
+
 CONFIGS = {0: config0, 1: config1, 2: config2, 3: config3, 4: config4_nominal}
 
 

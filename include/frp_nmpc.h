@@ -49,6 +49,14 @@ extern "C" {
 #define FRP_EXIT_BADFUNCEVAL (-6)
 #define FRP_EXIT_NOPROGRESS (-7)
 #define FRP_EXIT_PARAM_VALUE (-11)
+/* Return values of the two drop-in entry points that are NOT solver outcomes.  The reference's callers accept a plan only on
+   exitflag == 1 (nmpc_solver.cpp:398) and treat every other value alike, so these are safe for them; a caller that looks
+   closer can tell a machine problem from a bad parameter:
+     -100  the reference's own LICENSE_ERROR value, "solver not valid on this machine" (FORCESNLPsolver_normal.h:139): no usable
+           HIP device -- this library has no CPU path;
+     -101  (not a ForcesPro value) a HIP runtime call failed during the solve: allocation, copy, launch or synchronisation. */
+#define FRP_EXIT_NO_DEVICE (-100)
+#define FRP_EXIT_DEVICE_FAULT (-101)
 
 /* library-level errors */
 #define FRP_OK 0
@@ -57,7 +65,7 @@ extern "C" {
 #define FRP_ERR_ARG (-1003)
 #define FRP_ERR_MODEL_MISMATCH (-1004)
 
-#define FRP_INFO_STRIDE 8 /* doubles per problem in the info array, see frp_nmpc_batch.info */
+#define FRP_INFO_STRIDE 12 /* doubles per problem in the info array, see frp_nmpc_batch.info */
 
 typedef struct frp_nmpc_options {
     int maxit;        /* 200  (FORCESNLPsolver_normal.h:86)                */
@@ -93,8 +101,12 @@ typedef struct frp_nmpc_batch {
     double *z;            /* [B][N][17] out    output.x01..xN          (normal.h:173-236) */
     int *exitflag;        /* [B] out                                                     */
     int *iters;           /* [B] out, interior-point iterations (info.it)                */
-    double *info;         /* [B][FRP_INFO_STRIDE] out or NULL:
-                             res_eq, res_ineq, rsnorm, rcompnorm, pobj, mu, step_cc, n_gn_fallback */
+    double *info;         /* [B][FRP_INFO_STRIDE] out or NULL (FORCESNLPsolver_normal.h:241-301 where a field has a namesake):
+                             [0] res_eq, [1] res_ineq, [2] rsnorm, [3] rcompnorm, [4] pobj, [5] mu -- at the returned
+                             iterate; [6] step_cc, [8] mu_aff, [9] sigma, [10] step_aff -- of the last iteration taken
+                             (0 when none was); [7] iterations redone with the Gauss-Newton Hessian;
+                             [11] dgap = sum of slack * multiplier over all inequalities at the returned iterate (the
+                             duality gap of the local QP model: dobj = pobj - dgap, rdgap = |dgap / pobj|)            */
     const int *model_per_problem; /* [B] FRP_MODEL_* of each problem, or NULL: `model` for all.  A fleet whose
                              planners switch to the final solver one by one (switch_to_final,
                              nmpc_solver.cpp:381, 446-447) stays one batch.                    */

@@ -19,5 +19,8 @@ int main(int argc, char **argv)
     const int f1 = FORCESNLPsolver_normal_solve(&p, &o, &i, NULL, NULL);
     const int f2 = FORCESNLPsolver_final_solve(&pf, &of, &inf, NULL, NULL);
     printf("%d %d %.10f %.10f %d\n", f1, f2, i.pobj, inf.pobj, i.it);
+    // the diagnostic fields of the reference's info struct (FORCESNLPsolver_normal.h:241-301) through the reference's own type
+    printf("%.12e %.12e %.12e %.12e %.12e %.12e %.12e %.12e %d %d\n", i.dobj, i.dgap, i.rdgap, i.mu, i.mu_aff, i.sigma, i.step_aff, i.step_cc,
+           (int)i.lsit_aff, (int)i.lsit_cc);
     return 0;
 }

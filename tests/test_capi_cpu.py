@@ -92,6 +92,9 @@ static_assert(std::is_same<decltype(&frp_shadow_{m}_solve), int (*)(frp_forces_p
 // return codes the caller distinguishes (nmpc_solver.cpp:398-421)
 static_assert(OPTIMAL_{R} == FRP_EXIT_OPTIMAL && MAXITREACHED_{R} == FRP_EXIT_MAXIT && FACTORIZATION_ERROR_{R} == FRP_EXIT_FACTORIZATION &&
               BADFUNCEVAL_{R} == FRP_EXIT_BADFUNCEVAL && NOPROGRESS_{R} == FRP_EXIT_NOPROGRESS && PARAM_VALUE_ERROR_{R} == FRP_EXIT_PARAM_VALUE, "exit codes");
+// "no usable device" is reported with the reference's own "solver not valid on this machine" value; the runtime-fault code is
+// outside the reference's set
+static_assert(LICENSE_ERROR_{R} == FRP_EXIT_NO_DEVICE && FRP_EXIT_DEVICE_FAULT < LICENSE_ERROR_{R}, "machine-level codes");
 int main() {{
     // the reference's prototype resolved by this repo's library, exactly what plan_manage's link step does
     int (*solve)({R}_params *, {R}_output *, {R}_info *, FILE *, {R}_extfunc) = &{R}_solve;
@@ -126,7 +129,7 @@ def test_no_device_means_loud_failure_not_cpu_fallback():
     p = solver.ForcesParams(); o = solver.ForcesOutput(); info = solver.ForcesInfo()
     p.xinit[:] = w0["xinit"][0]; p.x0[:] = w0["x0"][0].ravel(); p.all_parameters[:] = w0["params"][0].ravel()
     flag = solver.lib().FORCESNLPsolver_normal_solve(ctypes.byref(p), ctypes.byref(o), ctypes.byref(info), None, None)
-    assert flag != 1 and flag < 0
+    assert flag == -100  # FRP_EXIT_NO_DEVICE = the reference's "solver not valid on this machine", not PARAM_VALUE
     assert np.all(np.array(o.x) == 0.0)
 
 
@@ -393,4 +396,4 @@ def test_static_archives_with_the_references_file_names_link_and_fail_loudly_wit
     import subprocess
     exe = _build_static_dropin_program(tmp_path)
     r = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert r.returncode == 0 and r.stdout.split()[:2] == ["-11", "-11"], r.stdout + r.stderr
+    assert r.returncode == 0 and r.stdout.split()[:2] == ["-100", "-100"], r.stdout + r.stderr

@@ -164,8 +164,10 @@ def _job(args):
     t = time.time()
     res = nlp.solve(Z0)
     eqn = float(np.max(np.abs(nlp.eq(res.x))))
+    c = nlp.ineq(res.x)
+    ineq = float(max(0.0, -c.min())) if c.size else 0.0
     return dict(z=res.x.reshape(N, 17), f=float(res.fun), status=int(res.status), nit=int(res.nit),
-                eq=eqn, secs=time.time() - t, start=start)
+                eq=eqn, ineq=ineq, secs=time.time() - t, start=start)
 
 
 def gen_stage_vectors(path, n=240, seed=W.SEED0):
@@ -202,6 +204,10 @@ def gen_solutions(outdir, workers=int(os.environ.get('GEN_WORKERS', '8'))):
         'config1': [(W.config1(80), list(range(80))), (W.config1(24, model=L.MODEL_FINAL, seed=W.SEED0 + 32), list(range(24)))],
         'config2': [(W.config2(100), list(range(100))), (W.config2(24, model=L.MODEL_FINAL, seed=W.SEED0 + 33), list(range(24)))],
         'config3': [(W.config3(80), list(range(80))), (W.config3(24, model=L.MODEL_FINAL, seed=W.SEED0 + 34), list(range(24)))],
+        # round 4: hard-but-feasible instances -- reference 3..5 m away, |f_ext| 6..9 m/s^2, 5..10 cm of
+        # corridor slack, post-replan warm starts (workloads.config_hard); the replan kind's old plans come from the oracle
+        'hard': [(W.config_hard(160, replan_solver=lambda wo: OL.solve_batch(wo)[0]), list(range(160))),
+                 (W.config_hard(32, model=L.MODEL_FINAL, seed=W.SEED0 + 42, replan_solver=lambda wo: OL.solve_batch(wo)[0]), list(range(32)))],
     }
     only = sys.argv[2:] if len(sys.argv) > 2 else None
     for fam, groups in fams.items():
@@ -219,12 +225,12 @@ def gen_solutions(outdir, workers=int(os.environ.get('GEN_WORKERS', '8'))):
         t = time.time()
         with Pool(workers) as pool:
             res = pool.map(_job, jobs, chunksize=1)
-        keep = dict(xinit=[], x0=[], params=[], nfaces=[], model=[], z=[], f=[], status=[], start=[], eq=[])
+        keep = dict(xinit=[], x0=[], params=[], nfaces=[], model=[], z=[], f=[], status=[], start=[], eq=[], ineq=[], nit=[])
         for w1, r in zip(meta, res):
             keep['xinit'].append(w1['xinit']); keep['x0'].append(w1['x0']); keep['params'].append(w1['params'])
             keep['nfaces'].append(w1['nfaces']); keep['model'].append(w1['model'])
             keep['z'].append(r['z']); keep['f'].append(r['f']); keep['status'].append(r['status'])
-            keep['start'].append(r['start']); keep['eq'].append(r['eq'])
+            keep['start'].append(r['start']); keep['eq'].append(r['eq']); keep['ineq'].append(r['ineq']); keep['nit'].append(r['nit'])
         path = os.path.join(outdir, f'solutions_{fam}.npz')
         np.savez_compressed(path, N=meta[0]['N'], M=meta[0]['M'], **{k: np.array(v) for k, v in keep.items()})
         st = np.array(keep['status'])
