@@ -312,7 +312,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    reps = [timed(step, args.steps) for _ in range(max(1, args.repeats))]
+    # the dominant kernel's duration comes from THE SAME launches as ms_per_step: a hipEvent pair around the solver kernel of
+    # every 4th launch of the timed regions, on the launch stream (frp_nmpc_kernel_timing_*), read after the last region
+    # (a pair costs its launch ~8 us of queue bubbles: observing every launch would slow the region it measures by 0.8 %)
+    nrep = max(1, args.repeats)
+    ev_stride = 4 if nrep * args.steps >= 16 else 1
+    solver.kernel_timing_begin(nrep * args.steps + 8, ev_stride)
+    reps = [timed(step, args.steps) for _ in range(nrep)]
+    kernel_ms, kernel_launches = solver.kernel_timing_end()
     if dist is not None:
         t = torch.tensor(reps, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # every repeat: the slowest rank
@@ -363,8 +370,6 @@ def main():
         dist.all_reduce(ranks_solving, op=dist.ReduceOp.SUM)
     ranks_solving = int(ranks_solving.item())
 
-    # dominant kernel: average duration over the same launches, HIP events on the launch stream
-    kernel_ms = ds.time_solve(max(1, args.steps), stream) if B > 0 else 0.0
     torch.cuda.synchronize(dev)
 
     if rank == 0:
@@ -395,12 +400,13 @@ def main():
                        "pipelined_solves_per_s": pipelined,
                        "pipelined_note": "the same steps issued round-robin on 2 HIP streams (the few long solves at the end of a launch overlap the head of the next); informational, never `value`",
                        "tolerances": 1e-4},
-            "roofline": {"bound": "mfma",
-                         "bound_detail": "fp64-issue: FP64 VALU + MFMA issue slots of in-order wavefronts on the serial stage chain (DESIGN 5); priced against the FP64 matrix == vector peak",
+            "roofline": {"bound": "fp64-issue",
+                         "bound_detail": "FP64 VALU + FP64 MFMA issue slots (they share the SIMD's FP64 datapath) of in-order wavefronts on the serial stage chain (DESIGN 5); priced against the FP64 matrix == vector peak",
                          "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel": kname, "kernel_ms": kernel_ms,
+                         "kernel": kname, "kernel_ms": kernel_ms, "kernel_launches_timed": kernel_launches,
+                         "kernel_ms_source": f"hipEvent pairs around the solver kernel of every {ev_stride}{'th' if ev_stride > 1 else 'st'} launch of the timed regions themselves (all repeats), on the launch stream",
                          "flops_per_launch": B * f_solve,
                          "note": "FP64 (vector == matrix peak 78.6 TFLOP/s); flops = SURVEY 8d definition "
                                  "mean_it * N * F_stage per solve (F_stage = 31.5 kflop at 6 faces)",
@@ -440,6 +446,19 @@ def main():
                 lat.append(time.perf_counter() - t1)
             out["dropin_latency_ms"] = {"value": float(np.median(lat[5:])) * 1e3, "exitflag": int(flag), "iterations": int(info.it),
                                         "what": "BASELINE configs[0] through FORCESNLPsolver_normal_solve (H2D of the 23.6 KB params, one-problem solve, D2H), warm, median of 20"}
+            # the whole planner tick on the device (SURVEY 8f rows f-1..f-4a around the solve): ms per stage of the tick, never `value`
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("full_tick_bench", os.path.join(ROOT, "tools", "full_tick_bench.py"))
+                ftb = importlib.util.module_from_spec(spec); spec.loader.exec_module(ftb)
+                ft = ftb.run(B=4096, TICKS=10, P=20000, GRID=0.5, SPLIT=0)
+                out["full_tick"] = {"ms_per_tick": ft["ms_per_tick"], "planner_ticks_per_s": ft["planner_ticks_per_s"], "ms_per_step": ft["ms_per_step"],
+                                    "converged_frac": ft["converged_frac"], "polytopes_per_planner": ft["polytopes_per_planner"],
+                                    "what": "DeviceFleet.full_tick for " + ft["workload"] + ": stage references -> tube -> corridor (cloud grid) -> pack -> solve "
+                                            "(corridors of up to 30 rows: the (20, 10) kernel variant) -> update, HIP events per step on the launch stream, mean of 10 ticks; "
+                                            "per-kernel rooflines: profiles/r04_tick_rooflines.json (tools/tick_rooflines.py)"}
+            except Exception as e:  # secondary evidence, never a reason to lose the bench line
+                out["full_tick"] = {"error": repr(e)}
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(wcpu, diverge_mu=float(ds.opt.diverge_mu))
         elif not args.no_cpu:

@@ -472,6 +472,19 @@ int frp_nmpc_time_solve(const frp_nmpc_batch *batch, const frp_nmpc_options *opt
     return FRP_OK;
 }
 
+int frp_nmpc_kernel_timing_begin(int max_launches, int stride)
+{
+    if (max_launches <= 0 || stride <= 0) return FRP_ERR_ARG;
+    return frp::kernel_timing_begin(max_launches, stride) == hipSuccess ? FRP_OK : FRP_ERR_ARG;
+}
+
+int frp_nmpc_kernel_timing_end(float *avg_ms, int *launches)
+{
+    if (!avg_ms || !launches) return FRP_ERR_ARG;
+    const hipError_t rc = frp::kernel_timing_end(avg_ms, launches);
+    return rc == hipSuccess ? FRP_OK : (rc == hipErrorInvalidValue ? FRP_ERR_ARG : FRP_ERR_HIP);
+}
+
 int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *opt)
 {
     // the same checks as fill_args, before anything is sized or copied from the caller's pointers

@@ -180,7 +180,10 @@ struct Scan {             // what a scan iterates over
 // 8-word tile that needs 256 VGPRs (full tick, 4096 planners: 1.32 -> 1.09 ms; 4 per CU spills too much: 1.28; two-wave
 // workgroups: 1.27-1.52).
 constexpr int CR_TILE = FRP_CR_TILE; // 64-position words per wave held in registers (CR_TILE * CR_THREADS points per planner)
-constexpr int CR_LIST = 8192; // capacity of the in-box index list (LDS); larger boxes fall back to cloud positions
+#ifndef FRP_CR_LIST
+#define FRP_CR_LIST 8192
+#endif
+constexpr int CR_LIST = FRP_CR_LIST; // capacity of the in-box index list (LDS); larger boxes fall back to cloud positions
 
 // Wave-uniform state of the running decomposition.  It lives in LDS and is advanced by thread 0 only, so the 3x3
 // algebra costs no registers in the scanning waves: a scan loads just the 9 + 3 (+ 6) doubles it needs.
@@ -276,10 +279,12 @@ __device__ __forceinline__ Best scan(const Scan &s, const uint64_t *in, uint64_t
 // The same pass when the whole list fits the wave's REGISTER TILE: up to CR_TILE words per wave (CR_TILE * 256 points
 // per workgroup), whose coordinates and cloud indices were loaded once after the first scan and stay in VGPRs for
 // the 20-30 scans of the decomposition -- no memory traffic at all besides the mask words.
-struct Tile { double x[CR_TILE], y[CR_TILE], z[CR_TILE]; int id[CR_TILE]; };
+// d2 = the squared metric distance of the point in the FINAL ellipsoid: the hyperplane loop (decomp_base.h:63-83) cuts with a fixed
+// ellipsoid, so the distances its rounds compare are computed once, by the KEEP_ALL scan that opens it
+struct Tile { double x[CR_TILE], y[CR_TILE], z[CR_TILE], d2[CR_TILE]; int id[CR_TILE]; };
 
 template <int MODE>
-__device__ __forceinline__ Best scan_tile(const Tile &t, int W, const uint64_t *in, uint64_t *out, const Uni &u, Best *s_red, int &phase,
+__device__ __forceinline__ Best scan_tile(Tile &t, int W, const uint64_t *in, uint64_t *out, const Uni &u, Best *s_red, int &phase,
                                           const double *pq = nullptr, const double *pn = nullptr)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -301,7 +306,9 @@ __device__ __forceinline__ Best scan_tile(const Tile &t, int W, const uint64_t *
         if (w[j] == 0) { if (out != in && lane == 0) out[g] = 0; continue; }
         bool alive = (w[j] >> lane) & 1;
         if (alive) {
-            const double dist = ell_dist2(Ci, d, t.x[j], t.y[j], t.z[j]);
+            // (the rounds of the hyperplane loop compare the distances its opening KEEP_ALL scan stored: same values, no recomputation)
+            const double dist = MODE == KEEP_BEHIND_PLANE ? t.d2[j] : ell_dist2(Ci, d, t.x[j], t.y[j], t.z[j]);
+            if (MODE == KEEP_ALL) t.d2[j] = dist;
             if (MODE == KEEP_OUTSIDE) alive = 1 - sqrt(dist) > CR_EPS;
             if (MODE == KEEP_INSIDE) alive = dist <= 1;
             if (MODE == KEEP_BEHIND_PLANE) alive = n[0] * (t.x[j] - q[0]) + n[1] * (t.y[j] - q[1]) + n[2] * (t.z[j] - q[2]) < 0;
@@ -620,6 +627,7 @@ __global__ __launch_bounds__(CR_THREADS) __attribute__((amdgpu_waves_per_eu(FRP_
             tile.x[j] = valid ? sc.pts[3 * (size_t)tile.id[j]] : 0.0;
             tile.y[j] = valid ? sc.pts[3 * (size_t)tile.id[j] + 1] : 0.0;
             tile.z[j] = valid ? sc.pts[3 * (size_t)tile.id[j] + 2] : 0.0;
+            tile.d2[j] = 0.0;
         }
         CR_ACC(tp_cloud)
         // shrink the second axis until no obstacle is inside (line_segment.h:156-181)

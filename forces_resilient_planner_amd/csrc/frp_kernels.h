@@ -63,6 +63,9 @@ struct KernelArgs {
 constexpr int CU_SLOT_ENTRIES = 2048; // (XCC, SE, SH, CU) of HW_ID
 size_t ws_bytes(int B, int N, int MF);
 hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream);
+// measurement hook: event pairs around the dominant kernel of the launches between begin and end (frp_nmpc_kernel_timing_*)
+hipError_t kernel_timing_begin(int max_launches, int stride);
+hipError_t kernel_timing_end(float *avg_ms, int *launches);
 // frp_ipm_lds.hip: the LDS-resident kernel (queue counter / order already set up by launch_ipm)
 int lds_workgroups_per_cu(int N);
 bool lds_kernel_supports(int N, int MF);

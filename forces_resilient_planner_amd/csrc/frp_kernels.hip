@@ -12,6 +12,7 @@
 #include <math.h>
 #include "frp_model.hpp"
 #include "../../include/frp_nmpc.h"
+#include <vector>
 #include "frp_kernels.h"
 #include "frp_device.hpp"
 #include <cstdlib>
@@ -372,6 +373,53 @@ static double order_weight(int i)
     return ow.w[i];
 }
 
+// ---- measurement hook: hipEvent pairs around the solver kernel of the launches between begin and end
+namespace {
+struct KernelTimer {
+    bool on = false;
+    int used = 0, stride = 1, seen = 0;
+    std::vector<hipEvent_t> ev; // 2 per launch
+    void clear()
+    {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        ev.clear(); used = 0; seen = 0; stride = 1; on = false;
+    }
+} g_timer;
+}
+hipError_t kernel_timing_begin(int max_launches, int stride)
+{
+    if (max_launches <= 0 || stride <= 0 || g_timer.on) return hipErrorInvalidValue;
+    g_timer.clear();
+    g_timer.stride = stride;
+    g_timer.ev.reserve(2 * (size_t)max_launches);
+    for (int i = 0; i < 2 * max_launches; i++) {
+        hipEvent_t e = nullptr;
+        // (timing enabled, no system-scope fence: a plain event makes the preceding kernel's writes host-visible when it is
+        // recorded -- a cache write-back between the kernels of a launch that the unobserved run does not have)
+        const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableSystemFence);
+        if (rc != hipSuccess) { g_timer.clear(); return rc; }
+        g_timer.ev.push_back(e);
+    }
+    g_timer.on = true;
+    return hipSuccess;
+}
+hipError_t kernel_timing_end(float *avg_ms, int *launches)
+{
+    if (!g_timer.on || !avg_ms || !launches) return hipErrorInvalidValue;
+    double total = 0.0;
+    hipError_t rc = hipSuccess;
+    for (int i = 0; i < g_timer.used && rc == hipSuccess; i++) {
+        float ms = 0.f;
+        rc = hipEventSynchronize(g_timer.ev[2 * i + 1]);
+        if (rc == hipSuccess) rc = hipEventElapsedTime(&ms, g_timer.ev[2 * i], g_timer.ev[2 * i + 1]);
+        total += ms;
+    }
+    *launches = g_timer.used;
+    *avg_ms = g_timer.used > 0 ? (float)(total / g_timer.used) : 0.f;
+    g_timer.clear();
+    return rc;
+}
+
 hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
 {
     if (!lds_kernel_supports(a.N, a.MF)) return hipErrorInvalidValue; // (fill_args rejects these before they get here)
@@ -397,7 +445,11 @@ hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
         // exhausted and the previous outputs in place
         hipLaunchKernelGGL(reset_counter_kernel, dim3(1), dim3(256), 0, stream, k.counter, k.cu_slots);
     }
-    return launch_ipm_lds(k, slots, stream);
+    const bool timed = g_timer.on && (g_timer.seen++ % g_timer.stride) == 0 && 2 * (size_t)g_timer.used + 1 < g_timer.ev.size();
+    if (timed) (void)hipEventRecord(g_timer.ev[2 * g_timer.used], stream);
+    const hipError_t rc = launch_ipm_lds(k, slots, stream);
+    if (timed) { (void)hipEventRecord(g_timer.ev[2 * g_timer.used + 1], stream); g_timer.used++; }
+    return rc;
 }
 
 hipError_t launch_stage_eval(int B, int N, int M, int model, const double *z, const double *params, double *f,

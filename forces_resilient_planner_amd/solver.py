@@ -125,7 +125,8 @@ EXPORTS = ["frp_nmpc_default_options", "frp_nmpc_workspace_bytes", "frp_nmpc_sol
            "FORCESNLPsolver_final_solve", "frp_nmpc_pack_batch", "frp_nmpc_update_batch", "frp_nmpc_tube_batch",
            "frp_nmpc_corridor_batch", "frp_nmpc_reference_batch",
            "frp_nmpc_coldstart_batch", "frp_nmpc_cloud_grid_build",
-           "frp_nmpc_mode_batch", "frp_nmpc_astar_batch", "frp_nmpc_astar_workspace_bytes"]
+           "frp_nmpc_mode_batch", "frp_nmpc_astar_batch", "frp_nmpc_astar_workspace_bytes",
+           "frp_nmpc_kernel_timing_begin", "frp_nmpc_kernel_timing_end"]
 
 _lib = None
 
@@ -154,6 +155,8 @@ def lib():
         l.frp_nmpc_time_solve.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(Options), ctypes.c_void_p,
                                           ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         l.frp_nmpc_solve_batch_host.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(Options)]
+        l.frp_nmpc_kernel_timing_begin.argtypes = [ctypes.c_int, ctypes.c_int]
+        l.frp_nmpc_kernel_timing_end.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
         l.frp_nmpc_pack_batch.argtypes = [ctypes.POINTER(Pack), ctypes.c_void_p]
         l.frp_nmpc_update_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_void_p]
@@ -278,6 +281,18 @@ class DeviceSolver:
         _check(lib().frp_nmpc_time_solve(ctypes.byref(b), ctypes.byref(self.opt), self.ws.data_ptr(), self.ws_bytes,
                                          ctypes.c_void_p(s.cuda_stream), reps, ctypes.byref(ms)), "frp_nmpc_time_solve")
         return ms.value
+
+
+def kernel_timing_begin(max_launches, stride=1):
+    """From here to kernel_timing_end() every `stride`-th solve launch carries a hipEvent pair around its dominant kernel (on its own stream)."""
+    _check(lib().frp_nmpc_kernel_timing_begin(int(max_launches), int(stride)), "frp_nmpc_kernel_timing_begin")
+
+
+def kernel_timing_end():
+    """(average ms of the dominant kernel over the launches since kernel_timing_begin, number of launches)."""
+    ms, n = ctypes.c_float(0), ctypes.c_int(0)
+    _check(lib().frp_nmpc_kernel_timing_end(ctypes.byref(ms), ctypes.byref(n)), "frp_nmpc_kernel_timing_end")
+    return ms.value, n.value
 
 
 def tube_batch_device(mpc_output, ellipsoid, consts=None, stream=None):

@@ -145,6 +145,15 @@ int frp_nmpc_stage_eval_host(int B, int N, int M, int model, const double *z, co
 int frp_nmpc_time_solve(const frp_nmpc_batch *batch, const frp_nmpc_options *opt, void *workspace,
                         size_t workspace_bytes, void *stream, int reps, float *avg_ms);
 
+/* Measurement hook (bench.py's roofline leg): between _begin and _end every `stride`-th frp_nmpc_solve_batch call records a
+ * hipEvent pair on ITS launch stream immediately around the dominant kernel (the interior-point solve; the launch-order
+ * kernels in front of it are outside the pair), for at most `max_launches` recorded calls.  _end waits for the recorded
+ * events and returns the number of launches recorded and their average duration in ms -- a sample of the SAME launches a
+ * caller timed from the host around the region (an event pair costs the launch ~8 us of queue bubbles on MI355X: stride 4
+ * keeps the observed region within 0.2 % of the unobserved one).  Process-global, not re-entrant; FRP_ERR_ARG when misused. */
+int frp_nmpc_kernel_timing_begin(int max_launches, int stride);
+int frp_nmpc_kernel_timing_end(float *avg_ms, int *launches);
+
 /* ---- (3) SURVEY 8f row f-1: the adapter's packing / result bookkeeping on the device (all pointers DEVICE) ---- */
 typedef struct frp_nmpc_pack {
     int B, N, M;   /* problems, horizon, corridor rows of the parameter layout (num_const, nmpc_utils.h:50)      */

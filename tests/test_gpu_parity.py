@@ -124,6 +124,31 @@ def test_batch_matches_scipy_fixtures(fam, golden_dir):
         assert np.max(np.abs(zt[conv] - g["z"][sel][conv])) < 3e-4
 
 
+def test_hip_path_converges_on_the_hard_family_at_default_options(golden_dir):
+    """>= 100 hard-but-feasible instances (reference 3..5 m away, |f_ext| 6..9 m/s^2, 5..10 cm of corridor
+    slack after tightening, post-replan warm starts) that SLSQP solves on the reference callbacks; the HIP path converges on ALL
+    of them at the default diverge_mu, to SLSQP's point or to a certified better KKT point (tests/test_oracle.py:hard_family_check)."""
+    from .test_oracle import hard_family_check
+    g = np.load(os.path.join(golden_dir, "solutions_hard.npz"), allow_pickle=False)
+    N, M = int(g["N"]), int(g["M"])
+    n = g["z"].shape[0]
+    z = np.zeros((n, N, 17)); zt = np.zeros((n, N, 17)); fl = np.zeros(n, dtype=int); flt = np.zeros(n, dtype=int); pobj = np.zeros(n)
+    tight = solver.default_options()
+    tight.tol_stat = tight.tol_eq = tight.tol_ineq = tight.tol_comp = 1e-8
+    for model in np.unique(g["model"]):
+        sel = np.where(g["model"] == model)[0]
+        w = dict(xinit=g["xinit"][sel], x0=g["x0"][sel], params=g["params"][sel], nfaces=g["nfaces"][sel], N=N, M=M, model=int(model))
+        z[sel], fl[sel], it, info = solver.solve_batch_host(w)      # default options: diverge_mu 1e3
+        pobj[sel] = info[:, 4]
+        zt[sel], flt[sel], _, _ = solver.solve_batch_host(w, tight)
+        # and the oracle agrees instance by instance (same algorithm): flags everywhere, iterates where the counts are equal
+        zo, flo, io = OL.solve_batch(w)
+        assert np.array_equal(fl[sel], flo)
+        same = (flo == 1) & (it == np.array([i.it for i in io]))
+        assert same.mean() > 0.9 and np.max(np.abs(z[sel][same] - zo[same])) < 1e-5
+    hard_family_check(g, z, fl, pobj, zt, flt)
+
+
 def test_full_size_properties():
     """BASELINE configs[2] at full size (B=4096): size-independent properties of the returned plans."""
     w = workloads.config2(4096)

@@ -1,5 +1,8 @@
-"""Soak test (GPU box): many launches with random batch sizes / configs / horizons, exit flags and iteration counts against
-the oracle on every launch.   python tests/tools/soak.py [seconds=90]"""
+"""Soak test (GPU box): many launches with random batch sizes / configs / horizons (and the hard family of workloads.config_hard),
+exit flags, iteration counts AND iterates against the oracle on every launch.   python tests/tools/soak.py [seconds=90]
+Bound on the iterates (round 4): two converged solves with equal iteration counts agree to DZ_TOL = 1e-3; a pair beyond it must be a
+documented bifurcation -- both points KKT points within the tolerances with different objectives -- and is PRINTED as an exception,
+at most MAX_EXCEPTIONS of them per run; anything else fails the run."""
 import sys, time
 import numpy as np
 import os
@@ -9,12 +12,15 @@ import tests.oracle_lib as OL
 T = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
 rng = np.random.default_rng(2026)
 t0 = time.time(); n = 0; solved = 0; worst = 0.0; worst_at = None
+DZ_TOL, MAX_EXCEPTIONS = 1e-3, 3
+exceptions = []; flag_mismatches = 0
 while time.time() - t0 < T:
-    kind = int(rng.integers(0, 4)); B = int(rng.integers(1, 5000)); seed = int(rng.integers(0, 1 << 30))
+    kind = int(rng.integers(0, 5)); B = int(rng.integers(1, 5000)); seed = int(rng.integers(0, 1 << 30))
     if kind == 0: w = workloads.config1(B, seed=seed)
     elif kind == 1: w = workloads.config2(B, seed=seed, model=int(rng.integers(0, 2)))
     elif kind == 2: w = workloads.config3(min(B, 1500), seed=seed, N=int(rng.integers(2, 41)), M=15)
-    else: w = workloads.config3(min(B, 800), seed=seed, N=int(rng.integers(41, 65)), M=int(rng.integers(15, 31)))
+    elif kind == 3: w = workloads.config3(min(B, 800), seed=seed, N=int(rng.integers(41, 65)), M=int(rng.integers(15, 31)))
+    else: w = workloads.config_hard(min(B, 2000), seed=seed, model=int(rng.integers(0, 2)))
     z, fl, it, info = solver.solve_batch_host(w)
     zo, flo, io = OL.solve_batch(w, nthreads=16)
     ito = np.array([i.it for i in io])
@@ -22,6 +28,18 @@ while time.time() - t0 < T:
     mism = int((fl != flo).sum())
     same = ok & (it == ito)
     dz = float(np.max(np.abs(z[same] - zo[same]))) if same.any() else 0.0
+    flag_mismatches += mism
+    # every pair of converged solves with equal iteration counts beyond DZ_TOL: a bifurcation (both are KKT points within the
+    # tolerances, the objectives differ) goes on the exception list, anything else is a failure
+    dall = np.where(same, np.abs(z - zo).reshape(len(fl), -1).max(1), 0.0)
+    for b in np.where(dall > DZ_TOL)[0]:
+        b = int(b)
+        rec = dict(kind=kind, B=B, seed=seed, N=int(w["N"]), M=int(w["M"]), problem=b, iterations=int(it[b]), dz=float(dall[b]), obj_gpu=float(info[b, 4]),
+                   obj_oracle=float(io[b].pobj), kkt_gpu=[float(x) for x in info[b, :4]], kkt_oracle=[io[b].res_eq, io[b].res_ineq, io[b].rsnorm, io[b].rcompnorm])
+        both_kkt = max(rec["kkt_gpu"]) <= 1e-4 and max(rec["kkt_oracle"]) <= 1e-4
+        assert both_kkt and abs(rec["obj_gpu"] - rec["obj_oracle"]) > 1e-6 * abs(rec["obj_oracle"]), ("converged solves differ and it is not a bifurcation", rec)
+        exceptions.append(rec)
+        assert len(exceptions) <= MAX_EXCEPTIONS, exceptions
     if dz > worst:
         worst = dz
         if dz > 1e-3: # two converged solves that differ: which problem, how many iterations, both objectives (a bifurcation between local minima?)
@@ -37,5 +55,7 @@ while time.time() - t0 < T:
     assert np.all(np.isfinite(z[fl == 1]))
     assert (it[ok] == ito[ok]).mean() > 0.97 if ok.any() else True
     n += 1; solved += len(fl)
-print(f"soak: {n} launches, {solved} problems, {time.time() - t0:.0f} s, worst |dz| at equal iteration counts {worst:.2e}: OK")
-if worst_at: print("largest difference between two converged solves with equal iteration counts:", worst_at)
+print(f"soak: {n} launches, {solved} problems, {time.time() - t0:.0f} s, {flag_mismatches} exit-flag mismatches ({flag_mismatches / max(1, solved):.2e} of the problems), "
+      f"worst |dz| at equal iteration counts {worst:.2e}; pairs beyond {DZ_TOL:g}: {len(exceptions)} (allowed: {MAX_EXCEPTIONS}, each a certified bifurcation)")
+for e in exceptions: print("EXCEPTION (two KKT points of one non-convex NLP):", e)
+print("PASS")
