@@ -38,6 +38,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/frp_nmpc.h"
 
 namespace frp {
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(CR_THREADS) __attribute__((amdgpu_waves_per_eu(FRP_
     uint32_t *list = reinterpret_cast<uint32_t *>(s_mask + 3 * sc.W);
     const double *ref = c.ref_pos + (size_t)b * c.N * 3, *yaw = c.ref_yaw + (size_t)b * c.N, *Eb = c.ellipsoid + (size_t)b * c.N * 9;
     const bool has_box = c.bbox[0] != 0.0 || c.bbox[1] != 0.0 || c.bbox[2] != 0.0;
-    if (!GRID && only_flagged && c.poly_index[(size_t)b * c.N] != -1) return;
+    if (only_flagged && c.poly_index[(size_t)b * c.N] != -1) return; // (behind another kernel: only the planners it left flagged)
     int npoly = 0, rows = 0; // rows = stored rows of the last polytope (s_A / s_b)
     // Every round of the reference's while-loops removes at least the closest point, so a list is exhausted after at
     // most Pn rounds; the bound only matters for non-finite input, where the reference would spin forever.
@@ -720,6 +721,343 @@ __global__ __launch_bounds__(CR_THREADS) __attribute__((amdgpu_waves_per_eu(FRP_
     }
 }
 
+
+// ================================================================== one wavefront per planner (round 4)
+// A decomposition is a chain of ~20 dependent rounds (pick the closest point, cut, filter), each a few hundred instructions: with four
+// wavefronts per planner a round pays a workgroup barrier, an LDS exchange of the per-wave minima and the latency of everything in
+// between, and the CU holds 3 planners (12 waves at the 168-register budget).  Measured on the full-tick workload (4096 planners,
+// 18 k points, ~1000 of them in a local box): per planner and tick 58 us in 42 scans, 33 us in the two first scans, 25 us between
+// scans, 15 us in 20 containment checks -- all latency; two waves per planner (6 per CU) already ran 0.90 -> 0.76 ms.  This kernel
+// gives a planner ONE wavefront, so nothing in a round crosses a wave:
+//   * the in-box points live in the wave's registers, CW_TILE points per lane; the point sets (obs_, obs, the working set) are one
+//     bit per point in three 32-bit registers PER LANE -- no LDS masks, no ballots to store them, empty tile rows are skipped;
+//   * the closest point of a round is a DPP minimum and six v_readlane: no barrier, no LDS;
+//   * the hyperplane loop (decomp_base.h:63-83) compares distances in a FIXED ellipsoid: they are computed once by its opening scan;
+//   * the containment checks of the stages behind a new polytope (nmpc_solver.cpp:291-313) are evaluated together, lane = stage, the
+//     rows read from LDS: one global round trip per polytope instead of one per stage;
+//   * the first scan reads the grid rows under the box's hull CW_ROWS at a time, their cell ranges fetched by 64 lanes at once.
+// The wave-uniform 3x3 algebra stays on lane 0 behind LDS (struct Uni) exactly as in the four-wave kernel -- same instructions, same
+// results: the two kernels produce bit-identical polytopes (tests/test_gpu_parity.py::test_corridor_wave_kernel_equals_the_workgroup_kernel).
+// Measured (full tick, 4096 planners): corridor 0.90 -> 0.40 ms at CW_TILE = 20 (1280 points in registers, 2 waves per SIMD = 8 planners per
+// CU); three waves per SIMD (168 registers) spills 115-132 registers and runs 0.60-0.73 ms, 24 tile rows 0.43, four grid rows in flight 0.40.
+// Needs the uniform grid and the local box (the production configuration); a planner whose box holds more than CW_CAP points flags
+// itself (poly_index[b][0] = -1) and is redone by the workgroup kernels launched behind.
+#ifndef FRP_CW_TILE
+#define FRP_CW_TILE 20
+#endif
+#ifndef FRP_CW_WPE
+#define FRP_CW_WPE 2
+#endif
+#ifndef FRP_CW_ROWS
+#define FRP_CW_ROWS 8
+#endif
+#ifndef FRP_CW_D2   // experiment knob: 0 = recompute the hyperplane loop's distances every round (20 registers fewer)
+#define FRP_CW_D2 1
+#endif
+constexpr int CW_TILE = FRP_CW_TILE, CW_CAP = 64 * CW_TILE, CW_ROWS = FRP_CW_ROWS;
+static_assert(CW_TILE <= 32, "one bit per tile row in a 32-bit lane mask");
+struct TileW { double x[CW_TILE], y[CW_TILE], z[CW_TILE], d2[FRP_CW_D2 ? CW_TILE : 1]; int id[CW_TILE]; };
+
+#define CW_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l) << 32) |
+                                            (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l)));
+}
+// the wave's minimum in (distance, cloud index) order, uniform in every lane; idx = INT_MAX when no lane had a point
+__device__ __forceinline__ Best wave_best(const Best &mine)
+{
+    const double d = wave_min_f64(mine.dist);
+    uint64_t own = __ballot(mine.dist == d && mine.idx != 0x7fffffff);
+    if (own == 0) return Best{1.7976931348623157e308, 0x7fffffff, 0.0, 0.0, 0.0};
+    if (own & (own - 1)) { // equal distances: the smaller cloud index (the reference's first minimum on its order-preserving lists)
+        const int i = wave_min_i32(mine.dist == d ? mine.idx : 0x7fffffff);
+        own = __ballot(mine.dist == d && mine.idx == i);
+    }
+    const int l = __builtin_ctzll(own);
+    Best r;
+    r.dist = d; r.idx = __builtin_amdgcn_readlane(mine.idx, l);
+    r.x = readlane_f64(mine.x, l); r.y = readlane_f64(mine.y, l); r.z = readlane_f64(mine.z, l);
+    return r;
+}
+
+template <int MODE>
+__device__ __forceinline__ Best scan_wave(TileW &t, int W, unsigned in, unsigned &out, const Uni &u, const double *pq = nullptr, const double *pn = nullptr)
+{
+    const M3 Ci = ld3(u.Ci);
+    const double d[3] = {u.mid[0], u.mid[1], u.mid[2]};
+    double q[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+    if (MODE == KEEP_BEHIND_PLANE) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { q[k] = pq[k]; n[k] = pn[k]; }
+    }
+    Best best{1.7976931348623157e308, 0x7fffffff, 0.0, 0.0, 0.0};
+    unsigned o = 0;
+#pragma unroll
+    for (int j = 0; j < CW_TILE; ++j) {
+        if (j < W) {
+            bool alive = (in >> j) & 1u;
+            if (__ballot(alive) != 0) { // (wave-uniform: a tile row with no member is skipped)
+                if (alive) {
+                    const double dist = (MODE == KEEP_BEHIND_PLANE && FRP_CW_D2) ? t.d2[FRP_CW_D2 ? j : 0] : ell_dist2(Ci, d, t.x[j], t.y[j], t.z[j]);
+                    if (MODE == KEEP_ALL && FRP_CW_D2) t.d2[FRP_CW_D2 ? j : 0] = dist;
+                    if (MODE == KEEP_OUTSIDE) alive = 1 - sqrt(dist) > CR_EPS;
+                    if (MODE == KEEP_INSIDE) alive = dist <= 1;
+                    if (MODE == KEEP_BEHIND_PLANE) alive = n[0] * (t.x[j] - q[0]) + n[1] * (t.y[j] - q[1]) + n[2] * (t.z[j] - q[2]) < 0;
+                    if (alive && before(dist, t.id[j], best.dist, best.idx)) best = Best{dist, t.id[j], t.x[j], t.y[j], t.z[j]};
+                }
+                o |= (alive ? 1u : 0u) << j;
+            }
+        }
+    }
+    out = o;
+    return wave_best(best);
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, FRP_CW_WPE))) void corridor_wave_kernel(frp_nmpc_corridor c)
+{
+    __shared__ double s_A[FRP_CORRIDOR_MAX_F * 3], s_b[FRP_CORRIDOR_MAX_F];
+    __shared__ uint32_t list[CW_CAP];
+    __shared__ Uni u;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const double *ref = c.ref_pos + (size_t)b * c.N * 3, *yaw = c.ref_yaw + (size_t)b * c.N, *Eb = c.ellipsoid + (size_t)b * c.N * 9;
+    const int P_cloud = c.P;
+    const int max_rounds = P_cloud + 8; // (see corridor_kernel: only non-finite input needs the bound)
+    if (lane == 0) u.overflow = 0;
+    int npoly = 0;
+    int i = 0;
+    while (i < c.N) {
+        // ---- new decomposition around the seed segment of stage i (nmpc_solver.cpp:315-329): lane 0, as in corridor_kernel ----
+        if (lane == 0) {
+            double sy, cy;
+            sincos(yaw[i], &sy, &cy);
+            const double p1[3] = {ref[3 * i], ref[3 * i + 1], ref[3 * i + 2]};
+            const double p2[3] = {p1[0] + c.seed_len * cy, p1[1] + c.seed_len * sy, p1[2]};
+            const double dv[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+            const double len = sqrt(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) u.mid[k] = (p1[k] + p2[k]) / 2;
+            u.len = len;
+            { // local box planes (line_segment.h:47-85)
+                const double dir[3] = {dv[0] / len, dv[1] / len, dv[2] / len};
+                double dh[3] = {dir[1], -dir[0], 0.0};
+                double hn = sqrt(dh[0] * dh[0] + dh[1] * dh[1]);
+                if (hn == 0.0) { dh[0] = -1.0; dh[1] = 0.0; hn = 1.0; }
+                dh[0] /= hn; dh[1] /= hn;
+                const double dvv[3] = {dir[1] * dh[2] - dir[2] * dh[1], dir[2] * dh[0] - dir[0] * dh[2], dir[0] * dh[1] - dir[1] * dh[0]};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    u.frame[0][k] = dh[k]; u.frame[1][k] = dir[k]; u.frame[2][k] = dvv[k]; u.p1[k] = p1[k];
+                    u.box[0][k] = p1[k] + dh[k] * c.bbox[1];  u.box[6][k] = dh[k];
+                    u.box[1][k] = p1[k] - dh[k] * c.bbox[1];  u.box[7][k] = -dh[k];
+                    u.box[2][k] = p2[k] + dir[k] * c.bbox[0]; u.box[8][k] = dir[k];
+                    u.box[3][k] = p1[k] - dir[k] * c.bbox[0]; u.box[9][k] = -dir[k];
+                    u.box[4][k] = p1[k] + dvv[k] * c.bbox[2]; u.box[10][k] = dvv[k];
+                    u.box[5][k] = p1[k] - dvv[k] * c.bbox[2]; u.box[11][k] = -dvv[k];
+                }
+            }
+            const double f = len / 2;
+            double ax0 = f + c.offset_x, ax1 = f, ax2 = f, c00 = f + c.offset_x, cdd = f;
+            if (ax0 > 0) { const double ratio = ax1 / ax0; ax0 *= ratio; ax1 *= ratio; ax2 *= ratio; c00 *= ratio; cdd *= ratio; }
+            u.ax[0] = ax0; u.ax[1] = ax1; u.ax[2] = ax2;
+            const double pitch = atan2(-dv[2], sqrt(dv[0] * dv[0] + dv[1] * dv[1])), yw = atan2(dv[1], dv[0]);
+            const M3 Ri = mul(quat_to_rot(cos(yw / 2), 0, 0, sin(yw / 2)), quat_to_rot(cos(pitch / 2), 0, sin(pitch / 2), 0));
+            st3(u.Ri, Ri); st3(u.Rf, Ri);
+            st3(u.Ci, inverse(rot_diag_rot(Ri, c00, cdd, cdd)));
+        }
+        CW_SYNC();
+        // ---- first scan through the grid: the in-box points -> list (cloud index | inside-the-seed-ellipsoid flag), the closest inside one
+        int count = 0;
+        Best cp;
+        {
+            const M3 Ci = ld3(u.Ci);
+            const double d[3] = {u.mid[0], u.mid[1], u.mid[2]};
+            double fr[3][3], o[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                o[k] = u.p1[k];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) fr[k][j] = u.frame[k][j];
+            }
+            const double bh = c.bbox[1] + CR_EPS, bd_lo = -c.bbox[0] - CR_EPS, bd_hi = u.len + c.bbox[0] + CR_EPS, bv = c.bbox[2] + CR_EPS;
+            int lo[3], hi[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double ctr = o[k] + 0.5 * (bd_lo + bd_hi) * fr[1][k];
+                const double half = bh * fabs(fr[0][k]) + 0.5 * (bd_hi - bd_lo) * fabs(fr[1][k]) + bv * fabs(fr[2][k]);
+                const double a = floor((ctr - half - c.grid_origin[k]) / c.grid_cell), bb = floor((ctr + half - c.grid_origin[k]) / c.grid_cell);
+                const int n = c.grid_dims[k];
+                lo[k] = a < 0 ? 0 : (a > n - 1 ? n - 1 : (int)a);
+                hi[k] = bb < 0 ? 0 : (bb > n - 1 ? n - 1 : (int)bb);
+            }
+            const int ny = hi[1] - lo[1] + 1, rows = ny * (hi[2] - lo[2] + 1), nx = c.grid_dims[0];
+            Best best{1.7976931348623157e308, 0x7fffffff, 0.0, 0.0, 0.0};
+            for (int rb = 0; rb < rows; rb += 64) { // 64 rows of cells at a time: lane = row, its point range in one round trip
+                int mbeg = 0, mend = 0;
+                if (rb + lane < rows) {
+                    const int r = rb + lane;
+                    const size_t row = ((size_t)(lo[2] + r / ny) * c.grid_dims[1] + (lo[1] + r % ny)) * nx;
+                    mbeg = c.grid_start[row + lo[0]];
+                    mend = c.grid_start[row + hi[0] + 1];
+                }
+                const int nr = rows - rb < 64 ? rows - rb : 64;
+                for (int r0 = 0; r0 < nr; r0 += CW_ROWS) {
+                    int beg[CW_ROWS], end[CW_ROWS], most = 0;
+#pragma unroll
+                    for (int k = 0; k < CW_ROWS; ++k) {
+                        const int rr = r0 + k < 64 ? r0 + k : 63;
+                        beg[k] = __builtin_amdgcn_readlane(mbeg, rr); end[k] = __builtin_amdgcn_readlane(mend, rr);
+                        if (r0 + k >= nr) beg[k] = end[k] = 0;
+                        most = max(most, end[k] - beg[k]);
+                    }
+                    for (int off = 0; off < most; off += 64) {
+                        double x[CW_ROWS], y[CW_ROWS], z[CW_ROWS];
+                        int id[CW_ROWS];
+#pragma unroll
+                        for (int k = 0; k < CW_ROWS; ++k) {
+                            const int p = beg[k] + off + lane;
+                            const bool ok = p < end[k];
+                            const size_t p3 = 3 * (size_t)(ok ? p : 0);
+                            x[k] = ok ? c.grid_points[p3] : 0.0; y[k] = ok ? c.grid_points[p3 + 1] : 0.0; z[k] = ok ? c.grid_points[p3 + 2] : 0.0;
+                            id[k] = ok ? c.grid_index[p] : -1;
+                        }
+#pragma unroll
+                        for (int k = 0; k < CW_ROWS; ++k) {
+                            bool in0 = id[k] >= 0, i1 = false;
+                            const double ex = x[k] - o[0], ey = y[k] - o[1], ez = z[k] - o[2];
+                            const double h = fr[0][0] * ex + fr[0][1] * ey + fr[0][2] * ez, tt = fr[1][0] * ex + fr[1][1] * ey + fr[1][2] * ez,
+                                         v = fr[2][0] * ex + fr[2][1] * ey + fr[2][2] * ez;
+                            in0 = in0 && !(h > bh) && !(-h > bh) && !(tt > bd_hi) && !(tt < bd_lo) && !(v > bv) && !(-v > bv);
+                            if (in0) {
+                                const double dist = ell_dist2(Ci, d, x[k], y[k], z[k]);
+                                i1 = dist <= 1;
+                                if (i1 && before(dist, id[k], best.dist, best.idx)) best = Best{dist, id[k], x[k], y[k], z[k]};
+                            }
+                            const uint64_t w0 = __ballot(in0);
+                            if (w0) {
+                                const int mine = count + (int)__popcll(w0 & ((1ull << lane) - 1));
+                                if (in0 && mine < CW_CAP) list[mine] = (uint32_t)id[k] | (i1 ? 0x80000000u : 0u);
+                                count += (int)__popcll(w0);
+                            }
+                        }
+                    }
+                }
+            }
+            cp = wave_best(best);
+        }
+        if (count > CW_CAP) { // more points in the box than the register tile holds: the workgroup kernels behind take this planner
+            if (lane == 0) c.poly_index[(size_t)b * c.N] = -1;
+            return;
+        }
+        CW_SYNC();
+        // ---- the register tile and the three point sets (one bit per tile row and lane)
+        const int W = (count + 63) / 64;
+        TileW tile;
+        unsigned m0 = 0, m1 = 0, m2 = 0;
+#pragma unroll
+        for (int j = 0; j < CW_TILE; ++j) {
+            const int pos = j * 64 + lane;
+            const bool valid = pos < count;
+            const uint32_t e = valid ? list[pos] : 0u;
+            const int idj = (int)(e & 0x7fffffffu);
+            tile.id[j] = idj;
+            tile.x[j] = valid ? c.cloud[3 * (size_t)idj] : 0.0;
+            tile.y[j] = valid ? c.cloud[3 * (size_t)idj + 1] : 0.0;
+            tile.z[j] = valid ? c.cloud[3 * (size_t)idj + 2] : 0.0;
+            if (FRP_CW_D2) tile.d2[FRP_CW_D2 ? j : 0] = 0.0;
+            m0 |= (valid ? 1u : 0u) << j;
+            m1 |= ((valid && (e >> 31)) ? 1u : 0u) << j;
+        }
+        m2 = m1;
+        // shrink the second axis until no obstacle is inside (line_segment.h:156-181)
+        for (int guard = 0; cp.idx != 0x7fffffff && guard < max_rounds; ++guard) {
+            if (lane == 0) {
+                const double pw[3] = {cp.x - u.mid[0], cp.y - u.mid[1], cp.z - u.mid[2]};
+                const M3 Ri = ld3(u.Ri);
+                double p[3];
+                tmul(Ri, pw, p);
+                const double roll = atan2(p[2], p[1]);
+                const M3 Rf = mul(Ri, quat_to_rot(cos(roll / 2), sin(roll / 2), 0, 0));
+                tmul(Rf, pw, p);
+                if (p[0] < u.ax[0]) u.ax[1] = fabs(p[1]) / sqrt(1 - (p[0] / u.ax[0]) * (p[0] / u.ax[0]));
+                st3(u.Rf, Rf);
+                st3(u.Ci, inverse(rot_diag_rot(Rf, u.ax[0], u.ax[1], u.ax[1])));
+            }
+            CW_SYNC();
+            cp = scan_wave<KEEP_OUTSIDE>(tile, W, m2, m2, u);
+        }
+        // third axis (line_segment.h:183-208)
+        if (lane == 0) st3(u.Ci, inverse(rot_diag_rot(ld3(u.Rf), u.ax[0], u.ax[1], u.ax[2])));
+        CW_SYNC();
+        cp = scan_wave<KEEP_INSIDE>(tile, W, m1, m2, u);
+        for (int guard = 0; cp.idx != 0x7fffffff && guard < max_rounds; ++guard) {
+            if (lane == 0) {
+                const double pw[3] = {cp.x - u.mid[0], cp.y - u.mid[1], cp.z - u.mid[2]};
+                const M3 Rf = ld3(u.Rf);
+                double p[3];
+                tmul(Rf, pw, p);
+                const double dd = 1 - (p[0] / u.ax[0]) * (p[0] / u.ax[0]) - (p[1] / u.ax[1]) * (p[1] / u.ax[1]);
+                if (dd > CR_EPS) u.ax[2] = fabs(p[2]) / sqrt(dd);
+                st3(u.Ci, inverse(rot_diag_rot(Rf, u.ax[0], u.ax[1], u.ax[2])));
+            }
+            CW_SYNC();
+            cp = scan_wave<KEEP_OUTSIDE>(tile, W, m2, m2, u);
+        }
+        // hyperplanes (decomp_base.h:63-83) + LinearConstraint rows (polyhedron.h:98-118)
+        double *gA = c.poly_A + (((size_t)b * c.N + npoly) * c.F) * 3, *gb = c.poly_b + ((size_t)b * c.N + npoly) * c.F;
+        if (lane == 0) {
+            const M3 Ci = ld3(u.Ci);
+            st3(u.CC, mul(Ci, transpose(Ci)));
+            u.rows = 0;
+        }
+        CW_SYNC();
+        cp = scan_wave<KEEP_ALL>(tile, W, m0, m2, u);
+        for (int guard = 0; cp.idx != 0x7fffffff && guard < max_rounds; ++guard) {
+            const double q[3] = {cp.x, cp.y, cp.z};
+            const double w[3] = {q[0] - u.mid[0], q[1] - u.mid[1], q[2] - u.mid[2]};
+            double n[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) n[k] = u.CC[3 * k] * w[0] + u.CC[3 * k + 1] * w[1] + u.CC[3 * k + 2] * w[2];
+            const double nl = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) n[k] /= nl;
+            if (lane == 0) emit_row(u, q, n, c.F, s_A, s_b, gA, gb);
+            cp = scan_wave<KEEP_BEHIND_PLANE>(tile, W, m2, m2, u, q, n);
+        }
+        if (lane == 0) {
+            for (int k = 0; k < 6; ++k) emit_row(u, u.box[k], u.box[6 + k], c.F, s_A, s_b, gA, gb);
+            c.poly_nfaces[(size_t)b * c.N + npoly] = u.rows;
+            c.poly_index[(size_t)b * c.N + i] = npoly;
+        }
+        CW_SYNC();
+        const int rows = u.rows < c.F ? u.rows : c.F;
+        // ---- which of the stages behind still fit this polytope (nmpc_solver.cpp:291-313)?  lane = stage, all of them at once
+        bool viol = false;
+        if (lane > i && lane < c.N) {
+            const double *E = Eb + 9 * lane;
+            const double E0 = E[0], E1 = E[1], E2 = E[2], E3 = E[3], E4 = E[4], E5 = E[5], E6 = E[6], E7 = E[7], E8 = E[8];
+            const double r0 = ref[3 * lane], r1 = ref[3 * lane + 1], r2 = ref[3 * lane + 2];
+            for (int r = 0; r < rows; ++r) {
+                const double a0 = s_A[3 * r], a1 = s_A[3 * r + 1], a2 = s_A[3 * r + 2];
+                const double e0 = E0 * a0 + E1 * a1 + E2 * a2, e1 = E3 * a0 + E4 * a1 + E5 * a2, e2 = E6 * a0 + E7 * a1 + E8 * a2;
+                const double add = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+                viol = viol || (a0 * r0 + a1 * r1 + a2 * r2 - (s_b[r] - c.inflation * add)) > 0;
+            }
+        }
+        const uint64_t vm = __ballot(viol);
+        const int next = vm ? (int)__builtin_ctzll(vm) : c.N; // the first stage whose inflated tube ellipsoid leaves the polytope
+        if (lane > i && lane < next) c.poly_index[(size_t)b * c.N + lane] = npoly;
+        ++npoly;
+        i = next;
+    }
+    if (lane == 0) {
+        for (int k = npoly; k < c.N; ++k) c.poly_nfaces[(size_t)b * c.N + k] = 0;
+        if (c.poly_count) c.poly_count[b] = u.overflow ? -npoly : npoly;
+    }
+}
+
 } // namespace frp
 
 namespace frp {
@@ -808,7 +1146,13 @@ extern "C" int frp_nmpc_corridor_batch(const frp_nmpc_corridor *p, void *stream)
     const size_t lds = (size_t)3 * ((p->P + 63) / 64) * sizeof(uint64_t) + frp::CR_LIST * sizeof(uint32_t);
     const bool has_box = p->bbox[0] != 0.0 || p->bbox[1] != 0.0 || p->bbox[2] != 0.0;
     const bool grid = p->grid_start && has_box && !p->cloud_count;
-    if (grid) hipLaunchKernelGGL(frp::corridor_kernel<true>, dim3((unsigned)p->B), dim3(frp::CR_THREADS), lds, static_cast<hipStream_t>(stream), *p, 0);
+    // production configuration (shared cloud with a grid, local box, N <= 64 = one lane per stage): one wavefront per planner;
+    // planners it flags (more in-box points than its register tile) go to the workgroup kernel through the grid, and what THAT
+    // one flags (more than its LDS list) to the plain-cloud kernel.  FRP_CORRIDOR_WAVE=0 (experiments, the equality test): workgroup kernels only
+    static const bool wave_off = [] { const char *e = getenv("FRP_CORRIDOR_WAVE"); return e && e[0] == '0'; }();
+    const bool wave = grid && !wave_off;
+    if (wave) hipLaunchKernelGGL(frp::corridor_wave_kernel, dim3((unsigned)p->B), dim3(64), 0, static_cast<hipStream_t>(stream), *p);
+    if (grid) hipLaunchKernelGGL(frp::corridor_kernel<true>, dim3((unsigned)p->B), dim3(frp::CR_THREADS), lds, static_cast<hipStream_t>(stream), *p, wave ? 1 : 0);
     hipLaunchKernelGGL(frp::corridor_kernel<false>, dim3((unsigned)p->B), dim3(frp::CR_THREADS), lds, static_cast<hipStream_t>(stream), *p, grid ? 1 : 0);
     return hipGetLastError() == hipSuccess ? FRP_OK : FRP_ERR_HIP;
 }
