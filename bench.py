@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="the K-step region is timed this many times; the MEDIAN is reported")
     ap.add_argument("--no-order-hint", action="store_true", help="configs[4]: queue the problems by the cost of the initial guess instead of by the previous tick's iteration counts")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / end-to-end / drop-in latency legs")
+    ap.add_argument("--chunks", type=int, default=0, help="--scaling strong: pieces every shard is cut into so that transfers overlap the solve (1 = serial scatter -> "
+                    "solve -> gather; 0 = auto: 2 when there is more than one rank and a shard holds at least two rounds of resident workgroups, else 1 -- measured on "
+                    "one GPU, where nothing is transferred: a piece smaller than a round of resident workgroups costs more than it hides, profiles/r04_strong_chunks.txt)")
     ap.add_argument("--streams", type=int, default=1,
                     help="informational: `value` is always the strictly serial single-stream rate; the rate with the steps issued "
                          "round-robin on 2 streams (the tail of one launch overlapping the next) is reported in config.pipelined_*")
@@ -233,11 +236,18 @@ def main():
             shard_in = [ds.xinit[:B], ds.x0[:B], ds.params[:B], ds.nfaces[:B]]
             shard_out = [ds.z[:B], ds.exitflag[:B], ds.iters[:B]]
 
+            # the step streams the transfers UNDER the solve: every shard in pieces, piece c + 1 arriving and the plans of piece
+            # c - 1 leaving while piece c is solved (distributed.strong_step_overlapped; --chunks 1 = the serial scatter -> solve -> gather)
+            comm_s, comp_s = torch.cuda.Stream(dev), [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+            if args.chunks <= 0:
+                slots = 256 * (3 if N <= 20 else (2 if N <= 32 else 1))
+                args.chunks = 2 if (world > 1 and B >= 2 * slots) else 1
+
             def step():
-                D.scatter_batch(full_in, shard_in, B_total, sdist)
-                if B > 0:
-                    ds.solve(stream)
-                D.gather_batch(shard_out, full_out, B_total, sdist)
+                # (pieces alternate between two compute streams: the long solves that end one piece's launch overlap the next piece)
+                D.strong_step_overlapped(full_in, shard_in, shard_out, full_out, B_total, sdist,
+                                         lambda a_, b_, c_: ds.solve_range(a_, b_, torch.cuda.current_stream(dev), piece=c_ % 2), chunks=args.chunks,
+                                         comm_stream=comm_s, compute_stream=comp_s)
             phases = (lambda: D.scatter_batch(full_in, shard_in, B_total, sdist), lambda: ds.solve(stream) if B > 0 else None,
                       lambda: D.gather_batch(shard_out, full_out, B_total, sdist))
         else:
@@ -316,10 +326,12 @@ def main():
     # every 4th launch of the timed regions, on the launch stream (frp_nmpc_kernel_timing_*), read after the last region
     # (a pair costs its launch ~8 us of queue bubbles: observing every launch would slow the region it measures by 0.8 %)
     nrep = max(1, args.repeats)
-    ev_stride = 4 if nrep * args.steps >= 16 else 1
-    solver.kernel_timing_begin(nrep * args.steps + 8, ev_stride)
+    ev_stride = 4 if nrep * args.steps >= 16 and not strong else 1   # (strong scaling: a step is several piece launches, all of them timed)
+    solver.kernel_timing_begin((nrep * args.steps + 8) * (max(1, args.chunks) if strong else 1), ev_stride)
     reps = [timed(step, args.steps) for _ in range(nrep)]
     kernel_ms, kernel_launches = solver.kernel_timing_end()
+    if strong and kernel_launches:  # per step: the sum over the pieces of this rank's shard
+        kernel_ms = kernel_ms * kernel_launches / (nrep * args.steps)
     if dist is not None:
         t = torch.tensor(reps, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # every repeat: the slowest rank
@@ -354,7 +366,11 @@ def main():
                 acc[i] += timed(ph, 1)
         if dist is not None:
             tt = torch.tensor(acc, dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); acc = [float(x) for x in tt.cpu()]
-        phase_ms = {"scatter_ms": acc[0] / 5 * 1e3, "solve_ms": acc[1] / 5 * 1e3, "gather_ms": acc[2] / 5 * 1e3}
+        phase_ms = {"scatter_ms": acc[0] / 5 * 1e3, "solve_ms": acc[1] / 5 * 1e3, "gather_ms": acc[2] / 5 * 1e3, "chunks": args.chunks,
+                    # what the overlapped step still pays for the transfers: its time minus the solve of the whole shard in one launch
+                    "exposed_transfer_ms": elapsed / args.steps * 1e3 - acc[1] / 5 * 1e3,
+                    "note": "scatter / solve / gather timed one after the other, each between barriers (what the serial step would cost); the timed "
+                            "step itself cuts every shard into `chunks` pieces and streams the transfers under the solves"}
 
     fl = ds.exitflag[:max(B, 1)].cpu().numpy(); it = ds.iters[:max(B, 1)].cpu().numpy()
     if B == 0:

@@ -1593,7 +1593,6 @@ for (int r = RB0; r < RB1; r++) {
     bool gn_retry = false;              // this iteration is being redone with the Gauss-Newton Hessian
     Norms nm = {0, 0, 0, 0, 0, 0};
     double mu = 0.0, step_cc = 0.0;
-    double i_muaff = 0.0, i_sigma = 0.0, i_stepaff = 0.0; // wave 0: the last iteration's affine-step quantities for the info block
 #ifndef FRP_R_PRIO
 #define FRP_R_PRIO 0
 #endif
@@ -1812,8 +1811,11 @@ for (int r = RB0; r < RB1; r++) {
             smu = sigma * mu;
             if (smu < MU_FLOOR_FRAC * a.tol_comp) smu = MU_FLOOR_FRAC * a.tol_comp;
             smu = uni(smu);
-            if constexpr (wave == 0) { // reported, not iterated on (info.mu_aff / sigma / step_aff, FORCESNLPsolver_normal.h:275-289)
-                i_muaff = uni(gap_aff * fast_rcp((double)mtot)); i_sigma = uni(sigma); i_stepaff = uni(ap);
+            // reported, not iterated on (info.mu_aff / sigma / step_aff, FORCESNLPsolver_normal.h:275-289): every wave has the values;
+            // the faces wave -- the one on the SIMD without a Riccati wave -- parks them in three free scratch slots, the Riccati wave
+            // picks them up at exit (carried in ITS registers across the sweeps they cost 0.5 % of the launch, measured)
+            if constexpr (wave == 3) {
+                if (lane == 0) { xs[X_RED + 3 * 16 + 14] = gap_aff * fast_rcp((double)mtot); xs[X_RED + 3 * 16 + 15] = sigma; xs[X_RED + 2 * 16 + 14] = ap; }
             }
         }
 
@@ -2023,7 +2025,8 @@ for (int r = RB0; r < RB1; r++) {
         if (a.info) {
             double *o = a.info + (size_t)b * FRP_INFO_STRIDE;
             o[0] = nm.eq; o[1] = nm.in; o[2] = nm.rs; o[3] = nm.rc; o[5] = mu; o[6] = step_cc; o[7] = (double)nfallback; // o[4] = objective: wave 1
-            o[8] = i_muaff; o[9] = i_sigma; o[10] = i_stepaff; o[11] = nm.gap;
+            o[8] = it > 0 ? xs[X_RED + 3 * 16 + 14] : 0.0; o[9] = it > 0 ? xs[X_RED + 3 * 16 + 15] : 0.0; o[10] = it > 0 ? xs[X_RED + 2 * 16 + 14] : 0.0;
+            o[11] = nm.gap;
 #ifdef FRP_PROFILE // tools/timeline.py: start and end of this solve on the 100 MHz wall clock instead of the last two fields
             o[6] = (double)pwall0_; o[7] = (double)wall_clock64();
 #endif

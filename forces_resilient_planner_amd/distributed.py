@@ -81,6 +81,131 @@ def gather_batch(shard, full, B: int, dist, dst: int = 0):
             req.wait()
 
 
+def chunk_bounds(n: int, chunks: int):
+    """Cut a shard of n problems into `chunks` pieces for the overlapped strong-scaling step: a small first piece (n / 8, so the
+    first solve starts early) and equal ones behind it.  Returns the boundaries [0, b1, ..., n] (empty pieces dropped)."""
+    if chunks <= 1 or n <= 1:
+        return [0, n]
+    first = max(1, n // 8)
+    rest = n - first
+    k = chunks - 1
+    b = [0, first] + [first + (rest * (i + 1)) // k for i in range(k)]
+    out = [0]
+    for x in b[1:]:
+        if x > out[-1]:
+            out.append(x)
+    return out
+
+
+def _exchange(full, part, B: int, dist, root: int, to_root: bool, piece, chunks: int):
+    """One grouped P2P exchange of piece `piece` of every rank's shard: root -> ranks (scatter) or ranks -> root (gather).
+    full: tensors [B, ...] on the root; part: this rank's shard tensors [hi - lo, ...]."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ops = []
+    if rank == root:
+        for r in range(world):
+            lo, hi = shard_range(B, r, world)
+            cb = chunk_bounds(hi - lo, chunks)
+            if piece + 1 >= len(cb):
+                continue
+            a, b = cb[piece], cb[piece + 1]
+            if b <= a:
+                continue
+            for f, s in zip(full, part):
+                if r == root:
+                    if to_root: f[lo + a:lo + b].copy_(s[a:b])
+                    else: s[a:b].copy_(f[lo + a:lo + b])
+                elif to_root:
+                    ops.append(dist.P2POp(dist.irecv, f[lo + a:lo + b], r))  # a leading-dimension slice is contiguous
+                else:
+                    ops.append(dist.P2POp(dist.isend, f[lo + a:lo + b], r))
+    else:
+        lo, hi = shard_range(B, rank, world)
+        cb = chunk_bounds(hi - lo, chunks)
+        if piece + 1 < len(cb):
+            a, b = cb[piece], cb[piece + 1]
+            for s in part:
+                if b > a:
+                    ops.append(dist.P2POp(dist.isend if to_root else dist.irecv, s[a:b], root))
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
+def strong_step_overlapped(full_in, shard_in, shard_out, full_out, B: int, dist, solve_range, chunks: int = 4,
+                           comm_stream=None, compute_stream=None, root: int = 0):
+    """SURVEY 8e's scatter -> solve -> gather with the transfers streamed UNDER the solve: every rank's shard
+    is cut into pieces (chunk_bounds); piece c + 1 is in flight from the root while piece c is being solved, and the plans of
+    piece c travel back while piece c + 1 is being solved -- the way HostPipe overlaps PCIe for the host-buffer API.
+    solve_range(a, b, c) solves the local problems [a, b) = piece c (asynchronous on the current stream on a GPU, synchronous in the gloo tests).
+    On a GPU pass two torch streams: the exchanges are enqueued on comm_stream, the solves on compute_stream, ordered by events; the
+    caller's current stream waits for both at the end.  Without streams (gloo / CPU tensors) the same schedule runs in order, so the
+    results are those of the one-piece step by construction -- and by test (tests/test_distributed_cpu.py).
+    Returns the number of pieces this rank solved."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_range(B, rank, world)
+    n_max = max(shard_range(B, r, world)[1] - shard_range(B, r, world)[0] for r in range(world))
+    pieces = len(chunk_bounds(n_max, chunks)) - 1   # every rank walks the same number of exchanges (grouped P2P is collective-like)
+    cb = chunk_bounds(hi - lo, chunks)
+    gpu = comm_stream is not None and compute_stream is not None
+    # compute_stream may be a list: piece c is solved on stream c mod len, so the few long solves that end one piece's launch overlap
+    # the head of the next (solve_range then gets the piece number and must give concurrent pieces their own queue workspace)
+    comp = list(compute_stream) if isinstance(compute_stream, (list, tuple)) else [compute_stream]
+    if gpu:
+        import torch
+        cur = torch.cuda.current_stream()
+        comm_stream.wait_stream(cur)
+        for cs in comp:
+            cs.wait_stream(cur)
+        arrived = [torch.cuda.Event() for _ in range(pieces)]
+        solved = [torch.cuda.Event() for _ in range(pieces)]
+
+    def scatter(c):
+        if gpu:
+            import torch
+            with torch.cuda.stream(comm_stream):
+                for req in _exchange(full_in, shard_in, B, dist, root, False, c, chunks):
+                    req.wait()
+                arrived[c].record(comm_stream)
+        else:
+            for req in _exchange(full_in, shard_in, B, dist, root, False, c, chunks):
+                req.wait()
+
+    def gather(c):
+        if gpu:
+            import torch
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(solved[c])
+                for req in _exchange(full_out, shard_out, B, dist, root, True, c, chunks):
+                    req.wait()
+        else:
+            for req in _exchange(full_out, shard_out, B, dist, root, True, c, chunks):
+                req.wait()
+
+    done = 0
+    scatter(0)
+    for c in range(pieces):
+        if c + 1 < pieces:
+            scatter(c + 1)             # in flight while piece c is solved
+        if c + 1 < len(cb):
+            if gpu:
+                import torch
+                cs = comp[c % len(comp)]
+                with torch.cuda.stream(cs):
+                    cs.wait_event(arrived[c])
+                    solve_range(cb[c], cb[c + 1], c)
+                    solved[c].record(cs)
+            else:
+                solve_range(cb[c], cb[c + 1], c)
+            done += 1
+        elif gpu:
+            solved[c].record(comp[c % len(comp)])
+        gather(c)                      # enqueued behind the solve of piece c; overlaps the solve of piece c + 1
+    if gpu:
+        cur.wait_stream(comm_stream)
+        for cs in comp:
+            cur.wait_stream(cs)
+    return done
+
+
 def broadcast_nominal(tensors, dist, src: int = 0):
     """One nominal problem (a handful of small tensors) to every rank."""
     for t in tensors:

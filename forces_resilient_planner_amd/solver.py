@@ -259,12 +259,31 @@ class DeviceSolver:
         self.params.copy_(t.from_numpy(np.ascontiguousarray(w["params"])))
         self.nfaces.copy_(t.from_numpy(np.ascontiguousarray(w["nfaces"], dtype=np.int32)))
 
-    def _batch(self):
-        return Batch(self.B, self.N, self.M, self.MF, self.model, self.xinit.data_ptr(), self.x0.data_ptr(),
-                     self.params.data_ptr(), self.nfaces.data_ptr() if self.use_nfaces else None, self.z.data_ptr(),
-                     self.exitflag.data_ptr(), self.iters.data_ptr(), self.info.data_ptr(),
-                     self.models.data_ptr() if getattr(self, "models", None) is not None else None,
-                     self.iters.data_ptr() if self.order_by_last_iters else None)
+    def _batch(self, lo=0, hi=None):
+        """The problems [lo, hi) of this solver's buffers as a frp_nmpc_batch (the whole batch by default)."""
+        hi = self.B if hi is None else hi
+        models = getattr(self, "models", None)
+        return Batch(hi - lo, self.N, self.M, self.MF, self.model, self.xinit[lo:].data_ptr(), self.x0[lo:].data_ptr(),
+                     self.params[lo:].data_ptr(), self.nfaces[lo:].data_ptr() if self.use_nfaces else None, self.z[lo:].data_ptr(),
+                     self.exitflag[lo:].data_ptr(), self.iters[lo:].data_ptr(), self.info[lo:].data_ptr(),
+                     models[lo:].data_ptr() if models is not None else None,
+                     self.iters[lo:].data_ptr() if self.order_by_last_iters else None)
+
+    def solve_range(self, lo, hi, stream=None, piece=0):
+        """Solve the problems [lo, hi) of the batch only (a piece of a shard whose later pieces are still arriving):
+        asynchronous on `stream`.  Pieces that may run at the same time (different streams) pass different `piece` numbers:
+        each gets a queue workspace of its own (the work-queue head lives there)."""
+        if hi <= lo:
+            return
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        if not hasattr(self, "_piece_ws"):
+            self._piece_ws = {}
+        if piece not in self._piece_ws:
+            self._piece_ws[piece] = self.ws if piece == 0 else self.torch.empty_like(self.ws)
+        ws = self._piece_ws[piece]
+        b = self._batch(lo, hi)
+        _check(lib().frp_nmpc_solve_batch(ctypes.byref(b), ctypes.byref(self.opt), ws.data_ptr(), self.ws_bytes,
+                                          ctypes.c_void_p(s.cuda_stream)), "frp_nmpc_solve_batch")
 
     def solve(self, stream=None):
         """Asynchronous launch on `stream` (a torch.cuda.Stream) or torch's current stream."""

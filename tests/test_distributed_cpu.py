@@ -101,6 +101,66 @@ def test_scatter_solve_gather_from_rank0_matches_single_process(B, world):
     assert np.array_equal(ig, np.array([i.it for i in info]))
 
 
+def _overlap_worker(rank, world, port, B, chunks, outq):
+    """The overlapped strong-scaling step (pieces of every shard scattered / solved / gathered in turn) with the oracle as the
+    per-piece solve: what bench.py --scaling strong runs on HBM tensors over RCCL with two streams."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = workloads.config2(B) if rank == 0 else None
+    N, npar = 20, 130
+    lo, hi = D.shard_range(B, rank, world)
+    f64 = torch.float64
+    full = [torch.from_numpy(w["xinit"]), torch.from_numpy(w["x0"]), torch.from_numpy(w["params"]),
+            torch.from_numpy(w["nfaces"].astype(np.int32))] if rank == 0 else [None] * 4
+    shard = [torch.zeros((hi - lo, 9), dtype=f64), torch.zeros((hi - lo, N, 17), dtype=f64),
+             torch.zeros((hi - lo, N, npar), dtype=f64), torch.zeros((hi - lo, N), dtype=torch.int32)]
+    out = [torch.full((hi - lo, N, 17), -7.0, dtype=f64), torch.full((hi - lo,), -99, dtype=torch.int32), torch.full((hi - lo,), -99, dtype=torch.int32)]
+    out_full = [torch.zeros((B, N, 17), dtype=f64), torch.zeros((B,), dtype=torch.int32), torch.zeros((B,), dtype=torch.int32)] if rank == 0 else [None] * 3
+    ranges = []
+
+    def solve_range(a, b, c):
+        ranges.append((a, b))
+        ws = dict(xinit=shard[0][a:b].numpy(), x0=shard[1][a:b].numpy(), params=shard[2][a:b].numpy(), nfaces=shard[3][a:b].numpy(), N=N, M=30, model=0)
+        z, fl, info = OL.solve_batch(ws, nthreads=2)
+        out[0][a:b] = torch.from_numpy(z); out[1][a:b] = torch.from_numpy(fl.astype(np.int32))
+        out[2][a:b] = torch.from_numpy(np.array([i.it for i in info], dtype=np.int32))
+
+    D.strong_step_overlapped(full, shard, out, out_full, B, dist, solve_range, chunks=chunks)
+    assert ranges == list(zip(D.chunk_bounds(hi - lo, chunks)[:-1], D.chunk_bounds(hi - lo, chunks)[1:])) or hi == lo
+    if rank == 0:
+        outq.put(tuple(t.numpy() for t in out_full))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B,world,chunks", [(21, 2, 4), (10, 3, 3), (2, 3, 4), (17, 2, 1)])
+def test_overlapped_strong_step_equals_the_unchunked_one(B, world, chunks):
+    """Chunked == unchunked: the pieces of every shard cover it exactly once, in order, and the gathered
+    plans / flags / iteration counts are those of the single-process solve of the whole batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, B, chunks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    zg, fg, ig = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w = workloads.config2(B)
+    z, fl, info = OL.solve_batch(w)
+    assert np.array_equal(fg, fl) and np.array_equal(zg, z)
+    assert np.array_equal(ig, np.array([i.it for i in info]))
+
+
+def test_chunk_bounds_partition_a_shard():
+    for n in (0, 1, 2, 7, 511, 512, 2048, 16384):
+        for c in (1, 2, 4, 8):
+            b = D.chunk_bounds(n, c)
+            assert b[0] == 0 and b[-1] == n and all(x < y for x, y in zip(b[:-1], b[1:])) or n == 0
+            assert len(b) - 1 <= max(1, c)
+
+
 def test_monte_carlo_samples_do_not_depend_on_the_sharding():
     fbar = np.array([0.3, -1.2, 0.8])
     full = D.monte_carlo_fext(fbar, 0.5, 0, 4099, 7, "cpu").numpy()
