@@ -7,18 +7,22 @@
 //   KinodynamicAstar::getKinoTraj(Ts)   :648-695  -> kino_path_, exactly the input of frp_nmpc_reference_batch
 // and the occupancy queries of OccMap::checkState (occ_grid/src/occ_map.cpp:645-718, raycast.cpp:263-365).
 //
-// One workgroup of four wavefronts = one planner.  A search is a chain of expansions; inside an expansion
-//   * thread 0 pops the open set: a binary heap of (f, node) pairs in HBM that reproduces std::priority_queue's
+// One workgroup (sixteen wavefronts, see NT) = one planner.  A search is a chain of expansions; inside an expansion
+//   * one lane pops the open set: a binary heap of (f, node) pairs in HBM that reproduces std::priority_queue's
 //     __push_heap / __adjust_heap step by step -- the reference changes keys in place without re-heapifying
-//     (kinodynamic_astar.cpp:220-226, :263-272), so the pop order is defined by those algorithms and nothing else;
+//     (kinodynamic_astar.cpp:220-226, :263-272), so the pop order is defined by those algorithms and nothing else; since round 4
+//     the pop runs on the last wavefront WHILE the others stage the window and run phase 1 (it touches nothing they read);
 //   * all lanes stage the occupancy columns around the node in LDS: the map is bit-packed once per call, one 64-bit word per
 //     (x, y) column (z = bit), and a 64 x 64-column window (32 KB) covers every cell a primitive of this node can touch;
 //   * thread = primitive (125 inputs x 1 duration; 1 x 8 for the first expansion of a continuous start): state transit, range /
 //     closed-set / velocity / same-voxel tests; thread = (primitive, collision sample) for the check_num samples through the
 //     staged window; thread = surviving primitive for the cost and the quartic heuristic; then every survivor finds the first
 //     survivor of its voxel;
-//   * thread 0 commits the survivors in input order -- node creation, in-place updates, heap pushes -- which is where the
-//     reference's sequential semantics live.
+//   * the first wavefront commits the survivors in input order -- node creation, in-place updates, heap pushes -- which is where the
+//     reference's sequential semantics live: it walks the survivors' bit mask (~17 of 125 primitives), takes their values through
+//     v_readlane, and climbs a push with all its ancestors fetched at once (round 4: 91 -> 47 us per expansion, 1104 -> 2130
+//     searches/s on the pillar world, profiles/r04_astar_bench.jsonl; what is left is the collision samples, ~800 instructions
+//     each x ~900 per expansion = the FP64 issue rate of one CU).
 // The closed / expanded set is an open-addressing hash from the voxel index to the node (exact map semantics).  Arithmetic
 // follows oracle/astar_oracle.c operation by operation (this file is compiled with -ffp-contract=off; cbrt / acos / cos are
 // the same fdlibm sequences), so node order, node count and path samples agree with it to the bit.
@@ -34,7 +38,14 @@ namespace astar {
 constexpr int MAX_CAND = 128;    // primitives per expansion (125 in the reference's configuration)
 constexpr int MAX_PATH = FRP_ASTAR_MAX_PATH;
 constexpr int WIN = 64;          // window of staged occupancy columns: WIN x WIN words
-constexpr int NT = 256;          // threads per planner (four wavefronts): the collision samples of an expansion are spread over them
+// Threads per planner.  A batch ends with its longest search (a chain of expansions, 10 k of them in the pillar world of
+// tests/tools/astar_bench.py against a mean of 650), so what counts is the latency of ONE expansion, not planners in flight: sixteen
+// wavefronts on a CU of their own deal the ~900 collision samples of an expansion in one pass (measured, us per expansion of the
+// longest search: 256 threads 65, 512 59, 768 50, 1024 47; 4096 trivial searches of an empty world 13.0 ms against 10.4 at 256).
+#ifndef FRP_ASTAR_NT
+#define FRP_ASTAR_NT 1024
+#endif
+constexpr int NT = FRP_ASTAR_NT;
 constexpr char IN_CLOSE_SET = 'a', IN_OPEN_SET = 'b';
 
 struct Node { // 128 bytes
@@ -158,7 +169,7 @@ struct Ctx {
     const unsigned char *occ;
     const unsigned long long *packed;
     const unsigned long long *win; // LDS window, WIN x WIN columns starting at (wx0, wy0)
-    int wx0, wy0, use_win;
+    int wx0, wy0, use_win, win_r; // win_r: the window holds the columns [wx0, wx0 + 2 win_r] x [wy0, wy0 + 2 win_r]
     int lmin[3], lmax[3], use_local;
     int fast, off[3]; // fast: the voxel of ray cell c is c + off on every axis (verified on the host for |c| <= CELL_SAFE)
     double res_inv, ext[3];
@@ -175,7 +186,7 @@ __device__ __forceinline__ int voxel_state_idx(const Ctx &c, int i0, int i1, int
         return 0;
     if (c.packed) {
         const int wx = i0 - c.wx0, wy = i1 - c.wy0;
-        const unsigned long long w = (c.use_win && ((wx | (WIN - 1 - wx) | wy | (WIN - 1 - wy)) >= 0)) ? c.win[wx * WIN + wy]
+        const unsigned long long w = (c.use_win && ((wx | (2 * c.win_r - wx) | wy | (2 * c.win_r - wy)) >= 0)) ? c.win[wx * WIN + wy]
                                                                                                   : c.packed[(size_t)i0 * P->grid[1] + i1];
         return (int)((w >> i2) & 1ull);
     }
@@ -225,8 +236,9 @@ __device__ int line_hits(const Ctx &c, double s0, double s1, double s2, double e
             if (cell_state(c, x, y, zz) != 0) return 1;
         return 0;
     }
-    double tMaxX = intbound(a0, dx), tMaxY = intbound(a1, dy), tMaxZ = intbound(a2, dz);
-    const double tDeltaX = ((double)stepX) / dx, tDeltaY = ((double)stepY) / dy, tDeltaZ = ((double)stepZ) / dz;
+    // (a segment inside one z layer: intbound(a2, 0) = (1 - s) / 0 = +inf exactly -- s = mod1(.) < 1 -- and tDeltaZ is never added)
+    double tMaxX = intbound(a0, dx), tMaxY = intbound(a1, dy), tMaxZ = (stepZ == 0 && a2 == a2) ? __builtin_huge_val() : intbound(a2, dz);
+    const double tDeltaX = ((double)stepX) / dx, tDeltaY = ((double)stepY) / dy, tDeltaZ = stepZ == 0 ? 0.0 : ((double)stepZ) / dz;
     for (int guard = 0;; guard++) {
         if (x == endX && y == endY && z == endZ) break;
         if (guard >= 4096) return 1;
@@ -257,6 +269,13 @@ __device__ int check_state(const Ctx &c, const double pos[3], const double vel[3
     return 1;
 }
 
+__device__ __forceinline__ double rl_f64(double v, int l) // v_readlane of a double (l wave-uniform)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l) << 32) |
+                                            (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l)));
+}
+
 // position of the n-th (0-based) set bit of m, n < popcount(m)
 __device__ __forceinline__ int nth_set_bit(unsigned long long m, int n)
 {
@@ -279,6 +298,12 @@ __device__ __forceinline__ void state_transit(const Ctx &c, const double s0[6], 
         s1[3 + i] = s0[3 + i] + tau * ud;
     }
 }
+
+// Eigen evaluates the reduction of a fixed-size 3-vector as a0 b0 + (a1 b1 + a2 b2) (redux_novec_unroller splits [0, 3) into [0, 1) and
+// [1, 3)); the search is steered by comparisons of nearly equal costs, so the order of these sums is part of the restatement.  The
+// 4-term dots of the shot polynomials (dynamic-size VectorXd: packet reductions that depend on the build's SIMD width) stay left
+// to right: parity with the reference at that level is structural, not bitwise.
+__device__ __forceinline__ double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]); }
 
 // cubic(a, b, c, d).front() (kinodynamic_astar.cpp:426-459): quartic() uses only the first root the reference computes
 __device__ double cubic_first(double a, double b, double c, double d)
@@ -326,10 +351,11 @@ __device__ double estimate_heuristic(const frp_nmpc_astar *P, const double x1[6]
     double dp[3], v0[3], v1[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) { dp[i] = x2[i] - x1[i]; v0[i] = x1[3 + i]; v1[i] = x2[3 + i]; }
-    const double c1 = -36 * (dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2]);
-    const double c2 = 24 * ((v0[0] + v1[0]) * dp[0] + (v0[1] + v1[1]) * dp[1] + (v0[2] + v1[2]) * dp[2]);
-    const double c3 = -4 * ((v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2]) + (v0[0] * v1[0] + v0[1] * v1[1] + v0[2] * v1[2]) +
-                            (v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]));
+    // (dot3: Eigen's unrolled reduction of a fixed-size 3-vector, a0 b0 + (a1 b1 + a2 b2) -- what dp.dot(dp), v0.dot(v1), .norm() compile to)
+    const double vs[3] = {v0[0] + v1[0], v0[1] + v1[1], v0[2] + v1[2]};
+    const double c1 = -36 * dot3(dp, dp);
+    const double c2 = 24 * dot3(vs, dp);
+    const double c3 = -4 * ((dot3(v0, v0) + dot3(v0, v1)) + dot3(v1, v1));
     double ts[5];
     quartic(P->w_time, 0, c3, c2, c1, ts[0], ts[1], ts[2], ts[3]);
     const double t_bar = fmax(fmax(fabs(x1[0] - x2[0]), fabs(x1[1] - x2[1])), fabs(x1[2] - x2[2])) / P->max_vel;
@@ -383,6 +409,27 @@ __device__ void heap_push_hole(HeapEnt *heap, Node *nodes, int hole, int top, do
     }
     heap[hole].f = vf; heap[hole].id = vid; nodes[vid].heap_pos = hole;
 }
+// The same push executed by a whole wavefront (all lanes call it with wave-uniform arguments): lane j fetches the j-th ancestor of
+// the hole -- index ((hole + 1) >> j) - 1 -- so the whole climb costs ONE trip to the L2 instead of one per level (a climb is a chain
+// of dependent loads otherwise: ~550 cycles each, 2 levels on average); lane 0 then does exactly heap_push_hole's stores.
+__device__ __forceinline__ void heap_push_hole_wave(HeapEnt *heap, Node *nodes, int hole, double vf, int vid)
+{
+    const int ln = threadIdx.x & 63;
+    const int anc = ((hole + 1) >> ln) - 1; // lane 0: the hole itself (unused), lane 1: its parent, ...
+    const bool has = ln >= 1 && ln < 32 && anc >= 0;
+    const double af = has ? heap[anc].f : 0.0;
+    const int aid = has ? heap[anc].id : 0;
+    int j = 1;
+    while (hole > 0) {
+        const double pf = rl_f64(af, j);
+        if (!(pf > vf)) break;
+        const int pid = __builtin_amdgcn_readlane(aid, j);
+        if (ln == 0) { heap[hole].f = pf; heap[hole].id = pid; nodes[pid].heap_pos = hole; }
+        hole = (hole - 1) / 2;
+        j++;
+    }
+    if (ln == 0) { heap[hole].f = vf; heap[hole].id = vid; nodes[vid].heap_pos = hole; }
+}
 __device__ void heap_pop(HeapEnt *heap, Node *nodes, int &size) // std::pop_heap + pop_back
 {
     if (size > 1) {
@@ -431,7 +478,7 @@ struct Shared {
 };
 
 // One search (KinodynamicAstar::search); leaves status / terminate / shot in the shared block.
-__device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, int b, bool init)
+__device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, int b, bool init, bool retry)
 {
     const frp_nmpc_astar *P = &a.p;
     const int lane = threadIdx.x;
@@ -439,7 +486,9 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
     Node *nodes = a.nodes + (size_t)b * A;
     HeapEnt *heap = a.heap + (size_t)b * A;
     HashEnt *hash = a.hash + (size_t)b * a.hcap;
-    const double *start_pt = P->start_pt + 3 * b, *start_v = P->start_vel + 3 * b, *start_a = P->start_acc + 3 * b;
+    // (the repeated search starts from the odometry state when the caller gives one: nmpc_solver.cpp:190-193)
+    const double *start_pt = (retry && P->retry_pt ? P->retry_pt : P->start_pt) + 3 * b, *start_v = (retry && P->retry_vel ? P->retry_vel : P->start_vel) + 3 * b,
+                 *start_a = P->start_acc + 3 * b;
     const double *end_pt = P->end_pt + 3 * b, *end_v = P->end_vel + 3 * b;
     // reset(): expanded_nodes_.clear(), open set emptied, counters zeroed
     for (int i = lane; i < a.hcap; i += NT) hash[i].val = -1;
@@ -484,20 +533,36 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
         const int cur = sh.cur;
         const bool near_end = abs(sh.cur_index[0] - end_index[0]) <= tolerance && abs(sh.cur_index[1] - end_index[1]) <= tolerance &&
                               abs(sh.cur_index[2] - end_index[2]) <= tolerance;
-        const double d0 = sh.cur_state[0] - start_pt[0], d1 = sh.cur_state[1] - start_pt[1], d2 = sh.cur_state[2] - start_pt[2];
-        const bool reach_horizon = sqrt(d0 * d0 + d1 * d1 + d2 * d2) >= P->horizon;
+        const double dst[3] = {sh.cur_state[0] - start_pt[0], sh.cur_state[1] - start_pt[1], sh.cur_state[2] - start_pt[2]};
+        const bool reach_horizon = sqrt(dot3(dst, dst)) >= P->horizon;
+        // ---- pop node and add to close set (kinodynamic_astar.cpp:108-112) -- by the first lane of the LAST wavefront, while the
+        // others stage the window and run phase 1: the sift-down is a chain of dependent loads that touches nothing those read
+        // (the heap and heap_pos fields only), and its result is not needed before the commit
+        const bool terminating = reach_horizon || near_end;
+        constexpr int NW = NT - 64; // lanes that share the parallel work of this stretch
+        if (!terminating && lane == NW) {
+            int hs = sh.heap_size;
+            heap_pop(heap, nodes, hs);
+            sh.heap_size = hs;
+            nodes[cur].node_state = IN_CLOSE_SET;
+            sh.iter_num += 1;
+        }
         // ---- stage the occupancy columns around the node (also used by the one-shot check below)
         if (ctx.packed) {
-            const int wx0 = sh.cur_index[0] - WIN / 2, wy0 = sh.cur_index[1] - WIN / 2;
-            for (int i = lane; i < WIN * WIN; i += NT) {
-                const int gx = wx0 + i / WIN, gy = wy0 + (i % WIN);
-                sh.win[i] = (gx >= 0 && gx < P->grid[0] && gy >= 0 && gy < P->grid[1]) ? ctx.packed[(size_t)gx * P->grid[1] + gy] : 0ull;
+            // (only the square of columns a primitive of this node can reach -- win_r columns either way, see astar_kernel -- is
+            // staged; a lookup outside it reads the packed map itself, so the extent is a cost, never a correctness, matter)
+            const int wr = ctx.win_r, side = 2 * wr + 1;
+            const int wx0 = sh.cur_index[0] - wr, wy0 = sh.cur_index[1] - wr;
+            for (int i = lane; i < side * side && lane < NW; i += NW) {
+                const int ix = i / side, iy = i - ix * side;
+                const int gx = wx0 + ix, gy = wy0 + iy;
+                sh.win[ix * WIN + iy] = (gx >= 0 && gx < P->grid[0] && gy >= 0 && gy < P->grid[1]) ? ctx.packed[(size_t)gx * P->grid[1] + gy] : 0ull;
             }
             ctx.wx0 = wx0; ctx.wy0 = wy0; ctx.use_win = 1;
         }
-        __syncthreads();
-        APROF(1);
-        if (reach_horizon || near_end) {
+        if (terminating) {
+            __syncthreads();
+            APROF(1);
             if (near_end) {
                 // one-shot trajectory: estimateHeuristic for its duration, computeShotTraj's ten samples on ten lanes
                 double ttg;
@@ -553,20 +618,11 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
             }
             break;
         }
-        // ---- pop node and add to close set
-        if (lane == 0) {
-            int hs = sh.heap_size;
-            heap_pop(heap, nodes, hs);
-            sh.heap_size = hs;
-            nodes[cur].node_state = IN_CLOSE_SET;
-            sh.iter_num += 1;
-        }
         // ---- primitives of this expansion: the continuous start uses its own acceleration with eight durations, every other
         // node the full input grid with one duration (kinodynamic_astar.cpp:116-137); candidate index = input-major order
         const bool use_init = init_search;
         init_search = false;
         const int n_cand = use_init ? sh.n_dur_init : sh.n_in;
-        __syncthreads();
         APROF(2);
         // phase 1, thread = primitive: state transit and the tests that need no map
         for (int c = lane; c < MAX_CAND; c += NT) {
@@ -594,7 +650,7 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
                 if (surv && i0 == sh.cur_index[0] && i1 == sh.cur_index[1] && i2 == sh.cur_index[2]) surv = 0;
             }
             sh.c_surv[c] = surv; sh.c_pre[c] = pre; sh.c_key[c] = key; sh.c_tau[c] = tau; sh.c_g[c] = 0.0; sh.c_f[c] = 0.0; sh.c_leader[c] = c;
-            static_assert(MAX_CAND == 128 && NT >= MAX_CAND, "one primitive per thread of the first two wavefronts");
+            static_assert(MAX_CAND == 128 && NT - 64 >= MAX_CAND, "one primitive per thread of the first two wavefronts, the last wavefront pops meanwhile");
             const unsigned long long bal = __ballot(surv != 0); // (c = lane: wavefront w holds the primitives 64 w .. 64 w + 63)
             if ((c & 63) == 0) sh.alive[c >> 6] = bal;
 #pragma unroll
@@ -607,9 +663,25 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
         // the reference stops at the first colliding sample -- the verdict of a primitive is the same)
         // The samples of the SURVIVING primitives only are dealt over the threads (the a-th survivor = the a-th set bit of the
         // masks): a dead primitive would hold check_num lanes idle through the longest ray cast of its wavefront.
+        // With eight or more wavefronts the first two leave the samples to the others and evaluate cost and heuristic of the phase-1
+        // survivors meanwhile (the quartic of estimateHeuristic is a 4 k-cycle dependency chain on at most 128 lanes; for a primitive
+        // that turns out to collide the values are simply never used).
+        constexpr bool HEUR_BESIDE = NT >= 512;
+        constexpr int CW0 = HEUR_BESIDE ? MAX_CAND : 0, CWN = NT - CW0; // first lane and number of lanes of the collision phase
         const unsigned long long al0 = sh.alive[0], al1 = sh.alive[1];
         const int n_al0 = __popcll(al0), n_alive = n_al0 + __popcll(al1);
-        for (int t = lane; t < n_alive * P->check_num; t += NT) {
+        auto cost_and_heuristic = [&](int c) {
+            double ttg;
+            const double um0 = sh.c_um[c][0], um1 = sh.c_um[c][1], um2 = sh.c_um[c][2];
+            const double g = ((um0 * um0 + (um1 * um1 + um2 * um2)) + P->w_time) * sh.c_tau[c] + sh.cur_g; // um.squaredNorm(): see dot3
+            double pro[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) pro[i] = sh.c_state[c][i];
+            sh.c_g[c] = g;
+            sh.c_f[c] = g + P->lambda_heu * estimate_heuristic(P, pro, sh.end_state, &ttg);
+        };
+        if (HEUR_BESIDE && lane < n_cand && sh.c_surv[lane]) cost_and_heuristic(lane);
+        for (int t = lane - CW0; t >= 0 && t < n_alive * P->check_num; t += CWN) {
             const int ai = t / P->check_num, k = t - ai * P->check_num + 1;
             const int c = ai < n_al0 ? nth_set_bit(al0, ai) : 64 + nth_set_bit(al1, ai - n_al0);
             const double um[3] = {sh.c_um[c][0], sh.c_um[c][1], sh.c_um[c][2]};
@@ -621,20 +693,15 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
         __syncthreads();
         APROF(4);
         // phase 3, thread = primitive: cost and heuristic of the survivors
-        for (int c = lane; c < n_cand; c += NT) {
-            int surv = sh.c_surv[c];
+        if (lane < MAX_CAND) { // (all 128 lanes of the first two wavefronts: the survivor masks below are ballots)
+            const int c = lane;
+            int surv = c < n_cand ? sh.c_surv[c] : 0;
             if (surv && sh.c_leader[c] == -1) surv = 0;
-            if (surv) {
-                double ttg;
-                const double um0 = sh.c_um[c][0], um1 = sh.c_um[c][1], um2 = sh.c_um[c][2];
-                const double g = ((um0 * um0 + um1 * um1 + um2 * um2) + P->w_time) * sh.c_tau[c] + sh.cur_g;
-                double pro[6];
-#pragma unroll
-                for (int i = 0; i < 6; i++) pro[i] = sh.c_state[c][i];
-                sh.c_g[c] = g;
-                sh.c_f[c] = g + P->lambda_heu * estimate_heuristic(P, pro, sh.end_state, &ttg);
-            }
-            sh.c_surv[c] = surv;
+            if (surv && !HEUR_BESIDE) cost_and_heuristic(c);
+            if (c < n_cand) sh.c_surv[c] = surv;
+            static_assert(MAX_CAND == 128, "two 64-bit survivor masks");
+            const unsigned long long sb = __ballot(surv != 0); // (n_cand <= 128 <= NT: c = lane, wavefront w holds the primitives 64 w ..)
+            if (c < MAX_CAND && (c & 63) == 0) sh.alive[c >> 6] = sb;
         }
         __syncthreads();
         APROF(5);
@@ -662,38 +729,59 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
         // pushes -- run beside thread 0's loop on the first lane of the second wavefront (node numbers are the running count).
         int use_new = 0, hs_new = 0;
         bool out_of_memory = false;
-        if (lane == 64) {
+        // (both walks visit the SURVIVORS only, by the bit masks phase 3 left: a typical expansion has ~17 of them among the 125
+        // primitives -- scanning all of them cost the walking lane 29-35 k cycles of dependent LDS round trips.  And what the walk
+        // needs of a survivor -- leader, open node, g, f -- is read by the whole wavefront at once, lane = primitive (two per lane),
+        // and handed to the walk through v_readlane: the decisions are wave-uniform, lane 0 of the wavefront does the memory side.)
+        const int wv = lane >> 6, ln = lane & 63;
+        if (wv == 1) { // second wavefront: the voxel hash of the new nodes (node numbers are the running count)
+            const int le0 = sh.c_leader[ln], le1 = sh.c_leader[64 + ln], pr0 = sh.c_pre[ln], pr1 = sh.c_pre[64 + ln];
             int use = sh.use_node_num;
-            for (int c = 0; c < n_cand; c++) {
-                if (!sh.c_surv[c] || sh.c_pre[c] >= 0 || sh.c_leader[c] != c) continue;
-                hash_insert(hash, a.hcap, sh.c_key[c], use);
-                if (++use == A) break;
+            bool full = false;
+            for (int w = 0; w < 2 && !full; w++) {
+                const unsigned long long mw = sh.alive[w];
+                unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mw >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mw);
+                for (; m && !full; m &= m - 1) {
+                    const int cl = __builtin_ctzll(m), c = 64 * w + cl;
+                    const int L = __builtin_amdgcn_readlane(w ? le1 : le0, cl), pre = __builtin_amdgcn_readlane(w ? pr1 : pr0, cl);
+                    if (pre >= 0 || L != c) continue;
+                    if (ln == 0) hash_insert(hash, a.hcap, sh.c_key[c], use);
+                    if (++use == A) full = true;
+                }
             }
         }
-        if (lane == 0) {
+        if (wv == 0) {
+            const int le0 = sh.c_leader[ln], le1 = sh.c_leader[64 + ln], pr0 = sh.c_pre[ln], pr1 = sh.c_pre[64 + ln];
+            const double g0 = sh.c_g[ln], g1 = sh.c_g[64 + ln], f0 = sh.c_f[ln], f1 = sh.c_f[64 + ln];
             int use = sh.use_node_num, hs = sh.heap_size;
-            for (int c = 0; c < n_cand && !out_of_memory; c++) {
-                if (!sh.c_surv[c]) continue;
-                const int L = sh.c_leader[c];
-                const double g = sh.c_g[c], f = sh.c_f[c];
-                if (L == c) sh.c_winner[c] = -1; // (winner of the voxel's group: the primitive whose values the node ends up with)
-                if (sh.c_pre[c] >= 0) { // a node of this voxel is in the open set: keep the cheaper way to it
-                    const int nid = sh.c_pre[c];
-                    if (L == c) { sh.grp_val[c] = nodes[nid].g; sh.c_created[c] = nid; }
-                    if (g < sh.grp_val[L]) {
-                        heap[nodes[nid].heap_pos].f = f; // the key changes in place: no re-heapify (as in the reference)
-                        sh.grp_val[L] = g; sh.c_winner[L] = c;
+            for (int w = 0; w < 2; w++) {
+                const unsigned long long mw = sh.alive[w];
+                unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mw >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mw);
+                for (; m && !out_of_memory; m &= m - 1) {
+                    const int cl = __builtin_ctzll(m), c = 64 * w + cl;
+                    const int L = __builtin_amdgcn_readlane(w ? le1 : le0, cl), pre = __builtin_amdgcn_readlane(w ? pr1 : pr0, cl);
+                    const double g = rl_f64(w ? g1 : g0, cl), f = rl_f64(w ? f1 : f0, cl);
+                    if (ln == 0 && L == c) sh.c_winner[c] = -1; // (winner of the voxel's group: the primitive whose values the node ends up with)
+                    if (pre >= 0) { // a node of this voxel is in the open set: keep the cheaper way to it
+                        if (ln == 0) {
+                            const int nid = pre;
+                            if (L == c) { sh.grp_val[c] = nodes[nid].g; sh.c_created[c] = nid; }
+                            if (g < sh.grp_val[L]) {
+                                heap[nodes[nid].heap_pos].f = f; // the key changes in place: no re-heapify (as in the reference)
+                                sh.grp_val[L] = g; sh.c_winner[L] = c;
+                            }
+                        }
+                    } else if (L == c) { // new node
+                        const int nid = use;
+                        hs++;
+                        heap_push_hole_wave(heap, nodes, hs - 1, f, nid); // (the whole wavefront: see there)
+                        if (ln == 0) { sh.c_created[c] = nid; sh.grp_val[c] = f; sh.c_winner[c] = c; }
+                        use++;
+                        if (use == A) out_of_memory = true; // "run out of memory", kinodynamic_astar.cpp:255-259
+                    } else if (ln == 0 && f < sh.grp_val[L]) { // a node of this voxel was created earlier in this expansion: keep the lower f
+                        heap[nodes[sh.c_created[L]].heap_pos].f = f;
+                        sh.grp_val[L] = f; sh.c_winner[L] = c;
                     }
-                } else if (L == c) { // new node
-                    const int nid = use;
-                    hs++;
-                    heap_push_hole(heap, nodes, hs - 1, 0, f, nid);
-                    sh.c_created[c] = nid; sh.grp_val[c] = f; sh.c_winner[c] = c;
-                    use++;
-                    if (use == A) out_of_memory = true; // "run out of memory", kinodynamic_astar.cpp:255-259
-                } else if (f < sh.grp_val[L]) { // a node of this voxel was created earlier in this expansion: keep the lower f
-                    heap[nodes[sh.c_created[L]].heap_pos].f = f;
-                    sh.grp_val[L] = f; sh.c_winner[L] = c;
                 }
             }
             use_new = use; hs_new = hs;
@@ -745,6 +833,15 @@ __global__ __launch_bounds__(NT) void astar_kernel(Args a)
     Ctx ctx;
     ctx.P = P; ctx.occ = P->occ; ctx.packed = a.packed; ctx.win = sh.win; ctx.wx0 = 0; ctx.wy0 = 0; ctx.use_win = 0;
     ctx.res_inv = 1.0 / P->resolution;
+    {   // reach of a primitive per axis: |v| tau + (max_acc + |f_ext|) tau^2 / 2 with |v| <= max_vel (nodes beyond it are never
+        // created), plus the inflated ego radius of checkState and two cells of slack
+        const double tau = fmax(P->max_tau, P->init_max_tau);
+        double fm = fmax(fabs(P->external_acc[3 * b]), fabs(P->external_acc[3 * b + 1]));
+        if (!(fm == fm)) fm = 0.0;
+        const double reach = P->max_vel * tau + 0.5 * (P->max_acc + fm) * tau * tau + 1.5 * P->ego_r;
+        int r = (int)ceil(reach / P->resolution) + 2;
+        ctx.win_r = r < 1 ? 1 : (r > (WIN - 1) / 2 ? (WIN - 1) / 2 : r);
+    }
     ctx.fast = a.fast; ctx.off[0] = a.off[0]; ctx.off[1] = a.off[1]; ctx.off[2] = a.off[2];
     ctx.use_local = P->local_box ? 1 : 0;
     for (int i = 0; i < 3; i++) {
@@ -773,26 +870,34 @@ __global__ __launch_bounds__(NT) void astar_kernel(Args a)
     Node *nodes = a.nodes + (size_t)b * A;
     int retried = 0;
     for (int attempt = 0; attempt < 2; attempt++) { // the second pass is the retry with the discontinuous initial state (nmpc_solver.cpp:190-207)
-        run_search(a, sh, ctx, b, attempt == 0 && P->init_search != 0);
+        run_search(a, sh, ctx, b, attempt == 0 && P->init_search != 0, attempt == 1);
         if (!(sh.status == FRP_ASTAR_NO_PATH && P->init_search && attempt == 0)) break;
         retried = 1;
         __syncthreads();
     }
-    const int status = sh.status;
     // ---- retrievePath (:308-320)
     if (lane == 0) {
         int n = 0;
-        if (status != FRP_ASTAR_NO_PATH && sh.terminate >= 0) {
+        int n_full = 0;
+        if (sh.status != FRP_ASTAR_NO_PATH && sh.terminate >= 0) {
             for (int c = sh.terminate; c >= 0; c = nodes[c].parent) n++;
-            if (n > MAX_PATH) n = MAX_PATH;
-            int c = sh.terminate;
-            for (int q = n - 1; q >= 0; q--, c = nodes[c].parent) sh.path_ids[q] = c;
+            n_full = n;
+            if (n > MAX_PATH) {
+                // a path of more nodes than path_ids holds would lose its ROOT (the walk starts at the terminate node): it is not
+                // returned at all -- NO_PATH, the planner keeps the path it has (nmpc_solver.cpp:209-213) -- and stats[3] = -(nodes)
+                n = 0;
+                sh.status = FRP_ASTAR_NO_PATH;
+            } else {
+                int c = sh.terminate;
+                for (int q = n - 1; q >= 0; q--, c = nodes[c].parent) sh.path_ids[q] = c;
+            }
         }
         sh.n_path = n;
-        P->status[b] = status;
-        if (P->stats) { P->stats[4 * b] = sh.use_node_num; P->stats[4 * b + 1] = sh.iter_num; P->stats[4 * b + 2] = retried; P->stats[4 * b + 3] = n; }
+        P->status[b] = sh.status;
+        if (P->stats) { P->stats[4 * b] = sh.use_node_num; P->stats[4 * b + 1] = sh.iter_num; P->stats[4 * b + 2] = retried; P->stats[4 * b + 3] = n_full > MAX_PATH ? -n_full : n; }
     }
     __syncthreads();
+    const int status = sh.status;
     const int n_path = sh.n_path;
     if (P->path_nodes) {
         double *o = P->path_nodes + (size_t)b * MAX_PATH * 11;
@@ -808,7 +913,7 @@ __global__ __launch_bounds__(NT) void astar_kernel(Args a)
     if (P->path_nodes && lane < 8) P->path_nodes[((size_t)b * MAX_PATH + MAX_PATH - 1) * 11 + lane] = (double)sh.prof[lane];
 #endif
     // ---- getKinoTraj(Ts) (:648-695): the search part is generated backwards in the reference and reversed; here the samples
-    // are counted first so that each one lands at its forward position (a path longer than K keeps its head)
+    // are counted first so that each one lands at its forward position (more samples than K: the first K are kept, stats[3] < 0)
     if (lane == 0) {
         const double delta_t = P->Ts;
         double *out = P->kino_path + (size_t)b * P->K * 3;

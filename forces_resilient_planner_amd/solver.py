@@ -84,7 +84,7 @@ class Astar(ctypes.Structure):  # frp_nmpc_astar (include/frp_nmpc.h)
                 ("end_vel", ctypes.c_void_p), ("external_acc", ctypes.c_void_p), ("active", ctypes.c_void_p), ("init_search", ctypes.c_int),
                 ("Ts", ctypes.c_double), ("K", ctypes.c_int),
                 ("kino_path", ctypes.c_void_p), ("kino_size", ctypes.c_void_p), ("status", ctypes.c_void_p), ("stats", ctypes.c_void_p),
-                ("path_nodes", ctypes.c_void_p)]
+                ("path_nodes", ctypes.c_void_p), ("retry_pt", ctypes.c_void_p), ("retry_vel", ctypes.c_void_p)]
 
 
 ASTAR_MAX_PATH = 256
@@ -384,6 +384,7 @@ class AstarPlanner:
         self.path_nodes = torch.zeros((B, ASTAR_MAX_PATH, 11), **f64) if want_path_nodes else None
         self.allocate_num = int(allocate_num or world["allocate_num"])
         self._q = [torch.zeros((B, 3), **f64) for _ in range(6)]
+        self._retry = None  # (retry_pt, retry_vel): the start of the repeated search, when it differs (upload(..., retry=...))
         a = self._args()
         self.ws_bytes = int(lib().frp_nmpc_astar_workspace_bytes(ctypes.byref(a)))
         self.ws = torch.empty((self.ws_bytes // 8 + 1,), **f64)
@@ -403,12 +404,23 @@ class AstarPlanner:
         a.Ts = self.Ts; a.K = self.K
         a.kino_path = self.kino_path.data_ptr(); a.kino_size = self.kino_size.data_ptr(); a.status = self.status.data_ptr()
         a.stats = self.stats.data_ptr(); a.path_nodes = self.path_nodes.data_ptr() if self.path_nodes is not None else None
+        a.retry_pt = self._retry[0].data_ptr() if self._retry is not None else None
+        a.retry_vel = self._retry[1].data_ptr() if self._retry is not None else None
         return a
 
-    def upload(self, start_pt, start_v, start_a, end_pt, end_v, f_ext):
+    def upload(self, start_pt, start_v, start_a, end_pt, end_v, f_ext, retry=None):
+        """retry = (pt [B,3], vel [B,3]): the start of the repeated search (getKinoPath retries from the odometry state,
+        nmpc_solver.cpp:190-193); None: the same start."""
         t = self.torch
+        cp = lambda dst, src: dst.copy_(src if t.is_tensor(src) else t.from_numpy(np.ascontiguousarray(src, dtype=np.float64)))
         for dst, src in zip(self._q, (start_pt, start_v, start_a, end_pt, end_v, f_ext)):
-            dst.copy_(src if t.is_tensor(src) else t.from_numpy(np.ascontiguousarray(src, dtype=np.float64)))
+            cp(dst, src)
+        if retry is None:
+            self._retry = None
+        else:
+            if self._retry is None:
+                self._retry = [t.zeros_like(self._q[0]), t.zeros_like(self._q[0])]
+            cp(self._retry[0], retry[0]); cp(self._retry[1], retry[1])
 
     def plan(self, init=True, local_box=None, stream=None, active=None):
         """Asynchronous on `stream` (or torch's current stream): every planner's search + retry + getKinoTraj.
@@ -612,29 +624,51 @@ class DeviceFleet:
         path (getCurTraj + calculate_yaw, nmpc_solver.cpp:109-142, 834-862), on the device."""
         reference_batch_device(kino_path, time_offset, self.mpc_output, ref_pos, ref_yaw, replan, kino_size, Ts, stream)
 
-    def replan(self, planner, end_pt, external_acc, replan, time_offset=None, end_vel=None, init=True, mass=0.74, g=9.81, stream=None):
+    def replan(self, planner, end_pt, external_acc, replan, time_offset=None, end_vel=None, init=True, mass=0.74, g=9.81, stream=None,
+               t_cur=None, odom=None, Ts=0.05):
         """The FSM's REPLAN_TRAJ step (nmpc_manage.cpp:215-235 -> NMPCSolver::getKinoPath, nmpc_solver.cpp:145-223) for the planners
-        whose tick raised kino_replan_ (`replan` [B] int32, as written by references() / full_tick): a kinodynamic A* from the
-        plan's next state -- position, velocity and the acceleration the planned thrust produces (:169-181) -- to end_pt [B,3]
-        with external_acc [B,3] in the primitives, on the device (AstarPlanner = frp_nmpc_astar_batch).  The planner object owns
-        the per-planner paths (planner.kino_path / kino_size): pass them to references() / full_tick as the path.  Planners
-        that found a path get time_offset = 0 (kino_start_time_ = now, :219) and go back to the normal solver (:218).
-        Returns the mask (bool [B]) of planners that received a new path.  Asynchronous on torch's current stream."""
+        whose tick raised kino_replan_ (`replan` [B] int32, as written by references() / full_tick): a kinodynamic A* to end_pt
+        [B,3] with external_acc [B,3] in the primitives, on the device (AstarPlanner = frp_nmpc_astar_batch).
+        Start state as in the reference (:159-186): a planner whose last solve succeeded (solver.exitflag == 1) starts from its plan
+        interpolated at t_cur [B] seconds after the plan's start -- row floor(t_cur / Ts) towards the next one; None = 0 = the plan's
+        first row -- with the acceleration the planned thrust produces (:169-181), provided floor(t_cur / Ts) < N - 1 and t_cur >= 0;
+        every other planner starts from odom = (pos [B,3], vel [B,3]) with zero acceleration (None: the plan's stage-1 state).  The
+        repeated search after NO_PATH starts from the odometry state (:190-193).
+        The planner object owns the per-planner paths (planner.kino_path / kino_size): pass them to references() / full_tick as the
+        path.  Planners that found a path get time_offset = 0 (kino_start_time_ = now, :219) and go back to the normal solver (:218).
+        Returns the mask (bool [B]) of planners that received a new path.  Everything here -- the state gather, the search, the
+        masks -- is enqueued on `stream` (torch's current stream when None)."""
         t = self.torch
-        mo = self.mpc_output[:, 1]
-        e = mo[:, 14:17]
-        sr, cr, sp, cp, sy, cy = t.sin(e[:, 0]), t.cos(e[:, 0]), t.sin(e[:, 1]), t.cos(e[:, 1]), t.sin(e[:, 2]), t.cos(e[:, 2])
-        zb = t.stack([cy * sp * cr + sy * sr, sy * sp * cr - cy * sr, cp * cr], 1)  # eulerToRot(e) [0 0 1]'
-        acc = zb * (mo[:, 3:4] / mass)
-        acc[:, 2] -= g
-        ev = end_vel if end_vel is not None else t.zeros_like(end_pt)
-        planner.upload(mo[:, 8:11].contiguous(), mo[:, 11:14].contiguous(), acc.contiguous(), end_pt, ev, external_acc)
-        planner.plan(init=init, active=replan, stream=stream)
-        ok = (replan != 0) & (planner.status != ASTAR_NO_PATH)
-        if time_offset is not None:
-            time_offset.masked_fill_(ok, 0.0)
-        if self.mode is not None:
-            self.mode.masked_fill_(ok, L.MODEL_NORMAL)
+        s = stream if stream is not None else t.cuda.current_stream(self.solver.device)
+        with t.cuda.stream(s):
+            B, N = self.B, self.N
+            rows = self.mpc_output[:, :N]                      # pre_mpc_output_: rows 0..N-1 of the deque
+            tc = t_cur if t_cur is not None else t.zeros((B,), dtype=t.float64, device=rows.device)
+            idx = t.floor(tc / Ts).to(t.int64)
+            use_plan = (self.solver.exitflag == 1) & (idx < N - 1) & (tc >= 0.0)
+            i0 = idx.clamp(0, N - 2)
+            ar = t.arange(B, device=rows.device)
+            r0, r1 = rows[ar, i0], rows[ar, i0 + 1]
+            mo = r0 + (t.fmod(tc, Ts) / Ts)[:, None] * (r1 - r0)
+            if t_cur is None:
+                mo = self.mpc_output[:, 1].clone()             # (the tick's convention here: the plan's next state)
+            e = mo[:, 14:17]
+            sr, cr, sp, cp, sy, cy = t.sin(e[:, 0]), t.cos(e[:, 0]), t.sin(e[:, 1]), t.cos(e[:, 1]), t.sin(e[:, 2]), t.cos(e[:, 2])
+            zb = t.stack([cy * sp * cr + sy * sr, sy * sp * cr - cy * sr, cp * cr], 1)  # eulerToRot(e) [0 0 1]'
+            acc = zb * (mo[:, 3:4] / mass)
+            acc[:, 2] -= g
+            o_pt, o_v = (odom if odom is not None else (self.mpc_output[:, 1, 8:11], self.mpc_output[:, 1, 11:14]))
+            up = use_plan[:, None]
+            s_pt = t.where(up, mo[:, 8:11], o_pt); s_v = t.where(up, mo[:, 11:14], o_v); s_a = t.where(up, acc, t.zeros_like(acc))
+            ev = end_vel if end_vel is not None else t.zeros_like(end_pt)
+            planner.upload(s_pt.contiguous(), s_v.contiguous(), s_a.contiguous(), end_pt, ev, external_acc,
+                           retry=(o_pt.contiguous(), o_v.contiguous()))
+            planner.plan(init=init, active=replan, stream=s)
+            ok = (replan != 0) & (planner.status != ASTAR_NO_PATH)
+            if time_offset is not None:
+                time_offset.masked_fill_(ok, 0.0)
+            if self.mode is not None:
+                self.mode.masked_fill_(ok, L.MODEL_NORMAL)
         return ok
 
     def full_tick(self, external_acc, kino_path, time_offset, cloud, ref_pos, ref_yaw, stream=None, replan=None,

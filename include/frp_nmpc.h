@@ -328,10 +328,14 @@ typedef struct frp_nmpc_astar {
     int *kino_size;            /* [B] kino_size_; a planner whose search ends in NO_PATH keeps its previous path and size
                                   (getKinoPath returns before assigning them, nmpc_solver.cpp:195-198)                     */
     int *status;               /* [B] FRP_ASTAR_*                                                                        */
-    int *stats;                /* [B][4] or NULL: nodes used, expansions, 1 if the search was repeated, path nodes (negated
-                                  when the path had more than K samples and lost its tail)                               */
+    int *stats;                /* [B][4] or NULL: nodes used, expansions, 1 if the search was repeated, path nodes -- negated when
+                                  something was lost: more than K samples (the first K are kept), or more path nodes than
+                                  FRP_ASTAR_MAX_PATH (then NOTHING is returned: status NO_PATH, the planner keeps its path) */
     double *path_nodes;        /* [B][FRP_ASTAR_MAX_PATH][11] or NULL: state(6), input(3), duration, pool index of every
                                   path node (path_nodes_, :308-320)                                                      */
+    const double *retry_pt, *retry_vel; /* [B][3] each or NULL: the start of the REPEATED search.  getKinoPath starts the first
+                                  search from the plan interpolated at t_cur with the planned thrust as acceleration, but the
+                                  retry from the odometry state (nmpc_solver.cpp:151-153, 190-193); NULL: start_pt / start_vel */
 } frp_nmpc_astar;
 
 /* Bytes of device workspace for (B, grid, allocate_num): bit-packed map + per planner node pool, open-set heap, voxel hash. */

@@ -36,6 +36,9 @@
 #include "astar_oracle.h"
 
 /* ------------------------------------------------------------------ deterministic elementary functions (fdlibm) */
+/* Eigen's unrolled reduction of a fixed-size 3-vector: a0 b0 + (a1 b1 + a2 b2) */
+static double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]); }
+
 static inline uint32_t hi_word(double x) { uint64_t u; memcpy(&u, &x, 8); return (uint32_t)(u >> 32); }
 static inline uint32_t lo_word(double x) { uint64_t u; memcpy(&u, &x, 8); return (uint32_t)u; }
 static inline double from_words(uint32_t hi, uint32_t lo) { uint64_t u = ((uint64_t)hi << 32) | lo; double x; memcpy(&x, &u, 8); return x; }
@@ -367,10 +370,12 @@ static double estimate_heuristic(const Search *S, const double x1[6], const doub
     const orc_astar_params *P = S->P;
     double dp[3], v0[3], v1[3];
     for (int i = 0; i < 3; i++) { dp[i] = x2[i] - x1[i]; v0[i] = x1[3 + i]; v1[i] = x2[3 + i]; }
-    const double c1 = -36 * (dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2]);
-    const double c2 = 24 * ((v0[0] + v1[0]) * dp[0] + (v0[1] + v1[1]) * dp[1] + (v0[2] + v1[2]) * dp[2]);
-    const double c3 = -4 * ((v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2]) + (v0[0] * v1[0] + v0[1] * v1[1] + v0[2] * v1[2]) +
-                            (v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]));
+    /* Eigen reduces a fixed-size 3-vector as a0 b0 + (a1 b1 + a2 b2) (redux_novec_unroller splits [0, 3) into [0, 1) and [1, 3)):
+     * dp.dot(dp), (v0 + v1).dot(dp), v0.dot(v0) + v0.dot(v1) + v1.dot(v1) of kinodynamic_astar.cpp:329-331 in that order */
+    const double vs[3] = {v0[0] + v1[0], v0[1] + v1[1], v0[2] + v1[2]};
+    const double c1 = -36 * dot3(dp, dp);
+    const double c2 = 24 * dot3(vs, dp);
+    const double c3 = -4 * ((dot3(v0, v0) + dot3(v0, v1)) + dot3(v1, v1));
     const double c4 = 0, c5 = P->w_time;
     double ts[5];
     int nt = quartic(c5, c4, c3, c2, c1, ts);
@@ -473,7 +478,7 @@ int orc_astar_search(const orc_astar_params *P, const double start_pt[3], const 
         const int near_end = abs(cur_node->index[0] - end_index[0]) <= tolerance && abs(cur_node->index[1] - end_index[1]) <= tolerance &&
                              abs(cur_node->index[2] - end_index[2]) <= tolerance;
         double dst[3] = {cur_node->state[0] - start_pt[0], cur_node->state[1] - start_pt[1], cur_node->state[2] - start_pt[2]};
-        const int reach_horizon = sqrt(dst[0] * dst[0] + dst[1] * dst[1] + dst[2] * dst[2]) >= P->horizon;
+        const int reach_horizon = sqrt(dot3(dst, dst)) >= P->horizon; /* (cur_node->state.head(3) - start_pt).norm() */
         if (reach_horizon || near_end) {
             terminate_node = cur;
             if (near_end) {
@@ -534,7 +539,7 @@ int orc_astar_search(const orc_astar_params *P, const double start_pt[3], const 
                 }
                 if (is_occ) continue;
                 double ttg;
-                const double tmp_g_score = ((um[0] * um[0] + um[1] * um[1] + um[2] * um[2]) + P->w_time) * tau + cur_node->g_score;
+                const double tmp_g_score = (dot3(um, um) + P->w_time) * tau + cur_node->g_score; /* um.squaredNorm() */
                 const double tmp_f_score = tmp_g_score + P->lambda_heu * estimate_heuristic(S, pro_state, end_state, &ttg);
                 int prune = 0;
                 for (int q = 0; q < n_tmp; ++q) {
@@ -595,7 +600,11 @@ done:
     if (terminate_node >= 0) { /* retrievePath, :308-320 */
         int n = 0;
         for (int c = terminate_node; c >= 0; c = S->pool[c].parent) n++;
-        if (n > ORC_ASTAR_MAX_PATH) n = ORC_ASTAR_MAX_PATH; /* (the head of an over-long path is cut; the caps are far above what the tests produce) */
+        if (n > ORC_ASTAR_MAX_PATH) { /* more nodes than the result holds: not returned at all (NO_PATH: the planner keeps its path), like the device */
+            n = 0;
+            status = ORC_ASTAR_NO_PATH;
+            out->status = status;
+        }
         out->n_path = n;
         int c = terminate_node;
         for (int q = n - 1; q >= 0; q--, c = S->pool[c].parent) {
@@ -685,13 +694,13 @@ int orc_astar_replay(const orc_astar_params *P, const double external_acc[3], co
  * the search that produced the path (NO_PATH: no path, kino_size = 0). */
 int orc_astar_plan(const orc_astar_params *P, const double start_pt[3], const double start_v[3], const double start_a[3],
                    const double end_pt[3], const double end_v[3], int init, const double external_acc[3], double Ts,
-                   double *kino_path, int cap, int *kino_size, orc_astar_result *res, int *retried)
+                   double *kino_path, int cap, int *kino_size, orc_astar_result *res, int *retried, const double *retry_pt, const double *retry_v)
 {
     int status = orc_astar_search(P, start_pt, start_v, start_a, end_pt, end_v, init, external_acc, res);
     *retried = 0;
     if (status == ORC_ASTAR_NO_PATH && init) {
-        *retried = 1;
-        status = orc_astar_search(P, start_pt, start_v, start_a, end_pt, end_v, 0, external_acc, res);
+        *retried = 1; /* "retry searching with discontinuous initial state": from the odometry state (start_pt_, start_v_), :190-193 */
+        status = orc_astar_search(P, retry_pt ? retry_pt : start_pt, retry_v ? retry_v : start_v, start_a, end_pt, end_v, 0, external_acc, res);
     }
     *kino_size = status == ORC_ASTAR_NO_PATH ? 0 : orc_astar_kino_traj(P, external_acc, res, Ts, kino_path, cap);
     return status;
@@ -699,7 +708,7 @@ int orc_astar_plan(const orc_astar_params *P, const double start_pt[3], const do
 
 void orc_astar_batch(int B, const orc_astar_params *P, const double *start_pt, const double *start_v, const double *start_a,
                      const double *end_pt, const double *end_v, int init, const double *external_acc, double Ts, double *kino_path,
-                     int cap, int *kino_size, int *status, orc_astar_result *res, int *retried, int nthreads)
+                     int cap, int *kino_size, int *status, orc_astar_result *res, int *retried, int nthreads, const double *retry_pt, const double *retry_v)
 {
 #ifdef _OPENMP
     extern void omp_set_num_threads(int);
@@ -710,7 +719,8 @@ void orc_astar_batch(int B, const orc_astar_params *P, const double *start_pt, c
         orc_astar_result local, *r = res ? res + b : &local;
         int rt = 0;
         status[b] = orc_astar_plan(P, start_pt + 3 * b, start_v + 3 * b, start_a + 3 * b, end_pt + 3 * b, end_v + 3 * b, init,
-                                   external_acc + 3 * b, Ts, kino_path + (size_t)b * cap * 3, cap, kino_size + b, r, &rt);
+                                   external_acc + 3 * b, Ts, kino_path + (size_t)b * cap * 3, cap, kino_size + b, r, &rt,
+                                   retry_pt ? retry_pt + 3 * b : 0, retry_v ? retry_v + 3 * b : 0);
         if (retried) retried[b] = rt;
     }
 }

@@ -55,10 +55,10 @@ int orc_astar_kino_traj(const orc_astar_params *P, const double external_acc[3],
 int orc_astar_replay(const orc_astar_params *P, const double external_acc[3], const orc_astar_result *r);
 int orc_astar_plan(const orc_astar_params *P, const double start_pt[3], const double start_v[3], const double start_a[3],
                    const double end_pt[3], const double end_v[3], int init, const double external_acc[3], double Ts,
-                   double *kino_path, int cap, int *kino_size, orc_astar_result *res, int *retried);
+                   double *kino_path, int cap, int *kino_size, orc_astar_result *res, int *retried, const double *retry_pt, const double *retry_v);
 void orc_astar_batch(int B, const orc_astar_params *P, const double *start_pt, const double *start_v, const double *start_a,
                      const double *end_pt, const double *end_v, int init, const double *external_acc, double Ts, double *kino_path,
-                     int cap, int *kino_size, int *status, orc_astar_result *res, int *retried, int nthreads);
+                     int cap, int *kino_size, int *status, orc_astar_result *res, int *retried, int nthreads, const double *retry_pt, const double *retry_v);
 #ifdef __cplusplus
 }
 #endif

@@ -49,7 +49,7 @@ def make_params(world):
     return p
 
 
-def plan_batch(world, start_pt, start_v, start_a, end_pt, end_v, f_ext, init=True, Ts=0.05, cap=2048, nthreads=0):
+def plan_batch(world, start_pt, start_v, start_a, end_pt, end_v, f_ext, init=True, Ts=0.05, cap=2048, nthreads=0, retry_pt=None, retry_v=None):
     """NMPCSolver::getKinoPath's search + getKinoTraj for B planners on the CPU oracle.
     Returns dict(status [B], kino_path [B,cap,3], kino_size [B], retried [B], results [B] AstarResult)."""
     B = start_pt.shape[0]
@@ -59,5 +59,6 @@ def plan_batch(world, start_pt, start_v, start_a, end_pt, end_v, f_ext, init=Tru
     path = np.zeros((B, cap, 3)); size = np.zeros(B, dtype=np.int32); status = np.zeros(B, dtype=np.int32); retried = np.zeros(B, dtype=np.int32)
     res = (AstarResult * B)()
     lib().orc_astar_batch(B, ctypes.byref(p), OL.P(sp), OL.P(sv), OL.P(sa), OL.P(ep), OL.P(ev), 1 if init else 0, OL.P(fe), ctypes.c_double(Ts),
-                          OL.P(path), cap, size.ctypes.data_as(IP), status.ctypes.data_as(IP), res, retried.ctypes.data_as(IP), nthreads)
+                          OL.P(path), cap, size.ctypes.data_as(IP), status.ctypes.data_as(IP), res, retried.ctypes.data_as(IP), nthreads,
+                          OL.P(c(retry_pt)) if retry_pt is not None else None, OL.P(c(retry_v)) if retry_v is not None else None)
     return dict(status=status, kino_path=path, kino_size=size, retried=retried, results=res)

@@ -164,16 +164,21 @@ def test_fleet_replans_the_flagged_planners_on_the_device():
     torch.cuda.synchronize()
     assert flags.cpu().tolist() == [0, 1, 0, 0, 1, 0]
     end = torch.from_numpy(q["end_pt"]).to(dev); fext = torch.from_numpy(q["f_ext"]).to(dev)
-    ok = fleet.replan(pl, end, fext, flags, time_offset=toff)
+    fleet.solver.exitflag.fill_(1)   # the last solve succeeded: the search starts from the plan (nmpc_solver.cpp:159-181)
+    fleet.solver.exitflag[5] = 0     # ... except planner 5's (not flagged here; its start is checked below all the same)
+    side = torch.cuda.Stream(dev)    # everything replan() does is enqueued on the stream it is given
+    side.wait_stream(torch.cuda.current_stream(dev))
+    ok = fleet.replan(pl, end, fext, flags, time_offset=toff, stream=side)
     torch.cuda.synchronize()
     st = pl.status.cpu().numpy()
+    assert np.array_equal(pl._q[2][5].cpu().numpy(), np.zeros(3))  # exit_code != 1: odometry state, zero acceleration (:151-153, :187-189)
     # the oracle from the same starts
     m = mpc[:, 1]; e = m[:, 14:17]
     sr, cr, sp, cp, sy, cy = np.sin(e[:, 0]), np.cos(e[:, 0]), np.sin(e[:, 1]), np.cos(e[:, 1]), np.sin(e[:, 2]), np.cos(e[:, 2])
     acc = np.stack([cy * sp * cr + sy * sr, sy * sp * cr - cy * sr, cp * cr], 1) * (m[:, 3:4] / 0.74); acc[:, 2] -= 9.81
     up = [t.cpu().numpy() for t in pl._q]
-    assert np.allclose(up[2], acc, rtol=0, atol=1e-12) and np.array_equal(up[0], m[:, 8:11])
-    o = AL.plan_batch(w, up[0], up[1], up[2], up[3], up[4], up[5], nthreads=4)
+    assert np.allclose(up[2][:5], acc[:5], rtol=0, atol=1e-12) and np.array_equal(up[0], m[:, 8:11])
+    o = AL.plan_batch(w, up[0], up[1], up[2], up[3], up[4], up[5], nthreads=4, retry_pt=pl._retry[0].cpu().numpy(), retry_v=pl._retry[1].cpu().numpy())
     for b in range(B):
         n = int(pl.kino_size[b])
         if b in (1, 4) and st[b] != solver.ASTAR_NO_PATH:
@@ -182,3 +187,31 @@ def test_fleet_replans_the_flagged_planners_on_the_device():
         else:
             assert not bool(ok[b]) and float(toff[b]) == 0.3 and torch.equal(pl.kino_path[b], path0[b]) and n == int(size0[b])
     assert bool(ok[1]) or bool(ok[4])
+
+
+def test_repeated_search_starts_from_the_odometry_state():
+    """getKinoPath repeats a failed search from the odometry state, not from the plan's interpolated one (nmpc_solver.cpp:190-193):
+    frp_nmpc_astar.retry_pt / retry_vel.  Starts inside an obstacle fail the first search at once; the retry from a free state finds a
+    path -- the oracle's, to the bit -- and from the same blocked state it does not."""
+    import torch
+    w = workloads.astar_world(33, "pillars", allocate_num=12000, n_obstacles=25)
+    B = 8
+    q = workloads.astar_queries(B, 33)
+    occ = w["occ"]; res = w["resolution"]; org = np.array(w["origin"])
+    ix, iy, iz = np.argwhere(occ[:, :, 5:15] > 0)[::max(1, int((occ[:, :, 5:15] > 0).sum()) // B)][:B].T
+    blocked = org + (np.stack([ix, iy, iz + 5], 1) + 0.5) * res
+    pl = solver.AstarPlanner(w, B, K=1024, want_path_nodes=True)
+    pl.upload(blocked, np.zeros((B, 3)), q["start_a"], q["end_pt"], q["end_v"], q["f_ext"], retry=(q["start_pt"], q["start_v"]))
+    pl.plan(); torch.cuda.synchronize()
+    st = pl.status.cpu().numpy(); stats = pl.stats.cpu().numpy()
+    o = AL.plan_batch(w, blocked, np.zeros((B, 3)), q["start_a"], q["end_pt"], q["end_v"], q["f_ext"], nthreads=4, cap=1024,
+                      retry_pt=q["start_pt"], retry_v=q["start_v"])
+    assert np.array_equal(st, o["status"]) and np.array_equal(stats[:, 2], o["retried"])
+    assert (stats[:, 2] == 1).all() and (st != solver.ASTAR_NO_PATH).any()
+    for b in range(B):
+        if st[b] != solver.ASTAR_NO_PATH:
+            n = int(pl.kino_size[b])
+            assert n == o["kino_size"][b] and np.array_equal(pl.kino_path[b, :n].cpu().numpy(), o["kino_path"][b, :n])
+    pl.upload(blocked, np.zeros((B, 3)), q["start_a"], q["end_pt"], q["end_v"], q["f_ext"])  # no retry state: the repeat starts blocked too
+    pl.plan(); torch.cuda.synchronize()
+    assert (pl.status.cpu().numpy() == solver.ASTAR_NO_PATH).all()

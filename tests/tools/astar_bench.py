@@ -25,7 +25,7 @@ t0 = time.perf_counter()
 o = AL.plan_batch(w, q["start_pt"][:nb], q["start_v"][:nb], q["start_a"][:nb], q["end_pt"][:nb], q["end_v"][:nb], q["f_ext"][:nb], cap=1024, nthreads=nthr)
 t_cpu = time.perf_counter() - t0
 same = bool(np.array_equal(st[:nb], o["status"]) and np.array_equal(pl.kino_size.cpu().numpy()[:nb][st[:nb] != 3], o["kino_size"][st[:nb] != 3]))
-print(json.dumps({"what": "frp_nmpc_astar_batch: searches/s, whole batch (one 256-thread workgroup per planner)", "B": B, "world": kind, "allocate_num": alloc,
+print(json.dumps({"what": "frp_nmpc_astar_batch: searches/s, whole batch (one 1024-thread workgroup per planner)", "B": B, "world": kind, "allocate_num": alloc,
                   "gpu_ms": float(np.median(ts)) * 1e3, "gpu_searches_per_s": B / float(np.median(ts)),
                   "expansions_total": int(stats[:, 1].sum()), "expansions_max": int(stats[:, 1].max()), "nodes_mean": float(stats[:, 0].mean()),
                   "gpu_us_per_expansion_of_the_longest_search": float(np.median(ts)) * 1e6 / max(1, int(stats[:, 1].max())),
