@@ -903,7 +903,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
                     mend = c.grid_start[row + hi[0] + 1];
                 }
                 const int nr = rows - rb < 64 ? rows - rb : 64;
-                for (int r0 = 0; r0 < nr; r0 += CW_ROWS) {
+                for (int r0 = 0; r0 < nr && count <= CW_CAP; r0 += CW_ROWS) { // (a box that has already overflowed the tile is left to the kernels behind: stop reading)
                     int beg[CW_ROWS], end[CW_ROWS], most = 0;
 #pragma unroll
                     for (int k = 0; k < CW_ROWS; ++k) {

@@ -81,7 +81,11 @@ def run(B=4096, TICKS=10, P=20000, GRID=0.5, SPLIT=2):
                       "grid_cell": GRID, "ms_per_tick": total, "planner_ticks_per_s": B / total * 1e3, "ms_per_step": ms,
                       "sub_fleets_on_own_streams": ({"parts": SPLIT, "ms_per_tick": split_ms, "planner_ticks_per_s": B / split_ms * 1e3} if split_ms else None),
                       "converged_frac": float((fl == 1).mean()), "mean_iters": float(it.mean()),
-                      "polytopes_per_planner": float((fleet.poly_nfaces > 0).sum().item() / B)})
+                      "polytopes_per_planner": float((fleet.poly_nfaces > 0).sum().item() / B),
+                      "mean_rows": float(fleet.poly_nfaces[fleet.poly_nfaces > 0].double().mean().item()),
+                      # work terms of tools/tick_rooflines.py: points in a local box (4.1 x 4 x 2 m) and in the grid cells under its hull, from the cloud's density
+                      "in_box_points_per_decomposition": float(len(cloud)) / (15.0 * 8.0 * 3.5) * 32.8 * 0.7,
+                      "grid_candidates_per_decomposition": float(len(cloud)) / (15.0 * 8.0 * 3.5) * (4.6 * 4.5 * 2.5)})
 
 
 if __name__ == "__main__":
