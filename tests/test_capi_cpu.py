@@ -136,7 +136,10 @@ def test_no_device_means_loud_failure_not_cpu_fallback():
 def _harness():
     exe = os.path.join(ROOT, "tests", "cpp", "adapter_harness")
     src = exe + ".cpp"
-    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+    # (rebuilt whenever the source, the C-ABI header, the C++ adapter or the library is newer: the harness sizes its buffers from the
+    # header's constants -- a binary built against an older FRP_INFO_STRIDE corrupts its heap)
+    deps = [src, os.path.join(ROOT, "include", "frp_nmpc.h"), os.path.join(ROOT, "forces_resilient_planner_amd", "csrc", "frp_adapter.hpp"), solver.LIB_PATH]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps if os.path.exists(d)):
         subprocess.check_call(["g++", "-O2", "-std=c++17", src, "-o", exe, "-L" + os.path.dirname(solver.LIB_PATH),
                                "-lfrp_nmpc_amd", "-Wl,-rpath," + os.path.dirname(solver.LIB_PATH),
                                "-Wl,-rpath,/opt/rocm/lib"])

@@ -991,7 +991,7 @@ def test_plain_c_program_drives_the_whole_tick_through_the_c_abi(tmp_path):
     exe = os.path.join(root, "tests", "cpp", "tick_harness")
     src = exe + ".c"
     libdir = os.path.dirname(solver.LIB_PATH)
-    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(solver.LIB_PATH)):
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(solver.LIB_PATH), os.path.getmtime(os.path.join(OL.ROOT, "include", "frp_nmpc.h"))):
         subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-I" + os.path.join(root, "include"), "-I/opt/rocm/include", src, "-o", exe,
                                "-L" + libdir, "-lfrp_nmpc_amd", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     B, N, K, T = 12, 20, 80, 3
