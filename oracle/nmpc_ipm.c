@@ -243,10 +243,204 @@ static void build_phi(solver_ws *W, const double *params, double sigmamu, int us
     }
 }
 
+/* ------------------------------------------------------------------------------------------------------------------------
+ * STUDY: the same Newton system solved from BOTH ends of the horizon.  Stages m..N-1 by the backward
+ * recursion above, stages 0..m-1 by an ARRIVAL-cost recursion in information form,
+ *     F_{k+1}(s+) = min_{w_k} [ l_k(u_k, w_k, x_k) + F_k(w_k, x_k) ],   u_k = w+ - d_w,   x_k = A^-1 (x+ - B u_k - d_x),
+ * a 4x4 pivot on w_k and two 13x13 congruences per stage (the mirror image of a backward stage: u and w swap roles); the pinned
+ * x_0 -- which makes the exact recursion rank-deficient for three stages -- enters as the penalty rho/2 |dx_0 - r_0|^2 (rho = 1e12:
+ * tools/study/twisted_riccati.py).  The halves meet at stage m: ds_m = -(Q_m + P_m)^-1 (q_m + p_m); the first half is then
+ * back-substituted m-1..0 and its multipliers are y_k = -(Q_k ds_k + q_k).  Switched on by the environment (ORC_TWIST=m, optional
+ * ORC_TWIST_RHO): a study switch of the test oracle, never a product path.
+ * ------------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    double Q[NS * NS], q[NS];          /* arrival cost AT s_k (before stage k's own cost)                         */
+    double Lw[16], Hwr[4 * NS], G[NS * NS], Tt[NS * NS], tt[NS]; /* kept by the factorising pass for the vector pass */
+    double Kw[4 * (NS + 1)];            /* w_k = -Kw [u; x; 1]                                                       */
+} arr_ws;
+
+static int chol(int n, const double *A, int lda, double *Lo) /* lower Cholesky, row-major n x n in Lo (ld n) */
+{
+    for (int j = 0; j < n; j++) {
+        double dsum = A[j * lda + j];
+        for (int l = 0; l < j; l++) dsum -= Lo[j * n + l] * Lo[j * n + l];
+        if (!(dsum > 0.0)) return -1;
+        const double dj = sqrt(dsum);
+        Lo[j * n + j] = dj;
+        for (int i = j + 1; i < n; i++) {
+            double a = A[i * lda + j];
+            for (int l = 0; l < j; l++) a -= Lo[i * n + l] * Lo[j * n + l];
+            Lo[i * n + j] = a / dj;
+        }
+        for (int i = 0; i < j; i++) Lo[i * n + j] = 0.0;
+    }
+    return 0;
+}
+static void chol_solve(int n, const double *Lo, double *b) /* b <- (L L')^-1 b */
+{
+    for (int i = 0; i < n; i++) { double a = b[i]; for (int l = 0; l < i; l++) a -= Lo[i * n + l] * b[l]; b[i] = a / Lo[i * n + i]; }
+    for (int i = n - 1; i >= 0; i--) { double a = b[i]; for (int l = i + 1; l < n; l++) a -= Lo[l * n + i] * b[l]; b[i] = a / Lo[i * n + i]; }
+}
+static int inv9(const double *A, double *Ai) /* Gauss-Jordan with partial pivoting */
+{
+    double M[9 * 18];
+    for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) { M[i * 18 + j] = A[i * 9 + j]; M[i * 18 + 9 + j] = i == j ? 1.0 : 0.0; }
+    for (int c = 0; c < 9; c++) {
+        int piv = c;
+        for (int i = c + 1; i < 9; i++) if (fabs(M[i * 18 + c]) > fabs(M[piv * 18 + c])) piv = i;
+        if (M[piv * 18 + c] == 0.0) return -1;
+        if (piv != c) for (int j = 0; j < 18; j++) { const double t = M[c * 18 + j]; M[c * 18 + j] = M[piv * 18 + j]; M[piv * 18 + j] = t; }
+        const double inv = 1.0 / M[c * 18 + c];
+        for (int j = 0; j < 18; j++) M[c * 18 + j] *= inv;
+        for (int i = 0; i < 9; i++) if (i != c) { const double f = M[i * 18 + c]; if (f != 0.0) for (int j = 0; j < 18; j++) M[i * 18 + j] -= f * M[c * 18 + j]; }
+    }
+    for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) Ai[i * 9 + j] = M[i * 18 + 9 + j];
+    return 0;
+}
+/* dense barrier-augmented Hessian of a stage over [u(0..3) w(4..7) x(8..16)], as riccati_step assembles it */
+static void stage_phi_dense(const stage_ws *w, double *Q)
+{
+    memset(Q, 0, 17 * 17 * sizeof(double));
+    for (int i = 0; i < 17; i++) Q[i * 17 + i] = w->PhiD[i];
+    for (int i = 0; i < 4; i++) Q[i * 17 + 4 + i] = Q[(4 + i) * 17 + i] = w->hc;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) Q[(8 + i) * 17 + 8 + j] += w->PhiPos[i * 3 + j];
+    if (w->useH) {
+        static const int zi[10] = {0, 1, 2, 3, 11, 12, 13, 14, 15, 16};
+        for (int i = 0; i < 10; i++)
+            for (int j = 0; j < 10; j++) Q[zi[i] * 17 + zi[j]] += w->thetaH * w->Hd[i * 10 + j];
+    }
+}
+/* one arrival step: (a->Q, a->q) at s_k  ->  (Qn, qn) at s_{k+1}.  idx maps the 13 kept variables [u; x] to z positions. */
+static int arrival_step(const stage_ws *w, arr_ws *a, double *Qn, double *qn, int full)
+{
+    static const int idx[NS] = {0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+    double gf[17];
+    memcpy(gf, w->phi, sizeof gf);
+    for (int i = 0; i < NS; i++) gf[4 + i] += a->q[i];
+    if (full) {
+        double Hf[17 * 17];
+        stage_phi_dense(w, Hf);
+        for (int i = 0; i < NS; i++)
+            for (int j = 0; j < NS; j++) Hf[(4 + i) * 17 + 4 + j] += a->Q[i * NS + j];
+        double Hww[16];
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) Hww[i * 4 + j] = Hf[(4 + i) * 17 + 4 + j];
+        if (chol(4, Hww, 4, a->Lw)) return -1;
+        for (int i = 0; i < 4; i++) for (int j = 0; j < NS; j++) a->Hwr[i * NS + j] = Hf[(4 + i) * 17 + idx[j]];
+        for (int j = 0; j < NS; j++) { /* Kw[:, j] = Hww^-1 Hwr[:, j] */
+            double col[4];
+            for (int i = 0; i < 4; i++) col[i] = a->Hwr[i * NS + j];
+            chol_solve(4, a->Lw, col);
+            for (int i = 0; i < 4; i++) a->Kw[i * (NS + 1) + j] = col[i];
+        }
+        for (int i = 0; i < NS; i++)
+            for (int j = 0; j < NS; j++) {
+                double v = Hf[idx[i] * 17 + idx[j]];
+                for (int l = 0; l < 4; l++) v -= a->Hwr[l * NS + i] * a->Kw[l * (NS + 1) + j];
+                a->G[i * NS + j] = v;
+            }
+        double Ai[81];
+        if (inv9(w->Ax, Ai)) return -1;
+        memset(a->Tt, 0, sizeof a->Tt);
+        for (int i = 0; i < 4; i++) a->Tt[i * NS + i] = 1.0;
+        for (int i = 0; i < 9; i++) {
+            for (int j = 0; j < 4; j++) { double v = 0; for (int l = 0; l < 9; l++) v += Ai[i * 9 + l] * w->Bx[l * 4 + j]; a->Tt[(4 + i) * NS + j] = -v; }
+            for (int j = 0; j < 9; j++) a->Tt[(4 + i) * NS + 4 + j] = Ai[i * 9 + j];
+        }
+        for (int i = 0; i < 4; i++) a->tt[i] = -w->d[i];
+        for (int i = 0; i < 9; i++) {
+            double v = 0;
+            for (int l = 0; l < 9; l++) { double bd = -w->d[4 + l]; for (int j = 0; j < 4; j++) bd += w->Bx[l * 4 + j] * w->d[j]; v += Ai[i * 9 + l] * bd; }
+            a->tt[4 + i] = v;
+        }
+        double GT[NS * NS];
+        for (int i = 0; i < NS; i++) for (int j = 0; j < NS; j++) { double v = 0; for (int l = 0; l < NS; l++) v += a->G[i * NS + l] * a->Tt[l * NS + j]; GT[i * NS + j] = v; }
+        for (int i = 0; i < NS; i++) for (int j = 0; j < NS; j++) { double v = 0; for (int l = 0; l < NS; l++) v += a->Tt[l * NS + i] * GT[l * NS + j]; Qn[i * NS + j] = v; }
+        for (int i = 0; i < NS; i++) for (int j = 0; j < i; j++) { const double v = 0.5 * (Qn[i * NS + j] + Qn[j * NS + i]); Qn[i * NS + j] = Qn[j * NS + i] = v; }
+    }
+    /* vector part */
+    double col[4], gg[NS], t2[NS];
+    for (int i = 0; i < 4; i++) col[i] = gf[4 + i];
+    chol_solve(4, a->Lw, col);
+    for (int i = 0; i < 4; i++) a->Kw[i * (NS + 1) + NS] = col[i];
+    for (int i = 0; i < NS; i++) { double v = gf[idx[i]]; for (int l = 0; l < 4; l++) v -= a->Hwr[l * NS + i] * col[l]; gg[i] = v; }
+    for (int i = 0; i < NS; i++) { double v = gg[i]; for (int l = 0; l < NS; l++) v += a->G[i * NS + l] * a->tt[l]; t2[i] = v; }
+    for (int i = 0; i < NS; i++) { double v = 0; for (int l = 0; l < NS; l++) v += a->Tt[l * NS + i] * t2[l]; qn[i] = v; }
+    return 0;
+}
+
+static int kkt_solve_twisted(solver_ws *W, const double *xinit, int full, int m, double rho)
+{
+    const int N = W->N;
+    static __thread arr_ws *A = 0;
+    static __thread int A_n = 0;
+    if (A_n < m + 1) { free(A); A = (arr_ws *)malloc(sizeof(arr_ws) * (size_t)(m + 1)); A_n = m + 1; }
+    for (int k = N - 1; k >= m; k--) {
+        const double *Pn = (k < N - 1) ? W->st[k + 1].P : 0, *pn = (k < N - 1) ? W->st[k + 1].p : 0;
+        if (riccati_step(&W->st[k], Pn, pn, full)) return -1;
+    }
+    if (full) { memset(A[0].Q, 0, sizeof A[0].Q); for (int i = 0; i < 9; i++) A[0].Q[(4 + i) * NS + 4 + i] = rho; }
+    memset(A[0].q, 0, sizeof A[0].q);
+    for (int i = 0; i < 9; i++) A[0].q[4 + i] = -rho * (xinit[i] - W->z[8 + i]);
+    for (int k = 0; k < m; k++)
+        if (arrival_step(&W->st[k], &A[k], A[k + 1].Q, A[k + 1].q, full)) return -1;
+    /* the halves meet at s_m */
+    double S[NS * NS], Ls[NS * NS], ds[NS], dsn[NS];
+    for (int i = 0; i < NS * NS; i++) S[i] = A[m].Q[i] + W->st[m].P[i];
+    if (chol(NS, S, NS, Ls)) return -1;
+    for (int i = 0; i < NS; i++) ds[i] = -(A[m].q[i] + W->st[m].p[i]);
+    chol_solve(NS, Ls, ds);
+    double dsm[NS];
+    memcpy(dsm, ds, sizeof ds);
+    /* second half forward (the loop of kkt_solve from stage m) */
+    for (int k = m; k < N; k++) {
+        const stage_ws *w = &W->st[k];
+        double *dzk = W->dz + 17 * k, *yn = W->ynew + NS * k;
+        for (int i = 0; i < NS; i++) { double a = w->p[i]; for (int j = 0; j < NS; j++) a += w->P[i * NS + j] * ds[j]; yn[i] = a; }
+        double t[4], du[4];
+        for (int i = 0; i < 4; i++) { double a = w->kt[i]; for (int j = 0; j < NS; j++) a += w->Kt[i * NS + j] * ds[j]; t[i] = -a; }
+        for (int i = 3; i >= 0; i--) { double a = t[i]; for (int l = i + 1; l < 4; l++) a -= w->L[l * 4 + i] * du[l]; du[i] = a / w->L[i * 4 + i]; }
+        for (int i = 0; i < 4; i++) dzk[i] = du[i];
+        for (int i = 0; i < NS; i++) dzk[4 + i] = ds[i];
+        if (k < N - 1) {
+            for (int i = 0; i < 4; i++) dsn[i] = du[i] + w->d[i];
+            for (int i = 0; i < 9; i++) {
+                double a = w->d[4 + i];
+                for (int j = 0; j < 9; j++) a += w->Ax[i * 9 + j] * ds[4 + j];
+                for (int j = 0; j < 4; j++) a += w->Bx[i * 4 + j] * du[j];
+                dsn[4 + i] = a;
+            }
+            memcpy(ds, dsn, sizeof ds);
+        }
+    }
+    /* first half backward: [u; x]_k = Tt s_{k+1} + tt, w_k = -Kw [u; x; 1], y_k = -(Q_k ds_k + q_k) */
+    double sp[NS];
+    memcpy(sp, dsm, sizeof sp);
+    for (int k = m - 1; k >= 0; k--) {
+        const arr_ws *a = &A[k];
+        double ux[NS], wk[4];
+        for (int i = 0; i < NS; i++) { double v = a->tt[i]; for (int l = 0; l < NS; l++) v += a->Tt[i * NS + l] * sp[l]; ux[i] = v; }
+        for (int i = 0; i < 4; i++) { double v = a->Kw[i * (NS + 1) + NS]; for (int l = 0; l < NS; l++) v += a->Kw[i * (NS + 1) + l] * ux[l]; wk[i] = -v; }
+        double *dzk = W->dz + 17 * k, *yn = W->ynew + NS * k;
+        for (int i = 0; i < 4; i++) { dzk[i] = ux[i]; dzk[4 + i] = wk[i]; }
+        for (int i = 0; i < 9; i++) dzk[8 + i] = ux[4 + i];
+        for (int i = 0; i < 4; i++) sp[i] = wk[i];
+        for (int i = 0; i < 9; i++) sp[4 + i] = ux[4 + i];
+        for (int i = 0; i < NS; i++) { double v = a->q[i]; for (int l = 0; l < NS; l++) v += a->Q[i * NS + l] * sp[l]; yn[i] = -v; }
+    }
+    return 0;
+}
+
 /* backward (full or vector-only) + forward sweep; fills W->dz and W->ynew */
 static int kkt_solve(solver_ws *W, const double *xinit, int full)
 {
     const int N = W->N;
+    {
+        static int tw_m = -2;
+        static double tw_rho = 1e12;
+        if (tw_m == -2) { const char *e = getenv("ORC_TWIST"); tw_m = e ? atoi(e) : -1; const char *r = getenv("ORC_TWIST_RHO"); if (r) tw_rho = atof(r); }
+        if (tw_m > 0 && tw_m < N - 1) return kkt_solve_twisted(W, xinit, full, tw_m, tw_rho);
+    }
     for (int k = N - 1; k >= 0; k--) {
         const double *Pn = (k < N - 1) ? W->st[k + 1].P : 0, *pn = (k < N - 1) ? W->st[k + 1].p : 0;
         if (riccati_step(&W->st[k], Pn, pn, full)) return -1;
