@@ -158,6 +158,8 @@ def main():
                          "configs[4]: one nominal problem is broadcast, the samples are drawn on every rank's device")
     ap.add_argument("--repeats", type=int, default=5, help="the K-step region is timed this many times; the MEDIAN is reported")
     ap.add_argument("--no-order-hint", action="store_true", help="configs[4]: queue the problems by the cost of the initial guess instead of by the previous tick's iteration counts")
+    ap.add_argument("--twist", type=int, default=0, help="frp_nmpc_options.twist: stages the model wave eliminates forward while the Riccati wave runs the rest backward "
+                    "(0 = the plain solve, -1 = N / 2; N <= 20 only; DESIGN 9.1)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / end-to-end / drop-in latency legs")
     ap.add_argument("--chunks", type=int, default=0, help="--scaling strong: pieces every shard is cut into so that transfers overlap the solve (1 = serial scatter -> "
                     "solve -> gather; 0 = auto: 2 when there is more than one rank and a shard holds at least two rounds of resident workgroups, else 1 -- measured on "
@@ -265,6 +267,7 @@ def main():
             # configs[3]'s generator makes (locally) infeasible instances; the benchmark opts into the early infeasibility
             # exit (frp_nmpc_options.diverge_mu, default 1e3) -- the CPU baseline below runs with the same setting
             ds.opt.diverge_mu = 10.0
+        ds.opt.twist = args.twist
     else:
         # configs[4]: Monte-Carlo f_ext around ONE nominal problem, warm-started receding horizon; a step = one tick
         from forces_resilient_planner_amd.workloads import _bbox_faces, _weights
@@ -415,7 +418,7 @@ def main():
                        "repeat_ms_per_step": [r / args.steps * 1e3 for r in reps],
                        "pipelined_solves_per_s": pipelined,
                        "pipelined_note": "the same steps issued round-robin on 2 HIP streams (the few long solves at the end of a launch overlap the head of the next); informational, never `value`",
-                       "tolerances": 1e-4},
+                       "tolerances": 1e-4, "twist": int(args.twist)},
             "roofline": {"bound": "fp64-issue",
                          "bound_detail": "FP64 VALU + FP64 MFMA issue slots (they share the SIMD's FP64 datapath) of in-order wavefronts on the serial stage chain (DESIGN 5); priced against the FP64 matrix == vector peak",
                          "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -61,7 +61,7 @@ bool fill_args(const frp_nmpc_batch *b, const frp_nmpc_options *opt_in, void *ws
     if (opt_in) o = *opt_in; else frp_nmpc_default_options(&o);
     a->B = b->B; a->N = b->N; a->M = b->M; a->MF = b->MF; a->model = b->model; a->maxit = o.maxit;
     a->tol_stat = o.tol_stat; a->tol_eq = o.tol_eq; a->tol_ineq = o.tol_ineq; a->tol_comp = o.tol_comp;
-    a->mu0 = o.mu0; a->ftb = o.ftb; a->hessian = o.hessian;
+    a->mu0 = o.mu0; a->ftb = o.ftb; a->hessian = o.hessian; a->twist = o.twist;
     a->diverge_mu = o.diverge_mu > 0.0 ? o.diverge_mu : 1e3;
     a->xinit = b->xinit; a->x0 = b->x0; a->params = b->params; a->nfaces = b->nfaces;
     a->z = b->z; a->exitflag = b->exitflag; a->iters = b->iters; a->info = b->info;
@@ -227,7 +227,13 @@ int forces_solve(int model, frp_forces_params *params, frp_forces_output *output
     b.z = g_ctx.d_out; b.info = g_ctx.d_out + 340;
     b.exitflag = reinterpret_cast<int *>(g_ctx.d_out + 340 + FRP_INFO_STRIDE); b.iters = b.exitflag + 1;
     frp::KernelArgs a;
-    if (!fill_args(&b, nullptr, g_ctx.d_ws, g_ctx.ws_bytes, &a)) return FRP_EXIT_PARAM_VALUE;
+    // FORCES' entry point has no options argument: the one option a caller of a SINGLE solve may want -- the latency option
+    // frp_nmpc_options.twist -- comes from the environment (FRP_NMPC_TWIST = m or -1; unset / 0: the plain solve)
+    static const int env_twist = [] { const char *e = getenv("FRP_NMPC_TWIST"); return e ? atoi(e) : 0; }();
+    frp_nmpc_options opt;
+    frp_nmpc_default_options(&opt);
+    opt.twist = env_twist;
+    if (!fill_args(&b, &opt, g_ctx.d_ws, g_ctx.ws_bytes, &a)) return FRP_EXIT_PARAM_VALUE;
     if (frp::launch_ipm(a, st) != hipSuccess) return device_fault("launch");
     if (hipMemcpyAsync(g_ctx.h_out, g_ctx.d_out, DI_OUT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
@@ -437,6 +443,7 @@ void frp_nmpc_default_options(frp_nmpc_options *o)
     o->ftb = 0.99;
     o->hessian = 1;
     o->diverge_mu = 1e3;
+    o->twist = 0;
 }
 
 size_t frp_nmpc_workspace_bytes(int B, int N, int MF) { return frp::ws_bytes(B, N, MF); }

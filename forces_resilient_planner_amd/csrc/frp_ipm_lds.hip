@@ -53,8 +53,18 @@ constexpr int R_ZERO = 287, R_ONE = 288, R_DT = 289; // constants the gathers pi
 constexpr int R_DUMP = 290;  // target of masked-out writes (never read)
 constexpr int R_DZ = 291;    // Newton step [du(4); ds(13)]
 constexpr int R_ZERO2 = R_ZERO + R_BC; // second zero, R_BC behind the first: masked (B, C) pair reads
+// Twisted solve: a stage of the FIRST half keeps the inverted transition [u; x]_k = T~ [w+; x+] + t~ where a stage of
+// the second half keeps the linearisation: A~ = A^-1 has A's block pattern (A~pv, A~pe, A~vv, A~ve in the slots of Apv, Ape, Avv, Ave),
+// B~ = -A^-1 B is dense in its p and v rows (12 + 12 entries), t~ takes d's place, and the record's dt slot holds -dt (the e rows of
+// B~).  The nine entries of B~ that do not fit the 51 linearisation slots live where a first-half record has room: the columns 14, 15
+// of T' (eight slots that only ever meet the zero rows 14, 15 of a sweep vector; the first-half sweeps do not store there), the second
+// zero (only the second half's vector sweep reads it) -- and one spare: the hole between CB and PHIC.
 constexpr int RS = 309;      // odd stride: lane == stage accesses are conflict-free
 static_assert(R_PHIC + 17 <= R_CC && R_CC + 3 <= R_HC && R_DZ + 17 <= R_ZERO2 && R_ZERO2 < RS, "record tail");
+#ifndef FRP_TW_RHO
+#define FRP_TW_RHO 1e12
+#endif
+constexpr double TW_RHO = FRP_TW_RHO; // penalty that pins x_0 in the arrival-cost recursion (tools/study/twisted_riccati.py)
 static_assert(R_HD + REC_HD_SIZE <= R_PV && R_PV + 13 <= R_PD, "overlay region");
 
 // workgroup-shared scratch (doubles)
@@ -108,7 +118,35 @@ __host__ __device__ constexpr int c_src(int row, int col, int which)
     }
     return which == 0 ? o1 : (which == 1 ? o2 : o3);
 }
-enum { T_M = 0, T_C1 = 4, T_C2 = 8, T_C3 = 12, T_PP = 16, T_PD = 20, T4_MT = 24, T4_MTT = 28, T4_P = 32, T4_MU = 36, T4_MTTU = 37, T4_TS = 38, T_ROWS = 39 };
+// T~[row][col] of a first-half stage: rows [u(0..3); x(4..12)] of stage k, cols [w+(0..3); x+(4..12); 13 = t~]
+__host__ __device__ constexpr int lbv_slot(int e) // entry e = 4 i + col of the v rows of B~
+{
+    if (e < 3) return R_LIN + 48 + e;
+    if (e == 11) return R_ZERO2;
+    const int q = e - 3; // 0..7 -> T'[q / 2][14 + q % 2]
+    return R_T + 16 * (q / 2) + 14 + (q % 2);
+}
+__host__ __device__ constexpr int ma_src(int row, int col)
+{
+    if (row > 12 || col > 13) return R_ZERO;
+    if (col == 13) return R_D + row;
+    if (row < 4) return (col == row) ? R_ONE : R_ZERO;
+    const int i = row - 4, bi = i / 3, ii = i % 3;
+    if (col < 4) { // B~[i][col]
+        if (bi == 0) return R_LIN + 36 + ii * 4 + col;
+        if (bi == 1) return lbv_slot(ii * 4 + col);
+        return (col < 3 && ii == col) ? R_DT : R_ZERO; // (a first-half record's dt slot holds -dt)
+    }
+    const int j = col - 4, bj = j / 3, jj = j % 3;
+    if (bi == 0) return bj == 0 ? (ii == jj ? R_ONE : R_ZERO) : R_LIN + (bj == 1 ? 0 : 9) + ii * 3 + jj;
+    if (bi == 1) return bj == 0 ? R_ZERO : R_LIN + (bj == 1 ? 18 : 27) + ii * 3 + jj;
+    return (bj == 2 && ii == jj) ? R_ONE : R_ZERO;
+}
+// twisted solve: workgroup scratch of its own for the arrival cost at the meeting stage -- (Q_m packed lower triangle (91), q_m (13)),
+// a dump slot, the factor of the meeting system (L strictly lower, packed (78), 1 / D (13)), a zero, the model wave's copy of ds_m (16)
+constexpr int TW_Q = 0, TW_QV = 91, TW_DUMP = 104, TW_L = 105, TW_DINV = 183, TW_ZERO = 196, TW_DS = 198, TW_TOTAL = 214;
+enum { T_M = 0, T_C1 = 4, T_C2 = 8, T_C3 = 12, T_PP = 16, T_PD = 20, T4_MT = 24, T4_MTT = 28, T4_P = 32, T4_MU = 36, T4_MTTU = 37, T4_TS = 38,
+       T_MA = 39, T4_MA = 43, T4_MAT = 47, T_SQ = 51, T_ROWS = 55 };
 struct LaneTables {
     unsigned short v[T_ROWS][64];
 };
@@ -133,6 +171,13 @@ constexpr LaneTables make_tables()
             t.v[T4_MTT + r][lane] = (unsigned short)((row < 4 || row > 12) ? R_ZERO : m_src(col, row));
             const int hi = row > col ? row : col, lo = row > col ? col : row;
             t.v[T4_P + r][lane] = (unsigned short)((row <= 12 && col <= 12) ? R_P + hi * (hi + 1) / 2 + lo : R_ZERO);
+            // first half: the tile of T~, [u; x] = T~ v (row 13 carries the constant 1), and its transpose for the arrival vector sweep
+            t.v[T_MA + r][lane] = (unsigned short)ma_src(trow, c);
+            t.v[T4_MA + r][lane] = (unsigned short)((row == 13 && col == 13) ? R_ONE : ma_src(row, col));
+            t.v[T4_MAT + r][lane] = (unsigned short)((row > 12 || col > 12) ? R_ZERO : ma_src(col, row));
+            // store of the arrival-cost tile at the meeting stage into the workgroup scratch (lower triangle + column 13)
+            t.v[T_SQ + r][lane] = (unsigned short)((trow <= 12 && c <= trow) ? TW_Q + trow * (trow + 1) / 2 + c
+                                                   : ((c == 13 && trow <= 12) ? TW_QV + trow : TW_DUMP));
         }
         // "sliced" operands (one register): block qI contracts ITS quarter 4 qI .. 4 qI + 3 of the long dimension, the four
         // blocks are summed afterwards -- for products with only four output rows (du, q_u) and for Mt[:, u] du
@@ -202,9 +247,14 @@ static __device__ long long g_prof_seg[32];
 #ifdef FRP_PROFILE
 #define SWEEP_T0() const long long sw0_ = clock64()
 #define SWEEP_T1(i) do { if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&g_prof_seg[8 + (i)], (unsigned long long)(clock64() - sw0_)); } while (0)
+// twisted solve: slot 22 + i gets the cycles since the last TW_T0() / TW_T1() of this wave
+#define TW_T0() long long tw0_ = clock64()
+#define TW_T1(i) do { const long long tn_ = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&g_prof_seg[(i)], (unsigned long long)(tn_ - tw0_)); tw0_ = tn_; } while (0)
 #else
 #define SWEEP_T0()
 #define SWEEP_T1(i)
+#define TW_T0()
+#define TW_T1(i)
 #endif
 
 // ------------------------------------------------------------------ values every wave derives from the LDS partials
@@ -269,7 +319,7 @@ __device__ __forceinline__ double stationarity_norm(cldouble *recs, int N)
 }
 
 struct Ctl { // workgroup-shared control words
-    int next, fail, bad, mtot;
+    int next, fail, bad, mtot, fail1, fail2; // twisted solve: fail1 = the first half's factorisation, fail2 = the system where the halves meet
 };
 
 // ================================================================== wave 0: Riccati sweeps
@@ -351,6 +401,9 @@ __device__ __forceinline__ void gather_tiles(cldouble *rn, const int (&c1)[4], c
 #else
 #define FRP_FACTOR_LINKAGE __noinline__
 #endif
+// twist (second half of a twisted solve: `recs` is the record of the meeting stage, N the stages from there to the end): the stage-0
+// tail is replaced by publishing p of the meeting stage (column 13 of the tile) in its R_PV slots.
+template <bool twist>
 __device__ FRP_FACTOR_LINKAGE int sweep_factor(ldouble *recs, ldouble *xs, int N, double theta)
 {
     N = uni(N); theta = uni(theta);
@@ -495,7 +548,11 @@ __device__ FRP_FACTOR_LINKAGE int sweep_factor(ldouble *recs, ldouble *xs, int N
     stage(integral_constant<int, 0>{}, std::true_type{}); // stage 0
     SEG_FLUSH();
     int fail = ok ? 0 : 1;
-    if (!fail) {
+    if constexpr (twist) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (c == 13 && 4 * r + g <= 12) recs[R_PV + 4 * r + g] = P[r];
+    } else if (!fail) {
         // stage 0: keep Pww^-1 and Pwx for the corrector pass, then solve for ds_0
         double q[16], Rw[16];
 #pragma unroll
@@ -635,6 +692,7 @@ __device__ __forceinline__ void back_tail(const BackAddr &p, BackOps &X, BackOps
     }
 }
 
+template <bool twist>
 __device__ __noinline__ void sweep_backvec(ldouble *recs, ldouble *xs, int N, double smu)
 {
     N = uni(N); smu = uni(smu);
@@ -683,7 +741,8 @@ __device__ __noinline__ void sweep_backvec(ldouble *recs, ldouble *xs, int N, do
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // p_w[g] sits in the quad-0 lanes of row g; the stage-0 solve wants it in the lanes (g, 13)
-    stage0_solve(xs, lane, __shfl(pv, lane & 48));
+    // (twisted solve: p of the meeting stage is already in its R_PV slots, stored like every stage's)
+    if constexpr (!twist) stage0_solve(xs, lane, __shfl(pv, lane & 48));
     WSYNC();
 }
 
@@ -793,6 +852,246 @@ __device__ __noinline__ void sweep_forward(ldouble *recs, ldouble *xs, int N)
     WSYNC();
 }
 
+// ================================================================== twisted solve: the first half
+// Stages 0 .. m-1 are eliminated FORWARD by the wave that is idle during the sweeps (the model wave) while the Riccati wave runs its
+// backward recursion over stages m .. N-1: an arrival-cost recursion in information form,
+//     F_{k+1}(s+) = min_{w_k} [ l_k(u_k, w_k, x_k) + F_k(w_k, x_k) ],   [u_k; x_k] = T~_k s+ + t~_k   (T~ from the model wave),
+// whose stage is the mirror image of a backward stage -- u and w swap roles -- on the same gathered operands:
+//     Z = Q_k + [Phi_w, phi_w; C_xx, c_x]      (stage cost of (w, x) added BEFORE the pivot)
+//     pivot on w (4 x 4):  K, T' = [R | Kbar_x | kbar] (gains of the back-substitution),  S = Z - K' D^-1 K  with -hc Kbar_x' in the u columns
+//     G^ = [C_u. - hc hc4 [R | Kbar_x | kbar] ; S + C_xu]      (the (u, .) rows analytically, like the w rows of P in the backward stage)
+//     X = G^ T~ (+ column 13),  Q_{k+1} = T~' X.
+// The pinned x_0 enters as the penalty TW_RHO / 2 |dx_0 - r_0|^2: Q_0 = diag(0, rho I), q_0 = [0; -rho r_0] (the exact recursion is
+// rank-deficient for three stages; validated in tools/study/twisted_riccati.py and, as a whole solver, in oracle/nmpc_ipm.c).
+// Packed Q_k (lower triangle) is stored in stage k's overlay slots for the multipliers y_k = -(Q_k ds_k + q_k); Q_m goes to the workgroup
+// scratch where both halves read it.  Returns 1 when a pivot block is not positive definite.
+__device__ __noinline__ int sweep_arrive(ldouble *recs, ldouble *xs, ldouble *tw, int m, double theta)
+{
+    m = uni(m); theta = uni(theta);
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15, c3_ = c & 3;
+    int mo[4], c1[4], c2[4], c3[4], ppo[4], pdo[4], sqo[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        mo[r] = tab(T_MA + r, lane); c1[r] = tab(T_C1 + r, lane); c2[r] = tab(T_C2 + r, lane);
+        c3[r] = tab(T_C3 + r, lane); ppo[r] = tab(T_PP + r, lane); pdo[r] = tab(T_PD + r, lane); sqo[r] = tab(T_SQ + r, lane);
+    }
+    const int pqo = (c < 4 && g == c) ? R_PHID + 4 + g : (c == 13 ? R_PHI + 4 + g : R_ZERO);
+    const int mhi = g > c3_ ? g : c3_, mlo = g > c3_ ? c3_ : g;
+    const int msel = mhi == mlo ? 6 : mhi * (mhi - 1) / 2 + mlo;
+    const bool m_lower = c3_ <= g, m_upper = g <= c3_;
+    const double m4 = c < 4 ? 1.0 : 0.0, m4c = 1.0 - m4, m13 = c == 13 ? 1.0 : 0.0;
+    const int to = c < 14 ? R_T + lane : R_DUMP; // (columns 14, 15 of T' hold part of B~ in a first-half record)
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    d4 Qn = zero;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int trow = 4 * r + g;
+        if (trow >= 4 && trow <= 12) {
+            if (c == trow) Qn[r] = TW_RHO;
+            if (c == 13) Qn[r] = -TW_RHO * xs[X_DX0 + trow - 4];
+        }
+    }
+    bool ok = true;
+    for (int k = 0; k < m; k++) {
+        ldouble *rec = recs + k * RS;
+        d4 C, Mt;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            C[r] = r == 1 ? rec[c1[r]] + rec[c2[r]] + theta * rec[c3[r]] : rec[c1[r]] + theta * rec[c3[r]];
+            Mt[r] = rec[mo[r]];
+        }
+        const double hc = rec[R_HC], pq = rec[pqo];
+        // Q_k (packed lower triangle) for y_k; it overwrites the Hessian pieces of this stage, gathered above
+#pragma unroll
+        for (int r = 0; r < 4; r++) rec[ppo[r]] = Qn[r];
+        d4 Z;
+        Z[0] = Qn[0] + pq;
+        Z[1] = __builtin_fma(m4c, C[1], Qn[1]); Z[2] = __builtin_fma(m4c, C[2], Qn[2]); Z[3] = __builtin_fma(m4c, C[3], Qn[3]);
+        double q[16], Mi[6], Di[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) q[i * 4 + j] = lane_bcast(Z[0], 16 * i + j);
+        ok &= ldl4(q, Mi, Di);
+        double me = msel == 6 ? 1.0 : Mi[0];
+#pragma unroll
+        for (int i = 1; i < 6; i++) me = msel == i ? Mi[i] : me;
+        const double m_gc = m_lower ? me : 0.0, m_cg = m_upper ? me : 0.0;
+        double dg = Di[3];
+        dg = g == 2 ? Di[2] : dg; dg = g == 1 ? Di[1] : dg; dg = g == 0 ? Di[0] : dg;
+        const double md = dg * m_gc;
+        const double K0 = mfma4(m_cg, Z[0], 0.0);
+        const double Kd = dg * K0;
+        const double tsel = mfma4(m_gc, c < 4 ? md : Kd, 0.0);
+        const double hcm = hc * m4;
+        const double Kb = __builtin_fma(hcm, m_gc, K0 * m4c);
+        d4 S = Z;
+        S[1] *= m4c; S[2] *= m4c; S[3] *= m4c;
+        S = __builtin_amdgcn_mfma_f64_16x16x4f64(-Kd, Kb, S, 0, 0, 0);
+        rec[to] = tsel;
+        const double hc4 = __builtin_fma(hc, m4, m4c);
+        d4 Gh;
+        Gh[0] = __builtin_fma(-hc, hc4 * tsel, C[0]);
+        Gh[1] = __builtin_fma(m4, C[1], S[1]); Gh[2] = __builtin_fma(m4, C[2], S[2]); Gh[3] = __builtin_fma(m4, C[3], S[3]);
+        d4 X = __builtin_amdgcn_mfma_f64_16x16x4f64(Gh[0], Mt[0], zero, 0, 0, 0);
+        X = __builtin_amdgcn_mfma_f64_16x16x4f64(Gh[1], Mt[1], X, 0, 0, 0);
+        X = __builtin_amdgcn_mfma_f64_16x16x4f64(Gh[2], Mt[2], X, 0, 0, 0);
+        X = __builtin_amdgcn_mfma_f64_16x16x4f64(Gh[3], Mt[3], X, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            rec[pdo[r]] = X[r];                        // G^ t~ (column 13) for the vector sweep
+            X[r] = __builtin_fma(m13, Gh[r], X[r]);    // + g^ in column 13
+        }
+        d4 Cz = zero;
+        Cz[0] = X[0]; // the rows u of T~ are [I 0 | t~_w]
+        Qn = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[1], X[1], Cz, 0, 0, 0);
+        Qn = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[2], X[2], Qn, 0, 0, 0);
+        Qn = __builtin_amdgcn_mfma_f64_16x16x4f64(Mt[3], X[3], Qn, 0, 0, 0);
+    }
+    // (Q_m, q_m) where both halves read it
+#pragma unroll
+    for (int r = 0; r < 4; r++) tw[sqo[r]] = Qn[r];
+    WSYNC();
+    return ok ? 0 : 1;
+}
+
+// Where the halves meet: ds_m = -(Q_m + P_m)^-1 (q_m + p_m), a 13 x 13 symmetric positive definite system, rows in lanes (lane i holds
+// row i).  P_m / p_m come from the meeting stage's record (packed, written by the backward half), Q_m / q_m from the workgroup scratch.
+// The factor L D L' of the meeting system lives in the workgroup scratch (L strictly lower, packed by rows, and 1 / D): the Riccati wave
+// factors once per iteration (predictor), every solve reads it from there -- lane i its row L[i][.] for the first triangular solve, its
+// column L[.][i] for the second -- so nothing of it is carried in registers across the phases of an iteration.
+__device__ __forceinline__ int tw_l(int i, int j) { return TW_L + i * (i - 1) / 2 + j; } // i > j
+__device__ __noinline__ int meet_factor(ldouble *recs, ldouble *tw, int m)
+{
+    m = uni(m);
+    const int lane = threadIdx.x & 63, i = lane < 13 ? lane : 12;
+    cldouble *rm = recs + m * RS;
+    int fail = 0;
+    double a[13];
+#pragma unroll
+    for (int j = 0; j < 13; j++) {
+        const int hi = i > j ? i : j, lo = i > j ? j : i, e = hi * (hi + 1) / 2 + lo;
+        a[j] = rm[R_P + e] + tw[TW_Q + e];
+    }
+    // right-looking, column by column: lane i holds row i; column j of the current Schur complement is a[j] in the lanes i >= j
+    const int rowb = TW_L + i * (i - 1) / 2;
+#pragma unroll
+    for (int j = 0; j < 13; j++) {
+        const double dj = lane_bcast(a[j], j);
+        if (!(dj > 0.0)) fail = 1;
+        const double inv = fast_rcp(dj);
+        const double lij = a[j] * inv;
+#pragma unroll
+        for (int kq = j + 1; kq < 13; kq++) a[kq] = __builtin_fma(-lij, lane_bcast(a[j], kq), a[kq]); // A[i][kq] -= L[i][j] A[kq][j]
+        if (lane > j && lane < 13) tw[rowb + j] = lij;
+        if (lane == j) tw[TW_DINV + j] = inv;
+    }
+    WSYNC();
+    return fail;
+}
+// ds_m = -(Q_m + P_m)^-1 (q_m + p_m) from the stored factor; ds: 16 slots (13 + three zeros: rows 13..15 of the sweep vectors)
+__device__ __noinline__ void meet_solve(ldouble *recs, ldouble *tw, int m, ldouble *ds)
+{
+    m = uni(m);
+    const int lane = threadIdx.x & 63, i = lane < 13 ? lane : 12;
+    cldouble *rm = recs + m * RS;
+    double l[12], lt[13];
+#pragma unroll
+    for (int j = 0; j < 12; j++) l[j] = tw[j < i ? tw_l(i, j) : TW_ZERO];        // L[i][j], j < i
+#pragma unroll
+    for (int j = 1; j < 13; j++) lt[j] = tw[(j > i && lane < 13) ? tw_l(j, i) : TW_ZERO]; // L[j][i], j > i
+    const double dinv = tw[TW_DINV + i];
+    double b = -(rm[R_PV + i] + tw[TW_QV + i]);
+    // L y = b
+#pragma unroll
+    for (int j = 0; j < 12; j++) b = __builtin_fma(-l[j], lane_bcast(b, j), b);
+    b *= dinv;
+    // L' x = D^-1 y
+#pragma unroll
+    for (int j = 12; j >= 1; j--) b = __builtin_fma(-lt[j], lane_bcast(b, j), b);
+    if (lane < 16) ds[lane] = lane < 13 ? b : 0.0;
+    WSYNC();
+}
+
+// first half, vector sweep of the corrector (new right-hand side phi_cc = PHIB + smu PHIC): the arrival gradient q_k, stage by stage,
+//     z~ = phi_(w, x) + q_k,  E = T'' z~_w,  g^ = [phi_u - hc E_w; z~_x - E_x],  kbar = E_w -> T' column 13,  q_{k+1} = T~' (G^ t~ + g^).
+// Vectors in V layout (lane 16 a + 4 b + j holds row 4 b + a).  q_k is stored in stage k's R_PV slots (multipliers), q_m in the workgroup scratch.
+__device__ __noinline__ void sweep_arrive_vec(ldouble *recs, ldouble *xs, ldouble *tw, int m, double smu)
+{
+    m = uni(m); smu = uni(smu);
+    const int lane = threadIdx.x & 63, a = lane >> 4, b = (lane >> 2) & 3;
+    const int idx = 4 * b + a;
+    int mt[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) mt[r] = tab(T4_MAT + r, lane);
+    const int o_ph = R_PHIB + 4 + idx;                                   // (w, x) rows: z index 4 + idx; rows 13..15 read finite junk
+    const int o_cb = (idx >= 4 && idx <= 6) ? R_CB + idx - 4 : R_ZERO;   // corridor parts on the pos rows
+    const int o_pu = R_PHIB + a;                                         // phi_u[a] (used by the quad-0 lanes)
+    const int o_pd = idx <= 12 ? R_PD + idx : R_ZERO;
+    const int o_wk = b == 0 ? R_T + 16 * a + 13 : R_DUMP;
+    const int o_wq = idx <= 12 ? R_PV + idx : R_DUMP;
+    const bool q0 = b == 0;
+    double qk = (idx >= 4 && idx <= 12) ? -TW_RHO * xs[X_DX0 + idx - 4] : 0.0;
+    for (int k = 0; k < m; k++) {
+        ldouble *rec = recs + k * RS;
+        const double phb = rec[o_ph], phc = rec[o_ph + R_BC], cbb = rec[o_cb], cbc = rec[o_cb == R_ZERO ? R_ZERO : o_cb + R_BC];
+        const double pub = rec[o_pu], puc = rec[o_pu + R_BC];
+        const double tp = rec[R_T + lane], hcv = rec[R_HC], gt = rec[o_pd];
+        d4 A;
+#pragma unroll
+        for (int r = 0; r < 4; r++) A[r] = rec[mt[r]];
+        rec[o_wq] = qk;
+        const double zt = __builtin_fma(smu, phc + cbc, phb + cbb) + qk;   // z~ (rows 13..15: junk that meets zero columns)
+        // z~_w[a] into every lane of row a
+        double dq = q0 ? zt : 0.0;
+        dq += quad_rot<1>(dq);
+        dq += quad_rot<2>(dq);
+        const double E = mfma4(tp, dq, 0.0);
+        const double base = q0 ? __builtin_fma(smu, puc, pub) : zt;
+        const double gh = __builtin_fma(-(q0 ? hcv : 1.0), E, base);
+        rec[o_wk] = E; // kbar (rows 0..3)
+        const double v = gh + gt;
+        qk = matvec4s(A, v, 0.0);
+    }
+    if (idx <= 12 && (lane & 3) == 0) tw[TW_QV + idx] = qk;
+    WSYNC();
+}
+
+// first half, back-substitution (both passes): from v = [ds_m; 1] down to stage 0,
+//     [u; x]_k = T~ v (+ t~ through row 13),  w_k = -T' [hc u; x; 1],  dz_k -> the record,  v <- [w_k; x_k; 1].
+__device__ __noinline__ void sweep_backsub(ldouble *recs, cldouble *ds, int m)
+{
+    m = uni(m);
+    const int lane = threadIdx.x & 63, a = lane >> 4, b = (lane >> 2) & 3;
+    const int idx = 4 * b + a;
+    int ma[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) ma[r] = tab(T4_MA + r, lane);
+    const int o_ts = tab(T4_TS, lane);
+    const int o_hf = b == 0 ? R_HC : R_ONE;
+    const int o_wu = b == 0 ? R_DZ + a : R_DUMP;                       // du = u_k (rows 0..3 of T~ v)
+    const int o_ww = b == 0 ? R_DZ + 4 + a : R_DUMP;                   // dw_k
+    const int o_wx = (idx >= 4 && idx <= 12) ? R_DZ + 4 + idx : R_DUMP; // dx_k
+    double v = idx == 13 ? 1.0 : ds[idx];
+    for (int k = m - 1; k >= 0; k--) {
+        ldouble *rec = recs + k * RS;
+        d4 A;
+#pragma unroll
+        for (int r = 0; r < 4; r++) A[r] = rec[ma[r]];
+        const double ts = rec[o_ts], hf = rec[o_hf];
+        const double ux = matvec4s(A, v, 0.0);     // rows 0..3 u, 4..12 x, 13: 1
+        const double mm = hf * ux;
+        const double d = mfma4(ts, mm, 0.0);
+        const double r_ = -d - quad_rot<1>(d);
+        const double wk = r_ + quad_rot<2>(r_);    // w_k[a] in every lane of row a
+        rec[o_wu] = ux;
+        rec[o_ww] = wk;
+        rec[o_wx] = ux;
+        v = b == 0 ? wk : ux;
+    }
+    WSYNC();
+}
+
 // ================================================================== wave 1: model (lane == stage)
 // Owns the iterate z and the equality multipliers y of its stage.  Heun step + compact Jacobian -> the stage record,
 // equality residual, and the M'y part of the stationarity residual.  d needs the next stage's [w; x] and gm its
@@ -807,7 +1106,10 @@ struct ModelState {
 constexpr int RT_J1 = R_T, RT_Y = R_T + 24;
 // after the last forward sweep of an iteration wave 1 leaves here what wave 0 needs to rebuild its Hessian inputs for the
 // next one (so that nothing of it occupies registers across the sweeps): (rates, T, v, e) before the step, (y_p, y_v) too
-constexpr int RT_HZ = R_T + 40, RT_HY = R_T + 50;
+// (placed clear of RT_Y -- written at the start of the model phase while the Hessian lanes read these -- and of the columns 14, 15
+// of T', which hold part of B~ in a first-half record)
+constexpr int RT_HZ = R_T + 48, RT_HY = R_T + 37;
+static_assert(RT_HY >= RT_Y + 13 && RT_HY + 6 <= R_T + 46 && RT_HZ + 10 <= R_T + 62, "scratch in the T' slots");
 template <int NP>
 __device__ __forceinline__ void model_phase(ldouble *recs, ldouble *xs, ModelState &st, int N, double &l_eq)
 {
@@ -1014,6 +1316,7 @@ __device__ __forceinline__ void hessian_phase(ldouble *rec, const HessState &hs,
 // slots of the stage record that are dead in this phase.  Products with J = d acc / d v use its structure,
 // J c = d (zB (zB . c) - c), instead of nine multiply-adds per column.
 __device__ __forceinline__ double pick3(int sub, double a0, double a1, double a2) { return sub == 0 ? a0 : (sub == 1 ? a1 : a2); }
+__device__ __forceinline__ int pick3i(int sub, int a0, int a1, int a2) { return sub == 0 ? a0 : (sub == 1 ? a1 : a2); }
 // zB = (cy sp cr + sy sr, sy sp cr - cy sr, cp cr) and its derivatives.  A derivative by one angle replaces that angle's
 // (sin, cos) by (cos, -sin) in the terms that contain it and removes the terms that do not: the "sr" terms carry no pitch
 // (factor kB), the "cp cr" term no yaw (factor kC).  The rule composes, so second derivatives are two substitutions.
@@ -1077,7 +1380,7 @@ __device__ __forceinline__ void trig_shared(ldouble *sc, int sub, const double e
 // neighbour stage and the lane-dependent entries are read from there anyway), and every block below ends with the stores of
 // what it produced, so that little more than the trig sets and the step itself is live from block to block.
 template <int NP>
-__device__ __forceinline__ void model_phase3(ldouble *recs, ldouble *xs, ModelState &st, int N, double &l_eq)
+__device__ __forceinline__ void model_phase3(ldouble *recs, ldouble *xs, ModelState &st, int N, double &l_eq, int tw_m = 0)
 {
     // (`sub` opaque per call: what is derived from it -- masks, factors, addresses -- is loop invariant, and hoisted out of the
     // interior-point loop it is spilled and reloaded on this wave's critical phase; see ROW_PICK)
@@ -1203,6 +1506,96 @@ __device__ __forceinline__ void model_phase3(ldouble *recs, ldouble *xs, ModelSt
 #pragma unroll
         for (int i = 0; i < NS; i++) st.y[i] = yk[i];
     }
+    // ---- block 4 (twisted solve): the stages of the first half keep the INVERTED transition [u; x]_k = T~ [w+; x+] + t~ in place of the
+    // linearisation (layout: ma_src).  A = [I Apv Ape; 0 Avv Ave; 0 0 I] inverts in closed form around the 3 x 3 block Avv; lane `sub`
+    // forms row `sub` of every block:  A~vv = Avv^-1,  A~ve = -Avv^-1 Ave,  A~pv = -Apv Avv^-1,  A~pe = -Ape - A~pv Ave,
+    // B~ = -A~ B,  t~ = [-d_w; A~ (B d_w - d_x)].
+    if (tw_m) {
+        // Three passes, each: read, fence, store -- the three lanes of a stage read each other's slots, and what is live between the
+        // passes (beside this wave's 60 registers of persistent state) is one row of each inverse block.
+        WSYNC(); // the three lanes' columns of the linearisation are in the record; the y slots (which share two of B~'s) are read
+        const bool inv = act && k < tw_m;
+        ldouble *L = rec + R_LIN;
+        const int s3 = 3 * sub;
+        double vi[3], tpv[3], tpe[3], tve[3];
+        // pass 1: Avv^-1 (adjugate), rows `sub` of A~vv and A~pv
+        if (inv) {
+            double v[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) v[i] = L[18 + i];
+            const double ap0 = L[s3], ap1 = L[s3 + 1], ap2 = L[s3 + 2];
+            const double c00 = v[4] * v[8] - v[5] * v[7], c01 = v[5] * v[6] - v[3] * v[8], c02 = v[3] * v[7] - v[4] * v[6];
+            const double id = fast_rcp(v[0] * c00 + v[1] * c01 + v[2] * c02);
+            const double V0[3] = {c00 * id, (v[2] * v[7] - v[1] * v[8]) * id, (v[1] * v[5] - v[2] * v[4]) * id};
+            const double V1[3] = {c01 * id, (v[0] * v[8] - v[2] * v[6]) * id, (v[2] * v[3] - v[0] * v[5]) * id};
+            const double V2[3] = {c02 * id, (v[1] * v[6] - v[0] * v[7]) * id, (v[0] * v[4] - v[1] * v[3]) * id};
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                vi[j] = pick3(sub, V0[j], V1[j], V2[j]);
+                tpv[j] = -(ap0 * V0[j] + ap1 * V1[j] + ap2 * V2[j]);
+            }
+        }
+        WSYNC();
+        if (inv) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) { L[s3 + j] = tpv[j]; L[18 + s3 + j] = vi[j]; }
+        }
+        // pass 2: rows `sub` of A~ve = -Avv^-1 Ave and A~pe = -Ape - A~pv Ave
+        if (inv) {
+            double E[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) E[i] = L[27 + i];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                tpe[j] = -L[9 + s3 + j] - (tpv[0] * E[j] + tpv[1] * E[3 + j] + tpv[2] * E[6 + j]);
+                tve[j] = -(vi[0] * E[j] + vi[1] * E[3 + j] + vi[2] * E[6 + j]);
+            }
+        }
+        WSYNC();
+        if (inv) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) { L[9 + s3 + j] = tpe[j]; L[27 + s3 + j] = tve[j]; }
+        }
+        // pass 3: rows `sub` of B~ = -A~ B (B = [0 BpT; Bvw BvT; dt I 0]) and of t~ = A~ (B d_w - d_x); t~_u = -d_w
+        double o_bp[4], o_bv[4], o_t[3], o_tu[4];
+        if (inv) {
+            double Bv[12], dw[4], rv[3], re[3];
+#pragma unroll
+            for (int l = 0; l < 3; l++) {
+                Bv[4 * l + 0] = L[42 + 3 * l]; Bv[4 * l + 1] = L[43 + 3 * l]; Bv[4 * l + 2] = L[44 + 3 * l]; Bv[4 * l + 3] = L[39 + l];
+            }
+            const double bpt = L[36 + sub];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                o_bv[c] = -(vi[0] * Bv[c] + vi[1] * Bv[4 + c] + vi[2] * Bv[8 + c] + (c < 3 ? tve[c] * DT : 0.0));
+                o_bp[c] = -((c == 3 ? bpt : 0.0) + tpv[0] * Bv[c] + tpv[1] * Bv[4 + c] + tpv[2] * Bv[8 + c] + (c < 3 ? tpe[c] * DT : 0.0));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) { dw[i] = rec[R_D + i]; o_tu[i] = -dw[i]; }
+#pragma unroll
+            for (int l = 0; l < 3; l++) {
+                rv[l] = Bv[4 * l] * dw[0] + Bv[4 * l + 1] * dw[1] + Bv[4 * l + 2] * dw[2] + Bv[4 * l + 3] * dw[3] - rec[R_D + 7 + l];
+                re[l] = DT * dw[l] - rec[R_D + 10 + l];
+            }
+            const double rp = bpt * dw[3] - rec[R_D + 4 + sub];
+            o_t[0] = rp + tpv[0] * rv[0] + tpv[1] * rv[1] + tpv[2] * rv[2] + tpe[0] * re[0] + tpe[1] * re[1] + tpe[2] * re[2];
+            o_t[1] = vi[0] * rv[0] + vi[1] * rv[1] + vi[2] * rv[2] + tve[0] * re[0] + tve[1] * re[1] + tve[2] * re[2];
+            o_t[2] = pick3(sub, re[0], re[1], re[2]);
+        }
+        WSYNC();
+        if (inv) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                rec[R_LIN + 36 + 4 * sub + c] = o_bp[c];
+                rec[pick3i(sub, lbv_slot(c), lbv_slot(4 + c), lbv_slot(8 + c))] = o_bv[c];
+            }
+            rec[R_D + 4 + sub] = o_t[0]; rec[R_D + 7 + sub] = o_t[1]; rec[R_D + 10 + sub] = o_t[2];
+            if (sub == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) rec[R_D + i] = o_tu[i];
+            }
+        }
+    }
 }
 
 // wave 0, three lanes per stage: exact Hessian of y_{k+1}' c(z_k), rows / columns of angle `sub` (see rk2_hessian_core)
@@ -1321,7 +1714,7 @@ __device__ __noinline__ int count_live_faces(const double *pk, int M)
 
 // ================================================================== the solve, one role per wave
 struct Shared {
-    ldouble *recs, *xs;
+    ldouble *recs, *xs, *tw;
     Ctl *ctl;
 };
 
@@ -1340,7 +1733,9 @@ __device__ __forceinline__ void publish(ldouble *xs, int wave, int lane, int slo
 }
 __device__ __forceinline__ double red(cldouble *xs, int wave, int slot) { return xs[X_RED + wave * 16 + slot]; }
 
-template <int NP, int FL, bool FREG, int ROLE>
+// TW: the twisted solve (a.twist stages eliminated forward by the model wave while the Riccati wave runs the rest backward); a kernel
+// variant of its own, so that the plain solve carries none of it
+template <int NP, int FL, bool FREG, int ROLE, bool TW>
 __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, const Shared &sh)
 {
     constexpr int H = RowMap<NP>::H, R = RowMap<NP>::R;
@@ -1348,6 +1743,8 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     const int lane = threadIdx.x & 63;
     const int N = a.N, M = a.M, MF = a.MF, np = NPRE + 4 * M;
     ldouble *recs = sh.recs, *xs = sh.xs;
+    const int tw_m = TW ? uni(a.twist) : 0; // (validated by the launcher: 1 <= tw_m <= N - 2)
+    ldouble *tw = sh.tw;
     // three lanes per stage (H == 3: NP = 20) also on the Riccati wave's Hessian and on the model wave (model_phase3, hessian_phase3)
     constexpr bool H3 = (H == 3);
     const int k = (wave == 1 && !H3) ? lane : lane % NP, half = lane / NP; // stage of this lane; row / face group
@@ -1511,7 +1908,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 xs[X_FEXT + k] = ms.fext[0]; xs[X_FEXT + NP + k] = ms.fext[1]; xs[X_FEXT + 2 * NP + k] = ms.fext[2];
                 ldouble *rec = recs + k * RS;
                 rec[R_HC] = -2.0 * pk[8]; // (u_i, w_i) cost coupling of this stage (constant)
-                rec[R_ZERO] = 0.0; rec[R_ZERO2] = 0.0; rec[R_ONE] = 1.0; rec[R_DT] = DT; rec[R_DUMP] = 0.0;
+                rec[R_ZERO] = 0.0; rec[R_ZERO2] = 0.0; rec[R_ONE] = 1.0; rec[R_DT] = (TW && k < tw_m) ? -DT : DT; rec[R_DUMP] = 0.0;
                 if (k == N - 1) { // no dynamics behind the last stage: its M row stays zero
 #pragma unroll
                     for (int i = 0; i < 64; i++) rec[R_LIN + i] = 0.0;
@@ -1639,7 +2036,7 @@ for (int r = RB0; r < RB1; r++) {
             }
         } else if constexpr (wave == 1) {
             double l_eq;
-            if constexpr (H3) model_phase3<NP>(recs, xs, ms, N, l_eq);
+            if constexpr (H3) model_phase3<NP>(recs, xs, ms, N, l_eq, tw_m);
             else model_phase<NP>(recs, xs, ms, N, l_eq);
             publish(xs, 1, lane, 0, wave_max(l_eq));
         } else if constexpr (wave == 2) {
@@ -1704,15 +2101,48 @@ for (int r = RB0; r < RB1; r++) {
         }
 
         // ============================================================ predictor: factorisation + forward sweep
-        if constexpr (wave == 0) {
+        if constexpr (TW) {
+            // the two halves side by side; the Riccati wave factors and solves the meeting system; both continue from ds_m, outwards
+            TW_T0();
+            if constexpr (wave == 0) {
+                const int fr = sweep_factor<true>(recs + tw_m * RS, xs, N - tw_m, gn_retry ? 0.0 : theta_h);
+                if (lane == 0) sh.ctl->fail = fr;
+                TW_T1(22);
+            } else if constexpr (wave == 1) {
+                const int fr = sweep_arrive(recs, xs, tw, tw_m, gn_retry ? 0.0 : theta_h);
+                if (lane == 0) sh.ctl->fail1 = fr;
+                TW_T1(23);
+            }
+            BAR();
+            if constexpr (wave == 0) { // the system where the halves meet: factored and solved by this wave, ds_m -> X_DS0
+                TW_T1(6);
+                int mf = 0;
+                if (!(sh.ctl->fail | sh.ctl->fail1)) {
+                    mf = meet_factor(recs, tw, tw_m);
+                    TW_T1(24);
+                    if (!mf) meet_solve(recs, tw, tw_m, xs + X_DS0);
+                    TW_T1(25);
+                }
+                if (lane == 0) sh.ctl->fail2 = mf;
+            }
+            BAR();
+            if constexpr (wave <= 1) {
+                TW_T1(7);
+                if (!(sh.ctl->fail | sh.ctl->fail1 | sh.ctl->fail2)) {
+                    if constexpr (wave == 0) sweep_forward(recs + tw_m * RS, xs, N - tw_m);
+                    else sweep_backsub(recs, xs + X_DS0, tw_m);
+                }
+                TW_T1(26 + wave);
+            }
+        } else if constexpr (wave == 0) {
             SWEEP_T0();
-            const int fr = sweep_factor(recs, xs, N, gn_retry ? 0.0 : theta_h);
+            const int fr = sweep_factor<false>(recs, xs, N, gn_retry ? 0.0 : theta_h);
             SWEEP_T1(0);
             if (FWD_P == 0 && !fr) sweep_forward(recs, xs, N);
             SWEEP_T1(1);
             if (lane == 0) sh.ctl->fail = fr;
         }
-        if constexpr (FWD_P != 0) { // the forward sweep works from the records alone: it runs on the wave whose SIMD has room
+        if constexpr (FWD_P != 0 && !TW) { // the forward sweep works from the records alone: it runs on the wave whose SIMD has room
             BAR();
             if constexpr (wave == FWD_P) {
                 if (!sh.ctl->fail) sweep_forward(recs, xs, N);
@@ -1720,7 +2150,7 @@ for (int r = RB0; r < RB1; r++) {
         }
         BAR_P(1); // ------------------------------------------------------------- C
         {
-            const int fr = sh.ctl->fail;
+            const int fr = TW ? (sh.ctl->fail | sh.ctl->fail1 | sh.ctl->fail2) : sh.ctl->fail;
             if (fr && !gn_retry && theta_h > 0.0) {
                 // indefinite pivot block with the exact Hessian: the iteration is redone with the Gauss-Newton Hessian.
                 // P has overwritten part of the barrier Hessian in the records, so the evaluation phase runs again.
@@ -1820,14 +2250,37 @@ for (int r = RB0; r < RB1; r++) {
         }
 
         // ============================================================ corrector: vector backward sweep + forward sweep with y+
-        if constexpr (wave == 0) {
+        if constexpr (TW) {
+            TW_T0();
+            if constexpr (wave == 0) {
+                sweep_backvec<true>(recs + tw_m * RS, xs, N - tw_m, smu);
+                TW_T1(28);
+            } else if constexpr (wave == 1) {
+                sweep_arrive_vec(recs, xs, tw, tw_m, smu);
+                TW_T1(29);
+            }
+            BAR();
+            if constexpr (wave == 0) {
+                TW_T1(12);
+                meet_solve(recs, tw, tw_m, xs + X_DS0);
+                TW_T1(14);
+                sweep_forward(recs + tw_m * RS, xs, N - tw_m);
+                TW_T1(30);
+            } else if constexpr (wave == 1) {
+                TW_T1(13);
+                meet_solve(recs, tw, tw_m, tw + TW_DS); // (both waves solve, from the stored factor: no second barrier)
+                TW_T1(15);
+                sweep_backsub(recs, tw + TW_DS, tw_m);
+                TW_T1(31);
+            }
+        } else if constexpr (wave == 0) {
             SWEEP_T0();
-            sweep_backvec(recs, xs, N, smu);
+            sweep_backvec<false>(recs, xs, N, smu);
             SWEEP_T1(2);
             if (FWD_C == 0) sweep_forward(recs, xs, N);
             SWEEP_T1(3);
         }
-        if constexpr (FWD_C != 0) {
+        if constexpr (FWD_C != 0 && !TW) {
             BAR();
             if constexpr (wave == FWD_C) sweep_forward(recs, xs, N);
         }
@@ -1849,11 +2302,12 @@ for (int r = RB0; r < RB1; r++) {
         };
         // y+_k = P_k ds_k + p_k of the Newton system (P_k packed lower triangle): formed by the waves that consume it, off
         // the forward sweep's dependency chain
+        // (twisted solve, stages of the first half: the record holds the arrival cost, y+_k = -(Q_k ds_k + q_k))
         auto y_plus = [&](cldouble *rec, int i) {
             double acc = rec[R_PV + i];
 #pragma unroll
             for (int j = 0; j < NS; j++) acc = fma(rec[R_P + (i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i)], rec[R_DZ + 4 + j], acc);
-            return acc;
+            return (TW && k < tw_m) ? -acc : acc;
         };
         if constexpr (wave == 0) {
             // (the Newton step of the Hessian's inputs stays in the record: the next evaluation reads it there, before the forward
@@ -2036,7 +2490,7 @@ for (int r = RB0; r < RB1; r++) {
 
 // Persistent workgroups: grid = min(B, resident workgroups); each pulls the next problem index from a device counter
 // (zeroed by the launcher) until the batch is exhausted.
-template <int NP, int FL, bool FREG, int ROLE>
+template <int NP, int FL, bool FREG, int ROLE, bool TW>
 __device__ __forceinline__ void role_loop(const KernelArgs &a, const Shared &sh)
 {
     // (solve_one claims the next problem when it leaves its iteration)
@@ -2046,19 +2500,22 @@ __device__ __forceinline__ void role_loop(const KernelArgs &a, const Shared &sh)
         const int b = sh.ctl->next;
         if (b >= a.B) break;
         BAR(); // everybody has read the index before solve_one's exit overwrites it
-        solve_one<NP, FL, FREG, ROLE>(a, b, sh);
+        solve_one<NP, FL, FREG, ROLE, TW>(a, b, sh);
     }
 }
 
-template <int NP, int FL, bool FREG, int WPE>
+template <int NP, int FL, bool FREG, int WPE, bool TW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void nmpc_ipm_lds_kernel(KernelArgs a)
 {
     __shared__ double s_recs[NP * RS];
     __shared__ double s_xs[X_TOTAL + 3 * NP];
+    __shared__ double s_tw[TW ? TW_TOTAL : 1];
     __shared__ Ctl s_ctl;
     __shared__ int s_place[5];
+    static_assert(!TW || NP == 20, "the twisted solve is built on the three-lanes-per-stage model phase");
     Shared sh;
-    sh.recs = (ldouble *)s_recs; sh.xs = (ldouble *)s_xs; sh.ctl = &s_ctl;
+    sh.recs = (ldouble *)s_recs; sh.xs = (ldouble *)s_xs; sh.tw = (ldouble *)s_tw; sh.ctl = &s_ctl;
+    if (TW && threadIdx.x == 0) { s_tw[TW_DUMP] = 0.0; s_tw[TW_ZERO] = 0.0; s_ctl.fail1 = 0; s_ctl.fail2 = 0; }
     if (threadIdx.x == 0) { s_xs[X_C0] = 0.0; s_xs[X_C1] = 1.0; }
     // ---- which wave plays which role.  A wavefront stays on the SIMD it was launched on, and one wavefront of every
     // resident workgroup sits on each SIMD of the CU.  The Riccati role keeps its SIMD busy for ~70 % of an iteration, the
@@ -2103,17 +2560,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     }
     // one copy of the solver loop per role: the four waves run different code between the same barriers
     const int wave = __builtin_amdgcn_readfirstlane(role);
-    if (wave == 0) role_loop<NP, FL, FREG, 0>(a, sh);
-    else if (wave == 1) role_loop<NP, FL, FREG, 1>(a, sh);
-    else if (wave == 2) role_loop<NP, FL, FREG, 2>(a, sh);
-    else role_loop<NP, FL, FREG, 3>(a, sh);
+    if (wave == 0) role_loop<NP, FL, FREG, 0, TW>(a, sh);
+    else if (wave == 1) role_loop<NP, FL, FREG, 1, TW>(a, sh);
+    else if (wave == 2) role_loop<NP, FL, FREG, 2, TW>(a, sh);
+    else role_loop<NP, FL, FREG, 3, TW>(a, sh);
 }
 
-template <int NP, int FL, bool FREG, int WPE>
+template <int NP, int FL, bool FREG, int WPE, bool TW = false>
 static hipError_t launch_variant(const KernelArgs &k, int slots, hipStream_t stream)
 {
-    hipLaunchKernelGGL((nmpc_ipm_lds_kernel<NP, FL, FREG, WPE>), dim3(slots), dim3(256), 0, stream, k);
+    hipLaunchKernelGGL((nmpc_ipm_lds_kernel<NP, FL, FREG, WPE, TW>), dim3(slots), dim3(256), 0, stream, k);
     return hipGetLastError();
+}
+// the twisted variants: frp_nmpc_options.twist = m (stages eliminated forward), -1 = 9 N / 20; anything the twisted solve does not cover
+// (N > 20, N < 4, m outside 1 .. N - 2) runs the plain solve, like the oracle's (oracle/nmpc_ipm.c, kkt_solve)
+static inline int twist_stages(const KernelArgs &k)
+{
+    const int m = k.twist < 0 ? 9 * k.N / 20 : k.twist;
+    return (k.N >= 4 && k.N <= 20 && m >= 1 && m <= k.N - 2) ? m : 0;
 }
 
 } // namespace lr
@@ -2125,6 +2589,7 @@ static hipError_t launch_variant(const KernelArgs &k, int slots, hipStream_t str
 #ifdef FRP_LDS_MEM_TU
 hipError_t launch_ipm_lds_mem(const KernelArgs &k, int slots, hipStream_t stream)
 {
+    if (k.N <= 20 && k.twist) return lr::launch_variant<20, 10, false, 3, true>(k, slots, stream); // (k.twist: resolved by launch_ipm_lds)
     if (k.N <= 20) return lr::launch_variant<20, 10, false, 3>(k, slots, stream);
     if (k.N <= 32) return lr::launch_variant<32, 15, false, 2>(k, slots, stream);
     return lr::launch_variant<64, 30, false, 1>(k, slots, stream);
@@ -2151,6 +2616,7 @@ hipError_t launch_ipm_lds_mem(const KernelArgs &k, int slots, hipStream_t stream
 #else
 static hipError_t launch_ipm_lds_mem(const KernelArgs &k, int slots, hipStream_t stream)
 {
+    if (k.N <= 20 && k.twist) return lr::launch_variant<20, 10, false, 3, true>(k, slots, stream);
     if (k.N <= 20) return lr::launch_variant<20, 10, false, 3>(k, slots, stream);
     if (k.N <= 32) return lr::launch_variant<32, 15, false, 2>(k, slots, stream);
     return lr::launch_variant<64, 30, false, 1>(k, slots, stream);
@@ -2161,10 +2627,15 @@ static hipError_t launch_ipm_lds_mem(const KernelArgs &k, int slots, hipStream_t
 #define FRP_WPE20 3
 #endif
 // counter / order already set up by launch_ipm
-hipError_t launch_ipm_lds(const KernelArgs &k, int slots, hipStream_t stream)
+hipError_t launch_ipm_lds(const KernelArgs &k0, int slots, hipStream_t stream)
 {
+    KernelArgs k = k0;
+    k.twist = lr::twist_stages(k0);
     const int MF = k.MF;
-    if (k.N <= 20) {
+    if (k.N <= 20 && k.twist) {
+        if (MF <= 6) return lr::launch_variant<20, 2, true, FRP_WPE20, true>(k, slots, stream);
+        if (MF <= 15) return lr::launch_variant<20, 5, true, FRP_WPE20, true>(k, slots, stream);
+    } else if (k.N <= 20) {
         if (MF <= 6) return lr::launch_variant<20, 2, true, FRP_WPE20>(k, slots, stream);
         if (MF <= 15) return lr::launch_variant<20, 5, true, FRP_WPE20>(k, slots, stream);
     } else if (k.N <= 32) {

@@ -45,7 +45,7 @@ constexpr double KAPPA_LAM = 2.0;       // multiplier safeguard: s_i lam_i >= mu
 constexpr double DIVERGE_RS = 1e12;
 
 struct KernelArgs {
-    int B, N, M, MF, model, maxit, hessian;
+    int B, N, M, MF, model, maxit, hessian, twist;
     double tol_stat, tol_eq, tol_ineq, tol_comp, mu0, ftb, diverge_mu;
     const double *xinit, *x0, *params;
     const int *nfaces;

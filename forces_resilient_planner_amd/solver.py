@@ -23,7 +23,7 @@ c_int_p = ctypes.POINTER(ctypes.c_int)
 class Options(ctypes.Structure):
     _fields_ = [("maxit", ctypes.c_int), ("tol_stat", ctypes.c_double), ("tol_eq", ctypes.c_double),
                 ("tol_ineq", ctypes.c_double), ("tol_comp", ctypes.c_double), ("mu0", ctypes.c_double),
-                ("ftb", ctypes.c_double), ("hessian", ctypes.c_int), ("diverge_mu", ctypes.c_double)]
+                ("ftb", ctypes.c_double), ("hessian", ctypes.c_int), ("diverge_mu", ctypes.c_double), ("twist", ctypes.c_int)]
 
 
 class Batch(ctypes.Structure):

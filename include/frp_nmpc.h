@@ -81,6 +81,16 @@ typedef struct frp_nmpc_options {
                          diverge_mu * max(1, mu0) -- multipliers growing without bound = a (locally)
                          infeasible instance.  Converging solves of the BASELINE workloads stay below 10;
                          10 is the early-exit setting of the configs[3] benchmark (bench.py)          */
+    int twist;        /* 0 (default): one backward Riccati recursion over the horizon, on one wavefront.
+                         m > 0: the Newton system of an iteration is solved from both ends of the horizon at once -- the
+                         stages 0 .. m-1 forward (arrival-cost recursion, the pinned x_0 as a 1e12 penalty) on a second
+                         wavefront while the stages m .. N-1 run backward; the halves meet in a 13 x 13 system at stage m.
+                         -1: m = 9 N / 20.  Horizons 4 <= N <= 20 with 1 <= m <= N - 2, anything else runs the plain
+                         solve.  A LATENCY option: it shortens the dependency chain of an iteration (-11 % per launch
+                         while there are fewer problems than resident workgroups, <= ~1000), and costs throughput
+                         once the GPU is full (+5 % at 4096 problems).  The Newton direction carries the penalty's
+                         rounding (~1e-5 relative); residuals and termination tests are the plain solve's, so the
+                         same KKT points are reached (oracle: orc_options.twist).  DESIGN 9.1                     */
 } frp_nmpc_options;
 
 typedef struct frp_nmpc_batch {

@@ -50,6 +50,7 @@ void orc_default_options(orc_options *o)
     o->ftb = 0.99;
     o->hessian = ORC_HESSIAN_DEFAULT;
     o->diverge_mu = 1e3;
+    o->twist = 0;
 }
 
 typedef struct {
@@ -198,6 +199,7 @@ typedef struct {
     double *s, *lam, *ds, *dlam, *rin; /* [N*mc]: 0..16 lower, 17..33 upper, 34.. corridor */
     double *corr;                       /* Mehrotra second-order term ds_aff*dlam_aff */
     int *nf;
+    int twist;                          /* orc_options.twist */
 } solver_ws;
 
 static const double *face_A(const double *params, int M, int k) { return params + (size_t)k * (ORC_NPRE + 4 * M) + ORC_NPRE; }
@@ -439,7 +441,8 @@ static int kkt_solve(solver_ws *W, const double *xinit, int full)
         static int tw_m = -2;
         static double tw_rho = 1e12;
         if (tw_m == -2) { const char *e = getenv("ORC_TWIST"); tw_m = e ? atoi(e) : -1; const char *r = getenv("ORC_TWIST_RHO"); if (r) tw_rho = atof(r); }
-        if (tw_m > 0 && tw_m < N - 1) return kkt_solve_twisted(W, xinit, full, tw_m, tw_rho);
+        const int m = tw_m > 0 ? tw_m : (W->twist < 0 ? 9 * N / 20 : W->twist);
+        if (m > 0 && m < N - 1 && N >= 4) return kkt_solve_twisted(W, xinit, full, m, tw_rho);
     }
     for (int k = N - 1; k >= 0; k--) {
         const double *Pn = (k < N - 1) ? W->st[k + 1].P : 0, *pn = (k < N - 1) ? W->st[k + 1].p : 0;
@@ -566,6 +569,7 @@ int orc_solve(int N, int M, int model, const double *xinit, const double *z0,
     const int np = ORC_NPRE + 4 * M, mc = 34 + M;
     solver_ws W;
     W.N = N; W.M = M; W.mc = mc;
+    W.twist = opt_in ? opt_in->twist : 0;
     /* per-thread scratch, grown on demand and reused across solves (a calloc/free pair per solve
      * serialises 100+ OpenMP threads on the allocator) */
     static __thread stage_ws *tl_st = 0;

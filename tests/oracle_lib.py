@@ -20,7 +20,7 @@ class OrcInfo(ctypes.Structure):
 
 class OrcOptions(ctypes.Structure):
     _fields_ = [("maxit", ctypes.c_int)] + [(n, ctypes.c_double) for n in
-                                            "tol_stat tol_eq tol_ineq tol_comp mu0 ftb".split()] + [("hessian", ctypes.c_int), ("diverge_mu", ctypes.c_double)]
+                                            "tol_stat tol_eq tol_ineq tol_comp mu0 ftb".split()] + [("hessian", ctypes.c_int), ("diverge_mu", ctypes.c_double), ("twist", ctypes.c_int)]
 
 
 def P(a):

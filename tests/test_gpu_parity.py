@@ -149,6 +149,67 @@ def test_hip_path_converges_on_the_hard_family_at_default_options(golden_dir):
     hard_family_check(g, z, fl, pobj, zt, flt)
 
 
+@pytest.mark.parametrize("cfg,m", [(1, -1), (2, -1), (2, 3), (2, 18)])
+def test_twisted_solve_matches_the_oracles_twisted_solve(cfg, m):
+    """frp_nmpc_options.twist: stages 0..m-1 eliminated forward by the model wave while the Riccati wave runs m..N-1
+    backward.  Checked against the oracle running the same split (orc_options.twist) AND against the plain HIP solve: the linear
+    system is the same one, the iterates differ by the rounding of the 1e12 penalty that pins x_0 (~1e-5 after an iteration, measured;
+    tools/dbg/twist_check.py), flags and iteration counts agree, converged points agree far inside the tolerances (1e-4)."""
+    w = workloads.CONFIGS[cfg](256)
+    z, fl, it, info = solver.solve_batch_host(w, solver.default_options(twist=m))
+    zp, flp, itp, infop = solver.solve_batch_host(w)
+    zo, flo, io = OL.solve_batch(w, OL.default_options(twist=m))
+    ito = np.array([i.it for i in io])
+    assert np.array_equal(fl, flo) and np.array_equal(fl, flp)
+    ok = fl == 1
+    assert ok.mean() > 0.8 and np.all(np.isfinite(z))
+    assert (it[ok] == ito[ok]).mean() >= 0.97 and (it[ok] == itp[ok]).mean() >= 0.97
+    assert np.max(np.abs(z[ok] - zo[ok])) < 2e-4 and np.max(np.abs(z[ok] - zp[ok])) < 2e-4
+    pobj_o = np.array([i.pobj for i in io])
+    assert np.max(np.abs(info[ok, 4] - pobj_o[ok]) / (1 + np.abs(pobj_o[ok]))) < 1e-5
+    # one iteration in: the same Newton step up to the penalty's rounding
+    z1, _, _, _ = solver.solve_batch_host(w, solver.default_options(twist=m, maxit=1))
+    zo1, _, _ = OL.solve_batch(w, OL.default_options(twist=m, maxit=1))
+    assert np.max(np.abs(z1 - zo1)) < 2e-4
+    # the residuals the exit tests read are evaluated exactly as in the plain solve: converged means the same thing
+    assert info[ok, 0].max() <= 1e-4 and info[ok, 2].max() <= 1e-4 and info[ok, 3].max() <= 1e-4
+
+
+def test_twisted_solve_on_the_fixture_families(golden_dir):
+    """Every SLSQP-solved instance of the config1 / config2 / hard fixture families converges with twist = -1 too, to SLSQP's point
+    at default and at 1e-8 tolerances (the penalty leaves x_0 ~1e-9 off xinit: no obstacle to tol_eq = 1e-8)."""
+    for fam, tol_t in (("config1", 3e-4), ("config2", 3e-4), ("hard", 6e-4)):
+        g = np.load(os.path.join(golden_dir, f"solutions_{fam}.npz"), allow_pickle=False)
+        N, M = int(g["N"]), int(g["M"])
+        good = g["status"] == 0
+        for model in np.unique(g["model"]):
+            sel = np.where((g["model"] == model) & good)[0]
+            w = dict(xinit=g["xinit"][sel], x0=g["x0"][sel], params=g["params"][sel], nfaces=g["nfaces"][sel], N=N, M=M, model=int(model))
+            z, fl, it, info = solver.solve_batch_host(w, solver.default_options(twist=-1))
+            zp, flp, itp, _ = solver.solve_batch_host(w)
+            assert np.all(fl == 1), (fam, int(model), np.where(fl != 1)[0])
+            assert np.max(np.abs(z - zp)) < 2e-4 and (it == itp).mean() >= 0.95
+            opt = solver.default_options(twist=-1)
+            opt.tol_stat = opt.tol_eq = opt.tol_ineq = opt.tol_comp = 1e-8
+            zt, flt, _, _ = solver.solve_batch_host(w, opt)
+            assert np.all(flt == 1)
+            d = np.max(np.abs(zt - g["z"][sel]), axis=(1, 2))
+            assert (d < tol_t).mean() >= 0.97, (fam, int(model), d.max())  # (the hard family has a few other, better KKT points: hard_family_check)
+
+
+def test_twist_outside_its_range_is_the_plain_solve():
+    """N > 20, N < 4 or m outside 1..N-2: the option is ignored (bit-identical results), like the oracle's."""
+    w = workloads.config2(64)
+    zp, flp, itp, _ = solver.solve_batch_host(w)
+    for m in (19, 25, 0):  # N - 1, beyond the horizon, off
+        z, fl, it, _ = solver.solve_batch_host(w, solver.default_options(twist=m))
+        assert np.array_equal(z, zp) and np.array_equal(it, itp)
+    w3 = workloads.config3(32)  # N = 40
+    z3p, _, it3p, _ = solver.solve_batch_host(w3)
+    z3, _, it3, _ = solver.solve_batch_host(w3, solver.default_options(twist=-1))
+    assert np.array_equal(z3, z3p) and np.array_equal(it3, it3p)
+
+
 def test_full_size_properties():
     """BASELINE configs[2] at full size (B=4096): size-independent properties of the returned plans."""
     w = workloads.config2(4096)

@@ -97,6 +97,37 @@ def test_solver_matches_scipy_fixtures(fam, golden_dir):
     assert nconv == int((g["status"] == 0).sum()) and nconv >= 0.7 * n
 
 
+@pytest.mark.parametrize("fam", ["config1", "config2", "hard"])
+def test_twisted_solve_reaches_the_same_points(fam, golden_dir):
+    """orc_options.twist (what frp_nmpc_options.twist runs on the GPU): the Newton system solved from both ends of the
+    horizon -- stages 0..m-1 by an arrival-cost recursion with the pinned x_0 as a 1e12 penalty, stages m..N-1 by the backward
+    Riccati recursion, a 13 x 13 system where they meet -- is the SAME linear system, so the iteration is the plain one up to the
+    penalty's rounding: same flags, same iteration counts (but for a residual within rounding of its tolerance), same points;
+    it also converges at 1e-8 tolerances (the penalty leaves x_0 ~1e-9 off xinit)."""
+    g = np.load(os.path.join(golden_dir, f"solutions_{fam}.npz"))
+    N, M = int(g["N"]), int(g["M"])
+    good = np.where(g["status"] == 0)[0][:40]
+    tight = dict(tol_stat=1e-8, tol_eq=1e-8, tol_ineq=1e-8, tol_comp=1e-8)
+    same_it = 0
+    for m in (-1, 3, N - 2):
+        for i in good:
+            a = (g["xinit"][i], g["x0"][i], g["params"][i], g["nfaces"][i], N, M, int(g["model"][i]))
+            z0, f0, i0 = OL.solve_one(*a)
+            z1, f1, i1 = OL.solve_one(*a, OL.default_options(twist=m))
+            assert f0 == 1 and f1 == 1, (fam, m, i, f0, f1)
+            assert np.max(np.abs(z1 - z0)) < 2e-4 and abs(i1.pobj - i0.pobj) < 1e-5 * (1 + abs(i0.pobj)), (fam, m, i, np.max(np.abs(z1 - z0)))
+            same_it += int(i1.it == i0.it)
+            if m == -1:
+                zt, ft, _ = OL.solve_one(*a, OL.default_options(twist=m, **tight))
+                assert ft == 1 and np.max(np.abs(zt - g["z"][i])) < (6e-4 if fam == "hard" else 3e-4), (fam, i, ft)
+    assert same_it >= 0.95 * 3 * len(good)
+    # outside its range (m = N - 1, N < 4) the option is ignored: bit-identical to the plain solve
+    a = (g["xinit"][0], g["x0"][0], g["params"][0], g["nfaces"][0], N, M, int(g["model"][0]))
+    z0, _, _ = OL.solve_one(*a)
+    z1, _, _ = OL.solve_one(*a, OL.default_options(twist=N - 1))
+    assert np.array_equal(z0, z1)
+
+
 def hard_family_check(g, z, fl, pobj, zt, flt):
     """The judgement both the oracle (here) and the HIP path (tests/test_gpu_parity.py) are held to on tests/golden/solutions_hard.npz
     (workloads.config_hard: reference 3..5 m away, |f_ext| 6..9 m/s^2, 5..10 cm of corridor slack, post-replan warm starts):

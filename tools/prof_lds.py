@@ -7,10 +7,12 @@ from forces_resilient_planner_amd import solver, workloads
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 cfg = sys.argv[2] if len(sys.argv) > 2 else "2"
 w = {"1": workloads.config1, "2": workloads.config2, "3": workloads.config3}[cfg](B)
+twist = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+opt = solver.default_options(twist=twist)
 buf = (ctypes.c_longlong * 96)()
-solver.solve_batch_host(w)
+solver.solve_batch_host(w, opt)
 solver.lib().frp_debug_read_prof_lds(buf)
-z, fl, it, info = solver.solve_batch_host(w)
+z, fl, it, info = solver.solve_batch_host(w, opt)
 solver.lib().frp_debug_read_prof_lds(buf)
 p = np.array(buf[:64]).reshape(4, 16); sg = np.array(buf[64:96])
 its = p[0, 10]
@@ -22,3 +24,8 @@ for wv, role in enumerate(["riccati", "model", "bounds", "faces"]):
 print("  factor sweep segments (cycles per iteration): " + "  ".join(f"{n} {sg[i] / its:6.0f}" for i, n in enumerate(["mfma X/G", "gather", "pivot", "tail mfma", "P update+stores", "loop"])))
 print("  whole sweeps (cycles per iteration; forward and forward+y are cumulative with the sweep before them): " + "  ".join(f"{n} {sg[8 + i] / its:6.0f}" for i, n in enumerate(["factor", "+forward", "backvec", "+forward y"])))
 print("  model phase segments (cycles per iteration): " + "  ".join(f"{n} {sg[16 + i] / its:6.0f}" for i, n in enumerate(["park y, dx0", "trig1+accel1+J1", "trig2+accel2", "J2 J1 products", "d + shifts", "gm"])))
+if twist:
+    tn = {22: "factor (half)", 23: "arrive", 6: "wait B (riccati)", 7: "wait B (model)", 24: "meet factor+solve (riccati)", 25: "meet factor+solve (model)",
+          26: "forward (half)", 27: "backsub", 28: "backvec (half)", 29: "arrive vec", 12: "wait B' (riccati)", 13: "wait B' (model)",
+          14: "meet solve (riccati)", 15: "meet solve (model)", 30: "forward (half)", 31: "backsub"}
+    print(f"  twisted solve (m = {twist}), cycles per iteration: " + "  ".join(f"{n} {sg[i] / its:6.0f}" for i, n in tn.items()))
