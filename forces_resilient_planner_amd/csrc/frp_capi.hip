@@ -69,20 +69,26 @@ bool fill_args(const frp_nmpc_batch *b, const frp_nmpc_options *opt_in, void *ws
     a->models = b->model_per_problem;
     a->order_hint = b->order_hint;
     a->counter = nullptr; a->order = nullptr;
+    a->self_reset = 0;
     return true;
 }
 
 // ---- single-problem context of the drop-in ABI: created lazily on first call, freed at unload
 // (the reference has no init/teardown call; SURVEY 8b "Ownership"). Serialised by a mutex: the
 // reference library is not re-entrant either (static work arrays).
-// One call = ONE host-to-device copy and ONE device-to-host copy, both through pinned staging blocks:
+// The inputs are staged in ONE pinned, device-mapped block and the outputs land in another:
 //   in  (doubles): xinit(9) | x0(340) | all_parameters(2600) | nfaces(20 ints)
 //   out (doubles): z(340) | info(FRP_INFO_STRIDE) | exitflag, iterations (2 ints)
+// With at most 15 live corridor rows per stage (the kernel variants that read every input ONCE, at the start of the solve) the kernel
+// reads and writes those blocks in place over PCIe -- no copy commands around the launch, and no reset launch in front of it
+// (KernelArgs::self_reset): one call = one kernel launch and one stream synchronisation.  More rows (the variants that re-read
+// the rows every iteration) or FRP_NMPC_DROPIN_ZEROCOPY=0: one host-to-device and one device-to-host copy through the same blocks.
 constexpr int DI_IN_DOUBLES = 9 + 340 + 2600 + 10, DI_OUT_DOUBLES = 340 + FRP_INFO_STRIDE + 1;
 struct DropInCtx {
     bool ready = false;
     hipStream_t stream = nullptr;
     double *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr, *d_ws = nullptr;
+    double *m_in = nullptr, *m_out = nullptr; // device addresses of the pinned blocks (null: not mapped, copies only)
     size_t ws_bytes = 0;
     frp_forces_extfunc probed[2] = {nullptr, nullptr}; // the callback last probed per model (a different pointer is probed again)
     bool probe_ok[2] = {false, false};
@@ -101,7 +107,7 @@ void ctx_release()
     if (g_ctx.h_in) (void)hipHostFree(g_ctx.h_in);
     if (g_ctx.h_out) (void)hipHostFree(g_ctx.h_out);
     if (g_ctx.stream) (void)hipStreamDestroy(g_ctx.stream);
-    g_ctx.d_in = g_ctx.d_out = g_ctx.d_ws = g_ctx.h_in = g_ctx.h_out = nullptr;
+    g_ctx.d_in = g_ctx.d_out = g_ctx.d_ws = g_ctx.h_in = g_ctx.h_out = g_ctx.m_in = g_ctx.m_out = nullptr;
     g_ctx.stream = nullptr;
     g_ctx.ready = false;
 }
@@ -116,13 +122,23 @@ int ctx_init()
     const bool ok = hipStreamCreate(&g_ctx.stream) == hipSuccess &&
                     hipMalloc(&g_ctx.d_in, DI_IN_DOUBLES * sizeof(double)) == hipSuccess &&
                     hipMalloc(&g_ctx.d_out, DI_OUT_DOUBLES * sizeof(double)) == hipSuccess &&
-                    hipHostMalloc(&g_ctx.h_in, DI_IN_DOUBLES * sizeof(double), hipHostMallocDefault) == hipSuccess &&
-                    hipHostMalloc(&g_ctx.h_out, DI_OUT_DOUBLES * sizeof(double), hipHostMallocDefault) == hipSuccess &&
-                    hipMalloc(&g_ctx.d_ws, g_ctx.ws_bytes) == hipSuccess;
+                    hipHostMalloc(&g_ctx.h_in, DI_IN_DOUBLES * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+                    hipHostMalloc(&g_ctx.h_out, DI_OUT_DOUBLES * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+                    hipMalloc(&g_ctx.d_ws, g_ctx.ws_bytes) == hipSuccess &&
+                    hipMemset(g_ctx.d_ws, 0, 64) == hipSuccess; // (the queue head: zero between calls, see KernelArgs::self_reset)
     if (!ok) {
         fprintf(stderr, "[frp_nmpc] HIP error %s while creating the drop-in context\n", hipGetErrorString(hipGetLastError()));
         ctx_release();
         return FRP_ERR_HIP;
+    }
+    const char *zc = getenv("FRP_NMPC_DROPIN_ZEROCOPY");
+    if (!(zc && atoi(zc) == 0)) {
+        void *pi = nullptr, *po = nullptr;
+        if (hipHostGetDevicePointer(&pi, g_ctx.h_in, 0) == hipSuccess && hipHostGetDevicePointer(&po, g_ctx.h_out, 0) == hipSuccess) {
+            g_ctx.m_in = static_cast<double *>(pi); g_ctx.m_out = static_cast<double *>(po);
+        } else {
+            (void)hipGetLastError();
+        }
     }
     g_ctx.ready = true;
     return FRP_OK;
@@ -219,13 +235,16 @@ int forces_solve(int model, frp_forces_params *params, frp_forces_output *output
         ctx_release();
         return FRP_EXIT_DEVICE_FAULT;
     };
-    if (hipMemcpyAsync(g_ctx.d_in, hin, DI_IN_DOUBLES * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return device_fault("copy in");
+    // in place over PCIe when the kernel variant reads its inputs once (mf <= 15: the corridor rows live in registers)
+    const bool zero_copy = g_ctx.m_in && g_ctx.m_out && mf <= 15;
+    double *din = zero_copy ? g_ctx.m_in : g_ctx.d_in, *dout = zero_copy ? g_ctx.m_out : g_ctx.d_out;
+    if (!zero_copy && hipMemcpyAsync(g_ctx.d_in, hin, DI_IN_DOUBLES * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return device_fault("copy in");
     frp_nmpc_batch b;
     std::memset(&b, 0, sizeof b);
     b.B = 1; b.N = FRP_N_REF; b.M = FRP_NH_REF; b.MF = mf; b.model = model;
-    b.xinit = g_ctx.d_in; b.x0 = g_ctx.d_in + 9; b.params = g_ctx.d_in + 349; b.nfaces = reinterpret_cast<const int *>(g_ctx.d_in + 2949);
-    b.z = g_ctx.d_out; b.info = g_ctx.d_out + 340;
-    b.exitflag = reinterpret_cast<int *>(g_ctx.d_out + 340 + FRP_INFO_STRIDE); b.iters = b.exitflag + 1;
+    b.xinit = din; b.x0 = din + 9; b.params = din + 349; b.nfaces = reinterpret_cast<const int *>(din + 2949);
+    b.z = dout; b.info = dout + 340;
+    b.exitflag = reinterpret_cast<int *>(dout + 340 + FRP_INFO_STRIDE); b.iters = b.exitflag + 1;
     frp::KernelArgs a;
     // FORCES' entry point has no options argument: the one option a caller of a SINGLE solve may want -- the latency option
     // frp_nmpc_options.twist -- comes from the environment (FRP_NMPC_TWIST = m or -1; unset / 0: the plain solve)
@@ -234,8 +253,9 @@ int forces_solve(int model, frp_forces_params *params, frp_forces_output *output
     frp_nmpc_default_options(&opt);
     opt.twist = env_twist;
     if (!fill_args(&b, &opt, g_ctx.d_ws, g_ctx.ws_bytes, &a)) return FRP_EXIT_PARAM_VALUE;
+    a.self_reset = 1;
     if (frp::launch_ipm(a, st) != hipSuccess) return device_fault("launch");
-    if (hipMemcpyAsync(g_ctx.h_out, g_ctx.d_out, DI_OUT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+    if ((!zero_copy && hipMemcpyAsync(g_ctx.h_out, g_ctx.d_out, DI_OUT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) ||
         hipStreamSynchronize(st) != hipSuccess)
         return device_fault("copy out / synchronise");
     std::memcpy(output->x, g_ctx.h_out, 340 * sizeof(double));

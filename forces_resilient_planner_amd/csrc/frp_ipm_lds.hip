@@ -2560,8 +2560,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     }
     // one copy of the solver loop per role: the four waves run different code between the same barriers
     const int wave = __builtin_amdgcn_readfirstlane(role);
-    if (wave == 0) role_loop<NP, FL, FREG, 0, TW>(a, sh);
-    else if (wave == 1) role_loop<NP, FL, FREG, 1, TW>(a, sh);
+    if (wave == 0) {
+        role_loop<NP, FL, FREG, 0, TW>(a, sh);
+        // (single-problem launches of the drop-in context: this wave made the last claim; the head is zero again for the next call)
+        if (a.self_reset && (threadIdx.x & 63) == 0) *a.counter = 0;
+    } else if (wave == 1) role_loop<NP, FL, FREG, 1, TW>(a, sh);
     else if (wave == 2) role_loop<NP, FL, FREG, 2, TW>(a, sh);
     else role_loop<NP, FL, FREG, 3, TW>(a, sh);
 }

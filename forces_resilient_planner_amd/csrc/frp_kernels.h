@@ -58,6 +58,8 @@ struct KernelArgs {
     const int *order; // launch order of the problems, or null = index order (set by the launcher)
     const int *models; // per-problem FRP_MODEL_*, or null = `model` for the whole batch
     const int *order_hint; // per-problem expected work (last tick's iteration count), or null = order by the cost of the initial guess
+    int self_reset;        // B == 1 only (the drop-in context): the queue head is zero on entry and the kernel leaves it zero --
+                           // no reset launch in front of the solve; no role placement (one workgroup: nothing to place)
 };
 
 constexpr int CU_SLOT_ENTRIES = 2048; // (XCC, SE, SH, CU) of HW_ID

@@ -430,6 +430,7 @@ hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
     k.cu_slots = reinterpret_cast<int *>(q + 32);
     k.order = nullptr;
     if (a.B > slots) { // more problems than resident workgroups: order the queue, longest expected solve first
+        k.self_reset = 0;
         double *keys = q + QUEUE_RESERVED;
         int *order = reinterpret_cast<int *>(keys + a.B);
         k.order = order;
@@ -439,7 +440,10 @@ hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
             hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)((a.B + 4 * (64 / a.N) - 1) / (4 * (64 / a.N)))), dim3(256), 0, stream, a.B, a.N, a.M, a.model,
                                a.models, a.xinit, a.x0, a.params, a.nfaces, order_weight(0), order_weight(1), keys);
         hipLaunchKernelGGL(order_bucket_kernel, dim3(1), dim3(1024), 0, stream, a.B, keys, order, k.counter, k.cu_slots);
+    } else if (a.self_reset && a.B == 1) {
+        k.cu_slots = nullptr; // (the caller zeroed the queue head once; the kernel puts it back)
     } else {
+        k.self_reset = 0;
         // a one-thread kernel rather than hipMemsetAsync: as a node of a captured hipGraph the 4-byte memset was not
         // ordered before the solve on the graph's first launch (ROCm 7.2; tools/graph_tick.py), which left the queue
         // exhausted and the previous outputs in place
