@@ -173,6 +173,11 @@ struct Ctx {
     int lmin[3], lmax[3], use_local;
     int fast, off[3]; // fast: the voxel of ray cell c is c + off on every axis (verified on the host for |c| <= CELL_SAFE)
     double res_inv, ext[3];
+    double res_y, cn, cn_y; // div_rcp of the resolution and of check_num (divisors of every collision sample)
+    // the box of RAY CELLS whose state is a bit of the staged window -- inside the map, inside the local range, inside the window,
+    // inside the range the integer cell -> voxel offset was verified for -- as first cell, extent (0 = empty) and window / bit origin
+    int fx0, fy0, fz0, fwx, fwy, fwz;
+    unsigned fxn, fyn, fzn;
 };
 constexpr int CELL_SAFE = 4096;
 
@@ -210,6 +215,50 @@ __device__ __forceinline__ int cell_state(const Ctx &c, int x, int y, int z)
     return voxel_state(c, (double)x * res + res / 2.0, (double)y * res + res / 2.0, (double)z * res + res / 2.0);
 }
 
+// a / b the way the compiler expands an FP64 division (rcp, two Newton steps on the reciprocal, q0 = a y, one residual step), split so
+// that the reciprocal of a divisor that is used again -- the map resolution: twelve times per collision sample -- is formed once.
+// Without the range scaling and the special-case fix-up of that expansion: for finite operands whose quotient is far from the
+// denormal and overflow ranges (coordinates over a resolution, a vector over its norm, a sample index over check_num) the result is
+// the same bits, i.e. the correctly rounded quotient the reference's CPU division produces (tests/test_gpu_astar.py: bit-identical).
+__device__ __forceinline__ double div_rcp(double b)
+{
+    const double y0 = __builtin_amdgcn_rcp(b);
+    const double y1 = __builtin_fma(y0, __builtin_fma(-b, y0, 1.0), y0);
+    return __builtin_fma(y1, __builtin_fma(-b, y1, 1.0), y1);
+}
+__device__ __forceinline__ double div_y(double a, double b, double y)
+{
+    const double q0 = a * y;
+    const double q = __builtin_fma(__builtin_fma(-b, q0, a), y, q0);
+    return a == 0.0 ? a : q; // (+-0 / b keeps its sign)
+}
+
+// cell_state for the cells of the box above: three range tests, one LDS read (everything else: the general path)
+__device__ __forceinline__ int cell_state_box(const Ctx &c, int x, int y, int z)
+{
+    const unsigned ux = (unsigned)(x - c.fx0), uy = (unsigned)(y - c.fy0), uz = (unsigned)(z - c.fz0);
+    if (ux < c.fxn && uy < c.fyn && uz < c.fzn) return (int)((c.win[(ux + c.fwx) * WIN + (uy + c.fwy)] >> (uz + c.fwz)) & 1ull);
+    return cell_state(c, x, y, z);
+}
+// (re)compute the box for the window at (wx0, wy0) -- uniform over the workgroup, a few scalar operations per expansion
+__device__ __forceinline__ void set_cell_box(Ctx &c)
+{
+    c.fxn = c.fyn = c.fzn = 0;
+    if (!(c.fast && c.packed && c.use_win)) return;
+    const frp_nmpc_astar *P = c.P;
+    int lo[3] = {c.wx0, c.wy0, 0}, hi[3] = {c.wx0 + 2 * c.win_r, c.wy0 + 2 * c.win_r, P->grid[2] - 1};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        lo[i] = max(lo[i], 0); hi[i] = min(hi[i], P->grid[i] - 1);
+        if (c.use_local) { lo[i] = max(lo[i], c.lmin[i]); hi[i] = min(hi[i], c.lmax[i]); }
+        lo[i] = max(lo[i] - c.off[i], -CELL_SAFE); hi[i] = min(hi[i] - c.off[i], CELL_SAFE); // ray cells
+    }
+    if (hi[0] < lo[0] || hi[1] < lo[1] || hi[2] < lo[2] || hi[2] + c.off[2] > 63) return;
+    c.fx0 = lo[0]; c.fy0 = lo[1]; c.fz0 = lo[2];
+    c.fxn = (unsigned)(hi[0] - lo[0] + 1); c.fyn = (unsigned)(hi[1] - lo[1] + 1); c.fzn = (unsigned)(hi[2] - lo[2] + 1);
+    c.fwx = lo[0] + c.off[0] - c.wx0; c.fwy = lo[1] + c.off[1] - c.wy0; c.fwz = lo[2] + c.off[2];
+}
+
 __device__ __forceinline__ int signum_i(int x) { return x == 0 ? 0 : (x < 0 ? -1 : 1); }
 // mod(value, 1) = fmod(fmod(value, 1) + 1, 1) (raycast.cpp:11-14); fmod(v, 1) = v - trunc(v) exactly (the fraction of a double is a double)
 __device__ __forceinline__ double mod1(double v) { const double f = v - trunc(v); const double t = f + 1.0; return t - trunc(t); }
@@ -223,8 +272,9 @@ __device__ __forceinline__ double intbound(double s, double ds)
 // getlineGrids (occ_map.cpp:686-718) + the scan over its cells in checkState: 1 = some cell of the segment is not free
 __device__ int line_hits(const Ctx &c, double s0, double s1, double s2, double e0, double e1, double e2)
 {
-    const double res = c.P->resolution;
-    const double a0 = s0 / res, a1 = s1 / res, a2 = s2 / res, b0 = e0 / res, b1 = e1 / res, b2 = e2 / res;
+    const double res = c.P->resolution, ry = c.res_y;
+    const double a0 = div_y(s0, res, ry), a1 = div_y(s1, res, ry), a2 = div_y(s2, res, ry), b0 = div_y(e0, res, ry), b1 = div_y(e1, res, ry),
+                 b2 = div_y(e2, res, ry);
     int x = (int)floor(a0), y = (int)floor(a1), z = (int)floor(a2);
     const int endX = (int)floor(b0), endY = (int)floor(b1), endZ = (int)floor(b2);
     const double dx = endX - x, dy = endY - y, dz = endZ - z;
@@ -233,16 +283,23 @@ __device__ int line_hits(const Ctx &c, double s0, double s1, double s2, double e
         // a vertical segment visits the cells z .. endZ of one column (the traversal below would only ever step in z)
         const int zlo = z < endZ ? z : endZ, zhi = z < endZ ? endZ : z;
         for (int zz = zlo; zz <= zhi; zz++)
-            if (cell_state(c, x, y, zz) != 0) return 1;
+            if (cell_state_box(c, x, y, zz) != 0) return 1;
         return 0;
     }
-    // (a segment inside one z layer: intbound(a2, 0) = (1 - s) / 0 = +inf exactly -- s = mod1(.) < 1 -- and tDeltaZ is never added)
-    double tMaxX = intbound(a0, dx), tMaxY = intbound(a1, dy), tMaxZ = (stepZ == 0 && a2 == a2) ? __builtin_huge_val() : intbound(a2, dz);
-    const double tDeltaX = ((double)stepX) / dx, tDeltaY = ((double)stepY) / dy, tDeltaZ = stepZ == 0 ? 0.0 : ((double)stepZ) / dz;
+    // tMax = intbound(a, d) = (1 - mod1(+-a)) / |d| and tDelta = step / d = 1 / |d| share the reciprocal of |d|.  An axis the segment
+    // does not move on (d = 0) has tMax = (1 - s) / 0 = +inf exactly (s = mod1(.) < 1) and a tDelta that is never added.
+    auto axis = [](double a, double d, double &tmax, double &tdelta) {
+        const double ad = fabs(d), adn = d == 0.0 ? 1.0 : ad;
+        const double y = div_rcp(adn), s = mod1(d < 0 ? -a : a);
+        tmax = (d == 0.0 && a == a) ? __builtin_huge_val() : div_y(1 - s, adn, y); // (a NaN coordinate stays a NaN, as in (1 - s) / 0)
+        tdelta = div_y(1.0, adn, y);
+    };
+    double tMaxX, tMaxY, tMaxZ, tDeltaX, tDeltaY, tDeltaZ;
+    axis(a0, dx, tMaxX, tDeltaX); axis(a1, dy, tMaxY, tDeltaY); axis(a2, dz, tMaxZ, tDeltaZ);
     for (int guard = 0;; guard++) {
         if (x == endX && y == endY && z == endZ) break;
         if (guard >= 4096) return 1;
-        if (cell_state(c, x, y, z) != 0) return 1;
+        if (cell_state_box(c, x, y, z) != 0) return 1;
         if (tMaxX < tMaxY) {
             if (tMaxX < tMaxZ) { x += stepX; tMaxX += tDeltaX; }
             else { z += stepZ; tMaxZ += tDeltaZ; }
@@ -251,7 +308,7 @@ __device__ int line_hits(const Ctx &c, double s0, double s1, double s2, double e
             else { z += stepZ; tMaxZ += tDeltaZ; }
         }
     }
-    return cell_state(c, endX, endY, endZ) != 0; // "check end": the cell floor(end), occ_map.cpp:704-717
+    return cell_state_box(c, endX, endY, endZ) != 0; // "check end": the cell floor(end), occ_map.cpp:704-717
 }
 
 // OccMap::checkState (occ_map.cpp:645-684): 1 = free
@@ -262,7 +319,7 @@ __device__ int check_state(const Ctx &c, const double pos[3], const double vel[3
     if (v_hor_norm < 1e-4) { vh0 = 1; vh1 = 1; }
     double cw0 = vh1, cw1 = -vh0;
     const double n2 = cw0 * cw0 + cw1 * cw1;
-    if (n2 > 0.0) { const double nn = sqrt(n2); cw0 = cw0 / nn; cw1 = cw1 / nn; }
+    if (n2 > 0.0) { const double nn = sqrt(n2), ny = div_rcp(nn); cw0 = div_y(cw0, nn, ny); cw1 = div_y(cw1, nn, ny); }
     cw0 = cw0 * c.P->ego_r * inflate_ratio; cw1 = cw1 * c.P->ego_r * inflate_ratio;
     if (line_hits(c, pos[0] + cw0, pos[1] + cw1, pos[2], pos[0] - cw0, pos[1] - cw1, pos[2])) return 0;
     if (line_hits(c, pos[0], pos[1], pos[2] + c.P->ego_h * inflate_ratio, pos[0], pos[1], pos[2] - c.P->ego_h * inflate_ratio)) return 0;
@@ -559,6 +616,7 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
                 sh.win[ix * WIN + iy] = (gx >= 0 && gx < P->grid[0] && gy >= 0 && gy < P->grid[1]) ? ctx.packed[(size_t)gx * P->grid[1] + gy] : 0ull;
             }
             ctx.wx0 = wx0; ctx.wy0 = wy0; ctx.use_win = 1;
+            set_cell_box(ctx);
         }
         if (terminating) {
             __syncthreads();
@@ -681,11 +739,14 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
             sh.c_f[c] = g + P->lambda_heu * estimate_heuristic(P, pro, sh.end_state, &ttg);
         };
         if (HEUR_BESIDE && lane < n_cand && sh.c_surv[lane]) cost_and_heuristic(lane);
-        for (int t = lane - CW0; t >= 0 && t < n_alive * P->check_num; t += CWN) {
+        // samples 0 .. CWN-1 go to the collision lanes; what is left over (more than CWN / check_num phase-1 survivors) is dealt over
+        // ALL lanes -- the heuristic lanes take theirs when they are done, which is sooner than a second pass of the collision lanes
+        const int n_samples = n_alive * P->check_num;
+        for (int t = lane >= CW0 ? lane - CW0 : CWN + lane; t < n_samples; t = t < CWN ? CWN + lane : t + NT) {
             const int ai = t / P->check_num, k = t - ai * P->check_num + 1;
             const int c = ai < n_al0 ? nth_set_bit(al0, ai) : 64 + nth_set_bit(al1, ai - n_al0);
             const double um[3] = {sh.c_um[c][0], sh.c_um[c][1], sh.c_um[c][2]};
-            const double dt = sh.c_tau[c] * (double)k / (double)P->check_num;
+            const double dt = div_y(sh.c_tau[c] * (double)k, ctx.cn, ctx.cn_y);
             double xt[6];
             state_transit(ctx, sh.cur_state, xt, um, dt);
             if (!check_state(ctx, xt, xt + 3, 1.5)) sh.c_leader[c] = -1; // (c_leader doubles as the collision flag until phase 3 has read it)
@@ -833,6 +894,8 @@ __global__ __launch_bounds__(NT) void astar_kernel(Args a)
     Ctx ctx;
     ctx.P = P; ctx.occ = P->occ; ctx.packed = a.packed; ctx.win = sh.win; ctx.wx0 = 0; ctx.wy0 = 0; ctx.use_win = 0;
     ctx.res_inv = 1.0 / P->resolution;
+    ctx.res_y = div_rcp(P->resolution); ctx.cn = (double)P->check_num; ctx.cn_y = div_rcp(ctx.cn);
+    ctx.fxn = ctx.fyn = ctx.fzn = 0; ctx.fx0 = ctx.fy0 = ctx.fz0 = ctx.fwx = ctx.fwy = ctx.fwz = 0;
     {   // reach of a primitive per axis: |v| tau + (max_acc + |f_ext|) tau^2 / 2 with |v| <= max_vel (nodes beyond it are never
         // created), plus the inflated ego radius of checkState and two cells of slack
         const double tau = fmax(P->max_tau, P->init_max_tau);
