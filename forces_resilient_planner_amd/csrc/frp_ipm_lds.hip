@@ -1016,79 +1016,211 @@ __device__ __noinline__ void meet_solve(ldouble *recs, ldouble *tw, int m, ldoub
 // first half, vector sweep of the corrector (new right-hand side phi_cc = PHIB + smu PHIC): the arrival gradient q_k, stage by stage,
 //     z~ = phi_(w, x) + q_k,  E = T'' z~_w,  g^ = [phi_u - hc E_w; z~_x - E_x],  kbar = E_w -> T' column 13,  q_{k+1} = T~' (G^ t~ + g^).
 // Vectors in V layout (lane 16 a + 4 b + j holds row 4 b + a).  q_k is stored in stage k's R_PV slots (multipliers), q_m in the workgroup scratch.
+// Same construction as the Riccati wave's vector sweeps: per-lane byte addresses, the stage offset as the instruction's immediate,
+// two operand sets refilled one stage ahead, waits that count the younger LDS operations exactly.
+struct ArrAddr {
+    unsigned m0, m1, m2, m3, ph, cb, cc, pu, hf, tp, pd, wk, wq;
+    __device__ __forceinline__ void step(int n)
+    {
+        m0 += n; m1 += n; m2 += n; m3 += n; ph += n; cb += n; cc += n; pu += n; hf += n; tp += n; pd += n; wk += n; wq += n;
+        asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "+v"(ph), "+v"(cb), "+v"(cc), "+v"(pu), "+v"(hf), "+v"(tp), "+v"(pd), "+v"(wk), "+v"(wq));
+    }
+};
+struct ArrOps {
+    double m0, m1, m2, m3, phb, phc, cbb, cbc, pub, puc, hf, tp, pd;
+};
+template <int K>
+__device__ __forceinline__ void arr_gather(const ArrAddr &p, ArrOps &x)
+{
+    x.phb = lds_ld<K * RSB>(p.ph);
+    x.phc = lds_ld<K * RSB + R_BC * 8>(p.ph);
+    x.cbb = lds_ld<K * RSB>(p.cb);               // corridor parts: pos rows, 0 elsewhere (two addresses: a first-half record's second zero is in use)
+    x.cbc = lds_ld<K * RSB>(p.cc);
+    x.tp = lds_ld<K * RSB>(p.tp);
+    x.pub = lds_ld<K * RSB>(p.pu);
+    x.puc = lds_ld<K * RSB + R_BC * 8>(p.pu);
+    x.hf = lds_ld<K * RSB>(p.hf);                // quad 0: hc, other quads: 1
+    x.pd = lds_ld<K * RSB>(p.pd);
+    x.m0 = lds_ld<K * RSB>(p.m0);
+    x.m1 = lds_ld<K * RSB>(p.m1);
+    x.m2 = lds_ld<K * RSB>(p.m2);
+    x.m3 = lds_ld<K * RSB>(p.m3);
+}
+template <int YOUNGER>
+__device__ __forceinline__ void arr_wait(ArrOps &x)
+{
+    asm volatile("s_waitcnt lgkmcnt(%13)"
+                 : "+v"(x.m0), "+v"(x.m1), "+v"(x.m2), "+v"(x.m3), "+v"(x.phb), "+v"(x.phc), "+v"(x.cbb), "+v"(x.cbc), "+v"(x.pub), "+v"(x.puc),
+                   "+v"(x.hf), "+v"(x.tp), "+v"(x.pd)
+                 : "n"(YOUNGER));
+}
+template <int K>
+__device__ __forceinline__ void arr_step(const ArrAddr &p, const ArrOps &x, double smu, bool q0, double &qk)
+{
+    lds_st<K * RSB>(p.wq, qk);                                              // q_k for y_k = -(Q_k ds_k + q_k)
+    const double zt = __builtin_fma(smu, x.phc + x.cbc, x.phb + x.cbb) + qk; // z~ (rows 13..15: junk that meets zero columns)
+    double dq = q0 ? zt : 0.0;                                               // z~_w[a] into every lane of row a
+    dq += quad_rot<1>(dq);
+    dq += quad_rot<2>(dq);
+    const double E = mfma4(x.tp, dq, 0.0);
+    const double base = q0 ? __builtin_fma(smu, x.puc, x.pub) : zt;
+    const double gh = __builtin_fma(-x.hf, E, base);
+    const double v = gh + x.pd;
+    FRP_SB();
+    lds_st<K * RSB>(p.wk, E); // kbar (rows 0..3); behind VALU results computed from E (see back_step)
+    d4 A;
+    A[0] = x.m0; A[1] = x.m1; A[2] = x.m2; A[3] = x.m3;
+    qk = matvec4s(A, v, 0.0);
+}
+template <int K, int L> // stages K .. L-1 above the addresses; X holds the operands of stage K
+__device__ __forceinline__ void arr_tail(const ArrAddr &p, ArrOps &X, ArrOps &Y, double smu, bool q0, double &qk)
+{
+    if constexpr (K + 1 < L) {
+        arr_gather<K + 1>(p, Y); FRP_SB(); arr_step<K>(p, X, smu, q0, qk); arr_wait<2>(Y);
+        arr_tail<K + 1, L>(p, Y, X, smu, q0, qk);
+    } else {
+        arr_step<K>(p, X, smu, q0, qk);
+    }
+}
 __device__ __noinline__ void sweep_arrive_vec(ldouble *recs, ldouble *xs, ldouble *tw, int m, double smu)
 {
     m = uni(m); smu = uni(smu);
     const int lane = threadIdx.x & 63, a = lane >> 4, b = (lane >> 2) & 3;
     const int idx = 4 * b + a;
-    int mt[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) mt[r] = tab(T4_MAT + r, lane);
-    const int o_ph = R_PHIB + 4 + idx;                                   // (w, x) rows: z index 4 + idx; rows 13..15 read finite junk
-    const int o_cb = (idx >= 4 && idx <= 6) ? R_CB + idx - 4 : R_ZERO;   // corridor parts on the pos rows
-    const int o_pu = R_PHIB + a;                                         // phi_u[a] (used by the quad-0 lanes)
-    const int o_pd = idx <= 12 ? R_PD + idx : R_ZERO;
-    const int o_wk = b == 0 ? R_T + 16 * a + 13 : R_DUMP;
-    const int o_wq = idx <= 12 ? R_PV + idx : R_DUMP;
     const bool q0 = b == 0;
+    ArrAddr p;
+    p.m0 = lds_addr(recs + tab(T4_MAT + 0, lane)); p.m1 = lds_addr(recs + tab(T4_MAT + 1, lane));
+    p.m2 = lds_addr(recs + tab(T4_MAT + 2, lane)); p.m3 = lds_addr(recs + tab(T4_MAT + 3, lane));
+    p.ph = lds_addr(recs + R_PHIB + 4 + idx);                                    // (w, x) rows: z index 4 + idx; rows 13..15 read finite junk
+    p.cb = lds_addr(recs + ((idx >= 4 && idx <= 6) ? R_CB + idx - 4 : R_ZERO));  // corridor parts on the pos rows
+    p.cc = lds_addr(recs + ((idx >= 4 && idx <= 6) ? R_CC + idx - 4 : R_ZERO));
+    p.pu = lds_addr(recs + R_PHIB + a);                                          // phi_u[a] (used by the quad-0 lanes)
+    p.hf = lds_addr(recs + (q0 ? R_HC : R_ONE));
+    p.tp = lds_addr(recs + R_T + lane);
+    p.pd = lds_addr(recs + (idx <= 12 ? R_PD + idx : R_ZERO));
+    p.wk = lds_addr(recs + (q0 ? R_T + 16 * a + 13 : R_DUMP));
+    p.wq = lds_addr(recs + (idx <= 12 ? R_PV + idx : R_DUMP));
     double qk = (idx >= 4 && idx <= 12) ? -TW_RHO * xs[X_DX0 + idx - 4] : 0.0;
-    for (int k = 0; k < m; k++) {
-        ldouble *rec = recs + k * RS;
-        const double phb = rec[o_ph], phc = rec[o_ph + R_BC], cbb = rec[o_cb], cbc = rec[o_cb == R_ZERO ? R_ZERO : o_cb + R_BC];
-        const double pub = rec[o_pu], puc = rec[o_pu + R_BC];
-        const double tp = rec[R_T + lane], hcv = rec[R_HC], gt = rec[o_pd];
-        d4 A;
-#pragma unroll
-        for (int r = 0; r < 4; r++) A[r] = rec[mt[r]];
-        rec[o_wq] = qk;
-        const double zt = __builtin_fma(smu, phc + cbc, phb + cbb) + qk;   // z~ (rows 13..15: junk that meets zero columns)
-        // z~_w[a] into every lane of row a
-        double dq = q0 ? zt : 0.0;
-        dq += quad_rot<1>(dq);
-        dq += quad_rot<2>(dq);
-        const double E = mfma4(tp, dq, 0.0);
-        const double base = q0 ? __builtin_fma(smu, puc, pub) : zt;
-        const double gh = __builtin_fma(-(q0 ? hcv : 1.0), E, base);
-        rec[o_wk] = E; // kbar (rows 0..3)
-        const double v = gh + gt;
-        qk = matvec4s(A, v, 0.0);
+    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): nothing of the compiler's own LDS traffic is left in flight
+    ArrOps A, B;
+    arr_gather<0>(p, A);
+    arr_wait<0>(A);
+    int left = m; // stages to go; A holds the operands of the next one, the addresses sit on it
+    for (; left >= 5; left -= 4) {
+        arr_gather<1>(p, B); FRP_SB(); arr_step<0>(p, A, smu, q0, qk); arr_wait<2>(B);
+        arr_gather<2>(p, A); FRP_SB(); arr_step<1>(p, B, smu, q0, qk); arr_wait<2>(A);
+        arr_gather<3>(p, B); FRP_SB(); arr_step<2>(p, A, smu, q0, qk); arr_wait<2>(B);
+        arr_gather<4>(p, A); FRP_SB(); arr_step<3>(p, B, smu, q0, qk); arr_wait<2>(A);
+        p.step(4 * RSB);
     }
+    switch (left) {
+    case 4: arr_tail<0, 4>(p, A, B, smu, q0, qk); break;
+    case 3: arr_tail<0, 3>(p, A, B, smu, q0, qk); break;
+    case 2: arr_tail<0, 2>(p, A, B, smu, q0, qk); break;
+    default: arr_tail<0, 1>(p, A, B, smu, q0, qk); break;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (idx <= 12 && (lane & 3) == 0) tw[TW_QV + idx] = qk;
     WSYNC();
 }
 
 // first half, back-substitution (both passes): from v = [ds_m; 1] down to stage 0,
 //     [u; x]_k = T~ v (+ t~ through row 13),  w_k = -T' [hc u; x; 1],  dz_k -> the record,  v <- [w_k; x_k; 1].
+// (m >= 2; the addresses sit on the LOWEST stage a pass touches, see sweep_backvec)
+struct BsAddr {
+    unsigned m0, m1, m2, m3, ts, hf, wu, ww, wx;
+    __device__ __forceinline__ void step(int n)
+    {
+        m0 += n; m1 += n; m2 += n; m3 += n; ts += n; hf += n; wu += n; ww += n; wx += n;
+        asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "+v"(ts), "+v"(hf), "+v"(wu), "+v"(ww), "+v"(wx));
+    }
+};
+struct BsOps {
+    double m0, m1, m2, m3, ts, hf;
+};
+template <int K>
+__device__ __forceinline__ void bs_gather(const BsAddr &p, BsOps &x)
+{
+    x.m0 = lds_ld<K * RSB>(p.m0);
+    x.m1 = lds_ld<K * RSB>(p.m1);
+    x.m2 = lds_ld<K * RSB>(p.m2);
+    x.m3 = lds_ld<K * RSB>(p.m3);
+    x.hf = lds_ld<K * RSB>(p.hf); // quad 0: hc, other quads: 1
+    x.ts = lds_ld<K * RSB>(p.ts);
+}
+template <int YOUNGER>
+__device__ __forceinline__ void bs_wait(BsOps &x)
+{
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(x.m0), "+v"(x.m1), "+v"(x.m2), "+v"(x.m3), "+v"(x.ts), "+v"(x.hf) : "n"(YOUNGER));
+}
+template <int K>
+__device__ __forceinline__ void bs_step(const BsAddr &p, const BsOps &x, bool q0, double &v)
+{
+    d4 A;
+    A[0] = x.m0; A[1] = x.m1; A[2] = x.m2; A[3] = x.m3;
+    const double ux = matvec4s(A, v, 0.0);      // rows 0..3 u, 4..12 x, 13: 1
+    const double mm = x.hf * ux;
+    FRP_SB();
+    const double d = mfma4(x.ts, mm, 0.0);
+    FRP_SB();
+    const double r = -d - quad_rot<1>(d);
+    const double wk = r + quad_rot<2>(r);       // w_k[a] in every lane of row a
+    v = q0 ? wk : ux;
+    FRP_SB();
+    lds_st<K * RSB>(p.wu, ux);
+    lds_st<K * RSB>(p.ww, wk);
+    lds_st<K * RSB>(p.wx, ux);
+}
+template <int K> // stages K .. 0 above the addresses; X holds the operands of stage K
+__device__ __forceinline__ void bs_tail(const BsAddr &p, BsOps &X, BsOps &Y, bool q0, double &v)
+{
+    if constexpr (K > 0) {
+        bs_gather<K - 1>(p, Y); FRP_SB(); bs_step<K>(p, X, q0, v); bs_wait<3>(Y);
+        bs_tail<K - 1>(p, Y, X, q0, v);
+    } else {
+        bs_step<0>(p, X, q0, v); // stage 0
+    }
+}
 __device__ __noinline__ void sweep_backsub(ldouble *recs, cldouble *ds, int m)
 {
     m = uni(m);
     const int lane = threadIdx.x & 63, a = lane >> 4, b = (lane >> 2) & 3;
     const int idx = 4 * b + a;
-    int ma[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) ma[r] = tab(T4_MA + r, lane);
-    const int o_ts = tab(T4_TS, lane);
-    const int o_hf = b == 0 ? R_HC : R_ONE;
-    const int o_wu = b == 0 ? R_DZ + a : R_DUMP;                       // du = u_k (rows 0..3 of T~ v)
-    const int o_ww = b == 0 ? R_DZ + 4 + a : R_DUMP;                   // dw_k
-    const int o_wx = (idx >= 4 && idx <= 12) ? R_DZ + 4 + idx : R_DUMP; // dx_k
+    const bool q0 = b == 0;
+    ldouble *base = recs + (m - 2) * RS;
+    BsAddr p;
+    p.m0 = lds_addr(base + tab(T4_MA + 0, lane)); p.m1 = lds_addr(base + tab(T4_MA + 1, lane));
+    p.m2 = lds_addr(base + tab(T4_MA + 2, lane)); p.m3 = lds_addr(base + tab(T4_MA + 3, lane));
+    p.ts = lds_addr(base + tab(T4_TS, lane));
+    p.hf = lds_addr(base + (q0 ? R_HC : R_ONE));
+    p.wu = lds_addr(base + (q0 ? R_DZ + a : R_DUMP));                            // du = u_k (rows 0..3 of T~ v)
+    p.ww = lds_addr(base + (q0 ? R_DZ + 4 + a : R_DUMP));                        // dw_k
+    p.wx = lds_addr(base + ((idx >= 4 && idx <= 12) ? R_DZ + 4 + idx : R_DUMP)); // dx_k
     double v = idx == 13 ? 1.0 : ds[idx];
-    for (int k = m - 1; k >= 0; k--) {
-        ldouble *rec = recs + k * RS;
-        d4 A;
-#pragma unroll
-        for (int r = 0; r < 4; r++) A[r] = rec[ma[r]];
-        const double ts = rec[o_ts], hf = rec[o_hf];
-        const double ux = matvec4s(A, v, 0.0);     // rows 0..3 u, 4..12 x, 13: 1
-        const double mm = hf * ux;
-        const double d = mfma4(ts, mm, 0.0);
-        const double r_ = -d - quad_rot<1>(d);
-        const double wk = r_ + quad_rot<2>(r_);    // w_k[a] in every lane of row a
-        rec[o_wu] = ux;
-        rec[o_ww] = wk;
-        rec[o_wx] = ux;
-        v = b == 0 ? wk : ux;
+    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): nothing of the compiler's own LDS traffic is left in flight
+    BsOps A, B;
+    bs_gather<1>(p, A); // stage m-1
+    bs_wait<0>(A);
+    bs_gather<0>(p, B); // stage m-2
+    FRP_SB();
+    bs_step<1>(p, A, q0, v);
+    bs_wait<3>(B);
+    int s_ = m - 2; // B holds stage s_, the addresses sit on it
+    for (; s_ >= 4; s_ -= 4) {
+        p.step(-4 * RSB);
+        bs_gather<3>(p, A); FRP_SB(); bs_step<4>(p, B, q0, v); bs_wait<3>(A);
+        bs_gather<2>(p, B); FRP_SB(); bs_step<3>(p, A, q0, v); bs_wait<3>(B);
+        bs_gather<1>(p, A); FRP_SB(); bs_step<2>(p, B, q0, v); bs_wait<3>(A);
+        bs_gather<0>(p, B); FRP_SB(); bs_step<1>(p, A, q0, v); bs_wait<3>(B);
     }
+    p.step(-s_ * RSB);
+    switch (s_) {
+    case 3: bs_tail<3>(p, B, A, q0, v); break;
+    case 2: bs_tail<2>(p, B, A, q0, v); break;
+    case 1: bs_tail<1>(p, B, A, q0, v); break;
+    default: bs_tail<0>(p, B, A, q0, v); break;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     WSYNC();
 }
 
@@ -1743,7 +1875,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     const int lane = threadIdx.x & 63;
     const int N = a.N, M = a.M, MF = a.MF, np = NPRE + 4 * M;
     ldouble *recs = sh.recs, *xs = sh.xs;
-    const int tw_m = TW ? uni(a.twist) : 0; // (validated by the launcher: 1 <= tw_m <= N - 2)
+    const int tw_m = TW ? uni(a.twist) : 0; // (validated by the launcher: 2 <= tw_m <= N - 2)
     ldouble *tw = sh.tw;
     // three lanes per stage (H == 3: NP = 20) also on the Riccati wave's Hessian and on the model wave (model_phase3, hessian_phase3)
     constexpr bool H3 = (H == 3);
@@ -2576,11 +2708,11 @@ static hipError_t launch_variant(const KernelArgs &k, int slots, hipStream_t str
     return hipGetLastError();
 }
 // the twisted variants: frp_nmpc_options.twist = m (stages eliminated forward), -1 = 9 N / 20; anything the twisted solve does not cover
-// (N > 20, N < 4, m outside 1 .. N - 2) runs the plain solve, like the oracle's (oracle/nmpc_ipm.c, kkt_solve)
+// (N > 20, N < 4, m outside 2 .. N - 2) runs the plain solve, like the oracle's (oracle/nmpc_ipm.c, kkt_solve)
 static inline int twist_stages(const KernelArgs &k)
 {
     const int m = k.twist < 0 ? 9 * k.N / 20 : k.twist;
-    return (k.N >= 4 && k.N <= 20 && m >= 1 && m <= k.N - 2) ? m : 0;
+    return (k.N >= 4 && k.N <= 20 && m >= 2 && m <= k.N - 2) ? m : 0;
 }
 
 } // namespace lr

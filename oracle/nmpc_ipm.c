@@ -442,7 +442,7 @@ static int kkt_solve(solver_ws *W, const double *xinit, int full)
         static double tw_rho = 1e12;
         if (tw_m == -2) { const char *e = getenv("ORC_TWIST"); tw_m = e ? atoi(e) : -1; const char *r = getenv("ORC_TWIST_RHO"); if (r) tw_rho = atof(r); }
         const int m = tw_m > 0 ? tw_m : (W->twist < 0 ? 9 * N / 20 : W->twist);
-        if (m > 0 && m < N - 1 && N >= 4) return kkt_solve_twisted(W, xinit, full, m, tw_rho);
+        if (m > 1 && m < N - 1 && N >= 4) return kkt_solve_twisted(W, xinit, full, m, tw_rho);
     }
     for (int k = N - 1; k >= 0; k--) {
         const double *Pn = (k < N - 1) ? W->st[k + 1].P : 0, *pn = (k < N - 1) ? W->st[k + 1].p : 0;

@@ -198,10 +198,10 @@ def test_twisted_solve_on_the_fixture_families(golden_dir):
 
 
 def test_twist_outside_its_range_is_the_plain_solve():
-    """N > 20, N < 4 or m outside 1..N-2: the option is ignored (bit-identical results), like the oracle's."""
+    """N > 20, N < 4 or m outside 2..N-2: the option is ignored (bit-identical results), like the oracle's."""
     w = workloads.config2(64)
     zp, flp, itp, _ = solver.solve_batch_host(w)
-    for m in (19, 25, 0):  # N - 1, beyond the horizon, off
+    for m in (19, 25, 1, 0):  # N - 1, beyond the horizon, a single forward stage, off
         z, fl, it, _ = solver.solve_batch_host(w, solver.default_options(twist=m))
         assert np.array_equal(z, zp) and np.array_equal(it, itp)
     w3 = workloads.config3(32)  # N = 40
@@ -1224,3 +1224,15 @@ def test_statically_linked_planner_stub_solves_config0(tmp_path):
     assert flo[0] == 1 and io[0].it == int(it)
     assert abs(mu_aff - io[0].mu_aff) <= 1e-6 * (1 + abs(io[0].mu_aff)) and abs(sigma - io[0].sigma) <= 1e-6
     assert abs(step_aff - io[0].step_aff) <= 1e-6 and abs(step_cc - io[0].step_cc) <= 1e-6 and 0.0 < step_aff <= 1.0
+    # the two transports of the drop-in context -- inputs / outputs in place in pinned mapped memory (default) or copied around the
+    # launch -- return the same bits; the latency option (FRP_NMPC_TWIST) the same solution within the tolerances
+    env = dict(os.environ)
+    env["FRP_NMPC_DROPIN_ZEROCOPY"] = "0"
+    r0 = subprocess.run([stub, str(f)], capture_output=True, text=True, env=env)
+    assert r0.returncode == 0 and r0.stdout == r.stdout
+    env = dict(os.environ)
+    env["FRP_NMPC_TWIST"] = "-1"
+    rt = subprocess.run([stub, str(f)], capture_output=True, text=True, env=env)
+    assert rt.returncode == 0
+    t1, t2, tobj_n, tobj_f, tit = rt.stdout.strip().splitlines()[0].split()
+    assert t1 == "1" and t2 == "1" and abs(float(tobj_n) - float(obj_n)) < 1e-6 and abs(float(tobj_f) - float(obj_f)) < 1e-6 and tit == it
