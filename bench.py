@@ -464,7 +464,17 @@ def main():
                 flag = solver.lib().FORCESNLPsolver_normal_solve(ctypes.byref(p), ctypes.byref(o), ctypes.byref(info), None, None)
                 lat.append(time.perf_counter() - t1)
             out["dropin_latency_ms"] = {"value": float(np.median(lat[5:])) * 1e3, "exitflag": int(flag), "iterations": int(info.it),
-                                        "what": "BASELINE configs[0] through FORCESNLPsolver_normal_solve (H2D of the 23.6 KB params, one-problem solve, D2H), warm, median of 20"}
+                                        "what": "BASELINE configs[0] through FORCESNLPsolver_normal_solve (params staged in pinned mapped memory, read and written in place by "
+                                                "the one-problem solve; one launch + one synchronisation), warm, median of 20"}
+            try:  # the same call with the latency option; the environment variable is read once per process: a child measures it
+                import subprocess, re
+                e = dict(os.environ); e["FRP_NMPC_TWIST"] = "-1"
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "twist_latency.py"), "dropin"], env=e, capture_output=True, text=True, timeout=120)
+                mm = re.search(r"median ([0-9.]+) us", r.stdout)
+                if mm:
+                    out["dropin_latency_ms"]["with_FRP_NMPC_TWIST=-1"] = float(mm.group(1)) * 1e-3
+            except Exception as ex:  # noqa: BLE001 -- informational leg
+                out["dropin_latency_ms"]["with_FRP_NMPC_TWIST=-1"] = None
             # the whole planner tick on the device (SURVEY 8f rows f-1..f-4a around the solve): ms per stage of the tick, never `value`
             try:
                 import importlib.util

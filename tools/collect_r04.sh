@@ -15,6 +15,8 @@ python tools/bench_configs.py > $R/bench_configs.txt 2>&1
 if [ -f forces_resilient_planner_amd/lib_prof.so ]; then
   for b in 1 4096; do FRP_LIB=$PWD/forces_resilient_planner_amd/lib_prof.so python tools/prof_lds.py $b 2 >> $R/wave_phases.txt 2>&1; done
 fi
+python tools/twist_latency.py 2>&1 | grep -v amdgpu.ids > $R/twist_latency.txt
+python tools/twist_soak.py 3 2>&1 | grep -v amdgpu.ids > $R/twist_soak.txt
 python tests/tools/e2e_bench.py > $R/e2e.txt 2>/dev/null
 python tools/full_tick_bench.py 4096 10 20000 0.5 2 > $R/full_tick.json 2> $R/full_tick.err
 python tools/receding_bench.py 65536 20 > $R/configs4_receding.json 2>/dev/null
