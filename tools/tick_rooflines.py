@@ -15,7 +15,8 @@ Work definitions (per planner and tick; B planners, N = 20 stages) -- stated her
   tube       1.26 Mflop per planner (Gramian quadrature + Taylor steps + Jacobi sqrtm per stage and channel); FP64 VALU bound
   pack       HBM: N * (10 + 4 M) * 8 B parameters + N * 17 * 8 + 72 B written, N * (72 + 24 + 8) + polytopes 2 * rows * 32 B read
   reference / update / mode: launch-bound (tens of KB per launch): reported as time only
-  astar      one expansion of ONE search = ~900 collision samples (survivors * check_num) of ~800 FP64-heavy instructions on one CU (the FP64 issue
+  astar      one expansion of ONE search = ~900 collision samples (survivors * check_num) of ~500 FP64-heavy instructions (~800 before the cell box and the
+             shared reciprocals of round 4) on one CU (the FP64 issue
              rate of a CU: 64 lanes * 4 SIMDs / 4 cycles = 64 lane-instructions per cycle) + the serial pop / commit; reported per expansion of
              the longest search, which is what a batch waits for"""
 import csv, json, sys
@@ -78,7 +79,7 @@ if len(sys.argv) > 3:
         if a.get("world") != "pillars":
             continue
         us = a["gpu_us_per_expansion_of_the_longest_search"]
-        lane_instr = 900 * 800.0
+        lane_instr = 900 * 500.0
         out["kernels"]["astar"] = {"kernel": "astar_kernel (1024 threads per planner)", "bound": "latency of the serial expansion loop; inside an expansion the FP64 issue rate of ONE CU",
                                    "searches_per_s": a["gpu_searches_per_s"], "us_per_expansion_of_the_longest_search": us, "expansions_of_the_longest_search": a["expansions_max"],
                                    "algorithmic_lane_instructions_per_expansion": lane_instr,
