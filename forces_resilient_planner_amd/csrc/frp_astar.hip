@@ -525,7 +525,7 @@ struct Shared {
     unsigned long long vx_key[256]; // first-survivor-of-a-voxel search: open-addressing table voxel key -> lowest candidate index
     int vx_min[256];
     unsigned long long win[WIN * WIN];
-    double c_state[MAX_CAND][6], c_g[MAX_CAND], c_f[MAX_CAND], c_um[MAX_CAND][3], c_tau[MAX_CAND], grp_val[MAX_CAND];
+    double c_state[MAX_CAND][6], c_g[MAX_CAND], c_f[MAX_CAND], c_um[MAX_CAND][3], c_tau[MAX_CAND];
     long long c_key[MAX_CAND];
     int c_pre[MAX_CAND], c_surv[MAX_CAND], c_leader[MAX_CAND], c_created[MAX_CAND], c_winner[MAX_CAND];
     double cur_state[6], cur_g, end_state[6], coef_shot[12], t_shot;
@@ -814,37 +814,56 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
         if (wv == 0) {
             const int le0 = sh.c_leader[ln], le1 = sh.c_leader[64 + ln], pr0 = sh.c_pre[ln], pr1 = sh.c_pre[64 + ln];
             const double g0 = sh.c_g[ln], g1 = sh.c_g[64 + ln], f0 = sh.c_f[ln], f1 = sh.c_f[64 + ln];
+            // g of the open nodes the survivors may re-parent: fetched by all lanes at once (one trip to the L2 instead of one per
+            // survivor on the walking lane).  Nothing writes a node's g before the walk is over, and voxel groups are disjoint.
+            const bool od0 = pr0 >= 0 && ln < n_cand && sh.c_surv[ln], od1 = pr1 >= 0 && 64 + ln < n_cand && sh.c_surv[64 + ln];
+            const double og0 = od0 ? nodes[pr0].g : 0.0, og1 = od1 ? nodes[pr1].g : 0.0;
             int use = sh.use_node_num, hs = sh.heap_size;
+            // the walk's own bookkeeping -- value, node and winning primitive of every voxel group -- lives in registers, lane = primitive
+            // (two per lane), read with v_readlane and written with a compare-select: an LDS array would cost the walking lane a
+            // round trip per access (the lesson of the survivor walk itself); the arrays the node writes below read are stored once, after it
+            double gv0 = 0.0, gv1 = 0.0;
+            int cr0 = 0, cr1 = 0, wn0 = -1, wn1 = -1;
+            auto get_gv = [&](int i) { return i < 64 ? rl_f64(gv0, i) : rl_f64(gv1, i - 64); };
+            auto get_cr = [&](int i) { return i < 64 ? __builtin_amdgcn_readlane(cr0, i) : __builtin_amdgcn_readlane(cr1, i - 64); };
+            auto set_grp = [&](int i, double v, int win) { // group i: value and winner
+                if (i < 64) { gv0 = ln == i ? v : gv0; wn0 = ln == i ? win : wn0; }
+                else { gv1 = ln == i - 64 ? v : gv1; wn1 = ln == i - 64 ? win : wn1; }
+            };
+            auto set_cr = [&](int i, int nid) {
+                if (i < 64) cr0 = ln == i ? nid : cr0;
+                else cr1 = ln == i - 64 ? nid : cr1;
+            };
             for (int w = 0; w < 2; w++) {
                 const unsigned long long mw = sh.alive[w];
                 unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mw >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mw);
                 for (; m && !out_of_memory; m &= m - 1) {
                     const int cl = __builtin_ctzll(m), c = 64 * w + cl;
                     const int L = __builtin_amdgcn_readlane(w ? le1 : le0, cl), pre = __builtin_amdgcn_readlane(w ? pr1 : pr0, cl);
-                    const double g = rl_f64(w ? g1 : g0, cl), f = rl_f64(w ? f1 : f0, cl);
-                    if (ln == 0 && L == c) sh.c_winner[c] = -1; // (winner of the voxel's group: the primitive whose values the node ends up with)
+                    const double g = rl_f64(w ? g1 : g0, cl), f = rl_f64(w ? f1 : f0, cl), og = rl_f64(w ? og1 : og0, cl);
+                    // (winner of the voxel's group: the primitive whose values the node ends up with; -1 until one is better than the open node)
                     if (pre >= 0) { // a node of this voxel is in the open set: keep the cheaper way to it
-                        if (ln == 0) {
-                            const int nid = pre;
-                            if (L == c) { sh.grp_val[c] = nodes[nid].g; sh.c_created[c] = nid; }
-                            if (g < sh.grp_val[L]) {
-                                heap[nodes[nid].heap_pos].f = f; // the key changes in place: no re-heapify (as in the reference)
-                                sh.grp_val[L] = g; sh.c_winner[L] = c;
-                            }
+                        const int nid = pre;
+                        if (L == c) { set_grp(c, og, -1); set_cr(c, nid); }
+                        if (g < get_gv(L)) {
+                            if (ln == 0) heap[nodes[nid].heap_pos].f = f; // the key changes in place: no re-heapify (as in the reference)
+                            set_grp(L, g, c);
                         }
                     } else if (L == c) { // new node
                         const int nid = use;
                         hs++;
                         heap_push_hole_wave(heap, nodes, hs - 1, f, nid); // (the whole wavefront: see there)
-                        if (ln == 0) { sh.c_created[c] = nid; sh.grp_val[c] = f; sh.c_winner[c] = c; }
+                        set_cr(c, nid); set_grp(c, f, c);
                         use++;
                         if (use == A) out_of_memory = true; // "run out of memory", kinodynamic_astar.cpp:255-259
-                    } else if (ln == 0 && f < sh.grp_val[L]) { // a node of this voxel was created earlier in this expansion: keep the lower f
-                        heap[nodes[sh.c_created[L]].heap_pos].f = f;
-                        sh.grp_val[L] = f; sh.c_winner[L] = c;
+                    } else if (f < get_gv(L)) { // a node of this voxel was created earlier in this expansion: keep the lower f
+                        const int nl = get_cr(L);
+                        if (ln == 0) heap[nodes[nl].heap_pos].f = f;
+                        set_grp(L, f, c);
                     }
                 }
             }
+            sh.c_created[ln] = cr0; sh.c_created[64 + ln] = cr1; sh.c_winner[ln] = wn0; sh.c_winner[64 + ln] = wn1;
             use_new = use; hs_new = hs;
         }
         __syncthreads();
