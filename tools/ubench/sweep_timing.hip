@@ -23,11 +23,11 @@ __global__ __launch_bounds__(64) void timing_kernel(int N, int reps, const doubl
         for (int i = lane; i < 20 * RS; i += 64) { const int o = i % RS; if (o >= R_PHID && o < R_PD) recs[i] = init[i]; }
         __syncthreads();
         long long a = clock64();
-        fails += sweep_factor(recs, xs, N, 1.0);
+        fails += sweep_factor<false>(recs, xs, N, 1.0);
         long long b = clock64(); t[0] += b - a; a = b;
         sweep_forward(recs, xs, N);
         b = clock64(); t[1] += b - a; a = b;
-        sweep_backvec(recs, xs, N, 0.01);
+        sweep_backvec<false>(recs, xs, N, 0.01);
         b = clock64(); t[2] += b - a; a = b;
         sweep_forward(recs, xs, N);
         b = clock64(); t[3] += b - a;
