@@ -53,6 +53,11 @@ CODEGEN_FLAGS = ["-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-mllvm", "-disable-
 # the same weights).  A compiler bug, not undefined behaviour in the source.  check_device_code() below looks for that
 # encoding in every object that goes into a library, and the flags are only used with the compiler they were tuned on.
 NO_HOIST = ["-mllvm", "-disable-machine-licm"]
+# Round 4, after the re-reading variants fetch their corridor rows in chunks (frp_ipm_lds.hip: for_faces): CODEGEN_FLAGS without the
+# pressure trackers is their best set -- solve of the full tick ((20, 10) variant, 31 rows per stage) 1.062 ms with NO_HOIST alone,
+# 1.043 with the vectorizer off as well, 1.019-1.026 with all five, 1.011-1.017 without the trackers, 1.121-1.125 with the compiler's
+# defaults (tools/ab_tick.sh, two rounds on one box).
+MEM_FLAGS = [f for i, f in enumerate(CODEGEN_FLAGS) if "trackers" not in f and not (f == "-mllvm" and "trackers" in CODEGEN_FLAGS[i + 1])]
 TUNED_COMPILER = "roc-7.2.0"  # `hipcc --version` of the toolchain CODEGEN_FLAGS / NO_HOIST were measured and checked on
 
 
@@ -95,14 +100,14 @@ def check_device_code(obj):
             raise RuntimeError(f"{obj}: miscompiled 64-bit scalar immediate (literal cut to 32 bits): {line.strip()}")
     return n
 PER_SOURCE_FLAGS = {"frp_ipm_lds.hip": CODEGEN_FLAGS + ["-DFRP_LDS_SPLIT_TU"],
-                    "frp_ipm_lds_mem.hip": NO_HOIST,
+                    "frp_ipm_lds_mem.hip": MEM_FLAGS,
                     "frp_corridor.hip": NO_HOIST,
                     # the A* agrees with its oracle to the bit (node order depends on comparisons of nearly equal costs): no a * b + c contraction
                     "frp_astar.hip": ["-ffp-contract=off"]}
 OBJDIR = os.path.join(PKG, "_build")
 
 
-def build_native(force=False, verbose=True, lib=None, extra_flags=(), solver_flags=None, objdir=None, check=True):
+def build_native(force=False, verbose=True, lib=None, extra_flags=(), solver_flags=None, objdir=None, check=True, mem_flags=None):
     """hipcc --offload-arch=gfx950 -> forces_resilient_planner_amd/libfrp_nmpc_amd.so (in-tree): one object per source
     (compiled in parallel, per-source flags), linked into the shared library.
     Experiment builds (tools/build_variant.sh): `lib` = another output file, `extra_flags` for every source, `solver_flags`
@@ -127,6 +132,8 @@ def build_native(force=False, verbose=True, lib=None, extra_flags=(), solver_fla
             flags = [f for i, f in enumerate(flags) if f != "-mllvm" and (i == 0 or flags[i - 1] != "-mllvm")]
         if solver_flags is not None and name == "frp_ipm_lds.hip":
             flags = list(solver_flags) + ["-DFRP_LDS_SPLIT_TU"]
+        if mem_flags is not None and name == "frp_ipm_lds_mem.hip":  # (experiments: the re-reading variants' translation unit)
+            flags = list(mem_flags)
         cmd = common + flags + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -144,10 +151,10 @@ def build_native(force=False, verbose=True, lib=None, extra_flags=(), solver_fla
     return lib
 
 
-def build_variant(name, extra_flags=(), solver_flags=None, verbose=False, check=True):
+def build_variant(name, extra_flags=(), solver_flags=None, verbose=False, check=True, mem_flags=None):
     """forces_resilient_planner_amd/lib_<name>.so: the product sources with extra flags (selected with FRP_LIB=...)."""
     return build_native(force=True, verbose=verbose, lib=os.path.join(PKG, f"lib_{name}.so"), extra_flags=extra_flags,
-                        solver_flags=solver_flags, objdir=os.path.join(OBJDIR, "variant_" + name), check=check)
+                        solver_flags=solver_flags, objdir=os.path.join(OBJDIR, "variant_" + name), check=check, mem_flags=mem_flags)
 
 
 DROPIN_DIR = os.path.join(PKG, "dropin", "lib")
@@ -238,16 +245,19 @@ if __name__ == "__main__":
     import sys
     if len(sys.argv) > 2 and sys.argv[1] == "variant":  # python -m forces_resilient_planner_amd.build variant <name> [--solver-flags=...] [flags...]
         sf = None
+        mf = None
         rest = []
         chk = True
         for a_ in sys.argv[3:]:
             if a_.startswith("--solver-flags="):
                 sf = a_.split("=", 1)[1].split()
+            elif a_.startswith("--mem-flags="):
+                mf = a_.split("=", 1)[1].split()
             elif a_ == "--no-check":
                 chk = False
             else:
                 rest.append(a_)
-        print(build_variant(sys.argv[2], rest, sf, check=chk))
+        print(build_variant(sys.argv[2], rest, sf, check=chk, mem_flags=mf))
     else:
         build_native(force=True)
         build_ubench()

@@ -1927,6 +1927,52 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         if (FREG) { a0 = fa0[t]; a1 = fa1[t]; a2 = fa2[t]; bb = fbb[t]; }
         else { a0 = pkA[3 * H * t]; a1 = pkA[3 * H * t + 1]; a2 = pkA[3 * H * t + 2]; bb = pkB[H * t] + HU; }
     };
+    // body(t, a0, a1, a2, bb) for the live rows of this lane.  Re-reading variants: a load inside `if (row is live)` cannot be hoisted
+    // over the branch, so the rows of a lane were ten dependent trips to the L2 per phase (measured: the faces wave 14.6 k / 10.8 k /
+    // 8.9 k cycles in the evaluation / affine / step phases at 30 rows per stage against 6.1 / 3.3 / 2.6 k at 6); the constants of
+    // FCH rows are now fetched together, unconditionally (every row index of the lane is inside the stage's block when M covers
+    // FL * H rows -- else the row-by-row form), and only their use is predicated.
+#ifndef FRP_FCH // experiment knob: rows per fetch
+#define FRP_FCH 5
+#endif
+    constexpr int FCH = (!FREG && FL % FRP_FCH == 0) ? FRP_FCH : 1;
+    const bool rows_in_block = M >= FL * H;
+    auto for_faces = [&](auto body) __attribute__((always_inline)) {
+        if constexpr (FREG || FCH == 1) {
+#pragma unroll
+            for (int t = 0; t < FL; t++) {
+                if (t * H + half < nfk) {
+                    double a0, a1, a2, bb;
+                    face_consts(t, a0, a1, a2, bb);
+                    body(t, a0, a1, a2, bb);
+                }
+            }
+        } else if (rows_in_block) {
+#pragma unroll
+            for (int t0 = 0; t0 < FL; t0 += FCH) {
+                double c0[FCH], c1[FCH], c2[FCH], cb[FCH];
+#pragma unroll
+                for (int q = 0; q < FCH; q++) {
+                    const int t = t0 + q;
+                    c0[q] = pkA[3 * H * t]; c1[q] = pkA[3 * H * t + 1]; c2[q] = pkA[3 * H * t + 2]; cb[q] = pkB[H * t];
+                }
+#pragma unroll
+                for (int q = 0; q < FCH; q++) {
+                    const int t = t0 + q;
+                    if (t * H + half < nfk) body(t, c0[q], c1[q], c2[q], cb[q] + HU);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < FL; t++) {
+                if (t * H + half < nfk) {
+                    double a0, a1, a2, bb;
+                    face_consts(t, a0, a1, a2, bb);
+                    body(t, a0, a1, a2, bb);
+                }
+            }
+        }
+    };
 
     // The 17 bound pairs of a stage are shared by waves 2 and 3: rounds [RB0, RB1) of the row mapping each (wave 3 also
     // owns the corridor rows), so that neither is the long pole of the element-wise phases.
@@ -2181,24 +2227,19 @@ for (int r = RB0; r < RB1; r++) {
             double gp0 = 0, gp1 = 0, gp2 = 0, fp0 = 0, fp1 = 0, fp2 = 0, p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0;
             if (kact) {
                 face_bases();
-#pragma unroll
-                for (int t = 0; t < FL; t++) {
-                    if (t * H + half < nfk) {
-                        double a0, a1, a2, bb;
-                        face_consts(t, a0, a1, a2, bb);
-                        const double hj = a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb;
-                        const double sc = fs[t], lc = fl_[t];
-                        const double rc = hj + sc;
-                        l_in = fmax(l_in, fmax(hj, fabs(rc)));
-                        l_rc = fmax(l_rc, sc * lc);
-                        l_gap += sc * lc;
-                        gp0 += a0 * lc; gp1 += a1 * lc; gp2 += a2 * lc;
-                        const double sg = lc * fast_rcp(sc), tt = sg * rc;
-                        fp0 += a0 * tt; fp1 += a1 * tt; fp2 += a2 * tt;
-                        p0 += sg * a0 * a0; p1 += sg * a0 * a1; p2 += sg * a0 * a2;
-                        p3 += sg * a1 * a1; p4 += sg * a1 * a2; p5 += sg * a2 * a2;
-                    }
-                }
+                for_faces([&](int t, double a0, double a1, double a2, double bb) __attribute__((always_inline)) {
+                    const double hj = a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb;
+                    const double sc = fs[t], lc = fl_[t];
+                    const double rc = hj + sc;
+                    l_in = fmax(l_in, fmax(hj, fabs(rc)));
+                    l_rc = fmax(l_rc, sc * lc);
+                    l_gap += sc * lc;
+                    gp0 += a0 * lc; gp1 += a1 * lc; gp2 += a2 * lc;
+                    const double sg = lc * fast_rcp(sc), tt = sg * rc;
+                    fp0 += a0 * tt; fp1 += a1 * tt; fp2 += a2 * tt;
+                    p0 += sg * a0 * a0; p1 += sg * a0 * a1; p2 += sg * a0 * a2;
+                    p3 += sg * a1 * a1; p4 += sg * a1 * a2; p5 += sg * a2 * a2;
+                });
             }
             if (H > 1) {
                 gp0 = xsub_sum<NP>(gp0); gp1 = xsub_sum<NP>(gp1); gp2 = xsub_sum<NP>(gp2);
@@ -2323,29 +2364,24 @@ for (int r = RB0; r < RB1; r++) {
                 cldouble *rec = recs + k * RS;
                 const double d8 = rec[R_DZ + 8], d9 = rec[R_DZ + 9], d10 = rec[R_DZ + 10];
                 face_bases();
-#pragma unroll
-                for (int t = 0; t < FL; t++) {
-                    if (t * H + half < nfk) {
-                        double a0, a1, a2, bb;
-                        face_consts(t, a0, a1, a2, bb);
-                        const double s = fs[t], l = fl_[t];
-                        const double gdz = a0 * d8 + a1 * d9 + a2 * d10, viol = a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb;
-                        const double u = fast_rcp(s * l);
-                        const double sinv = u * l, linv = u * s;
-                        const double rin = viol + s;
-                        const double ds = -rin - gdz;
-                        const double dl = -l * (1.0 + ds * sinv);
-                        m_p = fmax(m_p, -ds * sinv);
-                        m_d = fmax(m_d, -dl * linv);
-                        s_sdl += s * dl; s_lds += l * ds;
-                        const double cr = ds * dl;
-                        s_dsdl += cr;
-                        fcr[t] = cr;
-                        const double t1 = (l * rin - cr) * sinv;
-                        b0 += a0 * t1; b1 += a1 * t1; b2 += a2 * t1;
-                        c0 += a0 * sinv; c1 += a1 * sinv; c2 += a2 * sinv;
-                    }
-                }
+                for_faces([&](int t, double a0, double a1, double a2, double bb) __attribute__((always_inline)) {
+                    const double s = fs[t], l = fl_[t];
+                    const double gdz = a0 * d8 + a1 * d9 + a2 * d10, viol = a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb;
+                    const double u = fast_rcp(s * l);
+                    const double sinv = u * l, linv = u * s;
+                    const double rin = viol + s;
+                    const double ds = -rin - gdz;
+                    const double dl = -l * (1.0 + ds * sinv);
+                    m_p = fmax(m_p, -ds * sinv);
+                    m_d = fmax(m_d, -dl * linv);
+                    s_sdl += s * dl; s_lds += l * ds;
+                    const double cr = ds * dl;
+                    s_dsdl += cr;
+                    fcr[t] = cr;
+                    const double t1 = (l * rin - cr) * sinv;
+                    b0 += a0 * t1; b1 += a1 * t1; b2 += a2 * t1;
+                    c0 += a0 * sinv; c1 += a1 * sinv; c2 += a2 * sinv;
+                });
             }
             if (H > 1) {
                 b0 = xsub_sum<NP>(b0); b1 = xsub_sum<NP>(b1); b2 = xsub_sum<NP>(b2);
@@ -2501,15 +2537,11 @@ for (int r = RB0; r < RB1; r++) {
                 cldouble *rec = recs + k * RS;
                 dzf[0] = rec[R_DZ + 8]; dzf[1] = rec[R_DZ + 9]; dzf[2] = rec[R_DZ + 10];
                 face_bases();
-#pragma unroll
-                for (int t = 0; t < FL; t++) {
-                    if (t * H + half < nfk) {
-                        double a0, a1, a2, bb, ds, dl;
-                        face_consts(t, a0, a1, a2, bb);
-                        cstep(fs[t], fl_[t], fcr[t], a0 * dzf[0] + a1 * dzf[1] + a2 * dzf[2],
-                              a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb, ds, dl);
-                    }
-                }
+                for_faces([&](int t, double a0, double a1, double a2, double bb) __attribute__((always_inline)) {
+                    double ds, dl;
+                    cstep(fs[t], fl_[t], fcr[t], a0 * dzf[0] + a1 * dzf[1] + a2 * dzf[2],
+                          a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb, ds, dl);
+                });
             }
         }
         if constexpr (wave >= 2) {
@@ -2567,14 +2599,9 @@ for (int r = RB0; r < RB1; r++) {
                     dzf[0] = rec[R_DZ + 8]; dzf[1] = rec[R_DZ + 9]; dzf[2] = rec[R_DZ + 10];
                 }
                 face_bases();
-#pragma unroll
-                for (int t = 0; t < FL; t++) {
-                    if (t * H + half < nfk) {
-                        double a0, a1, a2, bb;
-                        face_consts(t, a0, a1, a2, bb);
-                        commit(fs[t], fl_[t], fcr[t], a0 * dzf[0] + a1 * dzf[1] + a2 * dzf[2], a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb);
-                    }
-                }
+                for_faces([&](int t, double a0, double a1, double a2, double bb) __attribute__((always_inline)) {
+                    commit(fs[t], fl_[t], fcr[t], a0 * dzf[0] + a1 * dzf[1] + a2 * dzf[2], a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb);
+                });
                 fpos[0] += ap * dzf[0]; fpos[1] += ap * dzf[1]; fpos[2] += ap * dzf[2];
             }
         }
@@ -2785,4 +2812,15 @@ hipError_t launch_ipm_lds(const KernelArgs &k0, int slots, hipStream_t stream)
 
 #if defined(FRP_PROFILE) && !defined(FRP_LDS_MEM_TU)
 extern "C" void frp_debug_read_prof_lds(long long *out) { frp::debug_read_prof_lds(out); }
+#endif
+#if defined(FRP_PROFILE) && defined(FRP_LDS_MEM_TU)
+// (the re-reading variants are a translation unit of their own, with their own copy of the profile counters)
+extern "C" void frp_debug_read_prof_lds_mem(long long *out)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(frp::lr::g_prof_lds), sizeof(long long) * 64);
+    (void)hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(frp::lr::g_prof_seg), sizeof(long long) * 32);
+    long long z[64] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(frp::lr::g_prof_lds), z, sizeof z);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(frp::lr::g_prof_seg), z, sizeof(long long) * 32);
+}
 #endif
