@@ -505,6 +505,26 @@ def test_device_packing_matches_the_adapter():
     assert np.all(np.abs(yaw) <= np.pi + 1e-12)
 
 
+@pytest.mark.parametrize("M", [0, 1, 7])
+def test_device_packing_without_live_rows_and_small_layouts(M):
+    """The packing kernel's three regions (header, A block, b block) at the edges: no corridor rows in the layout at all (M = 0: the
+    stage block is its ten leading slots), one row, an odd count; nothing live -> everything behind the header is zero."""
+    import torch
+    w = workloads.config1(8)
+    B, N = w["B"], w["N"]
+    fleet = solver.DeviceFleet(B, N, M, max(M, 1), w["model"], workloads._weights(w["model"]))
+    fleet.mpc_output.copy_(fleet.to_device(w["mpc_output"]))
+    fleet.ellipsoid.copy_(fleet.to_device(w["E"]))
+    fleet.poly_A.zero_(); fleet.poly_b.zero_(); fleet.poly_nfaces.zero_()
+    fleet.solver.params.fill_(7.0)  # (stale contents must be overwritten, zeros included)
+    fleet.pack(fleet.to_device(w["f_ext"]), fleet.to_device(w["ref_pos"]), fleet.to_device(w["ref_yaw"]))
+    torch.cuda.synchronize()
+    p = fleet.solver.params.cpu().numpy()
+    assert p.shape[2] == 10 + 4 * M
+    assert np.array_equal(p[:, :, :10], w["params"][:, :, :10]) and np.all(p[:, :, 10:] == 0.0)
+    assert np.array_equal(fleet.solver.x0.cpu().numpy(), w["x0"]) and np.all(fleet.solver.nfaces.cpu().numpy() == 0)
+
+
 def test_receding_horizon_on_device_matches_host_loop():
     """configs[4] in miniature with the whole tick on the GPU (pack -> solve -> update) against the host-driven loop."""
     from forces_resilient_planner_amd import receding
