@@ -316,6 +316,28 @@ def test_header_is_plain_c99(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
 
 
+def test_python_mirrors_of_the_c_structs_have_the_headers_layout(tmp_path):
+    """solver.py drives the C-ABI through ctypes mirrors of the header's structs: their sizes, and the offsets of the fields that were
+    appended last, must be the compiler's (a field added to the header only would shift every argument behind it silently)."""
+    import subprocess
+    pairs = [("frp_nmpc_options", solver.Options, "twist"), ("frp_nmpc_batch", solver.Batch, "order_hint"), ("frp_nmpc_astar", solver.Astar, "retry_vel"),
+             ("frp_nmpc_pack", solver.Pack, None), ("frp_nmpc_tube", solver.Tube, None), ("frp_nmpc_corridor", solver.Corridor, None),
+             ("frp_nmpc_reference", solver.Reference, None),
+             ("frp_forces_params", solver.ForcesParams, "num_of_threads"), ("frp_forces_info", solver.ForcesInfo, None), ("frp_forces_output", solver.ForcesOutput, None)]
+    src = tmp_path / "layout.c"
+    body = "".join(f'  printf("%zu %zu\\n", sizeof({c}), {("offsetof(" + c + ", " + f + ")") if f else "(size_t)0"});\n' for c, _, f in pairs)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "frp_nmpc.h"\nint main(void) {\n' + body + '  return 0; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    for i, (cname, py, field) in enumerate(pairs):
+        size, off = int(out[2 * i]), int(out[2 * i + 1])
+        assert ctypes.sizeof(py) == size, (cname, ctypes.sizeof(py), size)
+        if field:
+            assert getattr(py, field).offset == off, (cname, field, getattr(py, field).offset, off)
+
+
 def test_widened_entry_points_reject_bad_arguments_before_touching_a_device():
     """Argument checks of the f-1 .. f-4 entry points run on the host, so they are testable without a GPU: NULL
     buffers, horizons beyond 64 stages, polytope capacities outside [6, 64], oversized clouds / grids, non-positive
