@@ -2715,6 +2715,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             // SIMDs, cyclically, so that every Riccati wave shares its SIMD with one of each
             const int s_model = FRP_PLACE_CYCLIC ? (rs + 1) % 3 : lo;
             role = simd == rs ? 0 : (simd == 3 ? 3 : (simd == s_model ? 1 : 2));
+#ifndef FRP_TW_PLACE // (0: the placement of the plain solve)
+#define FRP_TW_PLACE 1
+#endif
+            // twisted variants: the model wave runs the first half's sweeps, so IT is the heaviest helper and takes SIMD 3 (measured against
+            // the plain placement, m = 9: 768 problems 468 -> 447 us, 1024: 631 -> 619; 4096 problems, m = 6: 1.021 -> 0.974 ms)
+            if (TW && FRP_TW_PLACE) role = simd == rs ? 0 : (simd == 3 ? 1 : (simd == s_model ? 3 : 2));
         }
     }
     // one copy of the solver loop per role: the four waves run different code between the same barriers
@@ -2734,11 +2740,13 @@ static hipError_t launch_variant(const KernelArgs &k, int slots, hipStream_t str
     hipLaunchKernelGGL((nmpc_ipm_lds_kernel<NP, FL, FREG, WPE, TW>), dim3(slots), dim3(256), 0, stream, k);
     return hipGetLastError();
 }
-// the twisted variants: frp_nmpc_options.twist = m (stages eliminated forward), -1 = 9 N / 20; anything the twisted solve does not cover
+// the twisted variants: frp_nmpc_options.twist = m (stages eliminated forward), -1 = 9 N / 20 (3 N / 10 beyond 1024 problems); anything the twisted solve does not cover
 // (N > 20, N < 4, m outside 2 .. N - 2) runs the plain solve, like the oracle's (oracle/nmpc_ipm.c, kkt_solve)
 static inline int twist_stages(const KernelArgs &k)
 {
-    const int m = k.twist < 0 ? 9 * k.N / 20 : k.twist;
+    // -1: 9 N / 20 while the problems of the launch have a CU (nearly) to themselves; beyond ~1000 problems a shorter first half loses
+    // less (4096 problems: +7.8 % at 9, +2.5 % at 6 of 20 -- the option is not meant for that regime)
+    const int m = k.twist < 0 ? (k.B <= 1024 ? 9 * k.N / 20 : 3 * k.N / 10) : k.twist;
     return (k.N >= 4 && k.N <= 20 && m >= 2 && m <= k.N - 2) ? m : 0;
 }
 

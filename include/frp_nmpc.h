@@ -85,10 +85,10 @@ typedef struct frp_nmpc_options {
                          m > 0: the Newton system of an iteration is solved from both ends of the horizon at once -- the
                          stages 0 .. m-1 forward (arrival-cost recursion, the pinned x_0 as a 1e12 penalty) on a second
                          wavefront while the stages m .. N-1 run backward; the halves meet in a 13 x 13 system at stage m.
-                         -1: m = 9 N / 20.  Horizons 4 <= N <= 20 with 2 <= m <= N - 2, anything else runs the plain
-                         solve.  A LATENCY option: it shortens the dependency chain of an iteration (-11 % per launch
+                         -1: m = 9 N / 20 (3 N / 10 when the launch has more than 1024 problems).  Horizons 4 <= N <= 20 with 2 <= m <= N - 2, anything else runs the plain
+                         solve.  A LATENCY option: it shortens the dependency chain of an iteration (-13 % per launch
                          while there are fewer problems than resident workgroups, <= ~1000), and costs throughput
-                         once the GPU is full (+5 % at 4096 problems).  The Newton direction carries the penalty's
+                         once the GPU is full (+3 % at 4096 problems).  The Newton direction carries the penalty's
                          rounding (~1e-5 relative); residuals and termination tests are the plain solve's, so the
                          same KKT points are reached (oracle: orc_options.twist).  DESIGN 9.1                     */
 } frp_nmpc_options;
