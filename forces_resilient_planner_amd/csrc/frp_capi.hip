@@ -117,7 +117,7 @@ int ctx_init()
     if (g_ctx.ready) return FRP_OK;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FRP_ERR_NO_DEVICE;
-    g_ctx.ws_bytes = frp::ws_bytes(1, FRP_N_REF, FRP_NH_REF);
+    g_ctx.ws_bytes = std::max(frp::ws_bytes(1, FRP_N_REF, FRP_NH_REF), frp::ws_bytes(1, FRP_N_REF, 6)); // (the size depends on the face count: every shape a call can have)
     // (a failure half way leaves nothing behind: the next call starts from scratch)
     const bool ok = hipStreamCreate(&g_ctx.stream) == hipSuccess &&
                     hipMalloc(&g_ctx.d_in, DI_IN_DOUBLES * sizeof(double)) == hipSuccess &&
@@ -505,6 +505,8 @@ int frp_nmpc_kernel_timing_begin(int max_launches, int stride)
     return frp::kernel_timing_begin(max_launches, stride) == hipSuccess ? FRP_OK : FRP_ERR_ARG;
 }
 
+int frp_nmpc_set_q4_min_batch(int min_batch) { return frp::lds_q4_set_min_batch(min_batch); }
+
 int frp_nmpc_kernel_timing_end(float *avg_ms, int *launches)
 {
     if (!avg_ms || !launches) return FRP_ERR_ARG;
@@ -521,6 +523,12 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FRP_ERR_NO_DEVICE;
     std::lock_guard<std::mutex> lock(g_pipe.mtx);
+    // every chunk of this call runs on the kernel variants ONE launch of the whole batch would run on (the four-per-CU variants are
+    // chosen by batch size and sum in another order): the plans do not depend on how the staging is cut
+    struct VariantOfWholeBatch {
+        explicit VariantOfWholeBatch(int B) { frp::lds_q4_pin_for_batch(B); }
+        ~VariantOfWholeBatch() { frp::lds_q4_pin_for_batch(0); }
+    } pin(h->B);
     // The pipeline (streams, events, device and pinned buffers) belongs to ONE device: the one current when it was built.  A call
     // made with another device current rebuilds it there (the per-call allocation it replaced worked on any device).
     int dev = 0;

@@ -22,17 +22,54 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <math.h>
+#include <cstdlib>
 #include "frp_model.hpp"
 #include "../../include/frp_nmpc.h"
 #include "frp_kernels.h"
 #include "frp_device.hpp"
 
+// (the Q4 translation unit instantiates the same templates on another record layout: a namespace of its own)
+#ifdef FRP_LDS_Q4_TU
+#define FRP_LR lrq
+#else
+#define FRP_LR lr
+#endif
+
 namespace frp {
-namespace lr {
+namespace FRP_LR {
 
 // ------------------------------------------------------------------ per-stage LDS record (doubles)
+// Two layouts.  The "plain" one (RS = 309: three problems per CU) keeps the packed P_k of every stage in LDS.  The "Q4" one
+// (-DFRP_LDS_Q4_TU, frp_ipm_lds_q4.hip: RS = 241 -> 38.6 KB per problem, FOUR problems per CU on three-wave workgroups) moves P_k
+// -- written once by the factorisation sweep, read once by the multiplier recovery y = P ds + p -- to an L2-resident workspace in
+// global memory (KernelArgs::pws, 92 doubles per stage and resident workgroup) and lets T' and p share the slots of the
+// barrier-augmented Hessian, which is dead once the factorisation step of its stage has gathered it.
+// (three independent parts, switchable one by one for bisection builds: FRP_QP = P in global memory, FRP_QL = the 241-double
+// record, FRP_QW = three-wave workgroups; the Q4 translation unit defines all three)
+#ifdef FRP_LDS_Q4_TU
+#define FRP_QP 1
+#define FRP_QL 1
+#define FRP_QW 1
+#endif
+#ifdef FRP_QP
+constexpr bool QP = true;
+#else
+constexpr bool QP = false;
+#endif
+#ifdef FRP_QL
+constexpr bool QL = true;
+#else
+constexpr bool QL = false;
+#endif
+#ifdef FRP_QW
+constexpr bool QW = true;
+#else
+constexpr bool QW = false;
+#endif
+static_assert(!QL || QP, "the short record has no room for P");
 constexpr int R_LIN = 0;     // compact linearisation (51): Apv Ape Avv Ave BpT BvT Bvw
 constexpr int R_D = 51;      // d = prev(z_k) - s_{k+1}, s-order [w; x] (13)            } the "M row": 64 slots
+#ifndef FRP_QL
 constexpr int R_T = 64;      // T' = [R | Kbar_x | kbar | hc]: lane (g, c) <-> T'[g][c] (64)
 // overlay region (104): the barrier-augmented Hessian is dead once the factorisation step of the stage has gathered
 // it, and that step's output P_k takes its place
@@ -42,16 +79,35 @@ constexpr int R_PHI = 154;   // predictor rhs gradient phi_aff without its corri
 constexpr int R_HD = 171;    // exact Hessian of y'c(z): 45 structurally non-zero entries (hd_pack)
 constexpr int R_P = 128;     // P_k, packed lower triangle (91)
 constexpr int R_PV = 219;    // p_k of the corrector solve (13)
-constexpr int R_PD = 232;    // P_{k+1} d_k (13); after the corrector's backward sweep: y+_k of the Newton system
+constexpr int R_PD = 232;    // P_{k+1} d_k (13): written by the factorisation sweep, read by the corrector's backward sweep
 constexpr int R_PHIB = 245;  // corrector rhs phi_cc = PHIB + (sigma mu) PHIC (17 + 17), bound rows and cost;
-constexpr int R_CB = 262;    //   corridor part (pos entries) of PHIB; evaluation phase: A' lam (stationarity residual)
+constexpr int R_PHIW = R_HD + 40; // (QP bisection builds on this layout) Phi_w of the stage (4), left by the factorisation step in consumed Hessian slots
+#else
+// overlay region (88): [HD 45 | PHID 17 | PHIPOS 9 | PHI 17] until the factorisation step of the stage has gathered it, then
+// [T' 64 | p 13] (T' from that step, p from the corrector's backward sweep).  Scratch in it (all inside HD, whose only writer in the
+// evaluation phase is the wave that uses the scratch): the Riccati wave's trig hand-over (12) and the Hessian's inputs the model
+// wave leaves in the step phase (RT_HZ 10, RT_HY 6 -- T' slots, dead after the last forward sweep).
+constexpr int R_HD = 64;     // exact Hessian of y'c(z): 45 structurally non-zero entries (hd_pack)
+constexpr int R_PHID = 109;  // diag of Phi = cost Hessian + bound barriers (17)
+constexpr int R_PHIPOS = 126; // corridor barrier block on pos (3 x 3)
+constexpr int R_PHI = 135;   // predictor rhs gradient phi_aff without its corridor part (17)
+constexpr int R_T = 64;      // T' (64), over HD / PHID / the head of PHIPOS
+constexpr int R_PV = 128;    // p_k of the corrector solve (13), over PHIPOS / PHI
+constexpr int R_P = 0;       // (P_k lives in global memory: packed index 0..90 of the stage's block, 91 = dump)
+constexpr int R_PD = 152;    // P_{k+1} d_k (13): written by the factorisation sweep, read by the corrector's backward sweep;
+                             //   from there to the next factorisation: the model wave's parked y (RT_Y)
+constexpr int R_PHIB = 165;  // corrector rhs phi_cc = PHIB + (sigma mu) PHIC (17 + 17), bound rows and cost;
+constexpr int R_PHIW = R_PV + 13; // Phi_w of the stage (4) behind p, left by the factorisation step (the y+ rows of w are formed from T' and this)
+static_assert(R_PHIW + 4 <= R_PD, "Phi_w stash");
+#endif
+constexpr int R_CB = R_PHIB + 17; //   corridor part (pos entries) of PHIB; evaluation phase: A' lam (stationarity residual)
 constexpr int R_BC = 21;     // distance from every "B" slot (PHIB, CB) to its "C" twin (PHIC, CC): one ds_read2 fetches both
 constexpr int R_PHIC = R_PHIB + R_BC; // evaluation phase: PHIB = cost gradient + bound multipliers, PHIC = M'y part (stationarity residual)
 constexpr int R_CC = R_CB + R_BC;     // corridor part of PHIC; evaluation phase: corridor part of phi_aff
-constexpr int R_HC = 286;    // (u_i, w_i) cost coupling -2 w_rate of this stage
-constexpr int R_ZERO = 287, R_ONE = 288, R_DT = 289; // constants the gathers pick up
-constexpr int R_DUMP = 290;  // target of masked-out writes (never read)
-constexpr int R_DZ = 291;    // Newton step [du(4); ds(13)]
+constexpr int R_HC = R_PHIB + 41;    // (u_i, w_i) cost coupling -2 w_rate of this stage
+constexpr int R_ZERO = R_HC + 1, R_ONE = R_HC + 2, R_DT = R_HC + 3; // constants the gathers pick up
+constexpr int R_DUMP = R_HC + 4;  // target of masked-out writes (never read)
+constexpr int R_DZ = R_HC + 5;    // Newton step [du(4); ds(13)]
 constexpr int R_ZERO2 = R_ZERO + R_BC; // second zero, R_BC behind the first: masked (B, C) pair reads
 // Twisted solve: a stage of the FIRST half keeps the inverted transition [u; x]_k = T~ [w+; x+] + t~ where a stage of
 // the second half keeps the linearisation: A~ = A^-1 has A's block pattern (A~pv, A~pe, A~vv, A~ve in the slots of Apv, Ape, Avv, Ave),
@@ -59,13 +115,38 @@ constexpr int R_ZERO2 = R_ZERO + R_BC; // second zero, R_BC behind the first: ma
 // B~).  The nine entries of B~ that do not fit the 51 linearisation slots live where a first-half record has room: the columns 14, 15
 // of T' (eight slots that only ever meet the zero rows 14, 15 of a sweep vector; the first-half sweeps do not store there), the second
 // zero (only the second half's vector sweep reads it) -- and one spare: the hole between CB and PHIC.
+#ifndef FRP_QL
 constexpr int RS = 309;      // odd stride: lane == stage accesses are conflict-free
+static_assert(R_HD + REC_HD_SIZE <= R_PV && R_PV + 13 <= R_PD, "overlay region");
+static_assert(R_PHIB == 245 && R_HC == 286 && R_DZ == 291 && R_ZERO2 == 308, "the plain record");
+#else
+constexpr int RQ_MTRIG = R_ZERO2 + 1; // the model wave's trig hand-over (12): slots of its own (nothing else is free in the evaluation phase)
+constexpr int RS = RQ_MTRIG + 12;     // 241, odd
+static_assert(RS == 241 && (RS & 1), "the Q4 record");
+static_assert(R_HD + REC_HD_SIZE == R_PHID && R_PHID + 17 == R_PHIPOS && R_PHIPOS + 9 == R_PHI && R_PHI + 17 == R_PD, "overlay region");
+static_assert(R_T + 64 <= R_PV && R_PV + 13 <= R_PD && R_PD + 13 == R_PHIB, "overlay region after the factorisation");
+#endif
 static_assert(R_PHIC + 17 <= R_CC && R_CC + 3 <= R_HC && R_DZ + 17 <= R_ZERO2 && R_ZERO2 < RS, "record tail");
 #ifndef FRP_TW_RHO
 #define FRP_TW_RHO 1e12
 #endif
 constexpr double TW_RHO = FRP_TW_RHO; // penalty that pins x_0 in the arrival-cost recursion (tools/study/twisted_riccati.py)
-static_assert(R_HD + REC_HD_SIZE <= R_PV && R_PV + 13 <= R_PD, "overlay region");
+// QP: what the multiplier recovery y+ = P ds + p needs of P_k that is NOT in the record goes to global memory.  The w rows of P are
+// [Phi_w - hc^2 R | -hc Kbar_x] and the (x, w) block is their transpose: both follow from T' (in the record) and the four Phi_w (stashed in
+// the record by the factorisation step).  Only S_xx (9 x 9, symmetric) leaves: per resident workgroup NP blocks of PG = 48 doubles, three
+// groups of 16 -- group a (the lane of a stage that owns x rows 3a .. 3a+2) holds the diagonal block S_aa (lower triangle, 6) and the
+// block S_{a,a+1} (row-major, 9; a+1 cyclic): every unique entry exactly once, the same SHAPE for every lane (uniform code), one
+// 128-byte line per lane.  Slot 15 of group 0 is the dump of the masked lanes.
+constexpr int PG = 48, PG_DUMP = 15;
+__host__ __device__ constexpr int pg_slot(int trow, int c) // tile element (trow, c) -> slot of the stage's block, or the dump
+{
+    const int i = trow - 4, j = c - 4;
+    if (i < 0 || i > 8 || j < 0 || j > 8) return PG_DUMP;
+    const int bi = i / 3, ii = i % 3, bj = j / 3, jj = j % 3;
+    if (bi == bj) return ii >= jj ? bi * 16 + ii * (ii + 1) / 2 + jj : PG_DUMP;
+    if (bj == (bi + 1) % 3) return bi * 16 + 6 + 3 * ii + jj;
+    return PG_DUMP;
+}
 
 // workgroup-shared scratch (doubles)
 constexpr int X_RW = 16;              // stage-0 solve: Pww^-1 (16)
@@ -162,7 +243,8 @@ constexpr LaneTables make_tables()
             t.v[T_C1 + r][lane] = (unsigned short)c_src(trow, c, 0);
             t.v[T_C2 + r][lane] = (unsigned short)c_src(trow, c, 1);
             t.v[T_C3 + r][lane] = (unsigned short)c_src(trow, c, 2);
-            t.v[T_PP + r][lane] = (unsigned short)((trow <= 12 && c <= trow) ? R_P + trow * (trow + 1) / 2 + c : R_DUMP);
+            // (QP: the slot inside the stage's block in global memory)
+            t.v[T_PP + r][lane] = (unsigned short)(QP ? pg_slot(trow, c) : ((trow <= 12 && c <= trow) ? R_P + trow * (trow + 1) / 2 + c : R_DUMP));
             t.v[T_PD + r][lane] = (unsigned short)((c == 13 && trow <= 12) ? R_PD + trow : R_DUMP);
             const int row = 4 * qI + qj, col = 4 * ((qI + r) & 3) + qk;
             // forward sweep: the u columns go through T4_MU, row 13 carries the constant 1 from stage to stage
@@ -193,6 +275,13 @@ __device__ __forceinline__ int tab(int row, int lane) { return (int)g_tab.v[row]
 
 #define BAR() __syncthreads()
 #define FRP_SB() __builtin_amdgcn_sched_barrier(0)
+// between the rounds / rows of the element-wise loops (unrolled): keeps the scheduler from interleaving them, i.e. from multiplying
+// their temporaries in waves whose persistent state leaves ~30 registers (-DFRP_ROUND_SB)
+#ifdef FRP_ROUND_SB
+#define FRP_RSB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define FRP_RSB()
+#endif
 
 // LDS pointers carry their address space: through a generic double* every access of a non-inlined function would pay
 // 64-bit address arithmetic and the null check of the address-space cast
@@ -396,6 +485,31 @@ __device__ __forceinline__ void gather_tiles(cldouble *rn, const int (&c1)[4], c
     pq = rn[pqo];
 }
 
+// Q4: P_k leaves for the workgroup's block in global memory -- saddr form: uniform 64-bit base in scalar registers, a 32-bit byte
+// offset per lane, the stage as the instruction's immediate.
+template <int OFF>
+__device__ __forceinline__ void gst(const double *base, unsigned boff, double v)
+{
+    static_assert(OFF >= 0 && OFF < 4096, "immediate offset of a global store");
+#ifndef FRP_GST_CXX
+    // Inline asm: written in C++ the compiler keeps a 64-bit address per store in vector registers (8 VGPRs in a wave at the cap).
+    // CAUTION: the hazard recognizer does not look inside inline asm -- a memory instruction that reads the result of an MFMA needs
+    // 18 wait states behind it, which the compiler inserts for its own stores (s_nop 15; s_nop 0) and NOT here: the caller makes sure
+    // the MFMA has retired (first version: the rows 4..12 of P, which ARE an MFMA's result, left with stale registers -- the solves
+    // still converged, two iterations late, on wrong multipliers).  Not on the compiler's vmcnt scoreboard either: nothing in the
+    // sweeps reads global memory, and the predictor phase ends with an explicit s_waitcnt vmcnt(0).
+    asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" : : "v"(boff), "v"(v), "s"(base), "n"(OFF) : "memory");
+#else
+    *(__attribute__((address_space(1))) double *)((__attribute__((address_space(1))) char *)base + boff + OFF) = v;
+#endif
+}
+#ifdef FRP_QP
+#define FRP_GP_PARAM , double *gp
+#define FRP_GP_ARG(x) , x
+#else
+#define FRP_GP_PARAM
+#define FRP_GP_ARG(x)
+#endif
 #ifdef FRP_INLINE_FACTOR
 #define FRP_FACTOR_LINKAGE __forceinline__
 #else
@@ -404,9 +518,12 @@ __device__ __forceinline__ void gather_tiles(cldouble *rn, const int (&c1)[4], c
 // twist (second half of a twisted solve: `recs` is the record of the meeting stage, N the stages from there to the end): the stage-0
 // tail is replaced by publishing p of the meeting stage (column 13 of the tile) in its R_PV slots.
 template <bool twist>
-__device__ FRP_FACTOR_LINKAGE int sweep_factor(ldouble *recs, ldouble *xs, int N, double theta)
+__device__ FRP_FACTOR_LINKAGE int sweep_factor(ldouble *recs, ldouble *xs, int N, double theta FRP_GP_PARAM)
 {
     N = uni(N); theta = uni(theta);
+#ifdef FRP_QP
+    const double *gpk = uni(gp) + (size_t)(N - 1) * PG; // block of the stage the pointers sit on
+#endif
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15, c3_ = c & 3;
     int mo[4], c1[4], c2[4], c3[4], ppo[4], pdo[4];
 #pragma unroll
@@ -435,19 +552,44 @@ __device__ FRP_FACTOR_LINKAGE int sweep_factor(ldouble *recs, ldouble *xs, int N
     ldouble *base = recs + (N - 1) * RS;
     ldouble *p_c1[4], *p_c3[4], *p_mo[4], *p_pp[4], *p_pd[4];
     ldouble *p_c2 = base + c2[1], *p_pq = base + pqo, *p_t = base + lane;
+    ldouble *p_pw = base + ((c < 4 && g == c) ? R_PHIW + g : R_DUMP); // QP: Phi_w[g] stays in the record (the diagonal lanes of the w block hold it)
+    unsigned gb[4]; // Q4: byte offsets of this lane's four tile entries inside a stage's block of packed P
 #pragma unroll
-    for (int r = 0; r < 4; r++) { p_c1[r] = base + c1[r]; p_c3[r] = base + c3[r]; p_mo[r] = base + mo[r]; p_pp[r] = base + ppo[r]; p_pd[r] = base + pdo[r]; }
+    for (int r = 0; r < 4; r++) {
+        p_c1[r] = base + c1[r]; p_c3[r] = base + c3[r]; p_mo[r] = base + mo[r]; p_pd[r] = base + pdo[r];
+        if constexpr (QP) { gb[r] = 8u * (unsigned)ppo[r]; p_pp[r] = nullptr; }
+        else { p_pp[r] = base + ppo[r]; gb[r] = 0; }
+    }
+    if constexpr (QP) asm volatile("" : "+v"(gb[0]), "+v"(gb[1]), "+v"(gb[2]), "+v"(gb[3]));
     // (laundered through an empty asm: left to itself the optimiser turns every pointer back into base + 8 * index and
     // recomputes it at each use -- 28 address instructions per stage, which is what this is here to remove)
     auto opaque = [](ldouble *&q) { unsigned v = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void *)q; asm volatile("" : "+v"(v)); q = (ldouble *)(unsigned long long)v; };
-    auto move = [&](int by) {
+    auto move = [&](int stages) {
+        const int by = stages * RS;
         base -= by; p_c2 -= by; p_pq -= by; p_t -= by;
         opaque(base); opaque(p_c2); opaque(p_pq); opaque(p_t);
+        if constexpr (QP) { p_pw -= by; opaque(p_pw); }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            p_c1[r] -= by; p_c3[r] -= by; p_mo[r] -= by; p_pp[r] -= by; p_pd[r] -= by;
-            opaque(p_c1[r]); opaque(p_c3[r]); opaque(p_mo[r]); opaque(p_pp[r]); opaque(p_pd[r]);
+            p_c1[r] -= by; p_c3[r] -= by; p_mo[r] -= by; p_pd[r] -= by;
+            opaque(p_c1[r]); opaque(p_c3[r]); opaque(p_mo[r]); opaque(p_pd[r]);
+            if constexpr (!QP) { p_pp[r] -= by; opaque(p_pp[r]); }
         }
+#ifdef FRP_QP
+        gpk -= stages * PG;
+#endif
+    };
+    // P_k (packed lower triangle) for the multiplier recovery y_k = P_k ds_k + p_k: to the Hessian part of this stage's record, which was
+    // gathered one step ago (plain) / to the workgroup's block in global memory (Q4)
+    auto store_p = [&](auto orc, const d4 &Pt) {
+        constexpr int OR = decltype(orc)::value;
+#ifdef FRP_QP
+#pragma unroll
+        for (int r = 0; r < 4; r++) gst<(OR / RS) * PG * 8>(gpk, gb[r], Pt[r]);
+#else
+#pragma unroll
+        for (int r = 0; r < 4; r++) p_pp[r][OR] = Pt[r];
+#endif
     };
     // one stage: OR / OG = offsets of its record and of the record below it from the pointers; LAST = stage 0 (nothing below)
     auto stage = [&](auto orc, auto lastc) {
@@ -495,22 +637,23 @@ __device__ FRP_FACTOR_LINKAGE int sweep_factor(ldouble *recs, ldouble *xs, int N
         S[1] *= m4c; S[2] *= m4c; S[3] *= m4c;
         S = __builtin_amdgcn_mfma_f64_16x16x4f64(-Kd, Kb, S, 0, 0, 0); // [-hc Kbar_x' | S_xx | p_x] in rows 4..12
         p_t[OR + R_T] = tsel;
+        if constexpr (QP) p_pw[OR] = pq;
         const double hc4 = __builtin_fma(hc, m4, m4c);
         P[0] = __builtin_fma(-hc, hc4 * tsel, pq); // [Phi_w - hc^2 R | -hc Kbar_x | phi_w - hc kbar]
         P[1] = S[1]; P[2] = S[2]; P[3] = S[3];
         if constexpr (LAST) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) p_pp[r][OR] = P[r];
+            if constexpr (QP) { FRP_SB(); asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); } // (S, an MFMA result, goes out through inline asm: see gst)
+            store_p(orc, P);
         } else {
             // ---- X = P_k M_{k-1} (col 13: P d)
             d4 X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[0], Mt[0], zero, 0, 0, 0);
             X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[1], Mt[1], X, 0, 0, 0);
             X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[2], Mt[2], X, 0, 0, 0);
             X = __builtin_amdgcn_mfma_f64_16x16x4f64(P[3], Mt[3], X, 0, 0, 0);
-            // P_k (packed lower triangle) for the multiplier recovery y_k = P_k ds_k + p_k; it overwrites the Hessian part
-            // of this stage's record, which was gathered one step ago
-#pragma unroll
-            for (int r = 0; r < 4; r++) p_pp[r][OR] = P[r];
+            // (QP: behind the four dependent MFMAs of X -- pinned there -- the MFMA that produced S has long retired: see gst)
+            if constexpr (QP) FRP_SB();
+            store_p(orc, P);
+            if constexpr (QP) FRP_SB();
             // ---- G of the stage below = M'X + C~ (col 13: q~)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -528,20 +671,20 @@ __device__ FRP_FACTOR_LINKAGE int sweep_factor(ldouble *recs, ldouble *xs, int N
     using std::integral_constant;
     int kk = N - 1;
     for (; kk >= 4; kk -= 4) {
-        move(4 * RS); // pointers on stage kk - 4
+        move(4); // pointers on stage kk - 4
         stage(integral_constant<int, 4 * RS>{}, std::false_type{});
         stage(integral_constant<int, 3 * RS>{}, std::false_type{});
         stage(integral_constant<int, 2 * RS>{}, std::false_type{});
         stage(integral_constant<int, 1 * RS>{}, std::false_type{});
     }
     if (kk == 3) { // (N = 4 m: the reference's 20) the last four stages as one pass on stage 0's record
-        move(3 * RS);
+        move(3);
         stage(integral_constant<int, 3 * RS>{}, std::false_type{});
         stage(integral_constant<int, 2 * RS>{}, std::false_type{});
         stage(integral_constant<int, 1 * RS>{}, std::false_type{});
     } else {
         for (; kk >= 1; kk--) {
-            move(RS);
+            move(1);
             stage(integral_constant<int, RS>{}, std::false_type{});
         }
     }
@@ -1235,13 +1378,35 @@ struct ModelState {
 // Register budget (168 per lane with z and y resident): the phase is cut into sections that hand data to each other
 // through the T' slots of the stage record, which are dead between the last forward sweep and the next factorisation:
 // J1 (21) while J2 is formed, y (13) during the whole linearisation.
+// The Hessian lanes' inputs: RT_HU (rates, T: 4), RT_HVE (v, e: 6), RT_HY (y_p, y_v: 6) before the step, RT_HYP (y+ rows 4..9: 6).
+#if !defined(FRP_QL) && !defined(FRP_QP)
 constexpr int RT_J1 = R_T, RT_Y = R_T + 24;
 // after the last forward sweep of an iteration wave 1 leaves here what wave 0 needs to rebuild its Hessian inputs for the
 // next one (so that nothing of it occupies registers across the sweeps): (rates, T, v, e) before the step, (y_p, y_v) too
 // (placed clear of RT_Y -- written at the start of the model phase while the Hessian lanes read these -- and of the columns 14, 15
 // of T', which hold part of B~ in a first-half record)
-constexpr int RT_HZ = R_T + 48, RT_HY = R_T + 37;
-static_assert(RT_HY >= RT_Y + 13 && RT_HY + 6 <= R_T + 46 && RT_HZ + 10 <= R_T + 62, "scratch in the T' slots");
+constexpr int RT_HU = R_T + 48, RT_HVE = R_T + 52, RT_HY = R_T + 37, RT_HYP = R_DUMP /* (in registers) */, RT_YV = R_DUMP;
+static_assert(RT_HY >= RT_Y + 13 && RT_HY + 6 <= R_T + 46 && RT_HVE + 6 <= R_T + 62, "scratch in the T' slots");
+constexpr int RX_MTRIG = R_PV, RX_HTRIG = R_PD; // trig hand-over of the model wave / of the Riccati wave's Hessian lanes (12 each)
+#else
+// QP: the y+ lanes (bounds wave) read Kbar_x and kbar of T' in the step phase, while the model wave leaves the Hessian's inputs: those go
+// to the T' slots the y+ lanes do not read -- R (columns 0..3) and the zero columns 14, 15 of the rows 0..2.  The y+ lanes' own scratch
+// (block hand-over RT_YV, 9; y+ rows 4..9 for the Hessian lanes RT_HYP, 6) takes Kbar_x slots AFTER their last read of T' (same wave).
+constexpr int RT_HU = R_T + 0, RT_HVE = R_T + 14, RT_HY = R_T + 30, RT_YV = R_T + 4, RT_HYP = R_T + 20;
+constexpr int RT_J1 = R_T; // (the lane == stage model phase: not built with QP)
+#ifndef FRP_QL
+constexpr int RT_Y = R_T + 36; // (bisection builds: T' is a region of its own, dead in the evaluation phase)
+constexpr int RX_MTRIG = R_PV, RX_HTRIG = R_PD;
+#else
+// QL: T' shares the Hessian's slots, which the element-wise waves fill during the evaluation phase -- the model wave's scratch of that
+// phase has slots outside the overlay (y in the P d slots, dead from the corrector's backward sweep to the next factorisation; the trig
+// hand-over at the record's end); what the Riccati wave reads at the start of the evaluation (RT_H*) and its trig hand-over sit inside HD,
+// which only that wave writes in the phase (the hand-over overlaps RT_HYP / RT_HY: written after they were read, by the same wave)
+constexpr int RT_Y = R_PD;
+constexpr int RX_HTRIG = R_T + 20, RX_MTRIG = RQ_MTRIG;
+static_assert(RX_HTRIG + 12 <= R_HD + REC_HD_SIZE && RT_HY + 6 <= R_HD + REC_HD_SIZE, "the Riccati wave's scratch inside HD");
+#endif
+#endif
 template <int NP>
 __device__ __forceinline__ void model_phase(ldouble *recs, ldouble *xs, ModelState &st, int N, double &l_eq)
 {
@@ -1547,7 +1712,7 @@ __device__ __forceinline__ void model_phase3(ldouble *recs, ldouble *xs, ModelSt
         double et[3], a1[3];
 #pragma unroll
         for (int i = 0; i < 3; i++) et[i] = e[i] + DT * w[i];
-        trig_shared(rec + R_PV, sub, e, et, t1, t2);
+        trig_shared(rec + RX_MTRIG, sub, e, et, t1, t2);
         zb_of(t1, zb1); zb_of(t2, zb2);
         a1s = T * (1.0 / MASS) + DRAG * dot3(zb1, v);
 #pragma unroll
@@ -1741,7 +1906,7 @@ __device__ __forceinline__ void hessian_phase3(ldouble *rec, const HessState &hs
         double et[3];
 #pragma unroll
         for (int i = 0; i < 3; i++) et[i] = e[i] + DT * w[i];
-        ldouble *sc = rec + R_PD;
+        ldouble *sc = rec + RX_HTRIG;
         Trig t1, t2;
         trig_shared(sc, sub, e, et, t1, t2);
         double zb1[3], zb2[3], vt[3], beta[3], gam1[3];
@@ -1872,9 +2037,30 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 {
     constexpr int H = RowMap<NP>::H, R = RowMap<NP>::R;
     constexpr int wave = ROLE; // == threadIdx.x >> 6: every role is compiled on its own, so only ITS state occupies registers
+    // Who does what.  Plain: 0 Riccati, 1 model, 2 bounds, 3 faces (+ some bound rounds).  Q4 (three waves): 0 Riccati, 1 model + faces
+    // (+ the bound rounds [RQ, R), none by default), 2 the bound rounds [0, RQ).  Measured (profile build, one problem alone, cycles of
+    // the three element-wise phases' long pole): faces + 5 bound rounds on one wave 13.6 / 7.8 / 7.3 k (134 registers of persistent state:
+    // ~110 scratch accesses per iteration), faces on the Riccati wave 14.8 / 4.0 / 7.7 k (its state does not fit the callee-saved registers
+    // of the sweeps, and that wave runs at low priority), against 7.1 / 3.2 / 2.2 k of the four-wave split.
+    // The element-wise partial results are published per wave in X_RED and combined by everybody in the fixed order (WB, WF);
+    // WEQ = the row the model wave publishes the equality norm in.
+#ifndef FRP_Q4_FWAVE // Q4: the wave that owns the corridor rows (1 = with the model, 2 = with the bound rounds)
+#define FRP_Q4_FWAVE 1
+#endif
+    constexpr int WB = 2, WF = QW ? 1 : 3, WEQ = QW ? 3 : 1;                   // (WB, WF: the two rows of partial results)
+    constexpr bool IS_M = wave == 1, IS_F = wave == (QW ? FRP_Q4_FWAVE : 3);   // model; corridor rows
+    constexpr bool IS_B = wave == WB || wave == WF;                            // publishes element-wise partial results (bound rounds and / or corridor rows)
+    constexpr bool IS_BO = IS_B && !IS_F;                                      // ... bound rounds only
+    static_assert(!QP || (NP == 20 && !TW), "P in global memory: the y+ rows are dealt over the three lanes of a stage");
+    static_assert(!QW || (NP == 20 && !TW && FREG && wave < 3), "Q4: the three-lanes-per-stage model phase, plain solve, rows in registers");
     const int lane = threadIdx.x & 63;
     const int N = a.N, M = a.M, MF = a.MF, np = NPRE + 4 * M;
     ldouble *recs = sh.recs, *xs = sh.xs;
+    auto rmax = [&](int slot) { return fmax(red(xs, WB, slot), red(xs, WF, slot)); };
+    auto rmin = [&](int slot) { return fmin(red(xs, WB, slot), red(xs, WF, slot)); };
+    auto rsum = [&](int slot) { return red(xs, WB, slot) + red(xs, WF, slot); };
+    double *pws = nullptr; // Q4: this workgroup's NP blocks of packed P in global memory
+    if constexpr (QP) pws = uni(a.pws + (size_t)blockIdx.x * (NP * PG));
     const int tw_m = TW ? uni(a.twist) : 0; // (validated by the launcher: 2 <= tw_m <= N - 2)
     ldouble *tw = sh.tw;
     // three lanes per stage (H == 3: NP = 20) also on the Riccati wave's Hessian and on the model wave (model_phase3, hessian_phase3)
@@ -1903,6 +2089,20 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     // wave 0: what its Hessian lanes carry from the step phase to the next evaluation -- the Newton step of (rates, T), (v, e) and
     // y+ (p, v rows) of the next stage; the values before the step come from the model wave through the record (RT_HZ, RT_HY),
     // so that nothing of the Hessian's inputs is live across the sweeps
+#ifndef FRP_QP_YWAVE // QP: the wave that forms y+ (0 = the Riccati wave, fetching S_xx in the step phase; 2 = the bounds wave, prefetching behind barrier D)
+#define FRP_QP_YWAVE 0
+#endif
+    constexpr int WY = FRP_QP_YWAVE;
+    double sx[16];       // QP: this lane's block of S_xx
+#pragma unroll
+    for (int i = 0; i < 16; i++) sx[i] = 0.0;
+    auto fetch_sx = [&]() {
+        typedef double gd2 __attribute__((ext_vector_type(2)));
+        const int aq = opq(half) < 3 ? opq(half) : 2;
+        const gd2 *src = (const gd2 *)((const char *)pws + ((unsigned)opq(k) * (PG * 8) + (unsigned)aq * 128u));
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const gd2 v = src[q]; sx[2 * q] = v.x; sx[2 * q + 1] = v.y; }
+    };
     double hyp[6], hap = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; i++) hyp[i] = 0.0;
@@ -1941,6 +2141,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         if constexpr (FREG || FCH == 1) {
 #pragma unroll
             for (int t = 0; t < FL; t++) {
+                FRP_RSB();
                 if (t * H + half < nfk) {
                     double a0, a1, a2, bb;
                     face_consts(t, a0, a1, a2, bb);
@@ -1982,7 +2183,11 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 #endif
     constexpr int RSPLIT0 = R - (FL <= 2 ? R / 3 : (FL <= 5 ? R / 6 : 0));
     constexpr int RSPLIT = RSPLIT0 + FRP_RSPLIT_ADJ <= R ? RSPLIT0 + FRP_RSPLIT_ADJ : R;
-    constexpr int RB0 = wave == 3 ? RSPLIT : 0, RB1 = wave == 2 ? RSPLIT : R;
+#ifndef FRP_Q4_RM // Q4: bound rounds on the model + faces wave (the LAST ones: rows 15, 16 carry no rate coupling and need two cost parameters)
+#define FRP_Q4_RM 0
+#endif
+    constexpr int RQ = R - FRP_Q4_RM;
+    constexpr int RB0 = QW ? (wave == 1 ? RQ : 0) : (IS_F ? RSPLIT : 0), RB1 = QW ? (wave == 1 ? R : RQ) : (IS_F ? R : RSPLIT);
     // evaluation: residuals, barrier Hessian / predictor rhs of this wave's bound rows -> record; norms
     auto bounds_eval = [&](double &l_in, double &l_rc, double &l_gap) {
         if (!kact) return;
@@ -1991,6 +2196,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         const int halfp = opq(half);
 #pragma unroll
         for (int r = RB0; r < RB1; r++) {
+            FRP_RSB();
             const int ib = r * H, i = ib + half;
             if (i >= NZ) continue;
             const double hd = ROW_PICK(cq.hd(i));
@@ -2020,6 +2226,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         const int halfp = opq(half);
 #pragma unroll
         for (int r = RB0; r < RB1; r++) {
+            FRP_RSB();
             const int ib = r * H, i = ib + half;
             if (i >= NZ) continue;
             const double hd = ROW_PICK(cq.hd(i));
@@ -2062,6 +2269,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         const int halfp = opq(half);
 #pragma unroll
         for (int r = RB0; r < RB1; r++) {
+            FRP_RSB();
             const int ib = r * H, i = ib + half;
             if (i >= NZ) continue;
             const double lb = ROW_PICK(lower_bound(i));
@@ -2073,9 +2281,8 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             smin = fmin(smin, fmin(bsl[r], bsu[r]));
         }
     };
-    if constexpr (wave == 0) {
-        // (this wave is idle in the evaluation phase: it evaluates the dynamics Hessian there, from what wave 1 publishes)
-    } else if constexpr (wave == 1) {
+    // (wave 0 is idle in the evaluation phase: it evaluates the dynamics Hessian there, from what wave 1 publishes)
+    if constexpr (IS_M) {
         if (lane < 9) xs[X_XINIT + lane] = a.xinit[(size_t)b * 9 + lane];
         if (kact) {
             const double *z0 = a.x0 + ((size_t)b * N + k) * NZ;
@@ -2096,15 +2303,14 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 #pragma unroll
                 for (int i = 0; i < NZ; i++) rec[R_DZ + i] = 0.0; // (the first evaluation reads 0 * step: not a predecessor's NaN)
 #pragma unroll
-                for (int i = 0; i < 4; i++) rec[RT_HZ + i] = ms.z[i]; // the Hessian's inputs of the first iteration (y = 0)
+                for (int i = 0; i < 4; i++) rec[RT_HU + i] = ms.z[i]; // the Hessian's inputs of the first iteration (y = 0)
 #pragma unroll
-                for (int i = 0; i < 6; i++) { rec[RT_HZ + 4 + i] = ms.z[11 + i]; rec[RT_HY + i] = 0.0; }
+                for (int i = 0; i < 6; i++) { rec[RT_HVE + i] = ms.z[11 + i]; rec[RT_HY + i] = 0.0; if constexpr (QP) rec[RT_HYP + i] = 0.0; }
             }
         }
-    } else if constexpr (wave == 2) {
-        bounds_init();
-    } else if constexpr (wave == 3) {
-        bounds_init();
+    }
+    if constexpr (IS_B) bounds_init();
+    if constexpr (IS_F) {
         int nf = 0;
         if (kact) {
             if (a.nfaces) nf = a.nfaces[(size_t)b * N + k];
@@ -2128,7 +2334,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         nfk = nf;
     }
     smin = wave_min(smin);
-    if constexpr (wave == 3) {
+    if constexpr (IS_F) {
         const int mt = (int)wave_sum((double)mcount);
         const int bd = wave_max((double)bad_param) > 0.0 ? 1 : 0;
         if (lane == 0) { sh.ctl->mtot = mt; sh.ctl->bad = bd; }
@@ -2147,16 +2353,17 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     }
     {
         // infeasible-start initialisation: uniform slack shift (see oracle/nmpc_ipm.c)
-        smin = fmin(red(xs, 2, 13), red(xs, 3, 13));
+        smin = rmin(13);
         const double shift = (smin >= S_MIN) ? 0.0 : (S_MIN - smin) + fmax(0.0, -smin);
-        if constexpr (wave >= 2) {
+        if constexpr (IS_B) {
 #pragma unroll
-for (int r = RB0; r < RB1; r++) {
+            for (int r = RB0; r < RB1; r++) {
+            FRP_RSB();
                 bsl[r] += shift; bsu[r] += shift;
                 bll[r] = a.mu0 / bsl[r]; blu[r] = a.mu0 / bsu[r];
             }
         }
-        if constexpr (wave == 3) {
+        if constexpr (IS_F) {
 #pragma unroll
             for (int t = 0; t < FL; t++) { fs[t] += shift; fl_[t] = a.mu0 / fs[t]; }
         }
@@ -2199,29 +2406,38 @@ for (int r = RB0; r < RB1; r++) {
                 HessState hs; // the model wave's values before the last step + the step
                 cldouble *rec = recs + k * RS;
 #pragma unroll
-                for (int i = 0; i < 4; i++) hs.u[i] = rec[RT_HZ + i] + hap * rec[R_DZ + i]; // (the step is in the record until the next forward sweep)
+                for (int i = 0; i < 4; i++) hs.u[i] = rec[RT_HU + i] + hap * rec[R_DZ + i]; // (the step is in the record until the next forward sweep)
 #pragma unroll
-                for (int i = 0; i < 6; i++) hs.ve[i] = rec[RT_HZ + 4 + i] + hap * rec[R_DZ + 11 + i];
+                for (int i = 0; i < 6; i++) hs.ve[i] = rec[RT_HVE + i] + hap * rec[R_DZ + 11 + i];
 #pragma unroll
                 for (int i = 0; i < 6; i++) {
                     const double yo = (k < N - 1) ? rec[RS + RT_HY + i] : 0.0;
-                    hs.y6[i] = yo + hap * (hyp[i] - yo);
+                    const double yp = QP ? ((k < N - 1) ? rec[RS + RT_HYP + i] : 0.0) : hyp[i]; // (QP: left in the record by the y+ lanes)
+                    hs.y6[i] = yo + hap * (yp - yo);
                 }
                 hs.fext[0] = xs[X_FEXT + k]; hs.fext[1] = xs[X_FEXT + NP + k]; hs.fext[2] = xs[X_FEXT + 2 * NP + k];
                 WSYNC(); // (the neighbour lane's reads of this stage's RT_HY slots come before the scratch use of the record below)
                 if constexpr (H3) hessian_phase3(recs + k * RS, hs, half, k < N - 1, hess);
                 else hessian_phase(recs + k * RS, hs, k < N - 1, hess);
             }
-        } else if constexpr (wave == 1) {
+        }
+        auto model_block = [&]() __attribute__((always_inline)) {
             double l_eq;
             if constexpr (H3) model_phase3<NP>(recs, xs, ms, N, l_eq, tw_m);
             else model_phase<NP>(recs, xs, ms, N, l_eq);
-            publish(xs, 1, lane, 0, wave_max(l_eq));
-        } else if constexpr (wave == 2) {
+            publish(xs, WEQ, lane, 0, wave_max(l_eq));
+        };
+        // (Q4, corridor rows on the model wave: their state does not fit beside the model phase's temporaries -- ~25 scratch accesses, 14.9 k
+        // cycles for the phase instead of ~10 k.  Measured and dropped: evaluating the rows first, parking their 15 doubles in the global
+        // workspace across the model phase and fetching them back in one batch behind it -- the barrier waits for the loads: 18.7 k.)
+        constexpr bool PARK = false;
+        if constexpr (IS_M && !PARK) model_block();
+        if constexpr (IS_BO) {
             double l_in = 0.0, l_rc = 0.0, l_gap = 0.0;
             bounds_eval(l_in, l_rc, l_gap);
-            publish(xs, 2, lane, 0, wave_max(l_in)); publish(xs, 2, lane, 1, wave_max(l_rc)); publish(xs, 2, lane, 2, wave_sum_mx(l_gap));
-        } else if constexpr (wave == 3) {
+            publish(xs, wave, lane, 0, wave_max(l_in)); publish(xs, wave, lane, 1, wave_max(l_rc)); publish(xs, wave, lane, 2, wave_sum_mx(l_gap));
+        }
+        if constexpr (IS_F) {
             double l_in = 0.0, l_rc = 0.0, l_gap = 0.0;
             bounds_eval(l_in, l_rc, l_gap);
             double gp0 = 0, gp1 = 0, gp2 = 0, fp0 = 0, fp1 = 0, fp2 = 0, p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0;
@@ -2255,15 +2471,15 @@ for (int r = RB0; r < RB1; r++) {
                 rec[R_CB + 0] = gp0; rec[R_CB + 1] = gp1; rec[R_CB + 2] = gp2;
                 rec[R_CC + 0] = fp0; rec[R_CC + 1] = fp1; rec[R_CC + 2] = fp2;
             }
-            publish(xs, 3, lane, 0, wave_max(l_in)); publish(xs, 3, lane, 1, wave_max(l_rc)); publish(xs, 3, lane, 2, wave_sum_mx(l_gap));
+            publish(xs, wave, lane, 0, wave_max(l_in)); publish(xs, wave, lane, 1, wave_max(l_rc)); publish(xs, wave, lane, 2, wave_sum_mx(l_gap));
         }
         BAR_P(0); // ------------------------------------------------------------- A
         // (workgroup-uniform scalars that live across phases go to scalar registers: the element-wise roles are at the
         // 168-VGPR cap of three workgroups per CU, and every spilled value is an L2 round trip on an in-order wavefront)
-        nm.eq = uni(red(xs, 1, 0));
-        nm.in = uni(fmax(red(xs, 2, 0), red(xs, 3, 0)));
-        nm.rc = uni(fmax(red(xs, 2, 1), red(xs, 3, 1)));
-        nm.gap = uni(red(xs, 2, 2) + red(xs, 3, 2));
+        nm.eq = uni(red(xs, WEQ, 0));
+        nm.in = uni(rmax(0));
+        nm.rc = uni(rmax(1));
+        nm.gap = uni(rsum(2));
         nm.rs = uni(stationarity_norm<NP>(recs, N));
         mu = uni(nm.gap * (KAPPA_LAM * inv_kmtot));
         if (!gn_retry) {
@@ -2278,7 +2494,7 @@ for (int r = RB0; r < RB1; r++) {
             // the two halves side by side; the Riccati wave factors and solves the meeting system; both continue from ds_m, outwards
             TW_T0();
             if constexpr (wave == 0) {
-                const int fr = sweep_factor<true>(recs + tw_m * RS, xs, N - tw_m, gn_retry ? 0.0 : theta_h);
+                const int fr = sweep_factor<true>(recs + tw_m * RS, xs, N - tw_m, gn_retry ? 0.0 : theta_h FRP_GP_ARG(nullptr));
                 if (lane == 0) sh.ctl->fail = fr;
                 TW_T1(22);
             } else if constexpr (wave == 1) {
@@ -2309,11 +2525,12 @@ for (int r = RB0; r < RB1; r++) {
             }
         } else if constexpr (wave == 0) {
             SWEEP_T0();
-            const int fr = sweep_factor<false>(recs, xs, N, gn_retry ? 0.0 : theta_h);
+            const int fr = sweep_factor<false>(recs, xs, N, gn_retry ? 0.0 : theta_h FRP_GP_ARG(pws));
             SWEEP_T1(0);
             if (FWD_P == 0 && !fr) sweep_forward(recs, xs, N);
             SWEEP_T1(1);
             if (lane == 0) sh.ctl->fail = fr;
+            if constexpr (QP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the P stores of the factorisation sweep (long retired by now)
         }
         if constexpr (FWD_P != 0 && !TW) { // the forward sweep works from the records alone: it runs on the wave whose SIMD has room
             BAR();
@@ -2336,9 +2553,9 @@ for (int r = RB0; r < RB1; r++) {
                     if (own0) {
                         ldouble *rec = recs + k * RS;
 #pragma unroll
-                        for (int i = 0; i < 4; i++) rec[RT_HZ + i] = ms.z[i];
+                        for (int i = 0; i < 4; i++) rec[RT_HU + i] = ms.z[i];
 #pragma unroll
-                        for (int i = 0; i < 6; i++) { rec[RT_HZ + 4 + i] = ms.z[11 + i]; rec[RT_HY + i] = ms.y[4 + i]; }
+                        for (int i = 0; i < 6; i++) { rec[RT_HVE + i] = ms.z[11 + i]; rec[RT_HY + i] = ms.y[4 + i]; if constexpr (QP) rec[RT_HYP + i] = 0.0; }
                     }
                 }
                 hap = 0.0;
@@ -2351,12 +2568,13 @@ for (int r = RB0; r < RB1; r++) {
         }
 
         // ============================================================ affine step: lengths, second-order term, corrector rhs
-        if constexpr (wave == 2) {
+        if constexpr (IS_BO) {
             double m_p = 0.0, m_d = 0.0, s_sdl = 0.0, s_lds = 0.0, s_dsdl = 0.0;
             bounds_affine(m_p, m_d, s_sdl, s_lds, s_dsdl);
-            publish(xs, 2, lane, 3, wave_max(m_p)); publish(xs, 2, lane, 4, wave_max(m_d));
-            publish(xs, 2, lane, 5, wave_sum_mx(s_sdl)); publish(xs, 2, lane, 6, wave_sum_mx(s_lds)); publish(xs, 2, lane, 7, wave_sum_mx(s_dsdl));
-        } else if constexpr (wave == 3) {
+            publish(xs, wave, lane, 3, wave_max(m_p)); publish(xs, wave, lane, 4, wave_max(m_d));
+            publish(xs, wave, lane, 5, wave_sum_mx(s_sdl)); publish(xs, wave, lane, 6, wave_sum_mx(s_lds)); publish(xs, wave, lane, 7, wave_sum_mx(s_dsdl));
+        }
+        if constexpr (IS_F) {
             double m_p = 0.0, m_d = 0.0, s_sdl = 0.0, s_lds = 0.0, s_dsdl = 0.0;
             bounds_affine(m_p, m_d, s_sdl, s_lds, s_dsdl);
             double b0 = 0, b1 = 0, b2 = 0, c0 = 0, c1 = 0, c2 = 0;
@@ -2392,17 +2610,16 @@ for (int r = RB0; r < RB1; r++) {
                 rec[R_CB + 0] = b0; rec[R_CB + 1] = b1; rec[R_CB + 2] = b2;
                 rec[R_CC + 0] = c0; rec[R_CC + 1] = c1; rec[R_CC + 2] = c2;
             }
-            publish(xs, 3, lane, 3, wave_max(m_p)); publish(xs, 3, lane, 4, wave_max(m_d));
-            publish(xs, 3, lane, 5, wave_sum_mx(s_sdl)); publish(xs, 3, lane, 6, wave_sum_mx(s_lds)); publish(xs, 3, lane, 7, wave_sum_mx(s_dsdl));
+            publish(xs, wave, lane, 3, wave_max(m_p)); publish(xs, wave, lane, 4, wave_max(m_d));
+            publish(xs, wave, lane, 5, wave_sum_mx(s_sdl)); publish(xs, wave, lane, 6, wave_sum_mx(s_lds)); publish(xs, wave, lane, 7, wave_sum_mx(s_dsdl));
         }
         BAR_P(2); // ------------------------------------------------------------- D
         double smu;
         {
-            const double m_p = fmax(red(xs, 2, 3), red(xs, 3, 3)), m_d = fmax(red(xs, 2, 4), red(xs, 3, 4));
+            const double m_p = rmax(3), m_d = rmax(4);
             const double ap = (m_p > 1.0) ? fast_rcp(m_p) : 1.0;
             const double ad = (m_d > 1.0) ? fast_rcp(m_d) : 1.0;
-            const double gap_aff = mu * (double)mtot + ad * (red(xs, 2, 5) + red(xs, 3, 5)) + ap * (red(xs, 2, 6) + red(xs, 3, 6)) +
-                                   ap * ad * (red(xs, 2, 7) + red(xs, 3, 7));
+            const double gap_aff = mu * (double)mtot + ad * rsum(5) + ap * rsum(6) + ap * ad * rsum(7);
             double sigma = gap_aff * fast_rcp((double)mtot * mu);
             sigma = sigma * sigma * sigma;
             if (sigma > 1.0) sigma = 1.0;
@@ -2412,10 +2629,16 @@ for (int r = RB0; r < RB1; r++) {
             // reported, not iterated on (info.mu_aff / sigma / step_aff, FORCESNLPsolver_normal.h:275-289): every wave has the values;
             // the faces wave -- the one on the SIMD without a Riccati wave -- parks them in three free scratch slots, the Riccati wave
             // picks them up at exit (carried in ITS registers across the sweeps they cost 0.5 % of the launch, measured)
-            if constexpr (wave == 3) {
+            if constexpr (IS_F) {
                 if (lane == 0) { xs[X_RED + 3 * 16 + 14] = gap_aff * fast_rcp((double)mtot); xs[X_RED + 3 * 16 + 15] = sigma; xs[X_RED + 2 * 16 + 14] = ap; }
             }
         }
+
+        // QP: the bounds wave -- idle until barrier E -- fetches its block of S_xx (16 doubles per lane, one 128-byte line: the lane's
+        // diagonal block and the block to its right, stored by the factorisation sweep of this iteration) for the y+ rows of the step phase
+        // (FRP_QP_YWAVE = 2; the default is the Riccati wave, which fetches at the start of the step phase: the bounds wave has no
+        // room for 32 more registers between the barriers D and F -- 310 spilled VGPRs instead of 126)
+        if constexpr (wave == WY && WY != 0 && QP) fetch_sx();
 
         // ============================================================ corrector: vector backward sweep + forward sweep with y+
         if constexpr (TW) {
@@ -2477,7 +2700,73 @@ for (int r = RB0; r < RB1; r++) {
             for (int j = 0; j < NS; j++) acc = fma(rec[R_P + (i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i)], rec[R_DZ + 4 + j], acc);
             return (TW && k < tw_m) ? -acc : acc;
         };
-        if constexpr (wave == 0) {
+        // QP: y+ is formed by the bounds wave alone, from its prefetched block of S_xx (registers, see the prefetch behind barrier D)
+        // and from T', p, Phi_w, hc in the record -- no global memory access on the path:
+        //     y_w = Phi_w dw + hc (du + kbar) + p_w        (the w rows of P are [Phi_w - hc^2 R | -hc Kbar_x] and du = -(hc R dw + Kbar_x dx + kbar))
+        //     y_x = S_xx dx - hc Kbar_x' dw + p_x          (lane a of a stage: rows 3a .. 3a+2; S_aa and S_{a,a+1} are its own, the
+        //                                                   contribution S_{a,a+1}' dx_a goes to the lane that owns the rows a+1)
+        if constexpr (wave == WY && QP) {
+            if constexpr (WY == 0) { __builtin_amdgcn_s_setprio(FRP_H_PRIO); fetch_sx(); } // (one trip to the L2 on the path: 8 x 16 bytes per lane)
+            ldouble *rec = recs + k * RS;
+            const int aq = opq(half) < 3 ? opq(half) : 2, ia = 3 * aq, ib = aq == 2 ? 0 : ia + 3;
+            double ux[3], yw[4];
+            {
+                const double hcq = rec[R_HC];
+                double da[3], db[3], vx[3];
+#pragma unroll
+                for (int t = 0; t < 3; t++) { da[t] = rec[R_DZ + 8 + ia + t]; db[t] = rec[R_DZ + 8 + ib + t]; }
+                // S_aa: sx[0] = (0,0), sx[1] = (1,0), sx[2] = (1,1), sx[3] = (2,0), sx[4] = (2,1), sx[5] = (2,2);  S_ab[t][s] = sx[6 + 3 t + s]
+                ux[0] = sx[0] * da[0] + sx[1] * da[1] + sx[3] * da[2];
+                ux[1] = sx[1] * da[0] + sx[2] * da[1] + sx[4] * da[2];
+                ux[2] = sx[3] * da[0] + sx[4] * da[1] + sx[5] * da[2];
+#pragma unroll
+                for (int t = 0; t < 3; t++) ux[t] += sx[6 + 3 * t] * db[0] + sx[7 + 3 * t] * db[1] + sx[8 + 3 * t] * db[2];
+#pragma unroll
+                for (int q = 0; q < 3; q++) vx[q] = sx[6 + q] * da[0] + sx[9 + q] * da[1] + sx[12 + q] * da[2];
+                // - hc Kbar_x' dw and p_x
+                double dw[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) dw[g] = rec[R_DZ + 4 + g];
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    const double kd = rec[R_T + 4 + ia + t] * dw[0] + rec[R_T + 20 + ia + t] * dw[1] + rec[R_T + 36 + ia + t] * dw[2] + rec[R_T + 52 + ia + t] * dw[3];
+                    ux[t] = __builtin_fma(-hcq, kd, ux[t]) + rec[R_PV + 4 + ia + t];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    yw[g] = __builtin_fma(rec[R_PHIW + g], dw[g], __builtin_fma(hcq, rec[R_DZ + g] + rec[R_T + 16 * g + 13], rec[R_PV + g]));
+                WSYNC(); // every read of T' by this wave is behind us: its Kbar_x slots serve as scratch now
+                if (kact) {
+#pragma unroll
+                    for (int q = 0; q < 3; q++) rec[RT_YV + ib + q] = vx[q];
+                }
+            }
+            WSYNC();
+            if (kact) {
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    const double y = ux[t] + rec[RT_YV + ia + t];
+                    rec[R_D + 4 + ia + t] = y;
+                    rec[aq < 2 ? RT_HYP + ia + t : R_DUMP] = y; // rows 4..9 once more, for the Hessian lanes of the next evaluation
+                }
+                if (half == 0) {
+#pragma unroll
+                    for (int g = 0; g < 4; g++) rec[R_D + g] = yw[g];
+                }
+            }
+            if constexpr (WY == 0) __builtin_amdgcn_s_setprio(FRP_R_PRIO);
+        }
+        if constexpr (wave == 1 && QP) {
+            if (own0) { // the values before the step, for the Hessian lanes (T' slots the y+ lanes do not read)
+                ldouble *rec = recs + k * RS;
+#pragma unroll
+                for (int i = 0; i < 4; i++) rec[RT_HU + i] = ms.z[i];
+#pragma unroll
+                for (int i = 0; i < 6; i++) { rec[RT_HVE + i] = ms.z[11 + i]; rec[RT_HY + i] = ms.y[4 + i]; }
+            }
+        } else if constexpr (wave == 0 && QP) {
+            // (nothing: y+ and the Hessian's inputs come from the other two waves)
+        } else if constexpr (wave == 0) {
             // (the Newton step of the Hessian's inputs stays in the record: the next evaluation reads it there, before the forward
             // sweep that overwrites it)  y+ of the stage for the model wave's commit: it goes to the d slots of
             // the record, which are dead from the last sweep to the next model phase (the model wave has 60 registers of
@@ -2505,9 +2794,9 @@ for (int r = RB0; r < RB1; r++) {
             if (own0) { // the values before the step, for the Hessian lanes (T' is dead from here to the next factorisation)
                 ldouble *rec = recs + k * RS;
 #pragma unroll
-                for (int i = 0; i < 4; i++) rec[RT_HZ + i] = ms.z[i];
+                for (int i = 0; i < 4; i++) rec[RT_HU + i] = ms.z[i];
 #pragma unroll
-                for (int i = 0; i < 6; i++) { rec[RT_HZ + 4 + i] = ms.z[11 + i]; rec[RT_HY + i] = ms.y[4 + i]; }
+                for (int i = 0; i < 6; i++) { rec[RT_HVE + i] = ms.z[11 + i]; rec[RT_HY + i] = ms.y[4 + i]; }
                 // y+ rows 0..3 (w) and 10..12 (e) for the commit below; rows 4..9: the Riccati wave
 #pragma unroll
                 for (int i = 0; i < 4; i++) rec[R_D + i] = y_plus(rec, i);
@@ -2515,12 +2804,13 @@ for (int r = RB0; r < RB1; r++) {
                 for (int i = 10; i < NS; i++) rec[R_D + i] = y_plus(rec, i);
             }
         }
-        if constexpr (wave >= 2) { // bound rows of this wave
+        if constexpr (IS_B) { // bound rows of this wave
             if (kact) {
                 cldouble *rec = recs + k * RS;
         const int halfp = opq(half);
 #pragma unroll
         for (int r = RB0; r < RB1; r++) {
+            FRP_RSB();
                     const int ib = r * H, i = ib + half;
                     if (i >= NZ) continue;
                     const double lb = ROW_PICK(lower_bound(i));
@@ -2532,7 +2822,7 @@ for (int r = RB0; r < RB1; r++) {
                 }
             }
         }
-        if constexpr (wave == 3) { // corridor rows
+        if constexpr (IS_F) { // corridor rows
             if (kact) {
                 cldouble *rec = recs + k * RS;
                 dzf[0] = rec[R_DZ + 8]; dzf[1] = rec[R_DZ + 9]; dzf[2] = rec[R_DZ + 10];
@@ -2544,18 +2834,17 @@ for (int r = RB0; r < RB1; r++) {
                 });
             }
         }
-        if constexpr (wave >= 2) {
+        if constexpr (IS_B) {
             publish(xs, wave, lane, 8, wave_max(m_p)); publish(xs, wave, lane, 9, wave_max(m_d));
             publish(xs, wave, lane, 10, wave_sum_mx(q1)); publish(xs, wave, lane, 11, wave_sum_mx(q2)); publish(xs, wave, lane, 12, wave_sum_mx(q3));
         }
         BAR_P(4); // ------------------------------------------------------------- F
         {
-            const double mp = fmax(red(xs, 2, 8), red(xs, 3, 8)), md = fmax(red(xs, 2, 9), red(xs, 3, 9));
+            const double mp = rmax(8), md = rmax(9);
             const double ap = uni((mp > a.ftb) ? a.ftb * fast_rcp(mp) : 1.0);
             const double ad = uni((md > a.ftb) ? a.ftb * fast_rcp(md) : 1.0);
             // multiplier safeguard: s_i lam_i >= mu_new / KAPPA_LAM for every pair after the step
-            const double fprod = uni((mu * (double)mtot + ap * (red(xs, 2, 10) + red(xs, 3, 10)) +
-                                      ad * ((red(xs, 2, 11) + red(xs, 3, 11)) + ap * (red(xs, 2, 12) + red(xs, 3, 12)))) * inv_kmtot);
+            const double fprod = uni((mu * (double)mtot + ap * rsum(10) + ad * (rsum(11) + ap * rsum(12))) * inv_kmtot);
             step_cc = ap;
             auto commit = [&](double &s, double &l, double corr, double gdz, double viol) {
                 const double sinv = fast_rcp(s);
@@ -2577,10 +2866,11 @@ for (int r = RB0; r < RB1; r++) {
                     for (int i = 0; i < NS; i++) ms.y[i] += ap * (rec[R_D + i] - ms.y[i]); // y <- y + ap (y+ - y)
                 }
             }
-            if constexpr (wave >= 2) {
+            if constexpr (IS_B) {
         const int halfp = opq(half);
 #pragma unroll
         for (int r = RB0; r < RB1; r++) {
+            FRP_RSB();
                     const int ib = r * H, i = ib + half;
                     if (i >= NZ) continue;
                     const double lb = ROW_PICK(lower_bound(i));
@@ -2593,7 +2883,7 @@ for (int r = RB0; r < RB1; r++) {
                     if (ib < 8) bzp[r] += ap * rec[R_DZ + (i < 4 ? i + 4 : (i < 8 ? i - 4 : i))];
                 }
             }
-            if constexpr (wave == 3) {
+            if constexpr (IS_F) {
                 {
                     cldouble *rec = recs + k * RS;
                     dzf[0] = rec[R_DZ + 8]; dzf[1] = rec[R_DZ + 9]; dzf[2] = rec[R_DZ + 10];
@@ -2664,8 +2954,9 @@ __device__ __forceinline__ void role_loop(const KernelArgs &a, const Shared &sh)
 }
 
 template <int NP, int FL, bool FREG, int WPE, bool TW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void nmpc_ipm_lds_kernel(KernelArgs a)
+__global__ __launch_bounds__(QW ? 192 : 256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void nmpc_ipm_lds_kernel(KernelArgs a)
 {
+    static_assert(!(QW && QL) || (size_t)(NP * RS + X_TOTAL + 3 * NP + 1) * 8 + sizeof(Ctl) + 5 * sizeof(int) <= 40960, "Q4: four workgroups per CU in 160 KB of LDS");
     __shared__ double s_recs[NP * RS];
     __shared__ double s_xs[X_TOTAL + 3 * NP];
     __shared__ double s_tw[TW ? TW_TOTAL : 1];
@@ -2690,7 +2981,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #ifndef FRP_NO_PLACE
 #define FRP_NO_PLACE 0
 #endif
-    if (WPE >= 3 && a.cu_slots && !FRP_NO_PLACE) {
+    if constexpr (QW) {
+        // Q4: four workgroups of three wavefronts per CU -- twelve waves, three per SIMD.  Every workgroup claims a SIMD for its Riccati
+        // wave that no other workgroup's Riccati wave has taken (a bit mask per CU in the workspace, zeroed by the launcher), trying the
+        // SIMDs its own waves sit on; its other two waves take the roles 1 and 2 in the cyclic order of their SIMDs behind the claimed
+        // one, so that with the dispatcher's rotation {s, s+1, s+2} every SIMD ends up with one Riccati wave, one model + bounds wave
+        // and one faces + bounds wave.  Anything unexpected (two waves on one SIMD, no free SIMD) falls back to role = wave index.
+        if (a.cu_slots && !FRP_NO_PLACE) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+            const int simd = (int)((hw >> 4) & 3u);
+            if ((threadIdx.x & 63) == 0) s_place[widx] = simd;
+            __syncthreads();
+            const int s0 = s_place[0], s1 = s_place[1], s2 = s_place[2];
+            if (threadIdx.x == 0) {
+                const unsigned key = ((xcc & 7u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+                int rs = -1;
+                if (s0 != s1 && s0 != s2 && s1 != s2) {
+                    const int cand[3] = {s0, s1, s2};
+                    for (int q = 0; q < 3 && rs < 0; q++) {
+                        const int old = atomicOr(a.cu_slots + key, 1 << cand[q]);
+                        if (!(old & (1 << cand[q]))) rs = cand[q];
+                    }
+                }
+                s_place[4] = rs;
+            }
+            __syncthreads();
+            const int rs = s_place[4];
+            if (rs >= 0) {
+                // the other two waves, ordered by (simd - rs) mod 4
+                const int da = (simd - rs) & 3;
+                int dmin = 4;
+                const int d0 = (s0 - rs) & 3, d1 = (s1 - rs) & 3, d2 = (s2 - rs) & 3;
+                if (d0 && d0 < dmin) dmin = d0;
+                if (d1 && d1 < dmin) dmin = d1;
+                if (d2 && d2 < dmin) dmin = d2;
+                role = da == 0 ? 0 : (da == dmin ? 1 : 2);
+            }
+#ifdef FRP_PROFILE
+            if (threadIdx.x == 0) atomicAdd((unsigned long long *)&g_prof_seg[24 + (rs >= 0 ? rs : 4)], 1ull);
+#endif
+        }
+    } else if (WPE >= 3 && a.cu_slots && !FRP_NO_PLACE) {
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID: SIMD_ID [5:4], CU_ID [11:8], SH_ID [12], SE_ID [15:13]
         const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID [3:0]
         const int simd = (int)((hw >> 4) & 3u);
@@ -2730,14 +3062,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         // (single-problem launches of the drop-in context: this wave made the last claim; the head is zero again for the next call)
         if (a.self_reset && (threadIdx.x & 63) == 0) *a.counter = 0;
     } else if (wave == 1) role_loop<NP, FL, FREG, 1, TW>(a, sh);
-    else if (wave == 2) role_loop<NP, FL, FREG, 2, TW>(a, sh);
-    else role_loop<NP, FL, FREG, 3, TW>(a, sh);
+    else if (wave == 2 || QW) role_loop<NP, FL, FREG, 2, TW>(a, sh);
+    else {
+        if constexpr (!QW) role_loop<NP, FL, FREG, 3, TW>(a, sh);
+    }
 }
 
 template <int NP, int FL, bool FREG, int WPE, bool TW = false>
 static hipError_t launch_variant(const KernelArgs &k, int slots, hipStream_t stream)
 {
-    hipLaunchKernelGGL((nmpc_ipm_lds_kernel<NP, FL, FREG, WPE, TW>), dim3(slots), dim3(256), 0, stream, k);
+    hipLaunchKernelGGL((nmpc_ipm_lds_kernel<NP, FL, FREG, WPE, TW>), dim3(slots), dim3(QW ? 192 : 256), 0, stream, k);
     return hipGetLastError();
 }
 // the twisted variants: frp_nmpc_options.twist = m (stages eliminated forward), -1 = 9 N / 20 (3 N / 10 beyond 1024 problems); anything the twisted solve does not cover
@@ -2750,34 +3084,89 @@ static inline int twist_stages(const KernelArgs &k)
     return (k.N >= 4 && k.N <= 20 && m >= 2 && m <= k.N - 2) ? m : 0;
 }
 
-} // namespace lr
+} // namespace lr / lrq
 
 // Two translation units (build.py): the variants that keep the corridor rows in registers (FREG) are compiled with
 // -amdgpu-use-amdgpu-trackers=1 (-4 % on the (20, 2) variant of the headline workload), the variants that re-read them from
 // the parameters without it (the same flag costs them 2-10 %).  frp_ipm_lds_mem.hip includes this file with FRP_LDS_MEM_TU
 // and contributes launch_ipm_lds_mem only; a build that defines neither macro (probes, experiments) gets everything here.
-#ifdef FRP_LDS_MEM_TU
+#if defined(FRP_LDS_Q4_TU)
+// frp_ipm_lds_q4.hip: the four-problems-per-CU variants (three-wave workgroups, P in global memory); contributes launch_ipm_lds_q4 only
+hipError_t launch_ipm_lds_q4(const KernelArgs &k, int slots, hipStream_t stream)
+{
+    return FRP_LR::launch_variant<20, 2, true, 3>(k, slots, stream);
+}
+#elif defined(FRP_LDS_MEM_TU)
 hipError_t launch_ipm_lds_mem(const KernelArgs &k, int slots, hipStream_t stream)
 {
-    if (k.N <= 20 && k.twist) return lr::launch_variant<20, 10, false, 3, true>(k, slots, stream); // (k.twist: resolved by launch_ipm_lds)
-    if (k.N <= 20) return lr::launch_variant<20, 10, false, 3>(k, slots, stream);
-    if (k.N <= 32) return lr::launch_variant<32, 15, false, 2>(k, slots, stream);
-    return lr::launch_variant<64, 30, false, 1>(k, slots, stream);
+    if (k.N <= 20 && k.twist) return FRP_LR::launch_variant<20, 10, false, 3, true>(k, slots, stream); // (k.twist: resolved by launch_ipm_lds)
+    if (k.N <= 20) return FRP_LR::launch_variant<20, 10, false, 3>(k, slots, stream);
+    if (k.N <= 32) return FRP_LR::launch_variant<32, 15, false, 2>(k, slots, stream);
+    return FRP_LR::launch_variant<64, 30, false, 1>(k, slots, stream);
 }
 #else
 #ifdef FRP_PROFILE
 void debug_read_prof_lds(long long *out)
 {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lr::g_prof_lds), sizeof(long long) * 64);
-    (void)hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(lr::g_prof_seg), sizeof(long long) * 32);
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(FRP_LR::g_prof_lds), sizeof(long long) * 64);
+    (void)hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(FRP_LR::g_prof_seg), sizeof(long long) * 32);
     long long z[64] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(lr::g_prof_lds), z, sizeof z);
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(lr::g_prof_seg), z, sizeof(long long) * 32);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(FRP_LR::g_prof_lds), z, sizeof z);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(FRP_LR::g_prof_seg), z, sizeof(long long) * 32);
 }
 #endif
 
-// workgroups resident per CU: LDS-bound (3 x 49 KB, 2 x 79 KB, 1 x 157 KB)
-int lds_workgroups_per_cu(int N) { return N <= 20 ? 3 : (N <= 32 ? 2 : 1); }
+// The Q4 variants (frp_ipm_lds_q4.hip) take the launches they cover: plain solve, N <= 20, at most six corridor rows per stage.
+// FRP_Q4=0 in the environment keeps the three-per-CU variants (A/B runs).
+#ifdef FRP_LDS_SPLIT_TU
+hipError_t launch_ipm_lds_q4(const KernelArgs &k, int slots, hipStream_t stream); // frp_ipm_lds_q4.hip
+static bool q4_enabled()
+{
+    static const bool on = [] { const char *e = getenv("FRP_Q4"); return !(e && e[0] == '0'); }();
+    return on;
+}
+#else
+static hipError_t launch_ipm_lds_q4(const KernelArgs &, int, hipStream_t) { return hipErrorInvalidValue; }
+static bool q4_enabled() { return false; } // (a single-translation-unit build has one record layout)
+#endif
+#if (defined(FRP_QP) || defined(FRP_QW)) && !defined(FRP_LDS_Q4_TU)
+static bool q4_covers(const KernelArgs &) { return false; } // (bisection builds: the launch stays on this translation unit)
+#else
+// ... and only launches with more problems than the three-per-CU variants hold at once: a problem that has a CU (nearly) to itself
+// iterates faster on four wavefronts (69 k cycles per iteration against 80 k: profiles/r05_wave_phases.txt)
+static int device_cus()
+{
+    static int cus[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (!cus[dev]) {
+        int n = 256;
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        cus[dev] = n > 0 ? n : 256;
+    }
+    return cus[dev];
+}
+static int g_q4_min_b = [] { const char *e = getenv("FRP_Q4_MIN_B"); return e ? atoi(e) : -1; }(); // (frp_nmpc_set_q4_min_batch; -1: three workgroups per CU)
+static int g_q4_pin_b = 0; // (lds_q4_pin_for_batch)
+static bool q4_covers(const KernelArgs &k)
+{
+    const int B = g_q4_pin_b > 0 ? g_q4_pin_b : k.B;
+    return q4_enabled() && k.pws && k.N <= 20 && k.MF <= 6 && FRP_LR::twist_stages(k) == 0 && B > (g_q4_min_b >= 0 ? g_q4_min_b : 3 * device_cus());
+}
+#endif
+
+// workgroups resident per CU: LDS-bound (4 x 40 KB on the Q4 variants; 3 x 51 KB, 2 x 79 KB, 1 x 157 KB)
+int lds_workgroups_per_cu(const KernelArgs &k) { return k.N <= 20 ? (q4_covers(k) ? 4 : 3) : (k.N <= 32 ? 2 : 1); }
+// doubles of packed-P workspace a resident workgroup of the Q4 variants needs (KernelArgs::pws)
+size_t lds_q4_pws_doubles_per_slot() { return (size_t)20 * FRP_LR::PG; }
+bool lds_q4_enabled() { return q4_enabled(); }
+#if (defined(FRP_QP) || defined(FRP_QW)) && !defined(FRP_LDS_Q4_TU)
+int lds_q4_set_min_batch(int) { return -1; }
+void lds_q4_pin_for_batch(int) {}
+#else
+void lds_q4_pin_for_batch(int B) { g_q4_pin_b = B > 0 ? B : 0; }
+int lds_q4_set_min_batch(int min_b) { const int old = g_q4_min_b; g_q4_min_b = min_b < 0 ? -1 : min_b; return old; }
+#endif
 
 bool lds_kernel_supports(int N, int MF) { return N >= 1 && N <= 64 && MF >= 0 && MF <= FRP_MAX_FACES; }
 
@@ -2786,10 +3175,10 @@ hipError_t launch_ipm_lds_mem(const KernelArgs &k, int slots, hipStream_t stream
 #else
 static hipError_t launch_ipm_lds_mem(const KernelArgs &k, int slots, hipStream_t stream)
 {
-    if (k.N <= 20 && k.twist) return lr::launch_variant<20, 10, false, 3, true>(k, slots, stream);
-    if (k.N <= 20) return lr::launch_variant<20, 10, false, 3>(k, slots, stream);
-    if (k.N <= 32) return lr::launch_variant<32, 15, false, 2>(k, slots, stream);
-    return lr::launch_variant<64, 30, false, 1>(k, slots, stream);
+    if (k.N <= 20 && k.twist) return FRP_LR::launch_variant<20, 10, false, 3, true>(k, slots, stream);
+    if (k.N <= 20) return FRP_LR::launch_variant<20, 10, false, 3>(k, slots, stream);
+    if (k.N <= 32) return FRP_LR::launch_variant<32, 15, false, 2>(k, slots, stream);
+    return FRP_LR::launch_variant<64, 30, false, 1>(k, slots, stream);
 }
 #endif
 
@@ -2800,35 +3189,51 @@ static hipError_t launch_ipm_lds_mem(const KernelArgs &k, int slots, hipStream_t
 hipError_t launch_ipm_lds(const KernelArgs &k0, int slots, hipStream_t stream)
 {
     KernelArgs k = k0;
-    k.twist = lr::twist_stages(k0);
+    k.twist = FRP_LR::twist_stages(k0);
     const int MF = k.MF;
+    if (q4_covers(k0)) return launch_ipm_lds_q4(k, slots, stream);
+#if (defined(FRP_QP) || defined(FRP_QW)) && !defined(FRP_LDS_Q4_TU) // bisection builds (parts of Q4 on the main translation unit): one variant
+    return (k.N <= 20 && MF <= 6 && !k.twist && k.pws) ? FRP_LR::launch_variant<20, 2, true, FRP_WPE20>(k, slots, stream) : hipErrorInvalidValue;
+#else
     if (k.N <= 20 && k.twist) {
-        if (MF <= 6) return lr::launch_variant<20, 2, true, FRP_WPE20, true>(k, slots, stream);
-        if (MF <= 15) return lr::launch_variant<20, 5, true, FRP_WPE20, true>(k, slots, stream);
+        if (MF <= 6) return FRP_LR::launch_variant<20, 2, true, FRP_WPE20, true>(k, slots, stream);
+        if (MF <= 15) return FRP_LR::launch_variant<20, 5, true, FRP_WPE20, true>(k, slots, stream);
     } else if (k.N <= 20) {
-        if (MF <= 6) return lr::launch_variant<20, 2, true, FRP_WPE20>(k, slots, stream);
-        if (MF <= 15) return lr::launch_variant<20, 5, true, FRP_WPE20>(k, slots, stream);
+        if (MF <= 6) return FRP_LR::launch_variant<20, 2, true, FRP_WPE20>(k, slots, stream);
+        if (MF <= 15) return FRP_LR::launch_variant<20, 5, true, FRP_WPE20>(k, slots, stream);
     } else if (k.N <= 32) {
-        if (MF <= 6) return lr::launch_variant<32, 3, true, 2>(k, slots, stream);
-        if (MF <= 16) return lr::launch_variant<32, 8, true, 2>(k, slots, stream);
-    } else if (MF <= 8) return lr::launch_variant<64, 8, true, 1>(k, slots, stream);
+        if (MF <= 6) return FRP_LR::launch_variant<32, 3, true, 2>(k, slots, stream);
+        if (MF <= 16) return FRP_LR::launch_variant<32, 8, true, 2>(k, slots, stream);
+    } else if (MF <= 8) return FRP_LR::launch_variant<64, 8, true, 1>(k, slots, stream);
     return launch_ipm_lds_mem(k, slots, stream);
+#endif
 }
 #endif // FRP_LDS_MEM_TU
 
 } // namespace frp
 
-#if defined(FRP_PROFILE) && !defined(FRP_LDS_MEM_TU)
+#if defined(FRP_PROFILE) && !defined(FRP_LDS_MEM_TU) && !defined(FRP_LDS_Q4_TU)
 extern "C" void frp_debug_read_prof_lds(long long *out) { frp::debug_read_prof_lds(out); }
 #endif
-#if defined(FRP_PROFILE) && defined(FRP_LDS_MEM_TU)
+#if defined(FRP_PROFILE) && defined(FRP_LDS_Q4_TU)
+// (the Q4 variants too; slots 24..28 of the segment counters: workgroups whose Riccati wave claimed SIMD 0..3 / fell back to role = wave index)
+extern "C" void frp_debug_read_prof_lds_q4(long long *out)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(frp::FRP_LR::g_prof_lds), sizeof(long long) * 64);
+    (void)hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(frp::FRP_LR::g_prof_seg), sizeof(long long) * 32);
+    long long z[64] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(frp::FRP_LR::g_prof_lds), z, sizeof z);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(frp::FRP_LR::g_prof_seg), z, sizeof(long long) * 32);
+}
+#endif
+#if defined(FRP_PROFILE) && defined(FRP_LDS_MEM_TU) && !defined(FRP_LDS_Q4_TU)
 // (the re-reading variants are a translation unit of their own, with their own copy of the profile counters)
 extern "C" void frp_debug_read_prof_lds_mem(long long *out)
 {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(frp::lr::g_prof_lds), sizeof(long long) * 64);
-    (void)hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(frp::lr::g_prof_seg), sizeof(long long) * 32);
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(frp::FRP_LR::g_prof_lds), sizeof(long long) * 64);
+    (void)hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(frp::FRP_LR::g_prof_seg), sizeof(long long) * 32);
     long long z[64] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(frp::lr::g_prof_lds), z, sizeof z);
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(frp::lr::g_prof_seg), z, sizeof(long long) * 32);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(frp::FRP_LR::g_prof_lds), z, sizeof z);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(frp::FRP_LR::g_prof_seg), z, sizeof(long long) * 32);
 }
 #endif

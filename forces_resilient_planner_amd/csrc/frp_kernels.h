@@ -52,7 +52,8 @@ struct KernelArgs {
     double *z;
     int *exitflag, *iters;
     double *info;
-    double *ws;       // queue workspace (ws_bytes): counter, per-CU counters, keys, order
+    double *ws;       // queue workspace (ws_bytes): counter, per-CU counters, keys, order, packed-P blocks of the Q4 variants
+    double *pws;      // packed P_k of the resident workgroups (Q4 variants: 20 x 92 doubles each; set by the launcher, null = not available)
     int *counter;     // work-queue head (set by the launcher)
     int *cu_slots;    // per-CU arrival counters of the resident workgroups, zeroed by the launcher (frp_ipm_lds.hip: role placement)
     const int *order; // launch order of the problems, or null = index order (set by the launcher)
@@ -69,7 +70,11 @@ hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream);
 hipError_t kernel_timing_begin(int max_launches, int stride);
 hipError_t kernel_timing_end(float *avg_ms, int *launches);
 // frp_ipm_lds.hip: the LDS-resident kernel (queue counter / order already set up by launch_ipm)
-int lds_workgroups_per_cu(int N);
+int lds_workgroups_per_cu(const KernelArgs &k);
+size_t lds_q4_pws_doubles_per_slot();
+bool lds_q4_enabled();
+int lds_q4_set_min_batch(int min_b); // (frp_nmpc_set_q4_min_batch)
+void lds_q4_pin_for_batch(int B);    // B > 0: launches decide as a launch of B problems would, until the next call with 0 (frp_nmpc_solve_batch_host's chunks)
 bool lds_kernel_supports(int N, int MF);
 hipError_t launch_ipm_lds(const KernelArgs &k, int slots, hipStream_t stream);
 hipError_t launch_stage_eval(int B, int N, int M, int model, const double *z, const double *params, double *f,

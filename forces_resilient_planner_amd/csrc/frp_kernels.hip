@@ -16,6 +16,7 @@
 #include "frp_kernels.h"
 #include "frp_device.hpp"
 #include <cstdlib>
+#include <cstdint>
 #include <cstdio>
 
 namespace frp {
@@ -328,13 +329,31 @@ __global__ __launch_bounds__(64) void stage_eval_kernel(int B, int N, int M, int
 }
 
 // ------------------------------------------------------------------ launchers
-// workspace = [work-queue counter, 256 B][per-CU arrival counters, 8 KB][keys: B doubles][order: B ints]
-// (the solver's per-iteration state lives in LDS and registers: nothing per problem in HBM)
+// workspace = [work-queue counter, 256 B][per-CU arrival counters, 8 KB][keys: B doubles][order: B ints][packed P of the resident
+// workgroups of the Q4 solver variants: 20 x 92 doubles each -- 15 MB for the 1024 workgroups of a full chip, L2-resident]
+// (the rest of the solver's per-iteration state lives in LDS and registers: nothing per problem in HBM)
 constexpr int QUEUE_RESERVED = 32 + CU_SLOT_ENTRIES / 2; // doubles
+static int resident_cap(int per_cu)
+{
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int cap = cus * per_cu;
+    if (const char *e = getenv("FRP_RESIDENT_SLOTS")) { // tuning knob
+        const int v = atoi(e);
+        if (v > 0) cap = v;
+    }
+    return cap;
+}
+static bool q4_shape(int N, int MF) { return lds_q4_enabled() && N <= 20 && MF <= 6; } // (frp_ipm_lds.hip: q4_covers also looks at the options)
+static size_t pws_doubles(int B, int N, int MF)
+{
+    if (!q4_shape(N, MF)) return 0;
+    const int cap = resident_cap(4);
+    return (size_t)(B <= cap ? B : cap) * lds_q4_pws_doubles_per_slot() + 16; // (+ 128 bytes: the blocks start on a cache line)
+}
 size_t ws_bytes(int B, int N, int MF)
 {
-    (void)N; (void)MF;
-    return (QUEUE_RESERVED + (size_t)B + ((size_t)B + 1) / 2) * sizeof(double);
+    return (QUEUE_RESERVED + (size_t)B + ((size_t)B + 1) / 2 + pws_doubles(B, N, MF)) * sizeof(double);
 }
 
 __global__ void reset_counter_kernel(int *counter, int *cu_slots)
@@ -343,15 +362,9 @@ __global__ void reset_counter_kernel(int *counter, int *cu_slots)
     for (int i = threadIdx.x; i < CU_SLOT_ENTRIES; i += blockDim.x) cu_slots[i] = 0;
 }
 
-static int lds_resident_slots(int B, int N)
+static int lds_resident_slots(int B, const KernelArgs &k)
 {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    int cap = cus * lds_workgroups_per_cu(N);
-    if (const char *e = getenv("FRP_RESIDENT_SLOTS")) { // tuning knob
-        const int v = atoi(e);
-        if (v > 0) cap = v;
-    }
+    const int cap = resident_cap(lds_workgroups_per_cu(k));
     // every resident workgroup is used: the queue is pulled dynamically, so evening the slots over the "rounds" of the batch
     // (what the single-wave kernel does) only lowers the residency -- measured 1.58 vs 1.71 ms at B = 4096 (768 vs 683)
     return B <= cap ? B : cap;
@@ -424,8 +437,13 @@ hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
 {
     if (!lds_kernel_supports(a.N, a.MF)) return hipErrorInvalidValue; // (fill_args rejects these before they get here)
     KernelArgs k = a;
-    const int slots = lds_resident_slots(a.B, a.N);
     double *q = a.ws;
+    k.pws = nullptr;
+    if (q4_shape(a.N, a.MF)) {
+        const uintptr_t p = reinterpret_cast<uintptr_t>(q + QUEUE_RESERVED + (size_t)a.B + ((size_t)a.B + 1) / 2);
+        k.pws = reinterpret_cast<double *>((p + 127) & ~(uintptr_t)127);
+    }
+    const int slots = lds_resident_slots(a.B, k);
     k.counter = reinterpret_cast<int *>(q);
     k.cu_slots = reinterpret_cast<int *>(q + 32);
     k.order = nullptr;

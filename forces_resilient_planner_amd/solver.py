@@ -126,7 +126,7 @@ EXPORTS = ["frp_nmpc_default_options", "frp_nmpc_workspace_bytes", "frp_nmpc_sol
            "frp_nmpc_corridor_batch", "frp_nmpc_reference_batch",
            "frp_nmpc_coldstart_batch", "frp_nmpc_cloud_grid_build",
            "frp_nmpc_mode_batch", "frp_nmpc_astar_batch", "frp_nmpc_astar_workspace_bytes",
-           "frp_nmpc_kernel_timing_begin", "frp_nmpc_kernel_timing_end"]
+           "frp_nmpc_kernel_timing_begin", "frp_nmpc_kernel_timing_end", "frp_nmpc_set_q4_min_batch"]
 
 _lib = None
 
@@ -155,6 +155,7 @@ def lib():
         l.frp_nmpc_time_solve.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(Options), ctypes.c_void_p,
                                           ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         l.frp_nmpc_solve_batch_host.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(Options)]
+        l.frp_nmpc_set_q4_min_batch.argtypes = [ctypes.c_int]
         l.frp_nmpc_kernel_timing_begin.argtypes = [ctypes.c_int, ctypes.c_int]
         l.frp_nmpc_kernel_timing_end.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
         l.frp_nmpc_pack_batch.argtypes = [ctypes.POINTER(Pack), ctypes.c_void_p]

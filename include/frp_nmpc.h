@@ -164,6 +164,13 @@ int frp_nmpc_time_solve(const frp_nmpc_batch *batch, const frp_nmpc_options *opt
 int frp_nmpc_kernel_timing_begin(int max_launches, int stride);
 int frp_nmpc_kernel_timing_end(float *avg_ms, int *launches);
 
+/* Tuning / test hook: launches of the plain solve with N <= 20 and at most 6 corridor rows per stage run on the
+ * four-problems-per-CU kernel variants (three-wavefront workgroups) when they hold MORE than `min_batch` problems;
+ * below that a problem has a CU nearly to itself and the four-wavefront variants iterate faster.  Default (and `min_batch` < 0):
+ * three workgroups per CU of the current device.  0 puts every covered launch on the four-per-CU variants (the parity tests
+ * do that at their small batch sizes).  Returns the previous value.  Process-global. */
+int frp_nmpc_set_q4_min_batch(int min_batch);
+
 /* ---- (3) SURVEY 8f row f-1: the adapter's packing / result bookkeeping on the device (all pointers DEVICE) ---- */
 typedef struct frp_nmpc_pack {
     int B, N, M;   /* problems, horizon, corridor rows of the parameter layout (num_const, nmpc_utils.h:50)      */

@@ -20,6 +20,33 @@ from . import oracle_lib as OL
 
 pytestmark = pytest.mark.gpu
 
+# The launches the four-problems-per-CU kernel variants cover (plain solve, N <= 20, at most 6 corridor rows per stage) go to them only
+# beyond three resident workgroups per CU worth of problems (frp_nmpc_set_q4_min_batch); the tests below run twice, the second time with
+# that threshold at zero, so that both sets of variants see every case at the tests' batch sizes.
+TWICE = {"test_dropin_abi_config0_known_answers", "test_batch_matches_oracle", "test_batch_matches_scipy_fixtures",
+         "test_hip_path_converges_on_the_hard_family_at_default_options", "test_gauss_newton_mode_matches_oracle",
+         "test_iteration_limit_returns_maxit_and_the_last_iterate", "test_indefinite_cost_reports_factorization_error",
+         "test_more_faces_than_workspace_is_a_parameter_error", "test_infeasible_corridor_reports_failure_not_nan",
+         "test_padding_detection_without_face_counts", "test_receding_horizon_warm_start_matches_oracle",
+         "test_horizon_lengths_cover_every_lane_mapping", "test_every_kernel_variant_reports_the_oracles_numbers",
+         "test_queue_order_hint_changes_the_order_and_nothing_else", "test_gpu_plans_satisfy_reference_kkt_measured_with_reference_callbacks",
+         "test_per_problem_model_equals_two_single_model_batches", "test_receding_horizon_on_device_matches_host_loop",
+         "test_full_tick_replayed_from_a_hipgraph_equals_eager_launches", "test_twist_outside_its_range_is_the_plain_solve"}
+
+
+@pytest.fixture
+def kernel_set(request):
+    q4 = request.param == "q4"
+    old = solver.lib().frp_nmpc_set_q4_min_batch(0 if q4 else -1)
+    yield request.param
+    solver.lib().frp_nmpc_set_q4_min_batch(old)
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.function.__name__ in TWICE:
+        metafunc.fixturenames.append("kernel_set")
+        metafunc.parametrize("kernel_set", ["3cu", "q4"], indirect=True)
+
 
 def _stage_class(st):
     return 0 if st == 0 else (2 if st == 19 else 1)

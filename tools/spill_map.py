@@ -10,7 +10,7 @@ with tempfile.TemporaryDirectory() as d:
                     "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={d}/dev.co"], check=True)
     lines = subprocess.run([f"{L}/llvm-objdump", "-d", f"{d}/dev.co"], capture_output=True, text=True).stdout.split("\n")
 start = [i for i, l in enumerate(lines) if want in l and l.endswith(">:")][0]
-end = [i for i, l in enumerate(lines) if i > start and l.endswith(">:")][0]
+end = ([i for i, l in enumerate(lines) if i > start and l.endswith(">:")] + [len(lines)])[0]
 n = ld = st = 0; tot = 0
 for l in lines[start + 1:end]:
     t = l.strip().split()
