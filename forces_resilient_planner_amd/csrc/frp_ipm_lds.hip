@@ -1710,6 +1710,9 @@ __device__ __forceinline__ void model_phase3(ldouble *recs, ldouble *xs, ModelSt
     if (dyn) {
         const double *w = z, T = z[3], *pp = z + 8, *v = z + 11, *e = z + 14;
         double et[3], a1[3];
+        // (three-wave workgroups: the model wave is short of registers -- the external force comes from the workgroup scratch, where
+        // the Hessian lanes read it too, instead of six registers of persistent state)
+        const double fx[3] = {QW ? xs[X_FEXT + k] : st.fext[0], QW ? xs[X_FEXT + NP + k] : st.fext[1], QW ? xs[X_FEXT + 2 * NP + k] : st.fext[2]};
 #pragma unroll
         for (int i = 0; i < 3; i++) et[i] = e[i] + DT * w[i];
         trig_shared(rec + RX_MTRIG, sub, e, et, t1, t2);
@@ -1717,13 +1720,13 @@ __device__ __forceinline__ void model_phase3(ldouble *recs, ldouble *xs, ModelSt
         a1s = T * (1.0 / MASS) + DRAG * dot3(zb1, v);
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            a1[i] = a1s * zb1[i] - DRAG * v[i] + st.fext[i] - (i == 2 ? GRAV : 0.0);
+            a1[i] = a1s * zb1[i] - DRAG * v[i] + fx[i] - (i == 2 ? GRAV : 0.0);
             vt[i] = v[i] + DT * a1[i];
         }
         a2s = T * (1.0 / MASS) + DRAG * dot3(zb2, vt);
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            const double a2 = a2s * zb2[i] - DRAG * vt[i] + st.fext[i] - (i == 2 ? GRAV : 0.0);
+            const double a2 = a2s * zb2[i] - DRAG * vt[i] + fx[i] - (i == 2 ? GRAV : 0.0);
             xn[i] = pp[i] + 0.5 * DT * (v[i] + vt[i]);
             xn[3 + i] = v[i] + 0.5 * DT * (a1[i] + a2);
             xn[6 + i] = et[i];
@@ -2044,21 +2047,45 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     // of the sweeps, and that wave runs at low priority), against 7.1 / 3.2 / 2.2 k of the four-wave split.
     // The element-wise partial results are published per wave in X_RED and combined by everybody in the fixed order (WB, WF);
     // WEQ = the row the model wave publishes the equality norm in.
-#ifndef FRP_Q4_FWAVE // Q4: the wave that owns the corridor rows (1 = with the model, 2 = with the bound rounds)
+#ifndef FRP_Q4_FWAVE // Q4: the wave that owns the corridor rows (0 = the Riccati wave, 1 = the model wave, 2 = the wave of the bound rounds)
 #define FRP_Q4_FWAVE 1
 #endif
-    constexpr int WB = 2, WF = QW ? 1 : 3, WEQ = QW ? 3 : 1;                   // (WB, WF: the two rows of partial results)
+#ifndef FRP_Q4_RM // Q4: bound rounds on the model wave (the LAST ones: rows 15, 16 carry no rate coupling and need two cost parameters)
+#define FRP_Q4_RM 0
+#endif
+    constexpr int WEQ = QW ? 3 : 1;
     constexpr bool IS_M = wave == 1, IS_F = wave == (QW ? FRP_Q4_FWAVE : 3);   // model; corridor rows
-    constexpr bool IS_B = wave == WB || wave == WF;                            // publishes element-wise partial results (bound rounds and / or corridor rows)
+    // CONTRIB(w): wave w owns bound rounds and / or corridor rows and publishes element-wise partial results
+    auto contrib = [](int w) constexpr { return QW ? (w == 2 || w == FRP_Q4_FWAVE || (w == 1 && FRP_Q4_RM > 0)) : (w == 2 || w == 3); };
+    constexpr bool IS_B = contrib(wave);
     constexpr bool IS_BO = IS_B && !IS_F;                                      // ... bound rounds only
     static_assert(!QP || (NP == 20 && !TW), "P in global memory: the y+ rows are dealt over the three lanes of a stage");
     static_assert(!QW || (NP == 20 && !TW && FREG && wave < 3), "Q4: the three-lanes-per-stage model phase, plain solve, rows in registers");
     const int lane = threadIdx.x & 63;
     const int N = a.N, M = a.M, MF = a.MF, np = NPRE + 4 * M;
     ldouble *recs = sh.recs, *xs = sh.xs;
-    auto rmax = [&](int slot) { return fmax(red(xs, WB, slot), red(xs, WF, slot)); };
-    auto rmin = [&](int slot) { return fmin(red(xs, WB, slot), red(xs, WF, slot)); };
-    auto rsum = [&](int slot) { return red(xs, WB, slot) + red(xs, WF, slot); };
+    // combined by every wave in the fixed order 2, 3 (plain) / 2, 1, 0 (Q4, the waves that contribute)
+    auto rmax = [&](int slot) {
+        double v = red(xs, 2, slot);
+        if constexpr (contrib(3)) v = fmax(v, red(xs, 3, slot));
+        if constexpr (contrib(1)) v = fmax(v, red(xs, 1, slot));
+        if constexpr (contrib(0)) v = fmax(v, red(xs, 0, slot));
+        return v;
+    };
+    auto rmin = [&](int slot) {
+        double v = red(xs, 2, slot);
+        if constexpr (contrib(3)) v = fmin(v, red(xs, 3, slot));
+        if constexpr (contrib(1)) v = fmin(v, red(xs, 1, slot));
+        if constexpr (contrib(0)) v = fmin(v, red(xs, 0, slot));
+        return v;
+    };
+    auto rsum = [&](int slot) {
+        double v = red(xs, 2, slot);
+        if constexpr (contrib(3)) v += red(xs, 3, slot);
+        if constexpr (contrib(1)) v += red(xs, 1, slot);
+        if constexpr (contrib(0)) v += red(xs, 0, slot);
+        return v;
+    };
     double *pws = nullptr; // Q4: this workgroup's NP blocks of packed P in global memory
     if constexpr (QP) pws = uni(a.pws + (size_t)blockIdx.x * (NP * PG));
     const int tw_m = TW ? uni(a.twist) : 0; // (validated by the launcher: 2 <= tw_m <= N - 2)
@@ -2111,6 +2138,9 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 #pragma unroll
     for (int t = 0; t < FL; t++) { fa0[t] = fa1[t] = fa2[t] = fbb[t] = 0.0; fs[t] = fl_[t] = 1.0; fcr[t] = 0.0; }
     fpos[0] = fpos[1] = fpos[2] = 0.0;
+    // (corridor rows on the model wave: the position is z[8..10] of that wave's own state -- updated by the same operations -- not a copy)
+    constexpr bool FPZ = IS_M && IS_F;
+    double *const fpq = FPZ ? ms.z + 8 : fpos;
 
     // face t of this lane is row j = t * H + half of its stage; its constants come from registers or from the parameters
     // (re-reading variants: two per-lane base pointers -- row `half` of A and of b -- made opaque once per phase by face_bases(),
@@ -2183,9 +2213,6 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 #endif
     constexpr int RSPLIT0 = R - (FL <= 2 ? R / 3 : (FL <= 5 ? R / 6 : 0));
     constexpr int RSPLIT = RSPLIT0 + FRP_RSPLIT_ADJ <= R ? RSPLIT0 + FRP_RSPLIT_ADJ : R;
-#ifndef FRP_Q4_RM // Q4: bound rounds on the model + faces wave (the LAST ones: rows 15, 16 carry no rate coupling and need two cost parameters)
-#define FRP_Q4_RM 0
-#endif
     constexpr int RQ = R - FRP_Q4_RM;
     constexpr int RB0 = QW ? (wave == 1 ? RQ : 0) : (IS_F ? RSPLIT : 0), RB1 = QW ? (wave == 1 ? R : RQ) : (IS_F ? R : RSPLIT);
     // evaluation: residuals, barrier Hessian / predictor rhs of this wave's bound rows -> record; norms
@@ -2318,7 +2345,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             if (nf > MF || nf < 0 || nf > FL * H) { bad_param = 1; nf = 0; }
             if (half == 0) mcount = 34 + nf;
             const double *z0 = a.x0 + ((size_t)b * N + k) * NZ;
-            fpos[0] = z0[8]; fpos[1] = z0[9]; fpos[2] = z0[10];
+            if constexpr (!FPZ) { fpos[0] = z0[8]; fpos[1] = z0[9]; fpos[2] = z0[10]; }
 #pragma unroll
             for (int t = 0; t < FL; t++) {
                 const int j = t * H + half;
@@ -2326,7 +2353,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                     const double a0 = pk[NPRE + 3 * j], a1 = pk[NPRE + 3 * j + 1], a2 = pk[NPRE + 3 * j + 2];
                     const double bb = pk[NPRE + 3 * M + j] + HU;
                     if (FREG) { fa0[t] = a0; fa1[t] = a1; fa2[t] = a2; fbb[t] = bb; }
-                    fs[t] = -(a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb);
+                    fs[t] = -(a0 * fpq[0] + a1 * fpq[1] + a2 * fpq[2] - bb);
                     smin = fmin(smin, fs[t]);
                 }
             }
@@ -2399,8 +2426,11 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 #endif
     constexpr int FWD_P = NP == 20 ? FRP_FWD_WAVE_P : 0, FWD_C = NP == 20 ? FRP_FWD_WAVE_C : 0;
     PROF_DECL();
+    // (Q4 with the corridor rows on the Riccati wave: that wave runs its element-wise phases at the helpers' priority, the sweeps at its own)
+    constexpr bool W0H = QW && wave == 0 && IS_F;
     for (it = 0;;) {
         // ============================================================ evaluation phase
+        if constexpr (W0H) __builtin_amdgcn_s_setprio(FRP_H_PRIO);
         if constexpr (wave == 0) {
             if (hact) {
                 HessState hs; // the model wave's values before the last step + the step
@@ -2444,7 +2474,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             if (kact) {
                 face_bases();
                 for_faces([&](int t, double a0, double a1, double a2, double bb) __attribute__((always_inline)) {
-                    const double hj = a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb;
+                    const double hj = a0 * fpq[0] + a1 * fpq[1] + a2 * fpq[2] - bb;
                     const double sc = fs[t], lc = fl_[t];
                     const double rc = hj + sc;
                     l_in = fmax(l_in, fmax(hj, fabs(rc)));
@@ -2490,6 +2520,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         }
 
         // ============================================================ predictor: factorisation + forward sweep
+        if constexpr (W0H) __builtin_amdgcn_s_setprio(FRP_R_PRIO);
         if constexpr (TW) {
             // the two halves side by side; the Riccati wave factors and solves the meeting system; both continue from ds_m, outwards
             TW_T0();
@@ -2568,6 +2599,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         }
 
         // ============================================================ affine step: lengths, second-order term, corrector rhs
+        if constexpr (W0H) __builtin_amdgcn_s_setprio(FRP_H_PRIO);
         if constexpr (IS_BO) {
             double m_p = 0.0, m_d = 0.0, s_sdl = 0.0, s_lds = 0.0, s_dsdl = 0.0;
             bounds_affine(m_p, m_d, s_sdl, s_lds, s_dsdl);
@@ -2584,7 +2616,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 face_bases();
                 for_faces([&](int t, double a0, double a1, double a2, double bb) __attribute__((always_inline)) {
                     const double s = fs[t], l = fl_[t];
-                    const double gdz = a0 * d8 + a1 * d9 + a2 * d10, viol = a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb;
+                    const double gdz = a0 * d8 + a1 * d9 + a2 * d10, viol = a0 * fpq[0] + a1 * fpq[1] + a2 * fpq[2] - bb;
                     const double u = fast_rcp(s * l);
                     const double sinv = u * l, linv = u * s;
                     const double rin = viol + s;
@@ -2639,6 +2671,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         // (FRP_QP_YWAVE = 2; the default is the Riccati wave, which fetches at the start of the step phase: the bounds wave has no
         // room for 32 more registers between the barriers D and F -- 310 spilled VGPRs instead of 126)
         if constexpr (wave == WY && WY != 0 && QP) fetch_sx();
+        if constexpr (W0H) __builtin_amdgcn_s_setprio(FRP_R_PRIO);
 
         // ============================================================ corrector: vector backward sweep + forward sweep with y+
         if constexpr (TW) {
@@ -2678,6 +2711,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         BAR_P(3); // ------------------------------------------------------------- E
 
         // ============================================================ step: pass A (ratios), pass B (commit)
+        if constexpr (W0H) __builtin_amdgcn_s_setprio(FRP_H_PRIO);
         double m_p = 0.0, m_d = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0; // q: sums of ds l, s dl, ds dl
         double dzf[3];                            // wave 3: dz of pos (the commit reads every dz from the record again: nothing is carried across barrier F)
         // one constraint of the corrector step
@@ -2754,7 +2788,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                     for (int g = 0; g < 4; g++) rec[R_D + g] = yw[g];
                 }
             }
-            if constexpr (WY == 0) __builtin_amdgcn_s_setprio(FRP_R_PRIO);
+            if constexpr (WY == 0 && !W0H) __builtin_amdgcn_s_setprio(FRP_R_PRIO);
         }
         if constexpr (wave == 1 && QP) {
             if (own0) { // the values before the step, for the Hessian lanes (T' slots the y+ lanes do not read)
@@ -2830,7 +2864,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 for_faces([&](int t, double a0, double a1, double a2, double bb) __attribute__((always_inline)) {
                     double ds, dl;
                     cstep(fs[t], fl_[t], fcr[t], a0 * dzf[0] + a1 * dzf[1] + a2 * dzf[2],
-                          a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb, ds, dl);
+                          a0 * fpq[0] + a1 * fpq[1] + a2 * fpq[2] - bb, ds, dl);
                 });
             }
         }
@@ -2857,15 +2891,6 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 s = sn; l = ln;
             };
             hap = ap;
-            if constexpr (wave == 1) {
-                if (kact) { // (the Newton step is valid until the next predictor's forward sweep, y+ until this wave's next model phase)
-                    cldouble *rec = recs + k * RS;
-#pragma unroll
-                    for (int i = 0; i < NZ; i++) ms.z[i] += ap * rec[R_DZ + i];
-#pragma unroll
-                    for (int i = 0; i < NS; i++) ms.y[i] += ap * (rec[R_D + i] - ms.y[i]); // y <- y + ap (y+ - y)
-                }
-            }
             if constexpr (IS_B) {
         const int halfp = opq(half);
 #pragma unroll
@@ -2890,9 +2915,19 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 }
                 face_bases();
                 for_faces([&](int t, double a0, double a1, double a2, double bb) __attribute__((always_inline)) {
-                    commit(fs[t], fl_[t], fcr[t], a0 * dzf[0] + a1 * dzf[1] + a2 * dzf[2], a0 * fpos[0] + a1 * fpos[1] + a2 * fpos[2] - bb);
+                    commit(fs[t], fl_[t], fcr[t], a0 * dzf[0] + a1 * dzf[1] + a2 * dzf[2], a0 * fpq[0] + a1 * fpq[1] + a2 * fpq[2] - bb);
                 });
-                fpos[0] += ap * dzf[0]; fpos[1] += ap * dzf[1]; fpos[2] += ap * dzf[2];
+                if constexpr (!FPZ) { fpos[0] += ap * dzf[0]; fpos[1] += ap * dzf[1]; fpos[2] += ap * dzf[2]; }
+            }
+            // (the iterate last: the corridor rows of the same wave take their violation from the position BEFORE the step)
+            if constexpr (wave == 1) {
+                if (kact) { // (the Newton step is valid until the next predictor's forward sweep, y+ until this wave's next model phase)
+                    cldouble *rec = recs + k * RS;
+#pragma unroll
+                    for (int i = 0; i < NZ; i++) ms.z[i] += ap * rec[R_DZ + i];
+#pragma unroll
+                    for (int i = 0; i < NS; i++) ms.y[i] += ap * (rec[R_D + i] - ms.y[i]); // y <- y + ap (y+ - y)
+                }
             }
         }
         it++;

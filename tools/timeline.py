@@ -22,7 +22,7 @@ print("  active solves over time:", " ".join(f"{t}us:{active(t)}" for t in range
 last = np.argsort(-en)[:8]
 for b in last:
     print(f"  problem {b}: start {st[b]:.0f} end {en[b]:.0f} its {it[b]} -> {1e3 * (en[b] - st[b]) / max(it[b], 1):.0f} ns/iter")
-slots = 768
+slots = 768 if os.environ.get("FRP_Q4") == "0" else 1024
 idle = sum(max(0.0, en.max() - t) for t in sorted(en)[-slots:])  # slot-time between a slot's last solve and the end of the launch
 print(f"  slot-time idle at the end of the launch: {idle / (slots * en.max()):.3f} of the launch; busy time per slot {((en - st).sum() / slots):.0f} us")
 dur = (en - st) / np.maximum(it, 1)
