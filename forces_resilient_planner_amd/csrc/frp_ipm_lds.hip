@@ -515,6 +515,11 @@ __device__ __forceinline__ void gst(const double *base, unsigned boff, double v)
 #else
 #define FRP_FACTOR_LINKAGE __noinline__
 #endif
+#ifdef FRP_INLINE_SWEEPS // (the vector sweeps too)
+#define FRP_SWEEP_LINKAGE __forceinline__
+#else
+#define FRP_SWEEP_LINKAGE __noinline__
+#endif
 // twist (second half of a twisted solve: `recs` is the record of the meeting stage, N the stages from there to the end): the stage-0
 // tail is replaced by publishing p of the meeting stage (column 13 of the tile) in its R_PV slots.
 template <bool twist>
@@ -836,7 +841,7 @@ __device__ __forceinline__ void back_tail(const BackAddr &p, BackOps &X, BackOps
 }
 
 template <bool twist>
-__device__ __noinline__ void sweep_backvec(ldouble *recs, ldouble *xs, int N, double smu)
+__device__ FRP_SWEEP_LINKAGE void sweep_backvec(ldouble *recs, ldouble *xs, int N, double smu)
 {
     N = uni(N); smu = uni(smu);
     const int lane = threadIdx.x & 63, a = lane >> 4, b = (lane >> 2) & 3;
@@ -958,7 +963,7 @@ __device__ __forceinline__ void fwd_tail(const FwdAddr &p, FwdOps &X, FwdOps &Y,
     }
 }
 
-__device__ __noinline__ void sweep_forward(ldouble *recs, ldouble *xs, int N)
+__device__ FRP_SWEEP_LINKAGE void sweep_forward(ldouble *recs, ldouble *xs, int N)
 {
     N = uni(N);
     const int lane = threadIdx.x & 63, a = lane >> 4, b = (lane >> 2) & 3;
@@ -2016,12 +2021,19 @@ __device__ __noinline__ int count_live_faces(const double *pk, int M)
 struct Shared {
     ldouble *recs, *xs, *tw;
     Ctl *ctl;
+    int cukey; // this workgroup's CU in the per-CU words of the workspace (KernelArgs::cu_slots), or -1
 };
 
 // The next problem of this workgroup: queue position from the device counter, mapped through the launch order (longest
 // expected solve first, see order_keys_kernel) by the one lane that claims it; a.B = the queue is exhausted.
-__device__ __forceinline__ int claim_next(const KernelArgs &a)
+// Q4 variants: a solve that reaches iteration a.iso_it has marked its CU (bits 8.. of the CU's word count such solves); the other
+// workgroups of that CU finish the solves they have and wait here -- a problem alone on a CU iterates a quarter faster, and the launch
+// ends with its longest solve.  (The marked solve itself never waits: it takes its mark back before it claims.)
+__device__ __forceinline__ int claim_next(const KernelArgs &a, int cukey = -1)
 {
+    if (QW && cukey >= 0 && a.iso_it > 0) {
+        while (__hip_atomic_load(a.cu_slots + cukey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 256) __builtin_amdgcn_s_sleep(64);
+    }
     const int p = atomicAdd(a.counter, 1);
     if (p >= a.B) return a.B;
     return a.order ? a.order[p] : p;
@@ -2370,7 +2382,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     BAR();
     const int mtot = sh.ctl->mtot;
     if (sh.ctl->bad) { // a stage has more live corridor rows than the caller sized the problem for (MF)
-        if (wave == 0 && lane == 0) { sh.ctl->next = claim_next(a); a.exitflag[b] = FRP_EXIT_PARAM_VALUE; a.iters[b] = 0; }
+        if (wave == 0 && lane == 0) { sh.ctl->next = claim_next(a, sh.cukey); a.exitflag[b] = FRP_EXIT_PARAM_VALUE; a.iters[b] = 0; }
         if (wave == 1 && own0) {
             double *zo = a.z + ((size_t)b * N + k) * NZ;
 #pragma unroll
@@ -2398,6 +2410,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 
     const double inv_kmtot = 1.0 / (KAPPA_LAM * (double)mtot);
     int flag = FRP_EXIT_MAXIT, it = 0, nfallback = 0;
+    bool iso_mine = false; // (Riccati wave) this solve holds a mark on its CU
     double theta_h = hess ? 1.0 : 0.0; // weight of the dynamics Hessian
     bool gn_retry = false;              // this iteration is being redone with the Gauss-Newton Hessian
     Norms nm = {0, 0, 0, 0, 0, 0};
@@ -2517,6 +2530,17 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             if (nm.eq <= a.tol_eq && nm.in <= a.tol_ineq && nm.rs <= a.tol_stat && nm.rc <= a.tol_comp) { flag = FRP_EXIT_OPTIMAL; break; }
             if (it >= a.maxit) { flag = FRP_EXIT_MAXIT; break; }
             if (mu > a.diverge_mu * fmax(1.0, a.mu0) || nm.rs > DIVERGE_RS) { flag = FRP_EXIT_NOPROGRESS; break; }
+        }
+        if constexpr (QW && wave == 0) { // a long solve: it takes the CU for itself (see claim_next)
+            if (it == a.iso_it && a.iso_it > 0 && sh.cukey >= 0 && !iso_mine) {
+                int got = 0;
+                if (lane == 0) {
+                    got = atomicAdd(a.counter + 1, 1) < a.iso_cap;
+                    if (got) atomicAdd(a.cu_slots + sh.cukey, 256);
+                    else atomicSub(a.counter + 1, 1);
+                }
+                iso_mine = uni(__shfl(got, 0)) != 0;
+            }
         }
 
         // ============================================================ predictor: factorisation + forward sweep
@@ -2938,7 +2962,10 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     __builtin_amdgcn_s_setprio(0);
     // the next problem is claimed only now (its latency hides behind the write-out): a slot that claimed it while it still
     // had a solve ahead of it would keep it from the slots that go idle at the end of the launch
-    if (wave == 0 && lane == 0) sh.ctl->next = claim_next(a); // (two dependent global round trips, under the model wave's write-out)
+    if constexpr (QW && wave == 0) { // (a long solve gives its CU back first)
+        if (iso_mine && lane == 0) { atomicSub(a.cu_slots + sh.cukey, 256); atomicSub(a.counter + 1, 1); }
+    }
+    if (wave == 0 && lane == 0) sh.ctl->next = claim_next(a, sh.cukey); // (two dependent global round trips, under the model wave's write-out)
     if constexpr (wave == 1) {
         // the objective is reported, not iterated on: evaluated once, at the returned iterate
         double l_obj = 0.0;
@@ -2978,7 +3005,7 @@ template <int NP, int FL, bool FREG, int ROLE, bool TW>
 __device__ __forceinline__ void role_loop(const KernelArgs &a, const Shared &sh)
 {
     // (solve_one claims the next problem when it leaves its iteration)
-    if (ROLE == 0 && (threadIdx.x & 63) == 0) sh.ctl->next = claim_next(a);
+    if (ROLE == 0 && (threadIdx.x & 63) == 0) sh.ctl->next = claim_next(a, sh.cukey);
     for (;;) {
         BAR();
         const int b = sh.ctl->next;
@@ -2999,7 +3026,7 @@ __global__ __launch_bounds__(QW ? 192 : 256) __attribute__((amdgpu_waves_per_eu(
     __shared__ int s_place[5];
     static_assert(!TW || NP == 20, "the twisted solve is built on the three-lanes-per-stage model phase");
     Shared sh;
-    sh.recs = (ldouble *)s_recs; sh.xs = (ldouble *)s_xs; sh.tw = (ldouble *)s_tw; sh.ctl = &s_ctl;
+    sh.recs = (ldouble *)s_recs; sh.xs = (ldouble *)s_xs; sh.tw = (ldouble *)s_tw; sh.ctl = &s_ctl; sh.cukey = -1;
     if (TW && threadIdx.x == 0) { s_tw[TW_DUMP] = 0.0; s_tw[TW_ZERO] = 0.0; s_ctl.fail1 = 0; s_ctl.fail2 = 0; }
     if (threadIdx.x == 0) { s_xs[X_C0] = 0.0; s_xs[X_C1] = 1.0; }
     // ---- which wave plays which role.  A wavefront stays on the SIMD it was launched on, and one wavefront of every
@@ -3026,11 +3053,12 @@ __global__ __launch_bounds__(QW ? 192 : 256) __attribute__((amdgpu_waves_per_eu(
             const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
             const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
             const int simd = (int)((hw >> 4) & 3u);
+            const unsigned key = ((xcc & 7u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+            sh.cukey = (int)__builtin_amdgcn_readfirstlane(key); // (every wave of a workgroup sits on the same CU)
             if ((threadIdx.x & 63) == 0) s_place[widx] = simd;
             __syncthreads();
             const int s0 = s_place[0], s1 = s_place[1], s2 = s_place[2];
             if (threadIdx.x == 0) {
-                const unsigned key = ((xcc & 7u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
                 int rs = -1;
                 if (s0 != s1 && s0 != s2 && s1 != s2) {
                     const int cand[3] = {s0, s1, s2};

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(1024) void order_bucket_kernel(int B, const double 
     __shared__ unsigned long long w_lo[16], w_hi[16];
     __shared__ int hist[1024], wtot[16];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    if (t == 0) *counter = 0; // queue head of the solve that follows on this stream
+    if (t == 0) { counter[0] = 0; counter[1] = 0; } // queue head of the solve that follows on this stream; CUs its long solves have to themselves
     for (int i = t; i < CU_SLOT_ENTRIES; i += 1024) cu_slots[i] = 0;
     hist[t] = 0;
     constexpr int KR = 4; // keys per thread held in registers
@@ -358,7 +358,7 @@ size_t ws_bytes(int B, int N, int MF)
 
 __global__ void reset_counter_kernel(int *counter, int *cu_slots)
 {
-    if (threadIdx.x == 0) *counter = 0;
+    if (threadIdx.x == 0) { counter[0] = 0; counter[1] = 0; }
     for (int i = threadIdx.x; i < CU_SLOT_ENTRIES; i += blockDim.x) cu_slots[i] = 0;
 }
 
@@ -446,6 +446,12 @@ hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
     const int slots = lds_resident_slots(a.B, k);
     k.counter = reinterpret_cast<int *>(q);
     k.cu_slots = reinterpret_cast<int *>(q + 32);
+    // Long solves get their CU to themselves (frp_ipm_lds.hip, Q4 variants): from iteration `iso_it` on the other workgroups of the CU
+    // finish what they have and wait -- the launch ends with its longest solve, and a solve alone on a CU iterates a quarter faster.
+    // At most `iso_cap` CUs at a time (a workload of long solves must not idle the chip).  FRP_ISO_IT=0 switches it off.
+    static const int iso_env = [] { const char *e = getenv("FRP_ISO_IT"); return e ? atoi(e) : 12; }();
+    k.iso_it = a.B > 1 ? iso_env : 0;
+    k.iso_cap = resident_cap(1) / 16;
     k.order = nullptr;
     if (a.B > slots) { // more problems than resident workgroups: order the queue, longest expected solve first
         k.self_reset = 0;
