@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="the K-step region is timed this many times; the MEDIAN is reported")
     ap.add_argument("--no-order-hint", action="store_true", help="configs[4]: queue the problems by the cost of the initial guess instead of by the previous tick's iteration counts")
     ap.add_argument("--twist", type=int, default=0, help="frp_nmpc_options.twist: stages the model wave eliminates forward while the Riccati wave runs the rest backward "
-                    "(0 = the plain solve, -1 = N / 2; N <= 20 only; DESIGN 9.1)")
+                    "(0 = the plain solve, -1 = 9 N / 20 up to 1024 problems and 3 N / 10 beyond; N <= 20 only; DESIGN 9.1)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / end-to-end / drop-in latency legs")
     ap.add_argument("--chunks", type=int, default=0, help="--scaling strong: pieces every shard is cut into so that transfers overlap the solve (1 = serial scatter -> "
                     "solve -> gather; 0 = auto: 2 when there is more than one rank and a shard holds at least two rounds of resident workgroups, else 1 -- measured on "

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstring>
+#include <stdexcept>
 #include <vector>
 #include "../../include/frp_nmpc.h"
 
@@ -44,6 +45,8 @@ public:
           nfaces_((size_t)batch * v.planning_horizon, 0), output_((size_t)batch * v.planning_horizon * FRP_NZ),
           exitflag_(batch, 0), iters_(batch, 0), info_((size_t)batch * FRP_INFO_STRIDE, 0.0)
     {
+        // (this header against the library that is actually loaded: a stale library would write another info stride into info_)
+        if (FRP_NMPC_ABI_CHECK() != FRP_OK) throw std::runtime_error("frp_nmpc: header / library ABI mismatch (see stderr)");
     }
 
     // forces_normal.cpp:36-52 / forces_final.cpp:36-51 -- same weights for every problem of the batch

@@ -383,7 +383,6 @@ struct HostPipe {
     std::mutex mtx;
     bool ready = false;
     int device = -1;    // the device the streams, events and buffers below belong to (the one current at their creation)
-    bool dirty = false; // an error return left work in flight on the shared slots: drained before they are reused
     hipStream_t s_in = nullptr, s_solve = nullptr, s_out = nullptr;
     static constexpr int NSLOT = 3;
     struct Slot {
@@ -405,14 +404,13 @@ struct HostPipe {
         if (s_solve) (void)hipStreamDestroy(s_solve);
         if (s_out) (void)hipStreamDestroy(s_out);
         s_in = s_solve = s_out = nullptr;
-        ready = false; dirty = false; device = -1;
+        ready = false; device = -1;
     }
     void drain_all()
     {
         if (s_in) (void)hipStreamSynchronize(s_in);
         if (s_solve) (void)hipStreamSynchronize(s_solve);
         if (s_out) (void)hipStreamSynchronize(s_out);
-        dirty = false;
     }
     ~HostPipe() { release(); }
 };
@@ -443,7 +441,19 @@ int pipe_reserve(HostPipe::Slot &s, size_t in_bytes, size_t out_bytes, size_t ws
 
 extern "C" {
 
-const char *frp_nmpc_version(void) { return "frp_nmpc_amd 0.4 (gfx950, FP64 interior point: four wavefronts per problem, stage records in LDS)"; }
+int frp_nmpc_abi_version(void) { return FRP_NMPC_ABI_VERSION; }
+
+int frp_nmpc_abi_check(int abi_version, size_t options_bytes, size_t batch_bytes, int info_stride)
+{
+    if (abi_version == FRP_NMPC_ABI_VERSION && options_bytes == sizeof(frp_nmpc_options) && batch_bytes == sizeof(frp_nmpc_batch) && info_stride == FRP_INFO_STRIDE)
+        return FRP_OK;
+    fprintf(stderr, "[frp_nmpc] the caller was built against another frp_nmpc.h: ABI version %d (library %d), frp_nmpc_options %zu B (%zu), "
+                    "frp_nmpc_batch %zu B (%zu), info stride %d (%d)\n",
+            abi_version, FRP_NMPC_ABI_VERSION, options_bytes, sizeof(frp_nmpc_options), batch_bytes, sizeof(frp_nmpc_batch), info_stride, FRP_INFO_STRIDE);
+    return FRP_ERR_ARG;
+}
+
+const char *frp_nmpc_version(void) { return "frp_nmpc_amd 0.5 (gfx950, FP64 interior point: three / four wavefronts per problem, stage records in LDS)"; }
 
 int frp_nmpc_device_count(void)
 {
@@ -540,8 +550,7 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
         g_pipe.release();
         FRP_HIP(hipSetDevice(dev));
     }
-    if (g_pipe.ready && g_pipe.dirty) g_pipe.drain_all(); // an earlier call returned an error with copies / solves still in flight
-    struct DirtyOnError { // every early return below leaves the slots in use: mark them, the next call (or the check above) drains
+    struct DirtyOnError { // every early return below leaves the slots in use: they are drained before the error is returned
         int rc = FRP_ERR_HIP;
         ~DirtyOnError() { if (rc != FRP_OK && g_pipe.ready) { g_pipe.drain_all(); } }
     } guard;

@@ -1000,6 +1000,19 @@ __device__ FRP_SWEEP_LINKAGE void sweep_forward(ldouble *recs, ldouble *xs, int 
     WSYNC();
 }
 
+// The plain recursion as the END GAME of the twisted variants (TW_EXACT_BELOW): both sweeps of a phase behind one call
+__device__ __noinline__ int endgame_predictor(ldouble *recs, ldouble *xs, int N, double theta FRP_GP_PARAM)
+{
+    const int fr = sweep_factor<false>(recs, xs, N, theta FRP_GP_ARG(gp));
+    if (!fr) sweep_forward(recs, xs, N);
+    return fr;
+}
+__device__ __noinline__ void endgame_corrector(ldouble *recs, ldouble *xs, int N, double smu)
+{
+    sweep_backvec<false>(recs, xs, N, smu);
+    sweep_forward(recs, xs, N);
+}
+
 // ================================================================== twisted solve: the first half
 // Stages 0 .. m-1 are eliminated FORWARD by the wave that is idle during the sweeps (the model wave) while the Riccati wave runs its
 // backward recursion over stages m .. N-1: an arrival-cost recursion in information form,
@@ -2158,10 +2171,13 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     // (re-reading variants: two per-lane base pointers -- row `half` of A and of b -- made opaque once per phase by face_bases(),
     // every row of the lane then an immediate offset from them.  Left to itself the compiler keeps a 64-bit address per
     // row for the whole solve: 40 registers at ten rows per lane, i.e. 40 spills)
-    const double *pkA = pk + NPRE + 3 * half, *pkB = pk + NPRE + 3 * M + half;
+    // (the row group clamped to the last one: the lanes 3 NP .. 63 of the three-lanes-per-stage mapping are inactive, but the chunked
+    // fetch below is unconditional -- with the unclamped group their last row would lie one row behind the stage's block)
+    const int halfc = half < H ? half : H - 1;
+    const double *pkA = pk + NPRE + 3 * halfc, *pkB = pk + NPRE + 3 * M + halfc;
     auto face_bases = [&]() {
         if constexpr (!FREG) {
-            pkA = pk + NPRE + 3 * half; pkB = pk + NPRE + 3 * M + half;
+            pkA = pk + NPRE + 3 * halfc; pkB = pk + NPRE + 3 * M + halfc;
             asm volatile("" : "+v"(pkA), "+v"(pkB));
         }
     };
@@ -2411,6 +2427,14 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     const double inv_kmtot = 1.0 / (KAPPA_LAM * (double)mtot);
     int flag = FRP_EXIT_MAXIT, it = 0, nfallback = 0;
     bool iso_mine = false; // (Riccati wave) this solve holds a mark on its CU
+    // Twisted variants: the iterations are solved the twisted way only until the residuals of an iteration fall below TW_EXACT_BELOW,
+    // the ones after that (one-way switch, decided one iteration ahead) by the plain recursion
+    // (the twisted solve is an inexact Newton method -- penalty on x_0 --: the end game, and with it the accuracy of the returned point,
+    // is the plain recursion's; same rule and constant as oracle/nmpc_ipm.c).  Decided one iteration ahead because the model phase
+    // writes the first-half records in another form.
+    constexpr double TW_EXACT_BELOW = 1e-4;
+    bool tw_on = true;
+    int tw_it = tw_m; // stages eliminated forward in THIS iteration (0: the plain recursion)
     double theta_h = hess ? 1.0 : 0.0; // weight of the dynamics Hessian
     bool gn_retry = false;              // this iteration is being redone with the Gauss-Newton Hessian
     Norms nm = {0, 0, 0, 0, 0, 0};
@@ -2466,7 +2490,14 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         }
         auto model_block = [&]() __attribute__((always_inline)) {
             double l_eq;
-            if constexpr (H3) model_phase3<NP>(recs, xs, ms, N, l_eq, tw_m);
+            if constexpr (TW) { // the form of this iteration's first-half records: -dt / the B~ entry in the second zero, or dt / zero
+                if (own0 && k < tw_m) {
+                    ldouble *rec = recs + k * RS;
+                    rec[R_DT] = tw_it ? -DT : DT;
+                    if (!tw_it) rec[R_ZERO2] = 0.0;
+                }
+            }
+            if constexpr (H3) model_phase3<NP>(recs, xs, ms, N, l_eq, tw_it);
             else model_phase<NP>(recs, xs, ms, N, l_eq);
             publish(xs, WEQ, lane, 0, wave_max(l_eq));
         };
@@ -2525,6 +2556,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         nm.gap = uni(rsum(2));
         nm.rs = uni(stationarity_norm<NP>(recs, N));
         mu = uni(nm.gap * (KAPPA_LAM * inv_kmtot));
+        const bool tw_next = TW && fmax(fmax(nm.eq, nm.in), fmax(nm.rs, nm.rc)) > TW_EXACT_BELOW; // (for the NEXT iteration)
         if (!gn_retry) {
             if (!(nm.eq == nm.eq) || !(nm.rs == nm.rs) || !(nm.gap == nm.gap)) { flag = FRP_EXIT_BADFUNCEVAL; break; }
             if (nm.eq <= a.tol_eq && nm.in <= a.tol_ineq && nm.rs <= a.tol_stat && nm.rc <= a.tol_comp) { flag = FRP_EXIT_OPTIMAL; break; }
@@ -2545,7 +2577,12 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 
         // ============================================================ predictor: factorisation + forward sweep
         if constexpr (W0H) __builtin_amdgcn_s_setprio(FRP_R_PRIO);
-        if constexpr (TW) {
+        if (TW && !tw_it) { // (twisted variants, end game: the plain recursion -- behind ONE call, so that the twisted path keeps its registers)
+            if constexpr (wave == 0) {
+                const int fr = endgame_predictor(recs, xs, N, gn_retry ? 0.0 : theta_h FRP_GP_ARG(pws));
+                if (lane == 0) sh.ctl->fail = fr;
+            }
+        } else if constexpr (TW) {
             // the two halves side by side; the Riccati wave factors and solves the meeting system; both continue from ds_m, outwards
             TW_T0();
             if constexpr (wave == 0) {
@@ -2698,7 +2735,9 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         if constexpr (W0H) __builtin_amdgcn_s_setprio(FRP_R_PRIO);
 
         // ============================================================ corrector: vector backward sweep + forward sweep with y+
-        if constexpr (TW) {
+        if (TW && !tw_it) {
+            if constexpr (wave == 0) endgame_corrector(recs, xs, N, smu);
+        } else if constexpr (TW) {
             TW_T0();
             if constexpr (wave == 0) {
                 sweep_backvec<true>(recs + tw_m * RS, xs, N - tw_m, smu);
@@ -2756,7 +2795,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             double acc = rec[R_PV + i];
 #pragma unroll
             for (int j = 0; j < NS; j++) acc = fma(rec[R_P + (i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i)], rec[R_DZ + 4 + j], acc);
-            return (TW && k < tw_m) ? -acc : acc;
+            return (TW && k < tw_it) ? -acc : acc;
         };
         // QP: y+ is formed by the bounds wave alone, from its prefetched block of S_xx (registers, see the prefetch behind barrier D)
         // and from T', p, Phi_w, hc in the record -- no global memory access on the path:
@@ -2954,6 +2993,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 }
             }
         }
+        if constexpr (TW) { tw_on = tw_on && tw_next; tw_it = tw_on ? tw_m : 0; } // (one way)
         it++;
     }
 

@@ -15,6 +15,7 @@ from . import layout as L
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRP_LIB") or os.path.join(_PKG, "libfrp_nmpc_amd.so")  # FRP_LIB: an experiment build (tools/build_variant.sh)
 INFO_STRIDE = 12
+ABI_VERSION = 5  # FRP_NMPC_ABI_VERSION of include/frp_nmpc.h
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int_p = ctypes.POINTER(ctypes.c_int)
@@ -126,7 +127,8 @@ EXPORTS = ["frp_nmpc_default_options", "frp_nmpc_workspace_bytes", "frp_nmpc_sol
            "frp_nmpc_corridor_batch", "frp_nmpc_reference_batch",
            "frp_nmpc_coldstart_batch", "frp_nmpc_cloud_grid_build",
            "frp_nmpc_mode_batch", "frp_nmpc_astar_batch", "frp_nmpc_astar_workspace_bytes",
-           "frp_nmpc_kernel_timing_begin", "frp_nmpc_kernel_timing_end", "frp_nmpc_set_q4_min_batch"]
+           "frp_nmpc_kernel_timing_begin", "frp_nmpc_kernel_timing_end", "frp_nmpc_set_q4_min_batch",
+           "frp_nmpc_abi_version", "frp_nmpc_abi_check"]
 
 _lib = None
 
@@ -147,6 +149,14 @@ def lib():
         except ImportError:
             pass
         l = ctypes.CDLL(LIB_PATH)
+        # the ctypes mirrors below against the library that was actually loaded (include/frp_nmpc.h: FRP_NMPC_ABI_CHECK): a stale
+        # library would write another info stride into our arrays / read short option structs
+        if not hasattr(l, "frp_nmpc_abi_check"):
+            raise RuntimeError(f"{LIB_PATH} predates the ABI check (frp_nmpc.h ABI {ABI_VERSION}): rebuild it")
+        l.frp_nmpc_abi_check.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int]
+        if l.frp_nmpc_abi_check(ABI_VERSION, ctypes.sizeof(Options), ctypes.sizeof(Batch), INFO_STRIDE) != 0:
+            raise RuntimeError(f"{LIB_PATH} was built from another include/frp_nmpc.h than these bindings (ABI {ABI_VERSION}, "
+                               f"options {ctypes.sizeof(Options)} B, batch {ctypes.sizeof(Batch)} B, info stride {INFO_STRIDE})")
         l.frp_nmpc_workspace_bytes.restype = ctypes.c_size_t
         l.frp_nmpc_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
         l.frp_nmpc_version.restype = ctypes.c_char_p
@@ -631,10 +641,11 @@ class DeviceFleet:
         whose tick raised kino_replan_ (`replan` [B] int32, as written by references() / full_tick): a kinodynamic A* to end_pt
         [B,3] with external_acc [B,3] in the primitives, on the device (AstarPlanner = frp_nmpc_astar_batch).
         Start state as in the reference (:159-186): a planner whose last solve succeeded (solver.exitflag == 1) starts from its plan
-        interpolated at t_cur [B] seconds after the plan's start -- row floor(t_cur / Ts) towards the next one; None = 0 = the plan's
-        first row -- with the acceleration the planned thrust produces (:169-181), provided floor(t_cur / Ts) < N - 1 and t_cur >= 0;
-        every other planner starts from odom = (pos [B,3], vel [B,3]) with zero acceleration (None: the plan's stage-1 state).  The
-        repeated search after NO_PATH starts from the odometry state (:190-193).
+        interpolated at t_cur [B] seconds after the plan's start -- row floor(t_cur / Ts) towards the next one; None = the plan's
+        stage-1 row (mpc_output[:, 1], the state the tick is about to apply) -- with the acceleration the planned thrust produces (:169-181), provided floor(t_cur / Ts) < N - 1 and t_cur >= 0;
+        every other planner starts from odom = (pos [B,3], vel [B,3]) with zero acceleration.  The repeated search after NO_PATH starts
+        from the odometry state too (:190-193).  odom = None is NOT the reference's behaviour: fallback and retry then start from the
+        plan's stage-1 state (a warning is issued once); a caller that has odometry passes it.
         The planner object owns the per-planner paths (planner.kino_path / kino_size): pass them to references() / full_tick as the
         path.  Planners that found a path get time_offset = 0 (kino_start_time_ = now, :219) and go back to the normal solver (:218).
         Returns the mask (bool [B]) of planners that received a new path.  Everything here -- the state gather, the search, the
@@ -658,6 +669,11 @@ class DeviceFleet:
             zb = t.stack([cy * sp * cr + sy * sr, sy * sp * cr - cy * sr, cp * cr], 1)  # eulerToRot(e) [0 0 1]'
             acc = zb * (mo[:, 3:4] / mass)
             acc[:, 2] -= g
+            if odom is None and not getattr(self, "_warned_no_odom", False):
+                import warnings
+                warnings.warn("DeviceFleet.replan without odom: fallback and retry start from the plan's stage-1 state, not from the "
+                              "odometry state as in the reference (nmpc_solver.cpp:151-153, 190-193)")
+                self._warned_no_odom = True
             o_pt, o_v = (odom if odom is not None else (self.mpc_output[:, 1, 8:11], self.mpc_output[:, 1, 11:14]))
             up = use_plan[:, None]
             s_pt = t.where(up, mo[:, 8:11], o_pt); s_v = t.where(up, mo[:, 11:14], o_v); s_a = t.where(up, acc, t.zeros_like(acc))

@@ -67,6 +67,17 @@ extern "C" {
 
 #define FRP_INFO_STRIDE 12 /* doubles per problem in the info array, see frp_nmpc_batch.info */
 
+/* Layout version of everything below (the two FORCES entry points keep the reference's layout for ever).  It changes whenever a
+ * struct of this header gains, loses or moves a field or FRP_INFO_STRIDE changes: a caller built against another header would
+ * hand over short structs / a short info array.  Call FRP_NMPC_ABI_CHECK() once after loading the library (the C++ adapter and the
+ * Python loader do) and refuse to continue unless it returns FRP_OK. */
+#define FRP_NMPC_ABI_VERSION 5
+int frp_nmpc_abi_version(void);
+/* FRP_OK when the caller's header agrees with the library on the version, on the size of frp_nmpc_options and frp_nmpc_batch and
+ * on the info stride; FRP_ERR_ARG otherwise (with one line on stderr saying what differs). */
+int frp_nmpc_abi_check(int abi_version, size_t options_bytes, size_t batch_bytes, int info_stride);
+#define FRP_NMPC_ABI_CHECK() frp_nmpc_abi_check(FRP_NMPC_ABI_VERSION, sizeof(frp_nmpc_options), sizeof(frp_nmpc_batch), FRP_INFO_STRIDE)
+
 typedef struct frp_nmpc_options {
     int maxit;        /* 200  (FORCESNLPsolver_normal.h:86)                */
     double tol_stat;  /* 1e-4 (mpc_generator_normal.m:76)                  */

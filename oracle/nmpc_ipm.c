@@ -200,6 +200,7 @@ typedef struct {
     double *corr;                       /* Mehrotra second-order term ds_aff*dlam_aff */
     int *nf;
     int twist;                          /* orc_options.twist */
+    int tw_on;                          /* this iteration's Newton systems are solved the twisted way (see TW_EXACT_BELOW) */
 } solver_ws;
 
 static const double *face_A(const double *params, int M, int k) { return params + (size_t)k * (ORC_NPRE + 4 * M) + ORC_NPRE; }
@@ -433,6 +434,17 @@ static int kkt_solve_twisted(solver_ws *W, const double *xinit, int full, int m,
     return 0;
 }
 
+/* The twisted solve is an inexact Newton method: the penalty that pins x_0 leaves an equality residual ~ |y_0| / rho and a
+ * direction error ~ 1e-5 relative.  Far from the solution that is immaterial; close to it the iteration would stall above tight
+ * tolerances (measured on the hard family at 1e-8: 84 of 96 instances end in MAXIT).  So an iteration is solved the twisted way
+ * only while the residuals of the PREVIOUS iteration (max of equality, inequality, stationarity, complementarity) exceed
+ * TW_EXACT_BELOW = the reference's tolerance 1e-4 -- a solve at the default tolerances has converged by then and stays twisted
+ * throughout, a solve at tighter tolerances finishes exactly; thresholds down to 1e-5 reach 1e-8 on every hard instance the plain
+ * solve does, 1e-6 loses 4 of 1988 --; ALL iterations after that (one-way switch) are exact Newton steps of the plain recursion -- the end game, and
+ * with it the accuracy of the returned point, is the plain solve's.  (The previous iteration's: the HIP kernel has to know before its model
+ * phase, which writes the first-half records in another form.)  Same rule, same constant in csrc/frp_ipm_lds.hip. */
+#define TW_EXACT_BELOW 1e-4
+
 /* backward (full or vector-only) + forward sweep; fills W->dz and W->ynew */
 static int kkt_solve(solver_ws *W, const double *xinit, int full)
 {
@@ -442,7 +454,7 @@ static int kkt_solve(solver_ws *W, const double *xinit, int full)
         static double tw_rho = 1e12;
         if (tw_m == -2) { const char *e = getenv("ORC_TWIST"); tw_m = e ? atoi(e) : -1; const char *r = getenv("ORC_TWIST_RHO"); if (r) tw_rho = atof(r); }
         const int m = tw_m > 0 ? tw_m : (W->twist < 0 ? 9 * N / 20 : W->twist);
-        if (m > 1 && m < N - 1 && N >= 4) return kkt_solve_twisted(W, xinit, full, m, tw_rho);
+        if (W->tw_on && m > 1 && m < N - 1 && N >= 4) return kkt_solve_twisted(W, xinit, full, m, tw_rho);
     }
     for (int k = N - 1; k >= 0; k--) {
         const double *Pn = (k < N - 1) ? W->st[k + 1].P : 0, *pn = (k < N - 1) ? W->st[k + 1].p : 0;
@@ -645,6 +657,7 @@ int orc_solve(int N, int M, int model, const double *xinit, const double *z0,
     double theta_h = 1.0;
     orc_info inf;
     memset(&inf, 0, sizeof inf);
+    W.tw_on = 1;
     for (it = 0;; it++) {
         /* ---- evaluate model, residuals ---- */
         double res_eq = 0, res_in = 0, rs = 0, rcomp = 0, gap = 0, pobj = 0;
@@ -705,6 +718,9 @@ int orc_solve(int N, int M, int model, const double *xinit, const double *z0,
             for (int i = 0; i < 17; i++) rs = fmax(rs, fabs(g[i]));
         }
         const double mu = gap / mtot;
+        static double tw_below = -1.0; /* (ORC_TW_EXACT_BELOW in the environment: study knob) */
+        if (tw_below < 0.0) { const char *e = getenv("ORC_TW_EXACT_BELOW"); tw_below = e ? atof(e) : TW_EXACT_BELOW; }
+        const int tw_next = fmax(fmax(res_eq, res_in), fmax(rs, rcomp)) > tw_below; /* (for the NEXT iteration: see TW_EXACT_BELOW) */
         inf.it = it; inf.res_eq = res_eq; inf.res_ineq = res_in; inf.rsnorm = rs; inf.rcompnorm = rcomp;
         inf.pobj = pobj; inf.mu = mu;
         if (!(res_eq == res_eq) || !(rs == rs) || !(pobj == pobj)) { flag = ORC_BADFUNCEVAL; break; }
@@ -804,6 +820,7 @@ int orc_solve(int N, int M, int model, const double *xinit, const double *z0,
                     if (W.lam[id] * W.s[id] < floor_prod) W.lam[id] = floor_prod / W.s[id];
                 }
         }
+        W.tw_on = W.tw_on && tw_next; /* (one way: an ill-conditioned instance whose residuals rise again stays on exact steps) */
     }
     memcpy(zout, W.z, sizeof(double) * 17 * N);
     inf.nfallback = nfallback;

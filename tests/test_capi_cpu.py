@@ -109,6 +109,22 @@ int main() {{
     assert r.returncode == 0, r.stderr
 
 
+def test_abi_check_rejects_a_caller_built_against_another_header():
+    """FRP_INFO_STRIDE went 8 -> 12 and frp_nmpc_options grew with only the version string bumped.  The header now
+    carries FRP_NMPC_ABI_VERSION; frp_nmpc_abi_check compares version, struct sizes and info stride with the library's own,
+    the Python loader and the C++ adapter call it before anything else."""
+    import ctypes, re
+    lib = solver.lib()
+    hdr = open(os.path.join(ROOT, "include", "frp_nmpc.h")).read()
+    ver = int(re.search(r"#define FRP_NMPC_ABI_VERSION (\d+)", hdr).group(1))
+    stride = int(re.search(r"#define FRP_INFO_STRIDE (\d+)", hdr).group(1))
+    assert lib.frp_nmpc_abi_version() == ver == solver.ABI_VERSION and stride == solver.INFO_STRIDE
+    so, sb = ctypes.sizeof(solver.Options), ctypes.sizeof(solver.Batch)
+    assert lib.frp_nmpc_abi_check(ver, so, sb, stride) == 0
+    for bad in ((ver - 1, so, sb, stride), (ver, so - 8, sb, stride), (ver, so, sb + 8, stride), (ver, so, sb, 8)):
+        assert lib.frp_nmpc_abi_check(*bad) == -1003  # FRP_ERR_ARG
+
+
 def test_workspace_size_formula():
     """The solver keeps its per-iteration state in LDS and registers: the device workspace is the work queue (counter 256 B,
     per-CU counters 8 KB, one key and one order entry per problem = 12 B per problem), whatever the horizon and the face

@@ -1,20 +1,32 @@
-"""Twisted vs plain solve on large seeded batches: exit flags, iteration counts, converged points."""
+"""Twisted vs plain solve on large seeded batches: exit flags, iteration counts, converged points -- and every pair of converged solves
+more than 1e-3 apart CERTIFIED with the reference's callbacks (tests/tools/twist_certify.py).   python tools/twist_soak.py [seeds = 3]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from forces_resilient_planner_amd import solver, workloads
-tot = dict(n=0, flag=0, it=0, worst=0.0, conv_p=0, conv_t=0, its_p=0, its_t=0)
+from tests.tools import twist_certify as TC
+tot = dict(n=0, flag=0, it=0, worst=0.0, pairs=0, certified=0, same_point=0)
+worse, uncertified, plain_too = [], [], []
 def run(name, w):
     z0, f0, i0, _ = solver.solve_batch_host(w)
     z1, f1, i1, _ = solver.solve_batch_host(w, solver.default_options(twist=-1))
     ok = (f0 == 1) & (f1 == 1)
     d = np.abs(z1[ok] - z0[ok]).max(axis=(1, 2)) if ok.any() else np.zeros(1)
+    c = TC.certify(w, z0, f0, z1, f1, label=name)
     print(f"{name:28s} B {len(f0):5d}  flags differ {int((f0 != f1).sum()):3d}  converged plain {int((f0 == 1).sum())} twist {int((f1 == 1).sum())}  "
-          f"iterations differ {int((i0 != i1)[ok].sum()):4d} (mean {i0[ok].mean():.3f} vs {i1[ok].mean():.3f})  max |dz| {d.max():.2e}  >1e-3: {int((d > 1e-3).sum())}", flush=True)
+          f"iterations differ {int((i0 != i1)[ok].sum()):4d} (mean {i0[ok].mean():.3f} vs {i1[ok].mean():.3f})  max |dz| {d.max():.2e}  >1e-3: {c['pairs']} "
+          f"(certified {c['certified']}, the same point at 1e-8 tolerances {c['same_point']}, twisted objective worse {len(c['worse'])})", flush=True)
     tot["n"] += len(f0); tot["flag"] += int((f0 != f1).sum()); tot["it"] += int((i0 != i1)[ok].sum()); tot["worst"] = max(tot["worst"], float(d.max()))
+    for k in ("pairs", "certified", "same_point"): tot[k] += c[k]
+    worse.extend(c["worse"]); uncertified.extend(c["uncertified"]); plain_too.extend(c["plain_fails_too"])
 for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
     run(f"configs[1] seed {seed}", workloads.config1(4096, seed=100 + seed))
     run(f"configs[2] seed {seed}", workloads.config2(4096, seed=200 + seed))
     for model in (0, 1):
         run(f"hard model {model} seed {seed}", workloads.config_hard(2048, seed=300 + seed, model=model))
 print(tot)
+for r in worse: print("twisted objective worse than plain:", r)
+for r in plain_too: print("the plain solve does not reach 1e-8 either (not certifiable by a re-solve):", r)
+for r in uncertified: print("UNCERTIFIED:", r)
+print(f"pairs more than 1e-3 apart: {tot['pairs']}; certified {tot['certified']} (the same point at 1e-8: {tot['same_point']}); plain fails too {len(plain_too)}; uncertified {len(uncertified)}")
+assert not uncertified, f"{len(uncertified)} pairs more than 1e-3 apart are not both KKT points of the reference NLP"
