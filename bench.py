@@ -143,6 +143,47 @@ def self_launch_command(n, argv, port=None):
             "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+def auto_chunks(world, B, N, MF):
+    """--chunks 0 of the strong-scaling step: pieces per shard and the reason (logged).  A piece below two rounds of resident workgroups
+    costs more than its transfer can hide (profiles/r04_strong_chunks.txt: 4 pieces +46 % at configs[2] on one GPU), and on one rank
+    nothing is transferred."""
+    per_cu = 4 if (N <= 20 and MF <= 6) else (3 if N <= 20 else (2 if N <= 32 else 1))  # resident workgroups per CU of the variant the launch takes
+    slots = 256 * per_cu
+    if world <= 1:
+        return 1, "one rank: nothing to overlap"
+    if B >= 2 * slots:
+        return 2, f"shard of {B} >= two rounds of the {slots} resident workgroups: transfers of piece c +- 1 under the solve of piece c"
+    return 1, f"shard of {B} < two rounds of the {slots} resident workgroups: a smaller piece costs more than its transfer hides"
+
+
+def launch_plan(args):
+    """What `bench.py --gpus N ...` would do, without a device: shards per rank, pieces per shard, the policy behind them."""
+    from forces_resilient_planner_amd import distributed as D
+    world = max(1, args.gpus)
+    cfg = args.config
+    base_B = {2: 4096, 3: 16384, 4: 65536}[cfg]
+    N, MF = {2: (20, 6), 3: (30, 15), 4: (20, 6)}[cfg]
+    strong = args.scaling == "strong"
+    if strong or cfg == 4:
+        B_total = args.batch or base_B
+        if cfg == 4 and not strong:
+            B_total = (args.batch or base_B // world) * world
+        shards = [D.shard_range(B_total, r, world) for r in range(world)]
+    else:
+        B = args.batch or (base_B if cfg == 2 else base_B // world)
+        B_total = B * world
+        shards = [(r * B, (r + 1) * B) for r in range(world)]
+    plan = {"world_size": world, "config": cfg, "scaling": args.scaling, "batch_total": B_total, "ranks": []}
+    for r, (lo, hi) in enumerate(shards):
+        ch, why = (auto_chunks(world, hi - lo, N, MF) if args.chunks <= 0 else (args.chunks, "--chunks given")) if (strong and cfg != 4) else (1, "weak scaling: no transfer in the step")
+        cb = D.chunk_bounds(hi - lo, ch)  # (the same boundaries strong_step_overlapped walks)
+        pieces = [[lo + int(a), lo + int(b)] for a, b in zip(cb[:-1], cb[1:])]
+        plan["ranks"].append({"rank": r, "problems": [lo, hi], "pieces": ch, "piece_ranges": pieces, "why": why})
+    plan["collectives"] = ("none on the data path (weak scaling: every rank solves its own problems); summary statistics by all_reduce / all_gather" if not strong
+                           else "grouped P2P scatter of the inputs from rank 0 / gather of the plans to rank 0 per piece (RCCL), under the solves")
+    return plan
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,10 +205,15 @@ def main():
     ap.add_argument("--chunks", type=int, default=0, help="--scaling strong: pieces every shard is cut into so that transfers overlap the solve (1 = serial scatter -> "
                     "solve -> gather; 0 = auto: 2 when there is more than one rank and a shard holds at least two rounds of resident workgroups, else 1 -- measured on "
                     "one GPU, where nothing is transferred: a piece smaller than a round of resident workgroups costs more than it hides, profiles/r04_strong_chunks.txt)")
+    ap.add_argument("--dry-run", action="store_true", help="print the planned shard / piece table of this launch (one JSON line: which rank solves which "
+                    "problems, in how many pieces and why) and exit: no device, no process group -- what an N-GPU run WOULD do")
     ap.add_argument("--streams", type=int, default=1,
                     help="informational: `value` is always the strictly serial single-stream rate; the rate with the steps issued "
                          "round-robin on 2 streams (the tail of one launch overlapping the next) is reported in config.pipelined_*")
     args = ap.parse_args()
+    if args.dry_run:
+        print(json.dumps(launch_plan(args)))
+        return
 
     # `python bench.py --gpus N` by itself must be an N-rank run: without a launcher around it (no WORLD_SIZE) re-execute under
     # torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve)
@@ -242,8 +288,9 @@ def main():
             # c - 1 leaving while piece c is solved (distributed.strong_step_overlapped; --chunks 1 = the serial scatter -> solve -> gather)
             comm_s, comp_s = torch.cuda.Stream(dev), [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
             if args.chunks <= 0:
-                slots = 256 * (3 if N <= 20 else (2 if N <= 32 else 1))
-                args.chunks = 2 if (world > 1 and B >= 2 * slots) else 1
+                args.chunks, why = auto_chunks(world, B, N, MF)
+                if rank == 0:
+                    print(f"[bench] --chunks 0: {args.chunks} piece(s) per shard ({why})", file=sys.stderr, flush=True)
 
             def step():
                 # (pieces alternate between two compute streams: the long solves that end one piece's launch overlap the next piece)
@@ -335,7 +382,13 @@ def main():
     kernel_ms, kernel_launches = solver.kernel_timing_end()
     if strong and kernel_launches:  # per step: the sum over the pieces of this rank's shard
         kernel_ms = kernel_ms * kernel_launches / (nrep * args.steps)
+    per_rank_s = [float(np.median(reps))]  # this rank's own median region time (before the max over ranks)
+    ranks_seen = 1
     if dist is not None:
+        ranks_seen = int(dist.get_world_size())  # what RCCL itself reports after init: the driver can see that N ranks took part
+        pr = [torch.zeros(1, **f64) for _ in range(ranks_seen)]
+        dist.all_gather(pr, torch.tensor(per_rank_s, **f64))  # (summary statistics, not on the data path)
+        per_rank_s = [float(x.item()) for x in pr]
         t = torch.tensor(reps, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # every repeat: the slowest rank
         reps = [float(x) for x in t.cpu()]
@@ -411,7 +464,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": names[cfg] + f"; batch {B} per GPU" + (f" of {B_total} in total, scattered from / gathered to rank 0 every step" if strong and cfg != 4 else ""),
-                       "baseline_config": cfg, "world_size": world, "collectives": ("RCCL (torch.distributed nccl backend)" if dist is not None else "none (single process)"),
+                       "baseline_config": cfg, "world_size": world, "ranks_seen": ranks_seen,
+                       "per_rank_ms_per_step": [x / args.steps * 1e3 for x in per_rank_s],
+                       "per_rank_solves_per_s": ([B_total / max(1, ranks_seen) * args.steps / x for x in per_rank_s] if not strong else None), "collectives": ("RCCL (torch.distributed nccl backend)" if dist is not None else "none (single process)"),
                        "batch_per_gpu": B, "batch_total": B_total, "horizon": int(N), "converged_frac": conv_frac,
                        "mean_ipm_iterations": mean_it, "max_ipm_iterations": int(stats[3]), "p95_ipm_iterations": float(np.percentile(it, 95)) if len(it) else 0.0,
                        "timing": f"median of {len(reps)} repeats of the {args.steps}-step region, strictly serial launches on one stream; max over ranks per repeat",
@@ -447,10 +502,26 @@ def main():
             e2c = []
             for _ in range(7):
                 t1 = time.perf_counter(); solver.solve_batch_host(wcomp, out=outc); e2c.append(time.perf_counter() - t1)
-            out["end_to_end"] = {"solves_per_s": B / float(np.median(e2e)), "ms_per_batch": float(np.median(e2e)) * 1e3,
+            # the same call with the caller's arrays registered once (frp_nmpc_host_register): nothing is staged, a gather kernel reads the
+            # live part of the inputs from the caller's memory, the solver writes the plans in place
+            wreg = {k: (np.ascontiguousarray(v, dtype=(np.int32 if k in ("nfaces", "models") else np.float64)) if isinstance(v, np.ndarray) else v) for k, v in wcpu.items()}
+            outr = tuple(np.zeros_like(a) for a in outs)
+            reg = [wreg[k] for k in ("xinit", "x0", "params", "nfaces") if isinstance(wreg.get(k), np.ndarray)] + list(outr)
+            e2r = []
+            try:
+                solver.host_register(*reg)
+                solver.solve_batch_host(wreg, out=outr)
+                for _ in range(7):
+                    t1 = time.perf_counter(); solver.solve_batch_host(wreg, out=outr); e2r.append(time.perf_counter() - t1)
+            finally:
+                solver.host_unregister(*reg)
+            out["end_to_end"] = {"solves_per_s": B / float(np.median(e2r)), "ms_per_batch": float(np.median(e2r)) * 1e3,
+                                 "buffers": "the caller's numpy arrays, registered once (frp_nmpc_host_register): pinned in place, read and written over PCIe by the kernels, no staging",
+                                 "pageable_solves_per_s": B / float(np.median(e2e)), "pageable_ms_per_batch": float(np.median(e2e)) * 1e3,
+                                 "registered_equals_pageable": bool(np.array_equal(outs[0], outr[0]) and np.array_equal(outs[1], outr[1])),
                                  "compact_layout_solves_per_s": B / float(np.median(e2c)), "compact_layout_ms_per_batch": float(np.median(e2c)) * 1e3,
                                  "same_plans": bool(np.array_equal(outs[0], outc[0])),
-                                 "what": "frp_nmpc_solve_batch_host, pageable host buffers in and out (PCIe-inclusive, median of 7): persistent device buffers, "
+                                 "what": "frp_nmpc_solve_batch_host, host buffers in and out (PCIe-inclusive, median of 7).  pageable_*: persistent device buffers, "
                                          "pinned staging filled by a few copy threads, chunks of B/16, B/4 and the rest whose copies and solves overlap; dense = the reference's "
                                          "30-row parameter layout in the caller's buffers (face counts given: the staging copy packs the 6 live rows, "
                                          "8.9 of 26.4 KB per problem cross PCIe), compact = the same problems handed over with M = 6 rows"}

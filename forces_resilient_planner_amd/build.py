@@ -111,7 +111,7 @@ PER_SOURCE_FLAGS = {"frp_ipm_lds.hip": CODEGEN_FLAGS + ["-DFRP_LDS_SPLIT_TU"],
 OBJDIR = os.path.join(PKG, "_build")
 
 
-def build_native(force=False, verbose=True, lib=None, extra_flags=(), solver_flags=None, objdir=None, check=True, mem_flags=None):
+def build_native(force=False, verbose=True, lib=None, extra_flags=(), solver_flags=None, objdir=None, check=True, mem_flags=None, q4_flags=None):
     """hipcc --offload-arch=gfx950 -> forces_resilient_planner_amd/libfrp_nmpc_amd.so (in-tree): one object per source
     (compiled in parallel, per-source flags), linked into the shared library.
     Experiment builds (tools/build_variant.sh): `lib` = another output file, `extra_flags` for every source, `solver_flags`
@@ -138,6 +138,8 @@ def build_native(force=False, verbose=True, lib=None, extra_flags=(), solver_fla
             flags = list(solver_flags) + ["-DFRP_LDS_SPLIT_TU"]
         if mem_flags is not None and name == "frp_ipm_lds_mem.hip":  # (experiments: the re-reading variants' translation unit)
             flags = list(mem_flags)
+        if q4_flags is not None and name == "frp_ipm_lds_q4.hip":    # (experiments: the four-per-CU variants' translation unit)
+            flags = list(q4_flags)
         cmd = common + flags + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -155,10 +157,10 @@ def build_native(force=False, verbose=True, lib=None, extra_flags=(), solver_fla
     return lib
 
 
-def build_variant(name, extra_flags=(), solver_flags=None, verbose=False, check=True, mem_flags=None):
+def build_variant(name, extra_flags=(), solver_flags=None, verbose=False, check=True, mem_flags=None, q4_flags=None):
     """forces_resilient_planner_amd/lib_<name>.so: the product sources with extra flags (selected with FRP_LIB=...)."""
     return build_native(force=True, verbose=verbose, lib=os.path.join(PKG, f"lib_{name}.so"), extra_flags=extra_flags,
-                        solver_flags=solver_flags, objdir=os.path.join(OBJDIR, "variant_" + name), check=check, mem_flags=mem_flags)
+                        solver_flags=solver_flags, objdir=os.path.join(OBJDIR, "variant_" + name), check=check, mem_flags=mem_flags, q4_flags=q4_flags)
 
 
 DROPIN_DIR = os.path.join(PKG, "dropin", "lib")
@@ -250,6 +252,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "variant":  # python -m forces_resilient_planner_amd.build variant <name> [--solver-flags=...] [flags...]
         sf = None
         mf = None
+        qf = None
         rest = []
         chk = True
         for a_ in sys.argv[3:]:
@@ -257,11 +260,13 @@ if __name__ == "__main__":
                 sf = a_.split("=", 1)[1].split()
             elif a_.startswith("--mem-flags="):
                 mf = a_.split("=", 1)[1].split()
+            elif a_.startswith("--q4-flags="):
+                qf = a_.split("=", 1)[1].split()
             elif a_ == "--no-check":
                 chk = False
             else:
                 rest.append(a_)
-        print(build_variant(sys.argv[2], rest, sf, check=chk, mem_flags=mf))
+        print(build_variant(sys.argv[2], rest, sf, check=chk, mem_flags=mf, q4_flags=qf))
     else:
         build_native(force=True)
         build_ubench()

@@ -416,6 +416,52 @@ struct HostPipe {
 };
 HostPipe g_pipe;
 
+// ---- caller buffers registered with frp_nmpc_host_register: pinned in place and mapped into the device's address space.  A batch whose
+// arrays ALL lie in registered ranges needs no staging: a gather kernel reads the live part of a chunk's inputs straight from the
+// caller's memory over PCIe into the chunk's device block (what the staging copy + hipMemcpyAsync did, without the host's memcpy, which
+// set the pace: 16 host threads against a 0.85 ms solve), and the solver writes plans, flags and diagnostics in place.
+struct HostRegistry {
+    struct Range { char *base; size_t bytes; char *dev; };
+    std::mutex mtx;
+    std::vector<Range> ranges;
+    template <typename T>
+    T *device_ptr(const T *p, size_t bytes)
+    {
+        const char *c = reinterpret_cast<const char *>(p);
+        for (const Range &r : ranges)
+            if (c >= r.base && c + bytes <= r.base + r.bytes) return reinterpret_cast<T *>(r.dev + (c - r.base));
+        return nullptr;
+    }
+};
+HostRegistry g_reg;
+
+// one chunk's device block [xinit | x0 | params (Md live rows of the caller's M) | nfaces | models] from the caller's (mapped) arrays
+__global__ __launch_bounds__(256) void gather_inputs_kernel(size_t nb, size_t N, int M, int Md, const double *__restrict__ xinit, const double *__restrict__ x0,
+                                                            const double *__restrict__ params, const int *__restrict__ nfaces, const int *__restrict__ models,
+                                                            double *__restrict__ d_in)
+{
+    const size_t np_h = FRP_NPAR(M), np = FRP_NPAR(Md), n_x = nb * 9, n_z = nb * N * 17, n_p = nb * N * np, nf_d = nfaces ? (N + 1) / 2 : 0;
+    const size_t total = n_x + n_z + n_p, stride = (size_t)gridDim.x * blockDim.x;
+    const size_t head = 10 + 3 * (size_t)Md, boff = 10 + 3 * (size_t)M;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        double v;
+        if (i < n_x) v = xinit[i];
+        else if (i < n_x + n_z) v = x0[i - n_x];
+        else {
+            const size_t q = i - n_x - n_z, row = q / np, e = q - row * np;
+            v = params[row * np_h + (e < head ? e : e - head + boff)];
+        }
+        d_in[i] = v;
+    }
+    int *d_nf = reinterpret_cast<int *>(d_in + total);
+    if (nfaces)
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb * N; i += stride) d_nf[i] = nfaces[i];
+    if (models) {
+        int *d_md = reinterpret_cast<int *>(d_in + total + nb * nf_d);
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) d_md[i] = models[i];
+    }
+}
+
 int pipe_reserve(HostPipe::Slot &s, size_t in_bytes, size_t out_bytes, size_t ws_bytes)
 {
     if (in_bytes > s.in_bytes) {
@@ -515,6 +561,32 @@ int frp_nmpc_kernel_timing_begin(int max_launches, int stride)
     return frp::kernel_timing_begin(max_launches, stride) == hipSuccess ? FRP_OK : FRP_ERR_ARG;
 }
 
+int frp_nmpc_host_register(void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return FRP_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FRP_ERR_NO_DEVICE;
+    std::lock_guard<std::mutex> lock(g_reg.mtx);
+    if (g_reg.device_ptr(reinterpret_cast<char *>(ptr), bytes)) return FRP_OK; // (already inside a registered range)
+    if (hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); return FRP_ERR_HIP; }
+    void *dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, ptr, 0) != hipSuccess || !dev) { (void)hipHostUnregister(ptr); (void)hipGetLastError(); return FRP_ERR_HIP; }
+    g_reg.ranges.push_back({reinterpret_cast<char *>(ptr), bytes, reinterpret_cast<char *>(dev)});
+    return FRP_OK;
+}
+
+int frp_nmpc_host_unregister(void *ptr)
+{
+    std::lock_guard<std::mutex> lock(g_reg.mtx);
+    for (size_t i = 0; i < g_reg.ranges.size(); i++)
+        if (g_reg.ranges[i].base == reinterpret_cast<char *>(ptr)) {
+            const hipError_t rc = hipHostUnregister(ptr);
+            g_reg.ranges.erase(g_reg.ranges.begin() + (long)i);
+            return rc == hipSuccess ? FRP_OK : FRP_ERR_HIP;
+        }
+    return FRP_ERR_ARG;
+}
+
 int frp_nmpc_set_q4_min_batch(int min_batch) { return frp::lds_q4_set_min_batch(min_batch); }
 
 int frp_nmpc_kernel_timing_end(float *avg_ms, int *launches)
@@ -574,6 +646,15 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
     // kernel reports either way): the staging copy packs the parameters to MF rows -- 26.4 -> 8.9 KB per problem over PCIe at
     // the reference's 30-row layout with 6-face corridors -- and the device solves the same problems in the compact layout.
     const bool compact = h->nfaces && h->MF < h->M;
+    // every array of the batch inside ranges the caller registered (frp_nmpc_host_register): no staging, see HostRegistry
+    std::lock_guard<std::mutex> reg_lock(g_reg.mtx);
+    const size_t Bz = (size_t)h->B, Tz = Bz * (size_t)h->N;
+    const double *m_xinit = g_reg.device_ptr(h->xinit, Bz * 9 * 8), *m_x0 = g_reg.device_ptr(h->x0, Tz * 17 * 8);
+    const double *m_params = g_reg.device_ptr(h->params, Tz * FRP_NPAR(h->M) * 8);
+    const int *m_nf = h->nfaces ? g_reg.device_ptr(h->nfaces, Tz * 4) : nullptr, *m_md = h->model_per_problem ? g_reg.device_ptr(h->model_per_problem, Bz * 4) : nullptr;
+    double *m_z = g_reg.device_ptr(h->z, Tz * 17 * 8), *m_info = h->info ? g_reg.device_ptr(h->info, Bz * FRP_INFO_STRIDE * 8) : nullptr;
+    int *m_flag = g_reg.device_ptr(h->exitflag, Bz * 4), *m_it = g_reg.device_ptr(h->iters, Bz * 4);
+    const bool mapped = m_xinit && m_x0 && m_params && (!h->nfaces || m_nf) && (!h->model_per_problem || m_md) && m_z && (!h->info || m_info) && m_flag && m_it;
     const int Md = compact ? h->MF : h->M; // corridor rows of the device-side layout
     const size_t N = h->N, np_h = FRP_NPAR(h->M), np = FRP_NPAR(Md);
     // per-problem doubles in a chunk's input block: xinit | x0 | params, then nfaces / models (ints, padded to doubles)
@@ -585,7 +666,7 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
     // equal ones 2.56, 256 + 1024 + 2816 2.09).
     size_t chunk = (size_t)h->B;
     std::vector<size_t> cb{0};
-    if (h->B >= 4096) {
+    if (h->B >= 4096 && !mapped) { // (registered buffers: one chunk, see the gather below)
         cb.push_back((size_t)h->B / 16);
         cb.push_back(cb.back() + (size_t)h->B / 4);
         const size_t rest = (size_t)h->B - cb.back(), nc = (rest + 4095) / 4096;
@@ -612,6 +693,7 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
     auto drain = [&](size_t c) -> int { // chunk c's results: wait for its copy-out, unpack from the pinned block
         HostPipe::Slot &s = g_pipe.slot[c % HostPipe::NSLOT];
         FRP_HIP(hipEventSynchronize(s.e_out));
+        if (mapped) return FRP_OK; // (the solver wrote the caller's arrays in place)
         const size_t b0 = cb[c], nb = cb[c + 1] - cb[c];
         const double *o = s.h_out;
         copy_pool().copy(h->z + b0 * N * 17, o, nb * N * 17 * sizeof(double)); o += nb * N * 17;
@@ -625,6 +707,32 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
         HostPipe::Slot &s = g_pipe.slot[c % HostPipe::NSLOT];
         if (c >= HostPipe::NSLOT) { const int rc = drain(c - HostPipe::NSLOT); if (rc != FRP_OK) return rc; } // the slot's previous chunk has left it
         const size_t b0 = cb[c], nb = cb[c + 1] - cb[c];
+        // (measured, 4096 problems of configs[2] in the reference's 30-row layout, host link ~25 GB/s: the gather KERNEL in one chunk 2.03 ms,
+        // in chunks 2.3-2.7 -- a resident gather block keeps the solver's persistent workgroups of the previous chunk off its CU --;
+        // the copy engines ("dma": two strided copies for the parameter rows) 2.07-2.33 whatever the split; staging from pageable memory
+        // 2.4-3.6.  The bound on that link is (28 MB in + 5.6 MB out) / 25 GB/s + the 0.85 ms solve = 2.0 ms without overlap.)
+        static const bool gather_dma = [] { const char *e = getenv("FRP_HOST_GATHER"); return e && e[0] == 'd'; }(); // (tuning knob: "dma")
+        if (mapped && gather_dma) {
+            // the copy engines read the caller's pinned memory: contiguous arrays as they are, the parameter rows as two strided copies
+            // (the ten leading parameters + the live A rows, then the live b rows) -- no CU is taken from the solves of the previous chunk
+            double *d_x0 = s.d_in + nb * 9, *d_par = d_x0 + nb * N * 17;
+            FRP_HIP(hipMemcpyAsync(s.d_in, h->xinit + b0 * 9, nb * 9 * sizeof(double), hipMemcpyHostToDevice, g_pipe.s_in));
+            FRP_HIP(hipMemcpyAsync(d_x0, h->x0 + b0 * N * 17, nb * N * 17 * sizeof(double), hipMemcpyHostToDevice, g_pipe.s_in));
+            const size_t headb = (10 + 3 * (size_t)Md) * 8;
+            FRP_HIP(hipMemcpy2DAsync(d_par, np * 8, h->params + b0 * N * np_h, np_h * 8, headb, nb * N, hipMemcpyHostToDevice, g_pipe.s_in));
+            if (Md > 0)
+                FRP_HIP(hipMemcpy2DAsync(reinterpret_cast<char *>(d_par) + headb, np * 8, h->params + b0 * N * np_h + 10 + 3 * (size_t)h->M, np_h * 8, (size_t)Md * 8, nb * N,
+                                         hipMemcpyHostToDevice, g_pipe.s_in));
+            int *d_nf = reinterpret_cast<int *>(d_par + nb * N * np);
+            if (h->nfaces) FRP_HIP(hipMemcpyAsync(d_nf, h->nfaces + b0 * N, nb * N * sizeof(int), hipMemcpyHostToDevice, g_pipe.s_in));
+            if (h->model_per_problem)
+                FRP_HIP(hipMemcpyAsync(reinterpret_cast<double *>(d_nf) + nb * nf_d, h->model_per_problem + b0, nb * sizeof(int), hipMemcpyHostToDevice, g_pipe.s_in));
+        } else if (mapped) {
+            const unsigned blocks = (unsigned)std::min<size_t>(2048, (nb * in_d + 255) / 256);
+            hipLaunchKernelGGL(gather_inputs_kernel, dim3(blocks), dim3(256), 0, g_pipe.s_in, nb, N, h->M, Md, m_xinit + b0 * 9, m_x0 + b0 * N * 17,
+                               m_params + b0 * N * np_h, m_nf ? m_nf + b0 * N : nullptr, m_md ? m_md + b0 : nullptr, s.d_in);
+            FRP_HIP(hipGetLastError());
+        } else {
         double *hi = s.h_in;
         std::memcpy(hi, h->xinit + b0 * 9, nb * 9 * sizeof(double)); double *h_x0 = hi + nb * 9;
         copy_pool().copy(h_x0, h->x0 + b0 * N * 17, nb * N * 17 * sizeof(double)); double *h_par = h_x0 + nb * N * 17;
@@ -636,6 +744,7 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
         if (h->model_per_problem) std::memcpy(h_md, h->model_per_problem + b0, nb * sizeof(int));
         const size_t in_bytes = (nb * (in_d + nf_d) + (md_d ? (nb + 1) / 2 : 0)) * sizeof(double);
         FRP_HIP(hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, g_pipe.s_in));
+        }
         FRP_HIP(hipEventRecord(s.e_in, g_pipe.s_in));
         frp_nmpc_batch d = *h;
         d.B = (int)nb; d.M = Md;
@@ -646,10 +755,12 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
         d.order_hint = nullptr; // (a queue-order hint is not worth a copy here: the chunks are at most two rounds of resident workgroups)
         d.z = s.d_out; d.info = h->info ? s.d_out + nb * N * 17 : nullptr;
         d.exitflag = reinterpret_cast<int *>(s.d_out + nb * N * 17 + (h->info ? nb * FRP_INFO_STRIDE : 0)); d.iters = d.exitflag + nb;
+        if (mapped) { d.z = m_z + b0 * N * 17; d.info = m_info ? m_info + b0 * FRP_INFO_STRIDE : nullptr; d.exitflag = m_flag + b0; d.iters = m_it + b0; }
         FRP_HIP(hipStreamWaitEvent(g_pipe.s_solve, s.e_in, 0));
         const int rc = frp_nmpc_solve_batch(&d, opt, s.d_ws, s.ws_bytes, g_pipe.s_solve);
         if (rc != FRP_OK) return rc;
         FRP_HIP(hipEventRecord(s.e_solve, g_pipe.s_solve));
+        if (mapped) { FRP_HIP(hipEventRecord(s.e_out, g_pipe.s_solve)); continue; }
         FRP_HIP(hipStreamWaitEvent(g_pipe.s_out, s.e_solve, 0));
         const size_t out_bytes = (nb * N * 17 + (h->info ? nb * FRP_INFO_STRIDE : 0) + nb) * sizeof(double);
         FRP_HIP(hipMemcpyAsync(s.h_out, s.d_out, out_bytes, hipMemcpyDeviceToHost, g_pipe.s_out));

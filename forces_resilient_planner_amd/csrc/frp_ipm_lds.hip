@@ -2164,6 +2164,9 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     for (int t = 0; t < FL; t++) { fa0[t] = fa1[t] = fa2[t] = fbb[t] = 0.0; fs[t] = fl_[t] = 1.0; fcr[t] = 0.0; }
     fpos[0] = fpos[1] = fpos[2] = 0.0;
     // (corridor rows on the model wave: the position is z[8..10] of that wave's own state -- updated by the same operations -- not a copy)
+    // (measured and dropped: the rows' slacks and multipliers in the record between the phases -- the model wave's trig hand-over slots,
+    // the trig sets through ds_bpermute instead -- frees 8 registers and changes nothing: 0.855 vs 0.853 ms; what the allocator keeps
+    // in scratch on this wave is two row constants, the second-order terms between the barriers D and F and three integers)
     constexpr bool FPZ = IS_M && IS_F;
     double *const fpq = FPZ ? ms.z + 8 : fpos;
 

@@ -128,7 +128,7 @@ EXPORTS = ["frp_nmpc_default_options", "frp_nmpc_workspace_bytes", "frp_nmpc_sol
            "frp_nmpc_coldstart_batch", "frp_nmpc_cloud_grid_build",
            "frp_nmpc_mode_batch", "frp_nmpc_astar_batch", "frp_nmpc_astar_workspace_bytes",
            "frp_nmpc_kernel_timing_begin", "frp_nmpc_kernel_timing_end", "frp_nmpc_set_q4_min_batch",
-           "frp_nmpc_abi_version", "frp_nmpc_abi_check"]
+           "frp_nmpc_abi_version", "frp_nmpc_abi_check", "frp_nmpc_host_register", "frp_nmpc_host_unregister"]
 
 _lib = None
 
@@ -166,6 +166,8 @@ def lib():
                                           ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         l.frp_nmpc_solve_batch_host.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(Options)]
         l.frp_nmpc_set_q4_min_batch.argtypes = [ctypes.c_int]
+        l.frp_nmpc_host_register.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        l.frp_nmpc_host_unregister.argtypes = [ctypes.c_void_p]
         l.frp_nmpc_kernel_timing_begin.argtypes = [ctypes.c_int, ctypes.c_int]
         l.frp_nmpc_kernel_timing_end.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
         l.frp_nmpc_pack_batch.argtypes = [ctypes.POINTER(Pack), ctypes.c_void_p]
@@ -223,6 +225,21 @@ def solve_batch_host(w, opt: Options | None = None, MF: int | None = None, x0=No
     _check(lib().frp_nmpc_solve_batch_host(ctypes.byref(b), ctypes.byref(opt) if opt is not None else None),
            "frp_nmpc_solve_batch_host")
     return z, flag, iters, info
+
+
+def host_register(*arrays):
+    """frp_nmpc_host_register for numpy arrays a caller reuses from call to call (inputs and the `out` arrays of solve_batch_host):
+    with every array of a call registered, frp_nmpc_solve_batch_host stages nothing.  Keep the arrays alive until host_unregister."""
+    for a in arrays:
+        if a is not None:
+            assert a.flags["C_CONTIGUOUS"]
+            _check(lib().frp_nmpc_host_register(a.ctypes.data, a.nbytes), "frp_nmpc_host_register")
+
+
+def host_unregister(*arrays):
+    for a in arrays:
+        if a is not None:
+            lib().frp_nmpc_host_unregister(a.ctypes.data)
 
 
 def stage_eval_host(z, params, M, model, want=("f", "gf", "c", "Jc", "h")):

@@ -49,6 +49,9 @@ extern "C" {
 #define FRP_EXIT_BADFUNCEVAL (-6)
 #define FRP_EXIT_NOPROGRESS (-7)
 #define FRP_EXIT_PARAM_VALUE (-11)
+/* Values of the reference's list that this solver NEVER returns (FORCESNLPsolver_normal.h:110-139): 2 TIMEOUT (:118 -- there is no
+   wall-clock budget: the iteration limit `maxit` bounds a solve, and exhausting it is 0 = MAXIT), -4 (wrong number of inequalities:
+   the face counts are validated as -11), -12 PARAM_VALUE_TIMEOUT (:136).  A caller that switches on them needs no new case. */
 /* Return values of the two drop-in entry points that are NOT solver outcomes.  The reference's callers accept a plan only on
    exitflag == 1 (nmpc_solver.cpp:398) and treat every other value alike, so these are safe for them; a caller that looks
    closer can tell a machine problem from a bad parameter:
@@ -150,6 +153,14 @@ int frp_nmpc_solve_batch(const frp_nmpc_batch *batch, const frp_nmpc_options *op
 
 /* Same with HOST buffers: allocates/copies/synchronises internally (plumbing + tests). */
 int frp_nmpc_solve_batch_host(const frp_nmpc_batch *batch_host, const frp_nmpc_options *opt);
+
+/* Optional: pin a caller buffer in place and map it into the device's address space (hipHostRegister).  When EVERY array of a
+ * frp_nmpc_solve_batch_host call lies inside registered ranges the call stages nothing: a gather kernel reads the live part of the
+ * inputs straight from the caller's memory and the solver writes plans, flags and diagnostics in place (same plans, bit for bit).
+ * The caller keeps the buffer alive and unchanged in size until frp_nmpc_host_unregister(ptr) (same `ptr`); registering costs
+ * milliseconds -- do it once for buffers that are reused from tick to tick, not per call. */
+int frp_nmpc_host_register(void *ptr, size_t bytes);
+int frp_nmpc_host_unregister(void *ptr);
 
 /* Batched model callback = the reference's extfunc (FORCESNLPsolver_normal.h:321,
  * FORCESNLPsolver_normal_casadi2forces.c:42-245) for B*N stage points at once.

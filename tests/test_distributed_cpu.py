@@ -208,3 +208,28 @@ def test_bench_gpus_n_relaunches_itself_one_rank_per_gpu(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert not calls and "MI355X" in str(e.value)
+
+
+def test_bench_dry_run_plans_eight_ranks_without_a_device():
+    """what `bench.py --gpus 8` WOULD do, asserted without a GPU: the shards tile the batch, every rank gets the same
+    share (weak) or a contiguous shard (strong), the piece count follows the logged policy, and the pieces tile their shard."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def plan(*a):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", *a], capture_output=True, text=True, check=True)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    p = plan("--gpus", "8")
+    assert p["world_size"] == 8 and p["batch_total"] == 8 * 4096 and [r["problems"] for r in p["ranks"]] == [[4096 * i, 4096 * (i + 1)] for i in range(8)]
+    assert all(r["pieces"] == 1 for r in p["ranks"])
+    for cfg, total in (("2", 4096), ("3", 16384)):
+        p = plan("--gpus", "8", "--scaling", "strong", "--config", cfg)
+        assert p["batch_total"] == total
+        edges = [r["problems"] for r in p["ranks"]]
+        assert edges[0][0] == 0 and edges[-1][1] == total and all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+        for r in p["ranks"]:
+            pr = r["piece_ranges"]
+            assert pr[0][0] == r["problems"][0] and pr[-1][1] == r["problems"][1] and all(a[1] == b[0] for a, b in zip(pr, pr[1:])) and len(pr) <= r["pieces"]
+            assert ("two rounds" in r["why"]) and r["pieces"] in (1, 2)
+    # configs[2] strong at 8 ranks: shards of 512 are below two rounds of resident workgroups -> one piece; configs[3]: 2048 >= 2 * 512 -> two
+    assert plan("--gpus", "8", "--scaling", "strong", "--config", "2")["ranks"][0]["pieces"] == 1
+    assert plan("--gpus", "8", "--scaling", "strong", "--config", "3")["ranks"][0]["pieces"] == 2

@@ -675,6 +675,32 @@ def test_host_path_packs_live_rows_and_chunks_without_changing_a_plan():
         assert np.array_equal(fl, f0) and np.array_equal(it, i0) and np.max(np.abs(z - z0)) == 0.0, split
 
 
+def test_host_path_with_registered_buffers_stages_nothing_and_changes_no_plan():
+    """frp_nmpc_host_register: with every array of the call pinned in place and mapped, frp_nmpc_solve_batch_host reads the inputs from the
+    caller's memory by a gather kernel and lets the solver write in place -- the plans, flags, counts and diagnostics are those of the
+    staged path, bit for bit; unregistering falls back to staging; a partly registered call is staged."""
+    B = 2500
+    w = workloads.config2(B, seed=17)
+    w = {k: (np.ascontiguousarray(v, dtype=(np.int32 if k == "nfaces" else np.float64)) if isinstance(v, np.ndarray) else v) for k, v in w.items()}
+    ref = solver.solve_batch_host(w)
+    out = tuple(np.full_like(a, -7) for a in ref)
+    reg = [w["xinit"], w["x0"], w["params"], w["nfaces"]] + list(out)
+    solver.host_register(*reg)
+    try:
+        solver.solve_batch_host(w, out=out)
+        for a, b in zip(ref, out):
+            assert np.array_equal(a, b)
+        # partly registered: staged, same results
+        solver.host_unregister(w["x0"])
+        out2 = tuple(np.full_like(a, -7) for a in ref)
+        solver.solve_batch_host(w, out=out2)
+        for a, b in zip(ref, out2):
+            assert np.array_equal(a, b)
+    finally:
+        solver.host_unregister(*reg)
+    assert solver.lib().frp_nmpc_host_unregister(w["xinit"].ctypes.data) != 0  # (already gone: an argument error, nothing else)
+
+
 def test_queue_order_hint_changes_the_order_and_nothing_else():
     """frp_nmpc_batch.order_hint (a receding-horizon caller's previous iteration counts): any hint -- the previous counts,
     garbage, negative, all equal -- gives bit-identical plans, flags and iteration counts; the hint may alias `iters`."""

@@ -13,7 +13,7 @@ T = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
 rng = np.random.default_rng(2026)
 t0 = time.time(); n = 0; solved = 0; worst = 0.0; worst_at = None
 DZ_TOL, MAX_EXCEPTIONS = 1e-3, 3
-exceptions = []; flag_mismatches = 0
+exceptions = []; flag_mismatches = 0; mismatch_list = []
 while time.time() - t0 < T:
     kind = int(rng.integers(0, 5)); B = int(rng.integers(1, 5000)); seed = int(rng.integers(0, 1 << 30))
     if kind == 0: w = workloads.config1(B, seed=seed)
@@ -29,6 +29,12 @@ while time.time() - t0 < T:
     same = ok & (it == ito)
     dz = float(np.max(np.abs(z[same] - zo[same]))) if same.any() else 0.0
     flag_mismatches += mism
+    #  every exit-flag mismatch by name: both implementations' flags, iteration counts and last residuals
+    for b in np.where(fl != flo)[0]:
+        b = int(b)
+        mismatch_list.append(dict(kind=kind, B=B, seed=seed, N=int(w["N"]), M=int(w["M"]), problem=b, flag_gpu=int(fl[b]), flag_oracle=int(flo[b]),
+                                  iterations_gpu=int(it[b]), iterations_oracle=int(ito[b]), residuals_gpu_eq_in_stat_comp=[float(x) for x in info[b, :4]],
+                                  residuals_oracle=[io[b].res_eq, io[b].res_ineq, io[b].rsnorm, io[b].rcompnorm], mu_gpu=float(info[b, 5]), mu_oracle=float(io[b].mu)))
     # every pair of converged solves with equal iteration counts beyond DZ_TOL: a bifurcation (both are KKT points within the
     # tolerances, the objectives differ) goes on the exception list, anything else is a failure
     dall = np.where(same, np.abs(z - zo).reshape(len(fl), -1).max(1), 0.0)
@@ -58,4 +64,5 @@ while time.time() - t0 < T:
 print(f"soak: {n} launches, {solved} problems, {time.time() - t0:.0f} s, {flag_mismatches} exit-flag mismatches ({flag_mismatches / max(1, solved):.2e} of the problems), "
       f"worst |dz| at equal iteration counts {worst:.2e}; pairs beyond {DZ_TOL:g}: {len(exceptions)} (allowed: {MAX_EXCEPTIONS}, each a certified bifurcation)")
 for e in exceptions: print("EXCEPTION (two KKT points of one non-convex NLP):", e)
+for m in mismatch_list: print("exit-flag mismatch:", m)
 print("PASS")
