@@ -152,6 +152,18 @@ def hard_family_check(g, z, fl, pobj, zt, flt):
         exceptions.append((int(i), float(dz), float(pobj[i]), float(g["f"][i])))
     print("hard family: %d SLSQP-solved instances, all converged; other (better) KKT point on:" % len(good), exceptions)
     assert len(exceptions) <= 0.03 * len(good)
+    #  EVERY instance the solver converges on -- also the ones SciPy did not solve, which used to be counted as wins
+    # on status alone -- is a KKT point of the reference NLP by the reference's own functions (the 1e-8 solve: stationarity <= 1e-6,
+    # feasibility <= 1e-8; three instances read 1e-6 .. 3e-6 with the bounded-least-squares multipliers, see tests/tools/twist_certify.py)
+    conv = np.where(flt == 1)[0]
+    worst = dict(stat=0.0, eq=0.0, ineq=0.0, bound=0.0)
+    for i in conv:
+        k = OL.reference_kkt(zt[i], g["xinit"][i], g["params"][i], g["nfaces"][i], N, M, int(g["model"][i]))
+        assert k["stat"] < 3e-6 and k["eq"] < 1e-8 and k["ineq"] < 1e-8 and k["bound"] < 1e-8, (int(i), k)
+        worst = {q: max(worst[q], k[q]) for q in worst}
+    unsolved = [int(i) for i in range(len(fl)) if fl[i] != 1]
+    print("hard family: %d of %d instances converge at 1e-8, every one a certified KKT point of the reference NLP (worst residuals %s); "
+          "exits at the default options: %s" % (len(conv), len(fl), worst, [(i, int(fl[i])) for i in unsolved]))
     return exceptions
 
 
