@@ -556,7 +556,7 @@ def main():
                                     "converged_frac": ft["converged_frac"], "polytopes_per_planner": ft["polytopes_per_planner"],
                                     "what": "DeviceFleet.full_tick for " + ft["workload"] + ": stage references -> tube -> corridor (cloud grid) -> pack -> solve "
                                             "(corridors of up to 30 rows: the (20, 10) kernel variant) -> update, HIP events per step on the launch stream, mean of 10 ticks; "
-                                            "per-kernel rooflines: profiles/r04_tick_rooflines.json (tools/tick_rooflines.py)"}
+                                            "per-kernel rooflines: profiles/r05_tick_rooflines.json (tools/tick_rooflines.py)"}
             except Exception as e:  # secondary evidence, never a reason to lose the bench line
                 out["full_tick"] = {"error": repr(e)}
         if not args.no_cpu and world == 1:

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Per-kernel roofline accounting of the device tick: every kernel of DeviceFleet.full_tick with its bound, its
 algorithmic work per launch, the achieved rate and the fraction of the MI355X peak -- from the rocprofv3 --kernel-trace --stats summary of
-`python tools/full_tick_bench.py 4096 10 20000 0.5 0` (tools/collect_r04.sh) and that run's own JSON line; the A* from tests/tools/astar_bench.py.
+`python tools/full_tick_bench.py 4096 10 20000 0.5 0` (tools/collect_r05.sh) and that run's own JSON line; the A* from tests/tools/astar_bench.py.
 
-   python tools/tick_rooflines.py <kernel_stats.csv> <full_tick.json> [astar_bench.jsonl] > profiles/r04_tick_rooflines.json
+   python tools/tick_rooflines.py <kernel_stats.csv> <full_tick.json> [astar_bench.jsonl] > profiles/r05_tick_rooflines.json
 
 Work definitions (per planner and tick; B planners, N = 20 stages) -- stated here so that the fractions can be recomputed:
   solve      SURVEY 8d: mean_it * N * F_stage flop with F_stage = 31.5 k + 18 (m - 6) k... i.e. 31.5e3 + 18 * (m - 6) flop for m live corridor rows
