@@ -103,7 +103,7 @@ PER_SOURCE_FLAGS = {"frp_ipm_lds.hip": CODEGEN_FLAGS + ["-DFRP_LDS_SPLIT_TU"],
                     "frp_ipm_lds_mem.hip": MEM_FLAGS,
                     # (the factorisation sweep inlined: as a function of its own it saves and restores 38 callee-saved registers per call
                     # whether or not the caller holds anything in them -- 0.858 -> 0.853 ms per 4096-problem launch; inlining the
-                    # vector sweeps as well loses that again, r05_ab_inline.txt)
+                    # vector sweeps as well loses that again, profiles/r05_q4_flags.txt)
                     "frp_ipm_lds_q4.hip": CODEGEN_FLAGS + ["-DFRP_INLINE_FACTOR"],
                     "frp_corridor.hip": NO_HOIST,
                     # the A* agrees with its oracle to the bit (node order depends on comparisons of nearly equal costs): no a * b + c contraction

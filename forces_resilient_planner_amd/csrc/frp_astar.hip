@@ -454,6 +454,9 @@ __device__ void hash_insert(HashEnt *h, int hcap, long long key, int node)
     }
 }
 
+#ifndef FRP_ASTAR_SLOW_PUSH
+#define FRP_ASTAR_SLOW_PUSH 0 // (1: every push fetches its own ancestors -- the round-4 commit, kept for A/B runs)
+#endif
 // std::__push_heap with NodeComparator (f_score greater = lower priority); entries carry their node's current f
 __device__ void heap_push_hole(HeapEnt *heap, Node *nodes, int hole, int top, double vf, int vid)
 {
@@ -520,7 +523,7 @@ __device__ void heap_pop(HeapEnt *heap, Node *nodes, int &size) // std::pop_heap
 #define APROF_DECL()
 #endif
 struct Shared {
-    long long prof[8];
+    long long prof[11];
     unsigned long long alive[2]; // survivors of phase 1 as bit masks over the primitives 0..63, 64..127
     unsigned long long vx_key[256]; // first-survivor-of-a-voxel search: open-addressing table voxel key -> lowest candidate index
     int vx_min[256];
@@ -819,6 +822,64 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
             const bool od0 = pr0 >= 0 && ln < n_cand && sh.c_surv[ln], od1 = pr1 >= 0 && 64 + ln < n_cand && sh.c_surv[64 + ln];
             const double og0 = od0 ? nodes[pr0].g : 0.0, og1 = od1 ? nodes[pr1].g : 0.0;
             int use = sh.use_node_num, hs = sh.heap_size;
+            // Round 5: the heap side of the walk without a trip to the L2 per push / per changed key.  The pushes of an expansion go to
+            // the consecutive holes hs, hs + 1, ...: the union of their ancestor chains is small (level j above n holes: n / 2^j + 2
+            // entries), so it is fetched ONCE, lane = (level, offset), together with the heap positions of the open nodes the survivors
+            // may re-key; the walk then replays std::__push_heap on that copy -- every store it makes to the heap goes to memory (lane 0,
+            // nothing waits for it) AND to the lanes that hold that heap index (a compare-select; an index cached at two levels, when the
+            // holes straddle a depth boundary, stays consistent that way), and every entry it moves updates the tracked position of
+            // the node it belongs to.  Up to 16 new nodes and a heap of at least 16 entries (no new hole is another's ancestor);
+            // anything else takes the per-push path (heap_push_hole_wave, one trip per push).
+            const bool nw0 = ln < n_cand && sh.c_surv[ln] && pr0 < 0 && le0 == ln, nw1 = 64 + ln < n_cand && sh.c_surv[64 + ln] && pr1 < 0 && le1 == 64 + ln;
+            const int n_new = __builtin_popcountll(__ballot(nw0)) + __builtin_popcountll(__ballot(nw1));
+            const int h0 = __builtin_amdgcn_readfirstlane(hs);
+            const bool fast = n_new >= 1 && n_new <= 16 && h0 >= 16 && h0 + n_new < (1 << 24) && !FRP_ASTAR_SLOW_PUSH;
+            // lane -> (level, offset): level 1: 10 slots, 2: 6, 3: 4, 4: 3, 5..24: 2 each (63 lanes)
+            const int lv = ln < 10 ? 1 : ln < 16 ? 2 : ln < 20 ? 3 : ln < 23 ? 4 : 5 + ((ln - 23) >> 1);
+            const int lo_ = ln < 10 ? ln : ln < 16 ? ln - 10 : ln < 20 ? ln - 16 : ln < 23 ? ln - 20 : ((ln - 23) & 1);
+            int cidx = -1;
+            if (fast && ln < 63) {
+                const int lo = ((h0 + 1) >> lv) - 1, hi = ((h0 + n_new) >> lv) - 1;
+                if (lo + lo_ >= 0 && lo + lo_ <= hi) cidx = lo + lo_;
+            }
+            double cf = cidx >= 0 ? heap[cidx].f : 0.0;
+            int cid = cidx >= 0 ? heap[cidx].id : -1;
+            // tracked heap positions: of the open nodes the survivors may re-key (lane = candidate) and of the nodes created here (lane = leader)
+            int hp0 = od0 ? nodes[pr0].heap_pos : -1, hp1 = od1 ? nodes[pr1].heap_pos : -1;
+            int np0 = -1, np1 = -1; // ids of the nodes created in this expansion, lane = their leader (cr0 / cr1 hold open nodes' ids too)
+            auto slot_of = [&](int j, int idx) { // wave-uniform: the lane that caches heap index idx as a level-j ancestor
+                const int lo = ((h0 + 1) >> j) - 1;
+                const int base = j == 1 ? 0 : j == 2 ? 10 : j == 3 ? 16 : j == 4 ? 20 : 23 + 2 * (j - 5);
+                return base + idx - lo;
+            };
+            auto moved = [&](int pid, int hole) { // entry of node pid now sits at heap index hole
+                hp0 = (od0 && pr0 == pid) ? hole : hp0; hp1 = (od1 && pr1 == pid) ? hole : hp1;
+                hp0 = (np0 == pid) ? hole : hp0; hp1 = (np1 == pid) ? hole : hp1;
+            };
+            auto rekey = [&](int pos, double f) { // heap[pos].f = f, in memory and in the copy
+                if (ln == 0) heap[pos].f = f;
+                cf = cidx == pos ? f : cf;
+            };
+            auto push_fast = [&](int h, double vf, int vid) {
+                int hole = h, j = 1;
+                while (hole > 0) {
+                    const int idx = (hole - 1) >> 1;
+                    const int sl = slot_of(j, idx);
+                    const double pf = rl_f64(cf, sl);
+                    if (!(pf > vf)) break;
+                    const int pid = __builtin_amdgcn_readlane(cid, sl);
+                    if (ln == 0) { heap[hole].f = pf; heap[hole].id = pid; nodes[pid].heap_pos = hole; }
+                    const bool up = cidx == hole;
+                    cf = up ? pf : cf; cid = up ? pid : cid;
+                    moved(pid, hole);
+                    hole = idx; j++;
+                }
+                if (ln == 0) { heap[hole].f = vf; heap[hole].id = vid; nodes[vid].heap_pos = hole; }
+                const bool up = cidx == hole;
+                cf = up ? vf : cf; cid = up ? vid : cid;
+                return hole;
+            };
+            APROF(8);
             // the walk's own bookkeeping -- value, node and winning primitive of every voxel group -- lives in registers, lane = primitive
             // (two per lane), read with v_readlane and written with a compare-select: an LDS array would cost the walking lane a
             // round trip per access (the lesson of the survivor walk itself); the arrays the node writes below read are stored once, after it
@@ -845,28 +906,36 @@ __device__ __forceinline__ void run_search(const Args &a, Shared &sh, Ctx &ctx, 
                     if (pre >= 0) { // a node of this voxel is in the open set: keep the cheaper way to it
                         const int nid = pre;
                         if (L == c) { set_grp(c, og, -1); set_cr(c, nid); }
-                        if (g < get_gv(L)) {
-                            if (ln == 0) heap[nodes[nid].heap_pos].f = f; // the key changes in place: no re-heapify (as in the reference)
+                        if (g < get_gv(L)) { // the key changes in place: no re-heapify (as in the reference)
+                            if (fast) rekey(__builtin_amdgcn_readlane(w ? hp1 : hp0, cl), f);
+                            else if (ln == 0) heap[nodes[nid].heap_pos].f = f;
                             set_grp(L, g, c);
                         }
                     } else if (L == c) { // new node
                         const int nid = use;
                         hs++;
-                        heap_push_hole_wave(heap, nodes, hs - 1, f, nid); // (the whole wavefront: see there)
+                        if (fast) {
+                            if (w) np1 = ln == cl ? nid : np1; else np0 = ln == cl ? nid : np0;
+                            const int at = push_fast(hs - 1, f, nid);
+                            if (w) hp1 = ln == cl ? at : hp1; else hp0 = ln == cl ? at : hp0;
+                        } else heap_push_hole_wave(heap, nodes, hs - 1, f, nid); // (the whole wavefront: see there)
                         set_cr(c, nid); set_grp(c, f, c);
                         use++;
                         if (use == A) out_of_memory = true; // "run out of memory", kinodynamic_astar.cpp:255-259
                     } else if (f < get_gv(L)) { // a node of this voxel was created earlier in this expansion: keep the lower f
                         const int nl = get_cr(L);
-                        if (ln == 0) heap[nodes[nl].heap_pos].f = f;
+                        if (fast) rekey(L < 64 ? __builtin_amdgcn_readlane(hp0, L) : __builtin_amdgcn_readlane(hp1, L - 64), f);
+                        else if (ln == 0) heap[nodes[nl].heap_pos].f = f;
                         set_grp(L, f, c);
                     }
                 }
             }
+            APROF(9);
             sh.c_created[ln] = cr0; sh.c_created[64 + ln] = cr1; sh.c_winner[ln] = wn0; sh.c_winner[64 + ln] = wn1;
             use_new = use; hs_new = hs;
         }
         __syncthreads();
+        APROF(10);
         if (lane == 0) { // (written back behind the barrier: the other lane reads the node count while this one loops)
             sh.use_node_num = use_new; sh.heap_size = hs_new;
             if (out_of_memory) { sh.status = FRP_ASTAR_NO_PATH; sh.terminate = -1; sh.heap_size = -1; }
@@ -931,7 +1000,7 @@ __global__ __launch_bounds__(NT) void astar_kernel(Args a)
         ctx.lmax[i] = P->local_box ? P->local_box[6 * b + 3 + i] : 0;
         ctx.ext[i] = P->external_acc[3 * b + i];
     }
-    if (lane < 8) sh.prof[lane] = 0;
+    if (lane < 11) sh.prof[lane] = 0;
     for (int i = lane; i < 256; i += NT) { sh.vx_key[i] = ~0ull; sh.vx_min[i] = 0x7fffffff; } // (every expansion leaves the table empty again)
     if (lane == 0) {
         // the primitive lists, by the reference's own loops (kinodynamic_astar.cpp:119-137): repeated addition, the same comparisons
@@ -992,7 +1061,7 @@ __global__ __launch_bounds__(NT) void astar_kernel(Args a)
         }
     }
 #ifdef FRP_ASTAR_PROFILE
-    if (P->path_nodes && lane < 8) P->path_nodes[((size_t)b * MAX_PATH + MAX_PATH - 1) * 11 + lane] = (double)sh.prof[lane];
+    if (P->path_nodes && lane < 11) P->path_nodes[((size_t)b * MAX_PATH + MAX_PATH - 1) * 11 + lane] = (double)sh.prof[lane];
 #endif
     // ---- getKinoTraj(Ts) (:648-695): the search part is generated backwards in the reference and reversed; here the samples
     // are counted first so that each one lands at its forward position (more samples than K: the first K are kept, stats[3] < 0)

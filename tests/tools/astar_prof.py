@@ -11,8 +11,8 @@ pl.plan(); torch.cuda.synchronize()
 t0 = time.time(); pl.plan(); torch.cuda.synchronize(); print("gpu ms", (time.time() - t0) * 1e3)
 stats = pl.stats.cpu().numpy(); pn = pl.path_nodes.cpu().numpy()
 it = stats[:, 1].astype(float)
-prof = pn[:, -1, :8]
-names = ["top", "window", "pop", "transit+hash", "collision", "heuristic", "leader", "commit"]
-tot = prof[:, :8].sum(0); its = it.sum()
+prof = pn[:, -1, :11]
+names = ["top", "window", "pop", "transit+hash", "collision", "heuristic", "leader", "commit: node writes", "commit: set-up loads", "commit: walk", "commit: wait for the hash lane"]
+tot = prof[:, :11].sum(0); its = it.sum()
 print("expansions", its, "cycles per expansion:", {n: round(tot[i] / its) for i, n in enumerate(names)}, "total/exp", round(tot.sum() / its))
 b = int(np.argmax(it)); print("longest: it", it[b], {n: round(prof[b, i] / it[b]) for i, n in enumerate(names)})
