@@ -41,7 +41,25 @@
 #include <stdlib.h>
 #include "../../include/frp_nmpc.h"
 
+// Which point a round picks is decided by comparisons of nearly equal distances (after find_ellipsoid the obstacle points that shaped the
+// ellipsoid sit at distance 1 +- 1 ulp), so every kernel of this file must compute the SAME bits from the same inputs.  Left to the
+// compiler, a * b + c is fused or not depending on the code around it (round 5: the shell kernel visited two touching points in the other
+// order -- same rows, swapped); hence no implicit contraction anywhere in this file, and the per-point expressions (metric distance,
+// box frame projection, side of a cut) written once, with their fused multiply-adds spelled out.
+#pragma clang fp contract(off)
+
 namespace frp {
+
+// a0 * x + a1 * y + a2 * z with the rounding every kernel uses
+__device__ __forceinline__ double dot3(double a0, double a1, double a2, double x, double y, double z)
+{
+    return __builtin_fma(a2, z, __builtin_fma(a1, y, a0 * x));
+}
+// on which side of the cut (q, n) the point lies (decomp_base.h:74-78: kept while negative)
+__device__ __forceinline__ double cut_side(const double n[3], const double q[3], double x, double y, double z)
+{
+    return dot3(n[0], n[1], n[2], x - q[0], y - q[1], z - q[2]);
+}
 
 #ifndef FRP_CR_WAVES
 #define FRP_CR_WAVES 4
@@ -109,9 +127,8 @@ __device__ __forceinline__ void tmul(const M3 &R, const double v[3], double o[3]
 __device__ __forceinline__ double ell_dist2(const M3 &Ci, const double d[3], double x, double y, double z)
 {
     const double u = x - d[0], v = y - d[1], w = z - d[2];
-    const double a = Ci.m[0] * u + Ci.m[1] * v + Ci.m[2] * w, b = Ci.m[3] * u + Ci.m[4] * v + Ci.m[5] * w,
-                 c = Ci.m[6] * u + Ci.m[7] * v + Ci.m[8] * w;
-    return a * a + b * b + c * c;
+    const double a = dot3(Ci.m[0], Ci.m[1], Ci.m[2], u, v, w), b = dot3(Ci.m[3], Ci.m[4], Ci.m[5], u, v, w), c = dot3(Ci.m[6], Ci.m[7], Ci.m[8], u, v, w);
+    return dot3(a, b, c, a, b, c);
 }
 
 struct Best { double dist; int idx; double x, y, z; }; // candidate closest point: SQUARED metric distance, cloud index, coordinates
@@ -259,7 +276,7 @@ __device__ __forceinline__ Best scan(const Scan &s, const uint64_t *in, uint64_t
                     const double dist = ell_dist2(Ci, d, x[k], y[k], z[k]); // squared: same order, same "<= 1"
                     if (MODE == KEEP_OUTSIDE) alive = 1 - sqrt(dist) > CR_EPS;
                     if (MODE == KEEP_INSIDE) alive = dist <= 1;
-                    if (MODE == KEEP_BEHIND_PLANE) alive = n[0] * (x[k] - q[0]) + n[1] * (y[k] - q[1]) + n[2] * (z[k] - q[2]) < 0;
+                    if (MODE == KEEP_BEHIND_PLANE) alive = cut_side(n, q, x[k], y[k], z[k]) < 0;
                     if (alive && before(dist, id[k], best.dist, best.idx)) best = Best{dist, id[k], x[k], y[k], z[k]};
                 }
                 const uint64_t o = __ballot(alive);
@@ -312,7 +329,7 @@ __device__ __forceinline__ Best scan_tile(Tile &t, int W, const uint64_t *in, ui
             if (MODE == KEEP_ALL) t.d2[j] = dist;
             if (MODE == KEEP_OUTSIDE) alive = 1 - sqrt(dist) > CR_EPS;
             if (MODE == KEEP_INSIDE) alive = dist <= 1;
-            if (MODE == KEEP_BEHIND_PLANE) alive = n[0] * (t.x[j] - q[0]) + n[1] * (t.y[j] - q[1]) + n[2] * (t.z[j] - q[2]) < 0;
+            if (MODE == KEEP_BEHIND_PLANE) alive = cut_side(n, q, t.x[j], t.y[j], t.z[j]) < 0;
             if (alive && before(dist, t.id[j], best.dist, best.idx)) best = Best{dist, t.id[j], t.x[j], t.y[j], t.z[j]};
         }
         const uint64_t o = __ballot(alive);
@@ -358,8 +375,8 @@ __device__ __forceinline__ Best scan_cloud(const Scan &s, uint64_t *m0, uint64_t
             i1[k] = false;
             if (has_box) { // Polyhedron::inside: rejected if signed_dist > epsilon_ (polyhedron.h:51-58)
                 const double ex = x[k] - o[0], ey = y[k] - o[1], ez = z[k] - o[2];
-                const double h = fr[0][0] * ex + fr[0][1] * ey + fr[0][2] * ez, t = fr[1][0] * ex + fr[1][1] * ey + fr[1][2] * ez,
-                             v = fr[2][0] * ex + fr[2][1] * ey + fr[2][2] * ez;
+                const double h = dot3(fr[0][0], fr[0][1], fr[0][2], ex, ey, ez), t = dot3(fr[1][0], fr[1][1], fr[1][2], ex, ey, ez),
+                             v = dot3(fr[2][0], fr[2][1], fr[2][2], ex, ey, ez);
                 in0 = in0 && !(h > bh) && !(-h > bh) && !(t > bd_hi) && !(t < bd_lo) && !(v > bv) && !(-v > bv);
             }
             if (in0) {
@@ -452,8 +469,8 @@ __device__ __forceinline__ Best scan_grid(const frp_nmpc_corridor &c, uint32_t *
                 bool in0 = id[k] >= 0;
                 i1[k] = false;
                 const double ex = x[k] - o[0], ey = y[k] - o[1], ez = z[k] - o[2];
-                const double h = fr[0][0] * ex + fr[0][1] * ey + fr[0][2] * ez, t = fr[1][0] * ex + fr[1][1] * ey + fr[1][2] * ez,
-                             v = fr[2][0] * ex + fr[2][1] * ey + fr[2][2] * ez;
+                const double h = dot3(fr[0][0], fr[0][1], fr[0][2], ex, ey, ez), t = dot3(fr[1][0], fr[1][1], fr[1][2], ex, ey, ez),
+                             v = dot3(fr[2][0], fr[2][1], fr[2][2], ex, ey, ez);
                 in0 = in0 && !(h > bh) && !(-h > bh) && !(t > bd_hi) && !(t < bd_lo) && !(v > bv) && !(-v > bv);
                 if (in0) {
                     const double dist = ell_dist2(Ci, d, x[k], y[k], z[k]);
@@ -737,11 +754,15 @@ __global__ __launch_bounds__(CR_THREADS) __attribute__((amdgpu_waves_per_eu(FRP_
 //     rows read from LDS: one global round trip per polytope instead of one per stage;
 //   * the first scan reads the grid rows under the box's hull CW_ROWS at a time, their cell ranges fetched by 64 lanes at once.
 // The wave-uniform 3x3 algebra stays on lane 0 behind LDS (struct Uni) exactly as in the four-wave kernel -- same instructions, same
-// results: the two kernels produce bit-identical polytopes (tests/test_gpu_parity.py::test_corridor_wave_kernel_equals_the_workgroup_kernel).
+// results: the two kernels produce bit-identical polytopes (tests/test_gpu_parity.py::_check_corridor compares every grid launch -- this kernel -- with
+// the plain-cloud launch of the workgroup kernel, array for array).
 // Measured (full tick, 4096 planners): corridor 0.90 -> 0.40 ms at CW_TILE = 20 (1280 points in registers, 2 waves per SIMD = 8 planners per
 // CU); three waves per SIMD (168 registers) spills 115-132 registers and runs 0.60-0.73 ms, 24 tile rows 0.43, four grid rows in flight 0.40.
 // Needs the uniform grid and the local box (the production configuration); a planner whose box holds more than CW_CAP points flags
-// itself (poly_index[b][0] = -1) and is redone by the workgroup kernels launched behind.
+// itself (poly_index[b][0] = -1) and is redone by the shell form launched behind (SHELL = true, below), and what that one gives up on
+// (more than a tile of points inside the seed ellipsoid, more than CS_PLANES cuts, a shell it cannot narrow) by the workgroup kernels.
+// Measured on dense clouds (4096 planners x 8 decompositions, tests/tools/corridor_bench.py; profiles/r05_corridor_bench.jsonl): boxes
+// of ~1650 points 4.13 -> 2.0 ms, of ~5300 points 11.6 -> 3.3 ms.
 #ifndef FRP_CW_TILE
 #define FRP_CW_TILE 20
 #endif
@@ -750,6 +771,9 @@ __global__ __launch_bounds__(CR_THREADS) __attribute__((amdgpu_waves_per_eu(FRP_
 #endif
 #ifndef FRP_CW_ROWS
 #define FRP_CW_ROWS 8
+#endif
+#ifndef FRP_CW_STREAM // experiment knob: 0 = the round-4 first scan of the plain form (eight grid rows at a time)
+#define FRP_CW_STREAM 1
 #endif
 #ifndef FRP_CW_D2   // experiment knob: 0 = recompute the hyperplane loop's distances every round (20 registers fewer)
 #define FRP_CW_D2 1
@@ -805,7 +829,7 @@ __device__ __forceinline__ Best scan_wave(TileW &t, int W, unsigned in, unsigned
                     if (MODE == KEEP_ALL && FRP_CW_D2) t.d2[FRP_CW_D2 ? j : 0] = dist;
                     if (MODE == KEEP_OUTSIDE) alive = 1 - sqrt(dist) > CR_EPS;
                     if (MODE == KEEP_INSIDE) alive = dist <= 1;
-                    if (MODE == KEEP_BEHIND_PLANE) alive = n[0] * (t.x[j] - q[0]) + n[1] * (t.y[j] - q[1]) + n[2] * (t.z[j] - q[2]) < 0;
+                    if (MODE == KEEP_BEHIND_PLANE) alive = cut_side(n, q, t.x[j], t.y[j], t.z[j]) < 0;
                     if (alive && before(dist, t.id[j], best.dist, best.idx)) best = Best{dist, t.id[j], t.x[j], t.y[j], t.z[j]};
                 }
                 o |= (alive ? 1u : 0u) << j;
@@ -816,12 +840,173 @@ __device__ __forceinline__ Best scan_wave(TileW &t, int W, unsigned in, unsigned
     return wave_best(best);
 }
 
+// ---- SHELL = true (round 5): boxes of ANY size on one wavefront.  The register tile holds 1280 points, a dense cloud puts 1650 .. 5300 into a
+// local box (profiles/r05_corridor_bench.jsonl) -- but a decomposition never needs them all at once:
+//   * find_ellipsoid (line_segment.h:136-211) only looks at the points inside the SEED ellipsoid: pass A streams the grid rows under the
+//     box's hull, counts the in-box points and lists just those (more than the tile holds: the planner stays flagged for the workgroup
+//     kernels);
+//   * find_polyhedron (decomp_base.h:63-83) visits the in-box points in order of their distance in the final ellipsoid, and every cut
+//     removes what lies behind it.  So the points are taken in SHELLS of that distance: pass B streams the hull again and lists the
+//     points with T_lo <= d2 < T_hi that are in front of every plane cut so far (the planes sit in LDS; the test is the scan's own
+//     expression, and a point is alive iff it is in front of ALL planes, whatever the order they are tried in); the tile runs the
+//     reference's loop on them until none is left, and since every point outside the shell is farther than every point inside, the
+//     closest alive point of the shell IS the closest alive point.  The first shell is sized from the box's point density for half a
+//     tile; behind it nearly everything is already cut, so the next shell is tried unbounded and narrowed only if it overflows.
+//   Same picks, same cuts, same rows as the other kernels (tests/test_gpu_parity.py::test_corridor_dense_clouds_boxes_beyond_the_register_tile).
+//   The cell-sorted copy of the cloud is read coalesced, 8 grid rows in flight; no list of the box in LDS, so 8 planners per CU.
+constexpr int CS_PLANES = 128; // cuts of one decomposition kept for the later shells (more: the planner is left to the workgroup kernels)
+constexpr int CS_RETRIES = 48;
+
+// the local box as the first scans test it (frame at p1, half widths with epsilon_), and its axis-aligned hull in grid cells
+struct BoxFrame { double fr[3][3], o[3], bh, bd_lo, bd_hi, bv; };
+__device__ __forceinline__ BoxFrame load_box(const Uni &u, const frp_nmpc_corridor &c)
+{
+    BoxFrame f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        f.o[k] = u.p1[k];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) f.fr[k][j] = u.frame[k][j];
+    }
+    f.bh = c.bbox[1] + CR_EPS; f.bd_lo = -c.bbox[0] - CR_EPS; f.bd_hi = u.len + c.bbox[0] + CR_EPS; f.bv = c.bbox[2] + CR_EPS;
+    return f;
+}
+__device__ __forceinline__ bool in_box(const BoxFrame &f, double x, double y, double z, int id)
+{
+    const double ex = x - f.o[0], ey = y - f.o[1], ez = z - f.o[2];
+    const double h = dot3(f.fr[0][0], f.fr[0][1], f.fr[0][2], ex, ey, ez), tt = dot3(f.fr[1][0], f.fr[1][1], f.fr[1][2], ex, ey, ez),
+                 v = dot3(f.fr[2][0], f.fr[2][1], f.fr[2][2], ex, ey, ez);
+    return id >= 0 && !(h > f.bh) && !(-h > f.bh) && !(tt > f.bd_hi) && !(tt < f.bd_lo) && !(v > f.bv) && !(-v > f.bv);
+}
+__device__ __forceinline__ void box_hull(const BoxFrame &f, const frp_nmpc_corridor &c, int (&lo)[3], int (&hi)[3])
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double ctr = f.o[k] + 0.5 * (f.bd_lo + f.bd_hi) * f.fr[1][k];
+        const double half = f.bh * fabs(f.fr[0][k]) + 0.5 * (f.bd_hi - f.bd_lo) * fabs(f.fr[1][k]) + f.bv * fabs(f.fr[2][k]);
+        const double a = floor((ctr - half - c.grid_origin[k]) / c.grid_cell), bb = floor((ctr + half - c.grid_origin[k]) / c.grid_cell);
+        const int n = c.grid_dims[k];
+        lo[k] = a < 0 ? 0 : (a > n - 1 ? n - 1 : (int)a);
+        hi[k] = bb < 0 ? 0 : (bb > n - 1 ? n - 1 : (int)bb);
+    }
+}
+
+// every point of the cell-sorted cloud under the hull [lo, hi] of a local box.  The grid rows under the hull (cells lo[0]..hi[0] of one
+// (iy, iz): one contiguous run of the sorted points each) are laid end to end -- lane = row fetches its run, a wave scan gives the run
+// offsets, a lane finds the run of its flat position by a 6-step search in LDS -- so every wavefront-wide load is full whatever the
+// runs' lengths, CS_U of them are in flight, and the next batch is fetched before the current one is looked at (a pass is a chain of
+// L2 round trips: 2500 .. 8000 candidates per pass, ~1.5x the in-box points).  f(batch, chunks) is called in uniform control flow with
+// the first `chunks` 64-point words of the batch live (id < 0: no point in this lane) and returns false (uniformly) to stop the pass.
+// s_row: 128 ints of LDS.
+constexpr int CS_U = 8;
+struct HullBatch { double x[CS_U], y[CS_U], z[CS_U]; int id[CS_U]; };
+
+// Before a row is read it is clipped: its cells form a box [x range] x [one cell in y] x [one cell in z] (border cells, which also hold
+// the points outside the grid, count as unbounded on their outer side), and a point can only matter if it is on the keep side of every
+// plane in s_cuts[0 .. ncuts) -- the six faces of the local box pushed out by a micrometre, then the cuts made so far -- so per plane the
+// row keeps just the x range in which SOME point of its y-z cross-section is on the keep side (bounds rounded outward; the exact tests
+// are still made per point).  The hull of a rotated box loses a third of its cells this way, the pass behind a finished shell four
+// fifths: what is alive by then lies inside the polytope under construction.
+template <class Fn>
+__device__ __forceinline__ void stream_hull(const frp_nmpc_corridor &c, const int (&lo)[3], const int (&hi)[3], int *s_row, const double *s_cuts, int ncuts, Fn &&f)
+{
+    const int lane = threadIdx.x;
+    const int ny = hi[1] - lo[1] + 1, rows = ny * (hi[2] - lo[2] + 1), nx = c.grid_dims[0];
+    const double inf = __builtin_huge_val();
+    for (int rb = 0; rb < rows; rb += 64) {
+        int mbeg = 0, run = 0;
+        if (rb + lane < rows) {
+            const int r = rb + lane;
+            const int iy = lo[1] + r % ny, iz = lo[2] + r / ny;
+            const double ylo = iy == 0 ? -inf : c.grid_origin[1] + iy * c.grid_cell, yhi = iy == c.grid_dims[1] - 1 ? inf : c.grid_origin[1] + (iy + 1) * c.grid_cell;
+            const double zlo = iz == 0 ? -inf : c.grid_origin[2] + iz * c.grid_cell, zhi = iz == c.grid_dims[2] - 1 ? inf : c.grid_origin[2] + (iz + 1) * c.grid_cell;
+            double xlo = -inf, xhi = inf;
+            for (int p = 0; p < ncuts; ++p) {
+                const double *pl = s_cuts + 6 * p;
+                const double n0 = pl[3], n1 = pl[4], n2 = pl[5];
+                // the least n1 (y - q1) + n2 (z - q2) over the cross-section: a point (x, y, z) is kept only if n0 (x - q0) + that < 0
+                const double ry = n1 > 0 ? n1 * (ylo - pl[1]) : (n1 < 0 ? n1 * (yhi - pl[1]) : 0.0), rz = n2 > 0 ? n2 * (zlo - pl[2]) : (n2 < 0 ? n2 * (zhi - pl[2]) : 0.0);
+                const double rmin = ry + rz;
+                if (n0 != 0.0) {
+                    const double off = -rmin * __builtin_amdgcn_rcp(n0), bnd = pl[0] + off, mg = 1e-6 + 1e-6 * fabs(off);
+                    if (n0 > 0) { if (bnd + mg < xhi) xhi = bnd + mg; } else { if (bnd - mg > xlo) xlo = bnd - mg; }
+                } else if (rmin > 1e-6)
+                    xlo = inf;
+            }
+            if (xlo <= xhi) {
+                const double a = floor((xlo - c.grid_origin[0]) / c.grid_cell), bb = floor((xhi - c.grid_origin[0]) / c.grid_cell);
+                const int ia = a > (double)lo[0] ? (a > (double)hi[0] ? hi[0] + 1 : (int)a) : lo[0], ib = bb < (double)hi[0] ? (bb < (double)lo[0] ? lo[0] - 1 : (int)bb) : hi[0];
+                if (ia <= ib) {
+                    const size_t row = ((size_t)iz * c.grid_dims[1] + iy) * nx;
+                    mbeg = c.grid_start[row + ia];
+                    run = c.grid_start[row + ib + 1] - mbeg;
+                }
+            }
+        }
+        int inc = run;
+#pragma unroll
+        for (int dl = 1; dl < 64; dl <<= 1) { const int v = __shfl_up(inc, dl); if (lane >= dl) inc += v; }
+        const int total = __builtin_amdgcn_readlane(inc, 63);
+        CW_SYNC(); // (the previous block's searches are done)
+        s_row[lane] = inc - run; s_row[64 + lane] = mbeg; // rows past the last one have an empty run: their offset is `total`, beyond every position
+        CW_SYNC();
+        if (total == 0) continue;
+        // (no branch in here: positions past the end are clamped to the last point, so the CS_U searches advance in lock step -- one LDS
+        // round trip per step, not per step and load -- and the loads of a batch are issued back to back)
+        auto fetch = [&](int t0, HullBatch &B) {
+            int t[CS_U], r[CS_U];
+#pragma unroll
+            for (int k = 0; k < CS_U; ++k) { const int tt = t0 + 64 * k + lane; t[k] = tt < total ? tt : total - 1; r[k] = 0; }
+#pragma unroll
+            for (int step = 32; step; step >>= 1) { // the last run that starts at or before t (never an empty one)
+                int v[CS_U];
+#pragma unroll
+                for (int k = 0; k < CS_U; ++k) v[k] = s_row[r[k] + step];
+#pragma unroll
+                for (int k = 0; k < CS_U; ++k) r[k] += v[k] <= t[k] ? step : 0;
+            }
+            int p[CS_U];
+#pragma unroll
+            for (int k = 0; k < CS_U; ++k) p[k] = s_row[64 + r[k]] + (t[k] - s_row[r[k]]);
+#pragma unroll
+            for (int k = 0; k < CS_U; ++k) {
+                const size_t p3 = 3 * (size_t)p[k];
+                B.x[k] = c.grid_points[p3]; B.y[k] = c.grid_points[p3 + 1]; B.z[k] = c.grid_points[p3 + 2];
+                B.id[k] = c.grid_index[p[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < CS_U; ++k) B.id[k] = t0 + 64 * k + lane < total ? B.id[k] : -1;
+        };
+        HullBatch cur, nxt;
+        fetch(0, cur);
+        for (int t0 = 0; t0 < total; t0 += 64 * CS_U) {
+            const bool has_next = t0 + 64 * CS_U < total;
+            if (has_next) fetch(t0 + 64 * CS_U, nxt);
+            const int left = (total - t0 + 63) / 64;
+            if (!f(cur, left < CS_U ? left : CS_U)) return;
+            if (has_next) cur = nxt;
+        }
+    }
+}
+
+template <bool SHELL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, FRP_CW_WPE))) void corridor_wave_kernel(frp_nmpc_corridor c)
 {
     __shared__ double s_A[FRP_CORRIDOR_MAX_F * 3], s_b[FRP_CORRIDOR_MAX_F];
     __shared__ uint32_t list[CW_CAP];
     __shared__ Uni u;
+    __shared__ double s_pl[SHELL ? (6 + CS_PLANES) * 6 : 36]; // SHELL: the local box's faces (pushed out, for the row clipping only), then the cuts of the running decomposition, (q, n) as the scans use them
+    __shared__ int s_row[128];                         // stream_hull's run offsets
+    __shared__ double s_seedCi[SHELL ? 9 : 1];         // SHELL: C^-1 of the seed ellipsoid, to tell whether find_ellipsoid changed it
+    __shared__ int s_same;
+    int nbox_prev = 0; // SHELL: in-box points of the planner's previous decomposition (the next box is a little further along the path)
     const int b = blockIdx.x, lane = threadIdx.x;
+    if (SHELL && c.poly_index[(size_t)b * c.N] != -1) return; // (behind the plain kernel: only the planners it left flagged)
+#ifdef FRP_CORRIDOR_PROFILE
+    long long tp_a = 0, tp_b = 0, tp_tile = 0, tp_shrink = 0, tp_rest = 0, tp_begin = wall_clock64();
+    int np_b = 0, np_retry = 0, np_shell = 0, np_dec = 0, np_round = 0, np_listed = 0, np_box = 0;
+    CR_T0
+#endif
     const double *ref = c.ref_pos + (size_t)b * c.N * 3, *yaw = c.ref_yaw + (size_t)b * c.N, *Eb = c.ellipsoid + (size_t)b * c.N * 9;
     const int P_cloud = c.P;
     const int max_rounds = P_cloud + 8; // (see corridor_kernel: only non-finite input needs the bound)
@@ -866,12 +1051,110 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
             const M3 Ri = mul(quat_to_rot(cos(yw / 2), 0, 0, sin(yw / 2)), quat_to_rot(cos(pitch / 2), 0, sin(pitch / 2), 0));
             st3(u.Ri, Ri); st3(u.Rf, Ri);
             st3(u.Ci, inverse(rot_diag_rot(Ri, c00, cdd, cdd)));
+            if (SHELL) st3(s_seedCi, ld3(u.Ci));
+            for (int k = 0; k < 6; ++k)
+                for (int j = 0; j < 3; ++j) { s_pl[6 * k + j] = u.box[k][j] + 1e-6 * u.box[6 + k][j]; s_pl[6 * k + 3 + j] = u.box[6 + k][j]; }
         }
         CW_SYNC();
         // ---- first scan through the grid: the in-box points -> list (cloud index | inside-the-seed-ellipsoid flag), the closest inside one
         int count = 0;
         Best cp;
-        {
+        int hlo[3] = {0, 0, 0}, hhi[3] = {0, 0, 0}, nbox = 0; // SHELL: the hull of the box in grid cells, the in-box points
+#ifdef FRP_CORRIDOR_PROFILE
+        if (SHELL) CR_ACC(tp_rest)
+#endif
+        double T1 = -1.0; // SHELL: bound of the shell pass A lists beside the points inside the seed ellipsoid (< 0: none)
+        int rest1 = 0;    //        in-box points beyond it
+        if constexpr (SHELL) {
+            // pass A: count the in-box points, list those inside the seed ellipsoid (flag bit), find the closest of them -- and, betting that
+            // none is inside (then find_ellipsoid leaves the seed ellipsoid as it is), list the first shell of the seed ellipsoid's metric too
+            const M3 Ci = ld3(u.Ci);
+            const double d[3] = {u.mid[0], u.mid[1], u.mid[2]};
+            const BoxFrame bf = load_box(u, c);
+            box_hull(bf, c, hlo, hhi);
+            { // half a tile at the previous box's mean density -- the cloud's, for the planner's first box (any value is correct; this one avoids retries)
+                const double vol = 8.0 * c.bbox[1] * c.bbox[2] * (0.5 * u.len + c.bbox[0]);
+                const double expect = nbox_prev > 0 ? (double)nbox_prev
+                                                    : (double)c.P / (c.grid_cell * c.grid_cell * c.grid_cell * c.grid_dims[0] * c.grid_dims[1] * c.grid_dims[2]) * vol;
+                if (expect > 0.9 * CW_CAP) {
+                    const double per_unit = expect / vol * 4.1887902047863905 * u.ax[0] * u.ax[1] * u.ax[2]; // points per unit of d2^(3/2)
+                    const double r = cbrt((double)(CW_CAP / 2) / per_unit);
+                    if (r * r > 1.0 && r * r < __builtin_huge_val()) T1 = r * r;
+                } else
+                    T1 = __builtin_huge_val();
+            }
+            for (;;) {
+                Best best{1.7976931348623157e308, 0x7fffffff, 0.0, 0.0, 0.0};
+                int n_in = 0;
+                count = 0; nbox = 0; rest1 = 0;
+                stream_hull(c, hlo, hhi, s_row, s_pl, 6, [&](const HullBatch &B, int chunks) {
+#pragma unroll
+                    for (int k = 0; k < CS_U; ++k) {
+                        if (k >= chunks) break;
+                        const double x = B.x[k], y = B.y[k], z = B.z[k];
+                        const int id = B.id[k];
+                        const bool in0 = in_box(bf, x, y, z, id);
+                        bool i1 = false, s1 = false;
+                        if (in0) {
+                            const double dist = ell_dist2(Ci, d, x, y, z);
+                            i1 = dist <= 1;
+                            s1 = !i1 && dist < T1;
+                            if (i1 && before(dist, id, best.dist, best.idx)) best = Best{dist, id, x, y, z};
+                        }
+                        nbox += (int)__popcll(__ballot(in0));
+                        n_in += (int)__popcll(__ballot(i1));
+                        rest1 += (int)__popcll(__ballot(in0 && !i1 && !s1));
+                        const uint64_t w1 = __ballot(i1 || s1);
+                        if (w1) {
+                            const int mine = count + (int)__popcll(w1 & ((1ull << lane) - 1));
+                            if ((i1 || s1) && mine < CW_CAP) list[mine] = (uint32_t)id | (i1 ? 0x80000000u : 0u);
+                            count += (int)__popcll(w1);
+                        }
+                    }
+                    return count <= CW_CAP;
+                });
+                if (count > CW_CAP && T1 > 0.0) { T1 = -1.0; CW_SYNC(); continue; } // the bet's shell overflowed the tile: the inside points alone
+                if (n_in > 0) T1 = -1.0; // find_ellipsoid has work to do: the listed shell is not one of the final ellipsoid (its points stay out of m1)
+                cp = wave_best(best);
+                break;
+            }
+            nbox_prev = nbox;
+#ifdef FRP_CORRIDOR_PROFILE
+            CR_ACC(tp_a) ++np_dec; np_box += nbox;
+#endif
+        } else {
+#if FRP_CW_STREAM
+            // the in-box points -> list, through the same stream as the shell form's passes: rows clipped to the local box, full loads,
+            // a batch ahead (round 5; before: eight grid rows at a time, each load waited for -- 16 of a decomposition's ~50 us)
+            const M3 Ci = ld3(u.Ci);
+            const double d[3] = {u.mid[0], u.mid[1], u.mid[2]};
+            const BoxFrame bf = load_box(u, c);
+            box_hull(bf, c, hlo, hhi);
+            Best best{1.7976931348623157e308, 0x7fffffff, 0.0, 0.0, 0.0};
+            stream_hull(c, hlo, hhi, s_row, s_pl, 6, [&](const HullBatch &B, int chunks) {
+#pragma unroll
+                for (int k = 0; k < CS_U; ++k) {
+                    if (k >= chunks) break;
+                    const double x = B.x[k], y = B.y[k], z = B.z[k];
+                    const int id = B.id[k];
+                    const bool in0 = in_box(bf, x, y, z, id);
+                    bool i1 = false;
+                    if (in0) {
+                        const double dist = ell_dist2(Ci, d, x, y, z);
+                        i1 = dist <= 1;
+                        if (i1 && before(dist, id, best.dist, best.idx)) best = Best{dist, id, x, y, z};
+                    }
+                    const uint64_t w0 = __ballot(in0);
+                    if (w0) {
+                        const int mine = count + (int)__popcll(w0 & ((1ull << lane) - 1));
+                        if (in0 && mine < CW_CAP) list[mine] = (uint32_t)id | (i1 ? 0x80000000u : 0u);
+                        count += (int)__popcll(w0);
+                    }
+                }
+                return count <= CW_CAP; // (a box that has overflowed the tile is left to the shell form behind: stop reading)
+            });
+            cp = wave_best(best);
+#else
             const M3 Ci = ld3(u.Ci);
             const double d[3] = {u.mid[0], u.mid[1], u.mid[2]};
             double fr[3][3], o[3];
@@ -927,8 +1210,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
                         for (int k = 0; k < CW_ROWS; ++k) {
                             bool in0 = id[k] >= 0, i1 = false;
                             const double ex = x[k] - o[0], ey = y[k] - o[1], ez = z[k] - o[2];
-                            const double h = fr[0][0] * ex + fr[0][1] * ey + fr[0][2] * ez, tt = fr[1][0] * ex + fr[1][1] * ey + fr[1][2] * ez,
-                                         v = fr[2][0] * ex + fr[2][1] * ey + fr[2][2] * ez;
+                            const double h = dot3(fr[0][0], fr[0][1], fr[0][2], ex, ey, ez), tt = dot3(fr[1][0], fr[1][1], fr[1][2], ex, ey, ez),
+                                         v = dot3(fr[2][0], fr[2][1], fr[2][2], ex, ey, ez);
                             in0 = in0 && !(h > bh) && !(-h > bh) && !(tt > bd_hi) && !(tt < bd_lo) && !(v > bv) && !(-v > bv);
                             if (in0) {
                                 const double dist = ell_dist2(Ci, d, x[k], y[k], z[k]);
@@ -946,6 +1229,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
                 }
             }
             cp = wave_best(best);
+#endif
         }
         if (count > CW_CAP) { // more points in the box than the register tile holds: the workgroup kernels behind take this planner
             if (lane == 0) c.poly_index[(size_t)b * c.N] = -1;
@@ -1013,6 +1297,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
             u.rows = 0;
         }
         CW_SYNC();
+        if constexpr (!SHELL) {
         cp = scan_wave<KEEP_ALL>(tile, W, m0, m2, u);
         for (int guard = 0; cp.idx != 0x7fffffff && guard < max_rounds; ++guard) {
             const double q[3] = {cp.x, cp.y, cp.z};
@@ -1025,6 +1310,139 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
             for (int k = 0; k < 3; ++k) n[k] /= nl;
             if (lane == 0) emit_row(u, q, n, c.F, s_A, s_b, gA, gb);
             cp = scan_wave<KEEP_BEHIND_PLANE>(tile, W, m2, m2, u, q, n);
+        }
+        } else { // the in-box points in shells of their distance in the final ellipsoid
+#ifdef FRP_CORRIDOR_PROFILE
+            CR_ACC(tp_shrink)
+#endif
+            const double inf = __builtin_huge_val();
+            int npl = 0, tries = 0;
+            double T_lo = -1.0, T_hi = inf;
+            bool have_tile = false;
+            if (T1 > 0.0) { // pass A's bet: is the final ellipsoid the seed ellipsoid, bit for bit?  Then its shell is the first one, already in the tile
+                if (lane == 0) {
+                    int same = 1;
+                    for (int k = 0; k < 9; ++k) same &= u.Ci[k] == s_seedCi[k] ? 1 : 0;
+                    s_same = same;
+                }
+                CW_SYNC();
+                have_tile = s_same != 0;
+            }
+            if (!have_tile && nbox > CW_CAP) { // first shell: half a tile at the box's mean density
+                const double vol = 8.0 * c.bbox[1] * c.bbox[2] * (0.5 * u.len + c.bbox[0]);
+                const double per_unit = (double)nbox / vol * 4.1887902047863905 * u.ax[0] * u.ax[1] * u.ax[2]; // points per unit of d2^(3/2)
+                const double r = cbrt((double)(CW_CAP / 2) / per_unit);
+                if (r * r > 1.0 && r * r < inf) T_hi = r * r;
+            }
+            // find_polyhedron's loop on the points of the tile (decomp_base.h:63-83); every cut is kept for the shells behind.  false: too many cuts
+            auto cut_tile = [&](int Ws, unsigned s0) -> bool {
+                unsigned s2 = 0;
+                cp = scan_wave<KEEP_ALL>(tile, Ws, s0, s2, u);
+                for (int guard = 0; cp.idx != 0x7fffffff && guard < max_rounds; ++guard) {
+                    const double q[3] = {cp.x, cp.y, cp.z};
+                    const double w[3] = {q[0] - u.mid[0], q[1] - u.mid[1], q[2] - u.mid[2]};
+                    double n[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) n[k] = u.CC[3 * k] * w[0] + u.CC[3 * k + 1] * w[1] + u.CC[3 * k + 2] * w[2];
+                    const double nl = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) n[k] /= nl;
+                    if (npl >= CS_PLANES) return false;
+                    if (lane == 0) {
+                        emit_row(u, q, n, c.F, s_A, s_b, gA, gb);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { s_pl[36 + 6 * npl + k] = q[k]; s_pl[36 + 6 * npl + 3 + k] = n[k]; }
+                    }
+                    ++npl;
+                    cp = scan_wave<KEEP_BEHIND_PLANE>(tile, Ws, s2, s2, u, q, n);
+                }
+                CW_SYNC(); // the new cuts are visible to every lane; the list may be overwritten
+                return true;
+            };
+            bool more = true;
+            if (have_tile) { // (its own copy of the loop: inside the shell loop below the tile is dead while a pass streams)
+                if (!cut_tile(W, m0)) { if (lane == 0) c.poly_index[(size_t)b * c.N] = -1; return; }
+#ifdef FRP_CORRIDOR_PROFILE
+                CR_ACC(tp_tile) np_round += npl; ++np_shell; np_listed += count;
+#endif
+                more = rest1 > 0 && T1 < inf;
+                T_lo = T1; T_hi = inf;
+            }
+            while (more) {
+                int cnt = 0, rest = 0;
+                {
+                    const M3 Ci = ld3(u.Ci);
+                    const double d[3] = {u.mid[0], u.mid[1], u.mid[2]};
+                    const BoxFrame bf = load_box(u, c);
+                    stream_hull(c, hlo, hhi, s_row, s_pl, 6 + npl, [&](const HullBatch &B, int chunks) {
+                        bool al[CS_U];
+                        double dist[CS_U];
+                        uint64_t any = 0;
+#pragma unroll
+                        for (int k = 0; k < CS_U; ++k) {
+                            al[k] = k < chunks && in_box(bf, B.x[k], B.y[k], B.z[k], B.id[k]);
+                            dist[k] = 0.0;
+                            if (al[k]) { dist[k] = ell_dist2(Ci, d, B.x[k], B.y[k], B.z[k]); al[k] = dist[k] >= T_lo; }
+                            any |= __ballot(al[k]);
+                        }
+                        // a point is alive iff it is in front of every cut so far (most are behind one of the first): a cut is fetched from
+                        // LDS once for the whole batch
+                        for (int p = 0; p < npl && any; ++p) {
+                            double q[3], n[3];
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) { q[j] = s_pl[36 + 6 * p + j]; n[j] = s_pl[36 + 6 * p + 3 + j]; }
+                            any = 0;
+#pragma unroll
+                            for (int k = 0; k < CS_U; ++k) {
+                                al[k] = al[k] && cut_side(n, q, B.x[k], B.y[k], B.z[k]) < 0;
+                                any |= __ballot(al[k]);
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < CS_U; ++k) {
+                            const bool sh = al[k] && dist[k] < T_hi;
+                            rest += (int)__popcll(__ballot(al[k] && !sh));
+                            const uint64_t w = __ballot(sh);
+                            if (w) {
+                                const int mine = cnt + (int)__popcll(w & ((1ull << lane) - 1));
+                                if (sh && mine < CW_CAP) list[mine] = (uint32_t)B.id[k];
+                                cnt += (int)__popcll(w);
+                            }
+                        }
+                        return cnt <= CW_CAP;
+                    });
+                }
+#ifdef FRP_CORRIDOR_PROFILE
+                CR_ACC(tp_b) ++np_b; if (cnt > CW_CAP) ++np_retry; else { ++np_shell; np_listed += cnt; }
+#endif
+                if (cnt > CW_CAP) { // more than a tile: narrow the shell and stream again
+                    if (++tries > CS_RETRIES) { if (lane == 0) c.poly_index[(size_t)b * c.N] = -1; return; }
+                    const double base = T_lo > 0.0 ? T_lo : 0.0;
+                    T_hi = T_hi == inf ? (base > 1.0 ? base : 1.0) * 2.5 : base + (T_hi - base) * 0.4;
+                    CW_SYNC();
+                    continue;
+                }
+                CW_SYNC();
+                unsigned s0 = 0;
+#pragma unroll
+                for (int j = 0; j < CW_TILE; ++j) {
+                    const int pos = j * 64 + lane;
+                    const bool valid = pos < cnt;
+                    const int idj = valid ? (int)list[pos] : 0;
+                    tile.id[j] = idj;
+                    tile.x[j] = valid ? c.cloud[3 * (size_t)idj] : 0.0;
+                    tile.y[j] = valid ? c.cloud[3 * (size_t)idj + 1] : 0.0;
+                    tile.z[j] = valid ? c.cloud[3 * (size_t)idj + 2] : 0.0;
+                    if (FRP_CW_D2) tile.d2[FRP_CW_D2 ? j : 0] = 0.0;
+                    s0 |= (valid ? 1u : 0u) << j;
+                }
+                if (!cut_tile((cnt + 63) / 64, s0)) { if (lane == 0) c.poly_index[(size_t)b * c.N] = -1; return; }
+#ifdef FRP_CORRIDOR_PROFILE
+                CR_ACC(tp_tile) np_round += npl;
+#endif
+                more = rest > 0 && T_hi < inf;
+                T_lo = T_hi; T_hi = inf;
+            }
         }
         if (lane == 0) {
             for (int k = 0; k < 6; ++k) emit_row(u, u.box[k], u.box[6 + k], c.F, s_A, s_b, gA, gb);
@@ -1052,6 +1470,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
         ++npoly;
         i = next;
     }
+#ifdef FRP_CORRIDOR_PROFILE
+    if (SHELL && lane == 0 && (b == 0 || b == 1000))
+        printf("shell wave %d: total %lld passA %lld passB %lld (%d passes, %d retries, %d shells) tile+rounds %lld shrink %lld rest %lld [100 MHz ticks]; %d decompositions, "
+               "%d in-box points, %d listed, %d cuts (cumulative per shell)\n", b, wall_clock64() - tp_begin, tp_a, tp_b, np_b, np_retry, np_shell, tp_tile, tp_shrink, tp_rest,
+               np_dec, np_box, np_listed, np_round);
+#endif
     if (lane == 0) {
         for (int k = npoly; k < c.N; ++k) c.poly_nfaces[(size_t)b * c.N + k] = 0;
         if (c.poly_count) c.poly_count[b] = u.overflow ? -npoly : npoly;
@@ -1151,7 +1575,9 @@ extern "C" int frp_nmpc_corridor_batch(const frp_nmpc_corridor *p, void *stream)
     // one flags (more than its LDS list) to the plain-cloud kernel.  FRP_CORRIDOR_WAVE=0 (experiments, the equality test): workgroup kernels only
     static const bool wave_off = [] { const char *e = getenv("FRP_CORRIDOR_WAVE"); return e && e[0] == '0'; }();
     const bool wave = grid && !wave_off;
-    if (wave) hipLaunchKernelGGL(frp::corridor_wave_kernel, dim3((unsigned)p->B), dim3(64), 0, static_cast<hipStream_t>(stream), *p);
+    static const bool shell_off = [] { const char *e = getenv("FRP_CORRIDOR_SHELL"); return e && e[0] == '0'; }(); // (experiments)
+    if (wave) hipLaunchKernelGGL(frp::corridor_wave_kernel<false>, dim3((unsigned)p->B), dim3(64), 0, static_cast<hipStream_t>(stream), *p);
+    if (wave && !shell_off) hipLaunchKernelGGL(frp::corridor_wave_kernel<true>, dim3((unsigned)p->B), dim3(64), 0, static_cast<hipStream_t>(stream), *p);
     if (grid) hipLaunchKernelGGL(frp::corridor_kernel<true>, dim3((unsigned)p->B), dim3(frp::CR_THREADS), lds, static_cast<hipStream_t>(stream), *p, wave ? 1 : 0);
     hipLaunchKernelGGL(frp::corridor_kernel<false>, dim3((unsigned)p->B), dim3(frp::CR_THREADS), lds, static_cast<hipStream_t>(stream), *p, grid ? 1 : 0);
     return hipGetLastError() == hipSuccess ? FRP_OK : FRP_ERR_HIP;

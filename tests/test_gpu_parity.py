@@ -897,6 +897,33 @@ def test_corridor_obstacles_inside_the_seed_ellipsoid_and_edge_cases():
     _check_corridor(cloud, ref[:, :1], yaw[:, :1], E[:, :1])
 
 
+def test_corridor_dense_clouds_boxes_beyond_the_register_tile():
+    """Local boxes with more points than the one-wavefront kernel's register tile (1280) go to its shell form (frp_corridor.hip,
+    corridor_wave_kernel<true>: the in-box points taken in shells of their distance in the final ellipsoid, filtered by the cuts made so
+    far).  Same polytopes, to the bit, as the workgroup kernels on the plain cloud (`_check_corridor` compares the grid launches with the
+    plain one) and the oracle's rows: ~1700 and ~5300 points per box, obstacles inside a long seed ellipsoid (both shrink loops on the
+    listed subset), a voxel-like cloud (ties), and a sphere of 3000 equidistant points that no shell can split (the planner is handed
+    back to the workgroup kernels after the retries)."""
+    cloud, ref, yaw, E = _corridor_world(21, P=20000, B=3)
+    _check_corridor(cloud, ref, yaw, E)
+    cloud, ref, yaw, E = _corridor_world(22, P=62000, B=3)
+    pi, A, b, nf = _check_corridor(cloud, ref, yaw, E)
+    assert pi.max() >= 1
+    cloud, ref, yaw, E = _corridor_world(23, P=40000, B=2, tunnel=0.25)
+    _check_corridor(cloud, ref, yaw, E, consts=dict(seed_len=1.5, bbox=(2.0, 2.0, 1.0), inflation=1.1), ordered=False)
+    cloud, ref, yaw, E = _corridor_world(24, P=50000, B=2, grid=0.12)
+    _check_corridor(cloud, ref, yaw, E)
+    cloud, ref, yaw, E = _corridor_world(25, P=6000, B=2)
+    rng = np.random.default_rng(25)
+    v = rng.normal(size=(3000, 3)); v /= np.linalg.norm(v, axis=1)[:, None]
+    sphere = ref[0, 0] + np.array([0.05, 0.0, 0.0]) + 0.9 * v        # (the seed segment's midpoint is 0.05 ahead of the first reference)
+    dense = np.r_[cloud, sphere]
+    plain = solver.corridor_batch_host(dense, ref, yaw, E)              # (3000-fold near-ties: which one an implementation visits first is
+    for cell in (0.5, 0.23):                                            #  rounding, so this one is checked kernel against kernel only)
+        g = solver.corridor_batch_host(dense, ref, yaw, E, grid_cell=cell)
+        assert all(np.array_equal(x, y) for x, y in zip(g, plain)), cell
+
+
 # ---- SURVEY 8f row f-4 (first half): stage references from the kinodynamic path ----
 def _reference_oracle():
     import sys
