@@ -772,6 +772,9 @@ __global__ __launch_bounds__(CR_THREADS) __attribute__((amdgpu_waves_per_eu(FRP_
 #ifndef FRP_CW_ROWS
 #define FRP_CW_ROWS 8
 #endif
+#ifndef FRP_CW_PACK   // experiment knob (shell form): 0 = the survivors of the cuts stay in the tile rows they were listed in
+#define FRP_CW_PACK 1
+#endif
 #ifndef FRP_CW_STREAM // experiment knob: 0 = the round-4 first scan of the plain form (eight grid rows at a time)
 #define FRP_CW_STREAM 1
 #endif
@@ -808,7 +811,8 @@ __device__ __forceinline__ Best wave_best(const Best &mine)
 }
 
 template <int MODE>
-__device__ __forceinline__ Best scan_wave(TileW &t, int W, unsigned in, unsigned &out, const Uni &u, const double *pq = nullptr, const double *pn = nullptr)
+__device__ __forceinline__ Best scan_wave(TileW &t, int W, unsigned in, unsigned &out, const Uni &u, const double *pq = nullptr, const double *pn = nullptr,
+                                          int *kept = nullptr)
 {
     const M3 Ci = ld3(u.Ci);
     const double d[3] = {u.mid[0], u.mid[1], u.mid[2]};
@@ -819,6 +823,7 @@ __device__ __forceinline__ Best scan_wave(TileW &t, int W, unsigned in, unsigned
     }
     Best best{1.7976931348623157e308, 0x7fffffff, 0.0, 0.0, 0.0};
     unsigned o = 0;
+    int nk = 0;
 #pragma unroll
     for (int j = 0; j < CW_TILE; ++j) {
         if (j < W) {
@@ -833,10 +838,12 @@ __device__ __forceinline__ Best scan_wave(TileW &t, int W, unsigned in, unsigned
                     if (alive && before(dist, t.id[j], best.dist, best.idx)) best = Best{dist, t.id[j], t.x[j], t.y[j], t.z[j]};
                 }
                 o |= (alive ? 1u : 0u) << j;
+                if (kept) nk += (int)__popcll(__ballot(alive));
             }
         }
     }
     out = o;
+    if (kept) *kept = nk;
     return wave_best(best);
 }
 
@@ -989,6 +996,43 @@ __device__ __forceinline__ void stream_hull(const frp_nmpc_corridor &c, const in
     }
 }
 
+// The points a cut leaves alive are scattered over all the tile rows they were listed in (a thousand points: after five cuts a hundred
+// are left, in seven rows of sixteen on average -- and a round costs its live ROWS).  Once no more than CW_PACK are alive they are moved
+// to the first rows, through LDS (the list's space: it has been read by then), and the rounds behind visit two rows.  Which lane holds a
+// point does not matter to any result: minima are taken in (distance, cloud index) order.
+constexpr int CW_PACK = 128;
+static_assert(CW_PACK * 36 <= CW_CAP * 4 && CW_PACK % 64 == 0, "the packing buffer is the list");
+__device__ __forceinline__ void pack_tile(TileW &t, unsigned &m, int &W, int alive, uint32_t *buf)
+{
+    const int lane = threadIdx.x;
+    double *bx = reinterpret_cast<double *>(buf), *by = bx + CW_PACK, *bz = by + CW_PACK, *bd = bz + CW_PACK;
+    int *bi = reinterpret_cast<int *>(bd + CW_PACK);
+    const int c = __popc(m);
+    int inc = c;
+#pragma unroll
+    for (int dl = 1; dl < 64; dl <<= 1) { const int v = __shfl_up(inc, dl); if (lane >= dl) inc += v; }
+    int slot = inc - c;
+#pragma unroll
+    for (int j = 0; j < CW_TILE; ++j) {
+        if (j < W && ((m >> j) & 1u)) {
+            bx[slot] = t.x[j]; by[slot] = t.y[j]; bz[slot] = t.z[j]; bd[slot] = t.d2[FRP_CW_D2 ? j : 0]; bi[slot] = t.id[j];
+            ++slot;
+        }
+    }
+    CW_SYNC();
+    unsigned o = 0;
+#pragma unroll
+    for (int j = 0; j < CW_PACK / 64; ++j) {
+        const int pos = j * 64 + lane;
+        const bool valid = pos < alive;
+        t.x[j] = valid ? bx[pos] : 0.0; t.y[j] = valid ? by[pos] : 0.0; t.z[j] = valid ? bz[pos] : 0.0;
+        t.d2[FRP_CW_D2 ? j : 0] = valid ? bd[pos] : 0.0; t.id[j] = valid ? bi[pos] : 0;
+        o |= (valid ? 1u : 0u) << j;
+    }
+    CW_SYNC();
+    m = o; W = CW_PACK / 64;
+}
+
 template <bool SHELL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, FRP_CW_WPE))) void corridor_wave_kernel(frp_nmpc_corridor c)
 {
@@ -1061,7 +1105,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
         Best cp;
         int hlo[3] = {0, 0, 0}, hhi[3] = {0, 0, 0}, nbox = 0; // SHELL: the hull of the box in grid cells, the in-box points
 #ifdef FRP_CORRIDOR_PROFILE
-        if (SHELL) CR_ACC(tp_rest)
+        CR_ACC(tp_rest)
 #endif
         double T1 = -1.0; // SHELL: bound of the shell pass A lists beside the points inside the seed ellipsoid (< 0: none)
         int rest1 = 0;    //        in-box points beyond it
@@ -1154,6 +1198,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
                 return count <= CW_CAP; // (a box that has overflowed the tile is left to the shell form behind: stop reading)
             });
             cp = wave_best(best);
+#ifdef FRP_CORRIDOR_PROFILE
+            CR_ACC(tp_a) ++np_dec; np_box += count;
+#endif
 #else
             const M3 Ci = ld3(u.Ci);
             const double d[3] = {u.mid[0], u.mid[1], u.mid[2]};
@@ -1298,7 +1345,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
         }
         CW_SYNC();
         if constexpr (!SHELL) {
+#ifdef FRP_CORRIDOR_PROFILE
+        CR_ACC(tp_shrink)
+#endif
         cp = scan_wave<KEEP_ALL>(tile, W, m0, m2, u);
+        // (packing the survivors -- pack_tile, the shell form's rounds -- was measured here too and lost: 36 of a tick's 44 rounds ran on
+        // two rows and still took 2.15 us each against 1.88; a round of this form is its dependent chain, not its rows)
         for (int guard = 0; cp.idx != 0x7fffffff && guard < max_rounds; ++guard) {
             const double q[3] = {cp.x, cp.y, cp.z};
             const double w[3] = {q[0] - u.mid[0], q[1] - u.mid[1], q[2] - u.mid[2]};
@@ -1310,7 +1362,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
             for (int k = 0; k < 3; ++k) n[k] /= nl;
             if (lane == 0) emit_row(u, q, n, c.F, s_A, s_b, gA, gb);
             cp = scan_wave<KEEP_BEHIND_PLANE>(tile, W, m2, m2, u, q, n);
+#ifdef FRP_CORRIDOR_PROFILE
+            ++np_round;
+#endif
         }
+#ifdef FRP_CORRIDOR_PROFILE
+        CR_ACC(tp_tile)
+#endif
         } else { // the in-box points in shells of their distance in the final ellipsoid
 #ifdef FRP_CORRIDOR_PROFILE
             CR_ACC(tp_shrink)
@@ -1354,7 +1412,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
                         for (int k = 0; k < 3; ++k) { s_pl[36 + 6 * npl + k] = q[k]; s_pl[36 + 6 * npl + 3 + k] = n[k]; }
                     }
                     ++npl;
-                    cp = scan_wave<KEEP_BEHIND_PLANE>(tile, Ws, s2, s2, u, q, n);
+                    if (FRP_CW_PACK && Ws > CW_PACK / 64) {
+                        int kept;
+                        cp = scan_wave<KEEP_BEHIND_PLANE>(tile, Ws, s2, s2, u, q, n, &kept);
+                        if (kept <= CW_PACK) pack_tile(tile, s2, Ws, kept, list);
+                    } else
+                        cp = scan_wave<KEEP_BEHIND_PLANE>(tile, Ws, s2, s2, u, q, n);
                 }
                 CW_SYNC(); // the new cuts are visible to every lane; the list may be overwritten
                 return true;
@@ -1471,9 +1534,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
         i = next;
     }
 #ifdef FRP_CORRIDOR_PROFILE
-    if (SHELL && lane == 0 && (b == 0 || b == 1000))
-        printf("shell wave %d: total %lld passA %lld passB %lld (%d passes, %d retries, %d shells) tile+rounds %lld shrink %lld rest %lld [100 MHz ticks]; %d decompositions, "
-               "%d in-box points, %d listed, %d cuts (cumulative per shell)\n", b, wall_clock64() - tp_begin, tp_a, tp_b, np_b, np_retry, np_shell, tp_tile, tp_shrink, tp_rest,
+    if (lane == 0 && (b == 0 || b == 1000) && np_dec > 0)
+        printf("%s wave %d: total %lld passA %lld passB %lld (%d passes, %d retries, %d shells) tile+rounds %lld shrink %lld rest %lld [100 MHz ticks]; %d decompositions, "
+               "%d in-box points, %d listed, %d cuts (cumulative per shell)\n", SHELL ? "shell" : "plain", b, wall_clock64() - tp_begin, tp_a, tp_b, np_b, np_retry, np_shell, tp_tile, tp_shrink, tp_rest,
                np_dec, np_box, np_listed, np_round);
 #endif
     if (lane == 0) {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # the plain one-wavefront kernel's first scan through stream_hull (lib_stream.so) against the product: corridor tests, dense bench, tick
 cd "$(dirname "$0")/../.."
-for n in "" stream; do
+for n in "" ${VARIANTS:-stream}; do
   export FRP_LIB=${n:+$PWD/forces_resilient_planner_amd/lib_$n.so}
   echo "== ${n:-product}"
   timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "corridor or tick" 2>&1 | tail -2
