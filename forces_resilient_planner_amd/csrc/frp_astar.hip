@@ -454,8 +454,13 @@ __device__ void hash_insert(HashEnt *h, int hcap, long long key, int node)
     }
 }
 
+// 1 (shipped): every push of an expansion fetches its own ancestor chain -- the round-4 commit.  0: the round-5 experiment (VERDICT r04
+// item 7: the ancestor chains of ALL pushes of an expansion fetched in one trip and the pushes replayed on the cached copy).  Measured on
+// one box (tools/dbg/astar_ab2.sh, pillar world, 1024 planners): the cached walk 2309 searches/s, 43.6 us per expansion of the longest
+// search; this one 2424 and 41.6 -- the union of the chains is ~4x the loads of one chain and the replay's bookkeeping costs what the
+// saved trips return (profile build: commit walk 13.2 k cycles per expansion against 12.3 k).  Kept for A/B runs.
 #ifndef FRP_ASTAR_SLOW_PUSH
-#define FRP_ASTAR_SLOW_PUSH 0 // (1: every push fetches its own ancestors -- the round-4 commit, kept for A/B runs)
+#define FRP_ASTAR_SLOW_PUSH 1
 #endif
 // std::__push_heap with NodeComparator (f_score greater = lower priority); entries carry their node's current f
 __device__ void heap_push_hole(HeapEnt *heap, Node *nodes, int hole, int top, double vf, int vid)
