@@ -739,49 +739,58 @@ __global__ __launch_bounds__(CR_THREADS) __attribute__((amdgpu_waves_per_eu(FRP_
 }
 
 
-// ================================================================== one wavefront per planner (round 4)
+// ================================================================== one wavefront per planner (round 4), boxes of any size (round 5)
 // A decomposition is a chain of ~20 dependent rounds (pick the closest point, cut, filter), each a few hundred instructions: with four
 // wavefronts per planner a round pays a workgroup barrier, an LDS exchange of the per-wave minima and the latency of everything in
 // between, and the CU holds 3 planners (12 waves at the 168-register budget).  Measured on the full-tick workload (4096 planners,
 // 18 k points, ~1000 of them in a local box): per planner and tick 58 us in 42 scans, 33 us in the two first scans, 25 us between
 // scans, 15 us in 20 containment checks -- all latency; two waves per planner (6 per CU) already ran 0.90 -> 0.76 ms.  This kernel
 // gives a planner ONE wavefront, so nothing in a round crosses a wave:
-//   * the in-box points live in the wave's registers, CW_TILE points per lane; the point sets (obs_, obs, the working set) are one
-//     bit per point in three 32-bit registers PER LANE -- no LDS masks, no ballots to store them, empty tile rows are skipped;
+//   * the points a round looks at live in the wave's registers, CW_TILE points per lane; the point sets (obs_, obs, the working set) are
+//     one bit per point in three 32-bit registers PER LANE -- no LDS masks, no ballots to store them, empty tile rows are skipped;
 //   * the closest point of a round is a DPP minimum and six v_readlane: no barrier, no LDS;
 //   * the hyperplane loop (decomp_base.h:63-83) compares distances in a FIXED ellipsoid: they are computed once by its opening scan;
 //   * the containment checks of the stages behind a new polytope (nmpc_solver.cpp:291-313) are evaluated together, lane = stage, the
-//     rows read from LDS: one global round trip per polytope instead of one per stage;
-//   * the first scan reads the grid rows under the box's hull CW_ROWS at a time, their cell ranges fetched by 64 lanes at once.
+//     rows read from LDS: one global round trip per polytope instead of one per stage.
 // The wave-uniform 3x3 algebra stays on lane 0 behind LDS (struct Uni) exactly as in the four-wave kernel -- same instructions, same
-// results: the two kernels produce bit-identical polytopes (tests/test_gpu_parity.py::_check_corridor compares every grid launch -- this kernel -- with
-// the plain-cloud launch of the workgroup kernel, array for array).
-// Measured (full tick, 4096 planners): corridor 0.90 -> 0.40 ms at CW_TILE = 20 (1280 points in registers, 2 waves per SIMD = 8 planners per
-// CU); three waves per SIMD (168 registers) spills 115-132 registers and runs 0.60-0.73 ms, 24 tile rows 0.43, four grid rows in flight 0.40.
-// Needs the uniform grid and the local box (the production configuration); a planner whose box holds more than CW_CAP points flags
-// itself (poly_index[b][0] = -1) and is redone by the shell form launched behind (SHELL = true, below), and what that one gives up on
-// (more than a tile of points inside the seed ellipsoid, more than CS_PLANES cuts, a shell it cannot narrow) by the workgroup kernels.
-// Measured on dense clouds (4096 planners x 8 decompositions, tests/tools/corridor_bench.py; profiles/r05_corridor_bench.jsonl): boxes
-// of ~1650 points 4.13 -> 2.0 ms, of ~5300 points 11.6 -> 3.3 ms.
+// results: the kernels produce bit-identical polytopes (tests/test_gpu_parity.py::_check_corridor compares every grid launch -- this
+// kernel -- with the plain-cloud launch of the workgroup kernel, array for array).
+// Round 4 held the WHOLE box in the tile (20 rows = 1280 points at 256 registers, 2 waves per SIMD = 8 planners per CU: 0.90 -> 0.40 ms
+// for the tick's corridor; boxes beyond the tile went back to the workgroup kernels: 4.13 / 11.6 ms on the 19 k / 62 k-point clouds of
+// tests/tools/corridor_bench.py).  Round 5: a decomposition never needs its box all at once --
+//   * find_ellipsoid (line_segment.h:136-211) only looks at the points inside the SEED ellipsoid: pass A streams the grid rows under the
+//     box's hull, counts the in-box points and lists just those (more than the tile holds: the planner is flagged, poly_index[b][0] =
+//     -1, for the workgroup kernels launched behind) -- and, betting that there are none, the first shell of the next step too;
+//   * find_polyhedron (decomp_base.h:63-83) visits the in-box points in order of their distance in the final ellipsoid, and every cut
+//     removes what lies behind it.  So the points are taken in SHELLS of that distance: pass B streams the hull again and lists the
+//     points with T_lo <= d2 < T_hi that are in front of every plane cut so far (the planes sit in LDS; the test is the scan's own
+//     expression, and a point is alive iff it is in front of ALL planes, whatever the order they are tried in); the tile runs the
+//     reference's loop on them until none is left, and since every point outside the shell is farther than every point inside, the
+//     closest alive point of the shell IS the closest alive point.  The first shell is sized from the box's point density for half a
+//     tile; behind it nearly everything is already cut, so the next shell is tried unbounded and narrowed only if it overflows.
+//   Same picks, same cuts, same rows (tests/test_gpu_parity.py::test_corridor_dense_clouds_boxes_beyond_the_register_tile).
+// -- and with the box out of the registers the tile can be SMALL: a wavefront's rounds are a dependent chain (one wave per SIMD instead
+// of two: the same 87 us per planner and tick), so what counts is wavefronts in flight.  Measured, every planner through this form
+// (19 k cloud / 62 k cloud / the tick's corridor, ms; tools/dbg/corridor_allshell.sh): 20 rows at 2 waves per SIMD 1.84 / 3.16 / 0.447,
+// 16 rows 1.74 / 2.99 / 0.427, 12 rows at 3 waves (108 spilled registers) 1.76 / 3.01 / 0.459, 8 rows at 4 waves 1.48 / 2.69 / 0.369 --
+// with 9 KB of LDS per planner (64 cuts kept, a one-row packing buffer) so that sixteen planners fit a CU 1.43 / 2.61 / 0.339, and with
+// the stream two words deep instead of eight (fewer registers in the passes) **1.23 / 2.16 / 0.293** (6 rows at 5 waves: 1.63 / 4.11 /
+// 0.395).  That is the shipped configuration; the round-4 form (whole box, 20 rows) is gone: 1.89 / 3.22 / 0.385 with it in front.
+// Needs the uniform grid and the local box (the production configuration).  What this kernel gives up on -- more than a tile of points
+// inside the seed ellipsoid, more than CS_PLANES cuts, a shell it cannot narrow -- it flags for the workgroup kernels.
 #ifndef FRP_CW_TILE
-#define FRP_CW_TILE 20
+#define FRP_CW_TILE 8
 #endif
 #ifndef FRP_CW_WPE
-#define FRP_CW_WPE 2
+#define FRP_CW_WPE 4
 #endif
-#ifndef FRP_CW_ROWS
-#define FRP_CW_ROWS 8
-#endif
-#ifndef FRP_CW_PACK   // experiment knob (shell form): 0 = the survivors of the cuts stay in the tile rows they were listed in
+#ifndef FRP_CW_PACK   // experiment knob: 0 = the survivors of the cuts stay in the tile rows they were listed in
 #define FRP_CW_PACK 1
 #endif
-#ifndef FRP_CW_STREAM // experiment knob: 0 = the round-4 first scan of the plain form (eight grid rows at a time)
-#define FRP_CW_STREAM 1
-#endif
-#ifndef FRP_CW_D2   // experiment knob: 0 = recompute the hyperplane loop's distances every round (20 registers fewer)
+#ifndef FRP_CW_D2   // experiment knob: 0 = recompute the hyperplane loop's distances every round (one register pair per tile row fewer)
 #define FRP_CW_D2 1
 #endif
-constexpr int CW_TILE = FRP_CW_TILE, CW_CAP = 64 * CW_TILE, CW_ROWS = FRP_CW_ROWS;
+constexpr int CW_TILE = FRP_CW_TILE, CW_CAP = 64 * CW_TILE;
 static_assert(CW_TILE <= 32, "one bit per tile row in a 32-bit lane mask");
 struct TileW { double x[CW_TILE], y[CW_TILE], z[CW_TILE], d2[FRP_CW_D2 ? CW_TILE : 1]; int id[CW_TILE]; };
 
@@ -847,21 +856,13 @@ __device__ __forceinline__ Best scan_wave(TileW &t, int W, unsigned in, unsigned
     return wave_best(best);
 }
 
-// ---- SHELL = true (round 5): boxes of ANY size on one wavefront.  The register tile holds 1280 points, a dense cloud puts 1650 .. 5300 into a
-// local box (profiles/r05_corridor_bench.jsonl) -- but a decomposition never needs them all at once:
-//   * find_ellipsoid (line_segment.h:136-211) only looks at the points inside the SEED ellipsoid: pass A streams the grid rows under the
-//     box's hull, counts the in-box points and lists just those (more than the tile holds: the planner stays flagged for the workgroup
-//     kernels);
-//   * find_polyhedron (decomp_base.h:63-83) visits the in-box points in order of their distance in the final ellipsoid, and every cut
-//     removes what lies behind it.  So the points are taken in SHELLS of that distance: pass B streams the hull again and lists the
-//     points with T_lo <= d2 < T_hi that are in front of every plane cut so far (the planes sit in LDS; the test is the scan's own
-//     expression, and a point is alive iff it is in front of ALL planes, whatever the order they are tried in); the tile runs the
-//     reference's loop on them until none is left, and since every point outside the shell is farther than every point inside, the
-//     closest alive point of the shell IS the closest alive point.  The first shell is sized from the box's point density for half a
-//     tile; behind it nearly everything is already cut, so the next shell is tried unbounded and narrowed only if it overflows.
-//   Same picks, same cuts, same rows as the other kernels (tests/test_gpu_parity.py::test_corridor_dense_clouds_boxes_beyond_the_register_tile).
-//   The cell-sorted copy of the cloud is read coalesced, 8 grid rows in flight; no list of the box in LDS, so 8 planners per CU.
-constexpr int CS_PLANES = 128; // cuts of one decomposition kept for the later shells (more: the planner is left to the workgroup kernels)
+#ifndef FRP_CS_FILL // eighths of a tile a shell is sized for
+#define FRP_CS_FILL 4
+#endif
+#ifndef FRP_CS_PLANES
+#define FRP_CS_PLANES 64
+#endif
+constexpr int CS_PLANES = FRP_CS_PLANES; // cuts of one decomposition kept for the later shells (more: the planner is left to the workgroup kernels)
 constexpr int CS_RETRIES = 48;
 
 // the local box as the first scans test it (frame at p1, half widths with epsilon_), and its axis-aligned hull in grid cells
@@ -905,7 +906,10 @@ __device__ __forceinline__ void box_hull(const BoxFrame &f, const frp_nmpc_corri
 // L2 round trips: 2500 .. 8000 candidates per pass, ~1.5x the in-box points).  f(batch, chunks) is called in uniform control flow with
 // the first `chunks` 64-point words of the batch live (id < 0: no point in this lane) and returns false (uniformly) to stop the pass.
 // s_row: 128 ints of LDS.
-constexpr int CS_U = 8;
+#ifndef FRP_CS_U
+#define FRP_CS_U 2
+#endif
+constexpr int CS_U = FRP_CS_U;
 struct HullBatch { double x[CS_U], y[CS_U], z[CS_U]; int id[CS_U]; };
 
 // Before a row is read it is clipped: its cells form a box [x range] x [one cell in y] x [one cell in z] (border cells, which also hold
@@ -1000,8 +1004,12 @@ __device__ __forceinline__ void stream_hull(const frp_nmpc_corridor &c, const in
 // are left, in seven rows of sixteen on average -- and a round costs its live ROWS).  Once no more than CW_PACK are alive they are moved
 // to the first rows, through LDS (the list's space: it has been read by then), and the rounds behind visit two rows.  Which lane holds a
 // point does not matter to any result: minima are taken in (distance, cloud index) order.
-constexpr int CW_PACK = 128;
-static_assert(CW_PACK * 36 <= CW_CAP * 4 && CW_PACK % 64 == 0, "the packing buffer is the list");
+#ifndef FRP_CW_PACKN
+#define FRP_CW_PACKN 64
+#endif
+constexpr int CW_PACK = FRP_CW_PACKN;
+constexpr int CW_LIST = CW_CAP > CW_PACK * 9 ? CW_CAP : CW_PACK * 9; // entries of the in-box list; also the packing buffer (36 bytes per packed point)
+static_assert(CW_PACK % 64 == 0, "whole tile rows");
 __device__ __forceinline__ void pack_tile(TileW &t, unsigned &m, int &W, int alive, uint32_t *buf)
 {
     const int lane = threadIdx.x;
@@ -1033,19 +1041,17 @@ __device__ __forceinline__ void pack_tile(TileW &t, unsigned &m, int &W, int ali
     m = o; W = CW_PACK / 64;
 }
 
-template <bool SHELL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, FRP_CW_WPE))) void corridor_wave_kernel(frp_nmpc_corridor c)
 {
     __shared__ double s_A[FRP_CORRIDOR_MAX_F * 3], s_b[FRP_CORRIDOR_MAX_F];
-    __shared__ uint32_t list[CW_CAP];
+    __shared__ uint32_t list[CW_LIST];
     __shared__ Uni u;
-    __shared__ double s_pl[SHELL ? (6 + CS_PLANES) * 6 : 36]; // SHELL: the local box's faces (pushed out, for the row clipping only), then the cuts of the running decomposition, (q, n) as the scans use them
+    __shared__ double s_pl[(6 + CS_PLANES) * 6]; // the local box's faces (pushed out, for the row clipping only), then the cuts of the running decomposition, (q, n) as the scans use them
     __shared__ int s_row[128];                         // stream_hull's run offsets
-    __shared__ double s_seedCi[SHELL ? 9 : 1];         // SHELL: C^-1 of the seed ellipsoid, to tell whether find_ellipsoid changed it
+    __shared__ double s_seedCi[9];                     // C^-1 of the seed ellipsoid, to tell whether find_ellipsoid changed it
     __shared__ int s_same;
-    int nbox_prev = 0; // SHELL: in-box points of the planner's previous decomposition (the next box is a little further along the path)
+    int nbox_prev = 0; // in-box points of the planner's previous decomposition (the next box is a little further along the path)
     const int b = blockIdx.x, lane = threadIdx.x;
-    if (SHELL && c.poly_index[(size_t)b * c.N] != -1) return; // (behind the plain kernel: only the planners it left flagged)
 #ifdef FRP_CORRIDOR_PROFILE
     long long tp_a = 0, tp_b = 0, tp_tile = 0, tp_shrink = 0, tp_rest = 0, tp_begin = wall_clock64();
     int np_b = 0, np_retry = 0, np_shell = 0, np_dec = 0, np_round = 0, np_listed = 0, np_box = 0;
@@ -1095,7 +1101,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
             const M3 Ri = mul(quat_to_rot(cos(yw / 2), 0, 0, sin(yw / 2)), quat_to_rot(cos(pitch / 2), 0, sin(pitch / 2), 0));
             st3(u.Ri, Ri); st3(u.Rf, Ri);
             st3(u.Ci, inverse(rot_diag_rot(Ri, c00, cdd, cdd)));
-            if (SHELL) st3(s_seedCi, ld3(u.Ci));
+            st3(s_seedCi, ld3(u.Ci));
             for (int k = 0; k < 6; ++k)
                 for (int j = 0; j < 3; ++j) { s_pl[6 * k + j] = u.box[k][j] + 1e-6 * u.box[6 + k][j]; s_pl[6 * k + 3 + j] = u.box[6 + k][j]; }
         }
@@ -1103,78 +1109,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
         // ---- first scan through the grid: the in-box points -> list (cloud index | inside-the-seed-ellipsoid flag), the closest inside one
         int count = 0;
         Best cp;
-        int hlo[3] = {0, 0, 0}, hhi[3] = {0, 0, 0}, nbox = 0; // SHELL: the hull of the box in grid cells, the in-box points
+        int hlo[3] = {0, 0, 0}, hhi[3] = {0, 0, 0}, nbox = 0; // the hull of the box in grid cells, the in-box points
 #ifdef FRP_CORRIDOR_PROFILE
         CR_ACC(tp_rest)
 #endif
-        double T1 = -1.0; // SHELL: bound of the shell pass A lists beside the points inside the seed ellipsoid (< 0: none)
+        double T1 = -1.0; // bound of the shell pass A lists beside the points inside the seed ellipsoid (< 0: none)
         int rest1 = 0;    //        in-box points beyond it
-        if constexpr (SHELL) {
-            // pass A: count the in-box points, list those inside the seed ellipsoid (flag bit), find the closest of them -- and, betting that
-            // none is inside (then find_ellipsoid leaves the seed ellipsoid as it is), list the first shell of the seed ellipsoid's metric too
-            const M3 Ci = ld3(u.Ci);
-            const double d[3] = {u.mid[0], u.mid[1], u.mid[2]};
-            const BoxFrame bf = load_box(u, c);
-            box_hull(bf, c, hlo, hhi);
-            { // half a tile at the previous box's mean density -- the cloud's, for the planner's first box (any value is correct; this one avoids retries)
-                const double vol = 8.0 * c.bbox[1] * c.bbox[2] * (0.5 * u.len + c.bbox[0]);
-                const double expect = nbox_prev > 0 ? (double)nbox_prev
-                                                    : (double)c.P / (c.grid_cell * c.grid_cell * c.grid_cell * c.grid_dims[0] * c.grid_dims[1] * c.grid_dims[2]) * vol;
-                if (expect > 0.9 * CW_CAP) {
-                    const double per_unit = expect / vol * 4.1887902047863905 * u.ax[0] * u.ax[1] * u.ax[2]; // points per unit of d2^(3/2)
-                    const double r = cbrt((double)(CW_CAP / 2) / per_unit);
-                    if (r * r > 1.0 && r * r < __builtin_huge_val()) T1 = r * r;
-                } else
-                    T1 = __builtin_huge_val();
-            }
-            for (;;) {
-                Best best{1.7976931348623157e308, 0x7fffffff, 0.0, 0.0, 0.0};
-                int n_in = 0;
-                count = 0; nbox = 0; rest1 = 0;
-                stream_hull(c, hlo, hhi, s_row, s_pl, 6, [&](const HullBatch &B, int chunks) {
-#pragma unroll
-                    for (int k = 0; k < CS_U; ++k) {
-                        if (k >= chunks) break;
-                        const double x = B.x[k], y = B.y[k], z = B.z[k];
-                        const int id = B.id[k];
-                        const bool in0 = in_box(bf, x, y, z, id);
-                        bool i1 = false, s1 = false;
-                        if (in0) {
-                            const double dist = ell_dist2(Ci, d, x, y, z);
-                            i1 = dist <= 1;
-                            s1 = !i1 && dist < T1;
-                            if (i1 && before(dist, id, best.dist, best.idx)) best = Best{dist, id, x, y, z};
-                        }
-                        nbox += (int)__popcll(__ballot(in0));
-                        n_in += (int)__popcll(__ballot(i1));
-                        rest1 += (int)__popcll(__ballot(in0 && !i1 && !s1));
-                        const uint64_t w1 = __ballot(i1 || s1);
-                        if (w1) {
-                            const int mine = count + (int)__popcll(w1 & ((1ull << lane) - 1));
-                            if ((i1 || s1) && mine < CW_CAP) list[mine] = (uint32_t)id | (i1 ? 0x80000000u : 0u);
-                            count += (int)__popcll(w1);
-                        }
-                    }
-                    return count <= CW_CAP;
-                });
-                if (count > CW_CAP && T1 > 0.0) { T1 = -1.0; CW_SYNC(); continue; } // the bet's shell overflowed the tile: the inside points alone
-                if (n_in > 0) T1 = -1.0; // find_ellipsoid has work to do: the listed shell is not one of the final ellipsoid (its points stay out of m1)
-                cp = wave_best(best);
-                break;
-            }
-            nbox_prev = nbox;
-#ifdef FRP_CORRIDOR_PROFILE
-            CR_ACC(tp_a) ++np_dec; np_box += nbox;
-#endif
-        } else {
-#if FRP_CW_STREAM
-            // the in-box points -> list, through the same stream as the shell form's passes: rows clipped to the local box, full loads,
-            // a batch ahead (round 5; before: eight grid rows at a time, each load waited for -- 16 of a decomposition's ~50 us)
-            const M3 Ci = ld3(u.Ci);
-            const double d[3] = {u.mid[0], u.mid[1], u.mid[2]};
-            const BoxFrame bf = load_box(u, c);
-            box_hull(bf, c, hlo, hhi);
+        // pass A: count the in-box points, list those inside the seed ellipsoid (flag bit), find the closest of them -- and, betting that
+        // none is inside (then find_ellipsoid leaves the seed ellipsoid as it is), list the first shell of the seed ellipsoid's metric too
+        const M3 Ci = ld3(u.Ci);
+        const double d[3] = {u.mid[0], u.mid[1], u.mid[2]};
+        const BoxFrame bf = load_box(u, c);
+        box_hull(bf, c, hlo, hhi);
+        { // half a tile at the previous box's mean density -- the cloud's, for the planner's first box (any value is correct; this one avoids retries)
+            const double vol = 8.0 * c.bbox[1] * c.bbox[2] * (0.5 * u.len + c.bbox[0]);
+            const double expect = nbox_prev > 0 ? (double)nbox_prev
+                                                : (double)c.P / (c.grid_cell * c.grid_cell * c.grid_cell * c.grid_dims[0] * c.grid_dims[1] * c.grid_dims[2]) * vol;
+            if (expect > 0.9 * CW_CAP) {
+                const double per_unit = expect / vol * 4.1887902047863905 * u.ax[0] * u.ax[1] * u.ax[2]; // points per unit of d2^(3/2)
+                const double r = cbrt((double)(CW_CAP * FRP_CS_FILL / 8) / per_unit);
+                if (r * r > 1.0 && r * r < __builtin_huge_val()) T1 = r * r;
+            } else
+                T1 = __builtin_huge_val();
+        }
+        for (;;) {
             Best best{1.7976931348623157e308, 0x7fffffff, 0.0, 0.0, 0.0};
+            int n_in = 0;
+            count = 0; nbox = 0; rest1 = 0;
             stream_hull(c, hlo, hhi, s_row, s_pl, 6, [&](const HullBatch &B, int chunks) {
 #pragma unroll
                 for (int k = 0; k < CS_U; ++k) {
@@ -1182,102 +1143,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
                     const double x = B.x[k], y = B.y[k], z = B.z[k];
                     const int id = B.id[k];
                     const bool in0 = in_box(bf, x, y, z, id);
-                    bool i1 = false;
+                    bool i1 = false, s1 = false;
                     if (in0) {
                         const double dist = ell_dist2(Ci, d, x, y, z);
                         i1 = dist <= 1;
+                        s1 = !i1 && dist < T1;
                         if (i1 && before(dist, id, best.dist, best.idx)) best = Best{dist, id, x, y, z};
                     }
-                    const uint64_t w0 = __ballot(in0);
-                    if (w0) {
-                        const int mine = count + (int)__popcll(w0 & ((1ull << lane) - 1));
-                        if (in0 && mine < CW_CAP) list[mine] = (uint32_t)id | (i1 ? 0x80000000u : 0u);
-                        count += (int)__popcll(w0);
+                    nbox += (int)__popcll(__ballot(in0));
+                    n_in += (int)__popcll(__ballot(i1));
+                    rest1 += (int)__popcll(__ballot(in0 && !i1 && !s1));
+                    const uint64_t w1 = __ballot(i1 || s1);
+                    if (w1) {
+                        const int mine = count + (int)__popcll(w1 & ((1ull << lane) - 1));
+                        if ((i1 || s1) && mine < CW_CAP) list[mine] = (uint32_t)id | (i1 ? 0x80000000u : 0u);
+                        count += (int)__popcll(w1);
                     }
                 }
-                return count <= CW_CAP; // (a box that has overflowed the tile is left to the shell form behind: stop reading)
+                return count <= CW_CAP;
             });
+            if (count > CW_CAP && T1 > 0.0) { T1 = -1.0; CW_SYNC(); continue; } // the bet's shell overflowed the tile: the inside points alone
+            if (n_in > 0) T1 = -1.0; // find_ellipsoid has work to do: the listed shell is not one of the final ellipsoid (its points stay out of m1)
             cp = wave_best(best);
-#ifdef FRP_CORRIDOR_PROFILE
-            CR_ACC(tp_a) ++np_dec; np_box += count;
-#endif
-#else
-            const M3 Ci = ld3(u.Ci);
-            const double d[3] = {u.mid[0], u.mid[1], u.mid[2]};
-            double fr[3][3], o[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                o[k] = u.p1[k];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) fr[k][j] = u.frame[k][j];
-            }
-            const double bh = c.bbox[1] + CR_EPS, bd_lo = -c.bbox[0] - CR_EPS, bd_hi = u.len + c.bbox[0] + CR_EPS, bv = c.bbox[2] + CR_EPS;
-            int lo[3], hi[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double ctr = o[k] + 0.5 * (bd_lo + bd_hi) * fr[1][k];
-                const double half = bh * fabs(fr[0][k]) + 0.5 * (bd_hi - bd_lo) * fabs(fr[1][k]) + bv * fabs(fr[2][k]);
-                const double a = floor((ctr - half - c.grid_origin[k]) / c.grid_cell), bb = floor((ctr + half - c.grid_origin[k]) / c.grid_cell);
-                const int n = c.grid_dims[k];
-                lo[k] = a < 0 ? 0 : (a > n - 1 ? n - 1 : (int)a);
-                hi[k] = bb < 0 ? 0 : (bb > n - 1 ? n - 1 : (int)bb);
-            }
-            const int ny = hi[1] - lo[1] + 1, rows = ny * (hi[2] - lo[2] + 1), nx = c.grid_dims[0];
-            Best best{1.7976931348623157e308, 0x7fffffff, 0.0, 0.0, 0.0};
-            for (int rb = 0; rb < rows; rb += 64) { // 64 rows of cells at a time: lane = row, its point range in one round trip
-                int mbeg = 0, mend = 0;
-                if (rb + lane < rows) {
-                    const int r = rb + lane;
-                    const size_t row = ((size_t)(lo[2] + r / ny) * c.grid_dims[1] + (lo[1] + r % ny)) * nx;
-                    mbeg = c.grid_start[row + lo[0]];
-                    mend = c.grid_start[row + hi[0] + 1];
-                }
-                const int nr = rows - rb < 64 ? rows - rb : 64;
-                for (int r0 = 0; r0 < nr && count <= CW_CAP; r0 += CW_ROWS) { // (a box that has already overflowed the tile is left to the kernels behind: stop reading)
-                    int beg[CW_ROWS], end[CW_ROWS], most = 0;
-#pragma unroll
-                    for (int k = 0; k < CW_ROWS; ++k) {
-                        const int rr = r0 + k < 64 ? r0 + k : 63;
-                        beg[k] = __builtin_amdgcn_readlane(mbeg, rr); end[k] = __builtin_amdgcn_readlane(mend, rr);
-                        if (r0 + k >= nr) beg[k] = end[k] = 0;
-                        most = max(most, end[k] - beg[k]);
-                    }
-                    for (int off = 0; off < most; off += 64) {
-                        double x[CW_ROWS], y[CW_ROWS], z[CW_ROWS];
-                        int id[CW_ROWS];
-#pragma unroll
-                        for (int k = 0; k < CW_ROWS; ++k) {
-                            const int p = beg[k] + off + lane;
-                            const bool ok = p < end[k];
-                            const size_t p3 = 3 * (size_t)(ok ? p : 0);
-                            x[k] = ok ? c.grid_points[p3] : 0.0; y[k] = ok ? c.grid_points[p3 + 1] : 0.0; z[k] = ok ? c.grid_points[p3 + 2] : 0.0;
-                            id[k] = ok ? c.grid_index[p] : -1;
-                        }
-#pragma unroll
-                        for (int k = 0; k < CW_ROWS; ++k) {
-                            bool in0 = id[k] >= 0, i1 = false;
-                            const double ex = x[k] - o[0], ey = y[k] - o[1], ez = z[k] - o[2];
-                            const double h = dot3(fr[0][0], fr[0][1], fr[0][2], ex, ey, ez), tt = dot3(fr[1][0], fr[1][1], fr[1][2], ex, ey, ez),
-                                         v = dot3(fr[2][0], fr[2][1], fr[2][2], ex, ey, ez);
-                            in0 = in0 && !(h > bh) && !(-h > bh) && !(tt > bd_hi) && !(tt < bd_lo) && !(v > bv) && !(-v > bv);
-                            if (in0) {
-                                const double dist = ell_dist2(Ci, d, x[k], y[k], z[k]);
-                                i1 = dist <= 1;
-                                if (i1 && before(dist, id[k], best.dist, best.idx)) best = Best{dist, id[k], x[k], y[k], z[k]};
-                            }
-                            const uint64_t w0 = __ballot(in0);
-                            if (w0) {
-                                const int mine = count + (int)__popcll(w0 & ((1ull << lane) - 1));
-                                if (in0 && mine < CW_CAP) list[mine] = (uint32_t)id[k] | (i1 ? 0x80000000u : 0u);
-                                count += (int)__popcll(w0);
-                            }
-                        }
-                    }
-                }
-            }
-            cp = wave_best(best);
-#endif
+            break;
         }
+        nbox_prev = nbox;
+#ifdef FRP_CORRIDOR_PROFILE
+        CR_ACC(tp_a) ++np_dec; np_box += nbox;
+#endif
         if (count > CW_CAP) { // more points in the box than the register tile holds: the workgroup kernels behind take this planner
             if (lane == 0) c.poly_index[(size_t)b * c.N] = -1;
             return;
@@ -1344,32 +1237,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
             u.rows = 0;
         }
         CW_SYNC();
-        if constexpr (!SHELL) {
-#ifdef FRP_CORRIDOR_PROFILE
-        CR_ACC(tp_shrink)
-#endif
-        cp = scan_wave<KEEP_ALL>(tile, W, m0, m2, u);
-        // (packing the survivors -- pack_tile, the shell form's rounds -- was measured here too and lost: 36 of a tick's 44 rounds ran on
-        // two rows and still took 2.15 us each against 1.88; a round of this form is its dependent chain, not its rows)
-        for (int guard = 0; cp.idx != 0x7fffffff && guard < max_rounds; ++guard) {
-            const double q[3] = {cp.x, cp.y, cp.z};
-            const double w[3] = {q[0] - u.mid[0], q[1] - u.mid[1], q[2] - u.mid[2]};
-            double n[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) n[k] = u.CC[3 * k] * w[0] + u.CC[3 * k + 1] * w[1] + u.CC[3 * k + 2] * w[2];
-            const double nl = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) n[k] /= nl;
-            if (lane == 0) emit_row(u, q, n, c.F, s_A, s_b, gA, gb);
-            cp = scan_wave<KEEP_BEHIND_PLANE>(tile, W, m2, m2, u, q, n);
-#ifdef FRP_CORRIDOR_PROFILE
-            ++np_round;
-#endif
-        }
-#ifdef FRP_CORRIDOR_PROFILE
-        CR_ACC(tp_tile)
-#endif
-        } else { // the in-box points in shells of their distance in the final ellipsoid
+        { // the in-box points in shells of their distance in the final ellipsoid
 #ifdef FRP_CORRIDOR_PROFILE
             CR_ACC(tp_shrink)
 #endif
@@ -1389,7 +1257,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
             if (!have_tile && nbox > CW_CAP) { // first shell: half a tile at the box's mean density
                 const double vol = 8.0 * c.bbox[1] * c.bbox[2] * (0.5 * u.len + c.bbox[0]);
                 const double per_unit = (double)nbox / vol * 4.1887902047863905 * u.ax[0] * u.ax[1] * u.ax[2]; // points per unit of d2^(3/2)
-                const double r = cbrt((double)(CW_CAP / 2) / per_unit);
+                const double r = cbrt((double)(CW_CAP * FRP_CS_FILL / 8) / per_unit);
                 if (r * r > 1.0 && r * r < inf) T_hi = r * r;
             }
             // find_polyhedron's loop on the points of the tile (decomp_base.h:63-83); every cut is kept for the shells behind.  false: too many cuts
@@ -1535,8 +1403,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
     }
 #ifdef FRP_CORRIDOR_PROFILE
     if (lane == 0 && (b == 0 || b == 1000) && np_dec > 0)
-        printf("%s wave %d: total %lld passA %lld passB %lld (%d passes, %d retries, %d shells) tile+rounds %lld shrink %lld rest %lld [100 MHz ticks]; %d decompositions, "
-               "%d in-box points, %d listed, %d cuts (cumulative per shell)\n", SHELL ? "shell" : "plain", b, wall_clock64() - tp_begin, tp_a, tp_b, np_b, np_retry, np_shell, tp_tile, tp_shrink, tp_rest,
+        printf("wave %d: total %lld passA %lld passB %lld (%d passes, %d retries, %d shells) tile+rounds %lld shrink %lld rest %lld [100 MHz ticks]; %d decompositions, "
+               "%d in-box points, %d listed, %d cuts (cumulative per shell)\n", b, wall_clock64() - tp_begin, tp_a, tp_b, np_b, np_retry, np_shell, tp_tile, tp_shrink, tp_rest,
                np_dec, np_box, np_listed, np_round);
 #endif
     if (lane == 0) {
@@ -1634,13 +1502,12 @@ extern "C" int frp_nmpc_corridor_batch(const frp_nmpc_corridor *p, void *stream)
     const bool has_box = p->bbox[0] != 0.0 || p->bbox[1] != 0.0 || p->bbox[2] != 0.0;
     const bool grid = p->grid_start && has_box && !p->cloud_count;
     // production configuration (shared cloud with a grid, local box, N <= 64 = one lane per stage): one wavefront per planner;
-    // planners it flags (more in-box points than its register tile) go to the workgroup kernel through the grid, and what THAT
-    // one flags (more than its LDS list) to the plain-cloud kernel.  FRP_CORRIDOR_WAVE=0 (experiments, the equality test): workgroup kernels only
+    // planners it flags (more than a tile of points inside a seed ellipsoid, more than CS_PLANES cuts) go to the workgroup kernel
+    // through the grid, and what THAT one flags (more in-box points than its LDS list) to the plain-cloud kernel.
+    // FRP_CORRIDOR_WAVE=0 (experiments): workgroup kernels only
     static const bool wave_off = [] { const char *e = getenv("FRP_CORRIDOR_WAVE"); return e && e[0] == '0'; }();
     const bool wave = grid && !wave_off;
-    static const bool shell_off = [] { const char *e = getenv("FRP_CORRIDOR_SHELL"); return e && e[0] == '0'; }(); // (experiments)
-    if (wave) hipLaunchKernelGGL(frp::corridor_wave_kernel<false>, dim3((unsigned)p->B), dim3(64), 0, static_cast<hipStream_t>(stream), *p);
-    if (wave && !shell_off) hipLaunchKernelGGL(frp::corridor_wave_kernel<true>, dim3((unsigned)p->B), dim3(64), 0, static_cast<hipStream_t>(stream), *p);
+    if (wave) hipLaunchKernelGGL(frp::corridor_wave_kernel, dim3((unsigned)p->B), dim3(64), 0, static_cast<hipStream_t>(stream), *p);
     if (grid) hipLaunchKernelGGL(frp::corridor_kernel<true>, dim3((unsigned)p->B), dim3(frp::CR_THREADS), lds, static_cast<hipStream_t>(stream), *p, wave ? 1 : 0);
     hipLaunchKernelGGL(frp::corridor_kernel<false>, dim3((unsigned)p->B), dim3(frp::CR_THREADS), lds, static_cast<hipStream_t>(stream), *p, grid ? 1 : 0);
     return hipGetLastError() == hipSuccess ? FRP_OK : FRP_ERR_HIP;
