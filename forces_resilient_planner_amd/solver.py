@@ -562,6 +562,10 @@ class DeviceFleet:
         self.NPOLY = N if npoly is None else npoly
         self.weights = tuple(float(x) for x in weights)  # (w_stage_wp, w_stage_input, w_input_rate, w_terminal_wp, w_terminal_input)
         self.solver = DeviceSolver(B, N, M, min(M, F), model, device)
+        # a fleet ticks: this tick's problem is the previous one shifted by a stage, and its iteration count is the best predictor of
+        # this one's (frp_nmpc_batch.order_hint; zero before the first solve = "typical").  Saves the key kernel's pass over the
+        # parameters as well (27 of a tick's 1590 us at 4096 planners).  FRP_FLEET_ORDER_HINT=0: the key of the initial guess, as before
+        self.solver.order_by_last_iters = os.environ.get("FRP_FLEET_ORDER_HINT", "1") != "0"
         dev = self.solver.device
         f64 = dict(dtype=torch.float64, device=dev)
         self.mpc_output = torch.zeros((B, N + 1, L.NZ), **f64)
