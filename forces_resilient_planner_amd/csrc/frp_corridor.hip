@@ -766,7 +766,7 @@ __global__ __launch_bounds__(CR_THREADS) __attribute__((amdgpu_waves_per_eu(FRP_
 //     points with T_lo <= d2 < T_hi that are in front of every plane cut so far (the planes sit in LDS; the test is the scan's own
 //     expression, and a point is alive iff it is in front of ALL planes, whatever the order they are tried in); the tile runs the
 //     reference's loop on them until none is left, and since every point outside the shell is farther than every point inside, the
-//     closest alive point of the shell IS the closest alive point.  The first shell is sized from the box's point density for half a
+//     closest alive point of the shell IS the closest alive point.  The first shell is sized from the box's point density for 5/8 of a
 //     tile; behind it nearly everything is already cut, so the next shell is tried unbounded and narrowed only if it overflows.
 //   Same picks, same cuts, same rows (tests/test_gpu_parity.py::test_corridor_dense_clouds_boxes_beyond_the_register_tile).
 // -- and with the box out of the registers the tile can be SMALL: a wavefront's rounds are a dependent chain (one wave per SIMD instead
@@ -774,12 +774,14 @@ __global__ __launch_bounds__(CR_THREADS) __attribute__((amdgpu_waves_per_eu(FRP_
 // (19 k cloud / 62 k cloud / the tick's corridor, ms; tools/dbg/corridor_allshell.sh): 20 rows at 2 waves per SIMD 1.84 / 3.16 / 0.447,
 // 16 rows 1.74 / 2.99 / 0.427, 12 rows at 3 waves (108 spilled registers) 1.76 / 3.01 / 0.459, 8 rows at 4 waves 1.48 / 2.69 / 0.369 --
 // with 9 KB of LDS per planner (64 cuts kept, a one-row packing buffer) so that sixteen planners fit a CU 1.43 / 2.61 / 0.339, and with
-// the stream two words deep instead of eight (fewer registers in the passes) **1.23 / 2.16 / 0.293** (6 rows at 5 waves: 1.63 / 4.11 /
-// 0.395).  That is the shipped configuration; the round-4 form (whole box, 20 rows) is gone: 1.89 / 3.22 / 0.385 with it in front.
+// the stream two words deep instead of eight (fewer registers in the passes) 1.23 / 2.16 / 0.293 (6 rows at 5 waves: 1.63 / 4.11 /
+// 0.395); the rows of the cuts made after the loop, lane = cut, instead of by lane 0 inside every round 1.20 / 2.11 / 0.284; 7 rows and
+// shells sized for 5/8 of a tile **1.18 / 2.08 / 0.280** (profiles/r05_corridor_knobs.txt).  That is the shipped configuration; the
+// round-4 form (whole box, 20 rows) is gone: 1.89 / 3.22 / 0.385 with it in front.
 // Needs the uniform grid and the local box (the production configuration).  What this kernel gives up on -- more than a tile of points
 // inside the seed ellipsoid, more than CS_PLANES cuts, a shell it cannot narrow -- it flags for the workgroup kernels.
 #ifndef FRP_CW_TILE
-#define FRP_CW_TILE 8
+#define FRP_CW_TILE 7
 #endif
 #ifndef FRP_CW_WPE
 #define FRP_CW_WPE 4
@@ -857,7 +859,7 @@ __device__ __forceinline__ Best scan_wave(TileW &t, int W, unsigned in, unsigned
 }
 
 #ifndef FRP_CS_FILL // eighths of a tile a shell is sized for
-#define FRP_CS_FILL 4
+#define FRP_CS_FILL 5
 #endif
 #ifndef FRP_CS_PLANES
 #define FRP_CS_PLANES 64
@@ -1121,7 +1123,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
         const double d[3] = {u.mid[0], u.mid[1], u.mid[2]};
         const BoxFrame bf = load_box(u, c);
         box_hull(bf, c, hlo, hhi);
-        { // half a tile at the previous box's mean density -- the cloud's, for the planner's first box (any value is correct; this one avoids retries)
+        { // FRP_CS_FILL eighths of a tile at the previous box's mean density -- the cloud's, for the planner's first box (any value is correct; this one avoids retries)
             const double vol = 8.0 * c.bbox[1] * c.bbox[2] * (0.5 * u.len + c.bbox[0]);
             const double expect = nbox_prev > 0 ? (double)nbox_prev
                                                 : (double)c.P / (c.grid_cell * c.grid_cell * c.grid_cell * c.grid_dims[0] * c.grid_dims[1] * c.grid_dims[2]) * vol;
@@ -1254,7 +1256,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
                 CW_SYNC();
                 have_tile = s_same != 0;
             }
-            if (!have_tile && nbox > CW_CAP) { // first shell: half a tile at the box's mean density
+            if (!have_tile && nbox > CW_CAP) { // first shell: the same fraction of a tile at the box's mean density
                 const double vol = 8.0 * c.bbox[1] * c.bbox[2] * (0.5 * u.len + c.bbox[0]);
                 const double per_unit = (double)nbox / vol * 4.1887902047863905 * u.ax[0] * u.ax[1] * u.ax[2]; // points per unit of d2^(3/2)
                 const double r = cbrt((double)(CW_CAP * FRP_CS_FILL / 8) / per_unit);
@@ -1264,18 +1266,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
             auto cut_tile = [&](int Ws, unsigned s0) -> bool {
                 unsigned s2 = 0;
                 cp = scan_wave<KEEP_ALL>(tile, Ws, s0, s2, u);
+                const double *hm = u.mid, *hC = u.CC; // (measured: the twelve values in scalar registers across the rounds instead -- no gain)
                 for (int guard = 0; cp.idx != 0x7fffffff && guard < max_rounds; ++guard) {
                     const double q[3] = {cp.x, cp.y, cp.z};
-                    const double w[3] = {q[0] - u.mid[0], q[1] - u.mid[1], q[2] - u.mid[2]};
+                    const double w[3] = {q[0] - hm[0], q[1] - hm[1], q[2] - hm[2]};
                     double n[3];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) n[k] = u.CC[3 * k] * w[0] + u.CC[3 * k + 1] * w[1] + u.CC[3 * k + 2] * w[2];
+                    for (int k = 0; k < 3; ++k) n[k] = hC[3 * k] * w[0] + hC[3 * k + 1] * w[1] + hC[3 * k + 2] * w[2];
                     const double nl = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) n[k] /= nl;
                     if (npl >= CS_PLANES) return false;
-                    if (lane == 0) {
-                        emit_row(u, q, n, c.F, s_A, s_b, gA, gb);
+                    if (lane == 0) { // (the cut is kept; its ROW is made after the loop, off this chain)
 #pragma unroll
                         for (int k = 0; k < 3; ++k) { s_pl[36 + 6 * npl + k] = q[k]; s_pl[36 + 6 * npl + 3 + k] = n[k]; }
                     }
@@ -1374,6 +1376,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
                 more = rest > 0 && T_hi < inf;
                 T_lo = T_hi; T_hi = inf;
             }
+            // the LinearConstraint rows of the cuts (polyhedron.h:98-118), lane = cut, all at once: emit_row's own arithmetic, but not one
+            // lane-0 detour (LDS counter, three dot products, eight stores) in every round of the loop above
+            static_assert(CS_PLANES <= 64, "one lane per cut");
+            if (lane < npl) {
+                const double *pl = s_pl + 36 + 6 * lane;
+                double n[3] = {pl[3], pl[4], pl[5]};
+                double cc = pl[0] * n[0] + pl[1] * n[1] + pl[2] * n[2];
+                if (n[0] * u.mid[0] + n[1] * u.mid[1] + n[2] * u.mid[2] - cc > 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; cc = -cc; }
+                if (lane < c.F) {
+                    s_A[3 * lane] = n[0]; s_A[3 * lane + 1] = n[1]; s_A[3 * lane + 2] = n[2]; s_b[lane] = cc;
+                    gA[3 * lane] = n[0]; gA[3 * lane + 1] = n[1]; gA[3 * lane + 2] = n[2]; gb[lane] = cc;
+                }
+            }
+            if (lane == 0) { u.rows = npl; if (npl > c.F) u.overflow = 1; }
+            CW_SYNC();
         }
         if (lane == 0) {
             for (int k = 0; k < 6; ++k) emit_row(u, u.box[k], u.box[6 + k], c.F, s_A, s_b, gA, gb);
