@@ -73,14 +73,14 @@ def native_oracle():
         return "-O3 -march=x86-64-v3 (in-tree build)"
 
 
-def cpu_baseline(w, seconds_target=12.0, diverge_mu=1e3):
+def cpu_baseline(w, seconds_target=12.0, diverge_mu=1e3, mu0=1.0):
     """The CPU oracle (same algorithm, FP64, OpenMP over problems) timed on a bounded sample of the
     same workload on this box's host cores.  Test infrastructure used only as the reported baseline."""
     import tests.oracle_lib as OL
     flags = native_oracle()
     cores = usable_cores()
     B = w["xinit"].shape[0]
-    oopt = OL.default_options(diverge_mu=diverge_mu)
+    oopt = OL.default_options(diverge_mu=diverge_mu, mu0=mu0)
     OL.solve_batch(w, oopt, nthreads=cores)  # warm up threads / page in
     reps, solved, t0 = 0, 0, time.perf_counter()
     conv = 0
@@ -199,6 +199,8 @@ def main():
                          "configs[4]: one nominal problem is broadcast, the samples are drawn on every rank's device")
     ap.add_argument("--repeats", type=int, default=5, help="the K-step region is timed this many times; the MEDIAN is reported")
     ap.add_argument("--no-order-hint", action="store_true", help="configs[4]: queue the problems by the cost of the initial guess instead of by the previous tick's iteration counts")
+    ap.add_argument("--mu0", type=float, default=None, help="frp_nmpc_options.mu0, the barrier parameter the interior-point iteration starts from (default: the library's 1.0); "
+                    "a caller of warm-started problems (configs[4], the device tick) lowers it; set for the GPU and for the CPU baseline alike, named in config")
     ap.add_argument("--twist", type=int, default=0, help="frp_nmpc_options.twist: stages the model wave eliminates forward while the Riccati wave runs the rest backward "
                     "(0 = the plain solve, -1 = 9 N / 20 up to 1024 problems and 3 N / 10 beyond; N <= 20 only; DESIGN 9.1)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / end-to-end / drop-in latency legs")
@@ -315,6 +317,8 @@ def main():
             # exit (frp_nmpc_options.diverge_mu, default 1e3) -- the CPU baseline below runs with the same setting
             ds.opt.diverge_mu = 10.0
         ds.opt.twist = args.twist
+        if args.mu0 is not None:
+            ds.opt.mu0 = args.mu0
     else:
         # configs[4]: Monte-Carlo f_ext around ONE nominal problem, warm-started receding horizon; a step = one tick
         from forces_resilient_planner_amd.workloads import _bbox_faces, _weights
@@ -334,6 +338,8 @@ def main():
             D.broadcast_nominal(nominal + [fbar], sdist)
         fleet = solver.DeviceFleet(max(B, 1), N, M, 6, model, _weights(model), f"cuda:{local_rank}")
         ds = fleet.solver
+        if args.mu0 is not None:
+            ds.opt.mu0 = args.mu0
         ds.order_by_last_iters = not args.no_order_hint  # queue order = the previous tick's iteration counts
         fleet.mpc_output.copy_(nominal[0].expand(max(B, 1), N + 1, L.NZ))
         fleet.ellipsoid.copy_(nominal[1].expand(max(B, 1), N, 3, 3))
@@ -473,7 +479,7 @@ def main():
                        "repeat_ms_per_step": [r / args.steps * 1e3 for r in reps],
                        "pipelined_solves_per_s": pipelined,
                        "pipelined_note": "the same steps issued round-robin on 2 HIP streams (the few long solves at the end of a launch overlap the head of the next); informational, never `value`",
-                       "tolerances": 1e-4, "twist": int(args.twist)},
+                       "tolerances": 1e-4, "twist": int(args.twist), "mu0": float(ds.opt.mu0)},
             "roofline": {"bound": "fp64-issue",
                          "bound_detail": "FP64 VALU + FP64 MFMA issue slots (they share the SIMD's FP64 datapath) of in-order wavefronts on the serial stage chain (DESIGN 5); priced against the FP64 matrix == vector peak",
                          "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -557,10 +563,16 @@ def main():
                                     "what": "DeviceFleet.full_tick for " + ft["workload"] + ": stage references -> tube -> corridor (cloud grid) -> pack -> solve "
                                             "(corridors of up to 30 rows: the (20, 10) kernel variant) -> update, HIP events per step on the launch stream, mean of 10 ticks; "
                                             "per-kernel rooflines: profiles/r05_tick_rooflines.json (tools/tick_rooflines.py)"}
+                # the same ticks with the barrier parameter a warm-started solve begins with as an OPTION of the caller (frp_nmpc_options.mu0 =
+                # 0.2 instead of 1: tools/full_tick_bench.py, profiles/r05_tick_mu0.txt) -- informational, beside the default above
+                fw = ftb.run(B=4096, TICKS=10, P=20000, GRID=0.5, SPLIT=0, mu0=0.2)
+                out["full_tick"]["with_options_mu0_0.2"] = {"ms_per_tick": fw["ms_per_tick"], "ms_per_step": fw["ms_per_step"], "converged_frac": fw["converged_frac"],
+                                                            "mean_iters": fw["mean_iters"], "mean_iters_default": ft["mean_iters"],
+                                                            "plans_vs_default_mu0": fw["plans_vs_default_mu0"]}
             except Exception as e:  # secondary evidence, never a reason to lose the bench line
                 out["full_tick"] = {"error": repr(e)}
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(wcpu, diverge_mu=float(ds.opt.diverge_mu))
+            out["cpu_baseline"] = cpu_baseline(wcpu, diverge_mu=float(ds.opt.diverge_mu), mu0=float(ds.opt.mu0))
         elif not args.no_cpu:
             out["cpu_baseline"] = None
         line = json.dumps(out)

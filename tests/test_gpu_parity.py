@@ -286,6 +286,29 @@ def test_gauss_newton_mode_matches_oracle():
     assert np.max(np.abs(z[ok] - zo[ok])) < 1e-3
 
 
+@pytest.mark.parametrize("mu0", [0.2, 5.0])
+def test_barrier_start_option_matches_oracle(mu0):
+    """frp_nmpc_options.mu0 (what a receding-horizon caller lowers for its warm-started ticks, tools/full_tick_bench.py): the kernel and
+    the oracle run the same iteration from the same barrier parameter -- flags, iteration counts, iterates -- on cold problems (both kernel
+    sets: 6-row and 30-row layouts) and on problems warm-started at their own solution shifted by a stage."""
+    for w in (workloads.config2(192), workloads.config3(96, N=20)):
+        z, fl, it, info = solver.solve_batch_host(w, solver.default_options(mu0=mu0))
+        zo, flo, io = OL.solve_batch(w, OL.default_options(mu0=mu0))
+        ito = np.array([i.it for i in io])
+        assert np.array_equal(fl, flo)
+        ok = fl == 1
+        assert (it[ok] == ito[ok]).mean() >= 0.95
+        assert np.max(np.abs(z[ok & (it == ito)] - zo[ok & (it == ito)])) < 1e-6
+    w = workloads.config2(192)
+    z1, fl1, _, _ = solver.solve_batch_host(w)
+    warm = dict(w); warm["x0"] = np.concatenate([z1[:, 1:], z1[:, -1:]], axis=1)  # the shift initialisation of a receding-horizon tick
+    z, fl, it, info = solver.solve_batch_host(warm, solver.default_options(mu0=mu0))
+    zo, flo, io = OL.solve_batch(warm, OL.default_options(mu0=mu0))
+    ito = np.array([i.it for i in io])
+    assert np.array_equal(fl, flo) and (it == ito).mean() >= 0.95
+    assert np.max(np.abs(z[(fl == 1) & (it == ito)] - zo[(fl == 1) & (it == ito)])) < 1e-6
+
+
 def test_long_horizon_uses_wide_lane_mapping():
     """N = 40 > 32 exercises the NP = 64 instantiation (one stage per lane in the element-wise phases)."""
     w = workloads.config3(32, N=40, M=15)
