@@ -32,7 +32,11 @@
 
 namespace frp {
 
-constexpr int TB_NZ = 17, TB_SYM = 45, TB_STAGES_PER_WAVE = 21, TB_TAYLOR = 14, TB_GSTEPS = 8;
+#ifndef FRP_TB_GSTEPS
+#define FRP_TB_GSTEPS 2
+#define FRP_TB_GTERMS 24
+#endif
+constexpr int TB_NZ = 17, TB_SYM = 45, TB_STAGES_PER_WAVE = 21, TB_TAYLOR = 14, TB_GSTEPS = FRP_TB_GSTEPS, TB_GTERMS = FRP_TB_GTERMS;
 
 // K rows 0..2 (nmpc_solver.cpp:28-30); row 3 = [0 0 -8 0 0 -6 0 0 0] (:31) is folded into PhiS::b8 / m3.
 #define TB_K(a, j) (tb_gain[(a) * 9 + (j)])
@@ -128,13 +132,13 @@ __device__ __forceinline__ void phiT_mul(const PhiS &P, const double v[9], doubl
 // v <- exp(h Phi) v  (TRANSPOSED: exp(h Phi') v), |h| ||Phi|| < 0.5: the TB_TAYLOR-term series in Horner form,
 // v + h Phi (v + h/2 Phi (v + h/3 Phi (...))) -- one product with Phi and nine multiply-adds per term (round 5; the term-by-term sum
 // cost a scaling and an addition per entry on top: 0.20 -> 0.18 ms per 4096 planners, same values to rounding)
-template <bool TRANSPOSED>
+template <bool TRANSPOSED, int TERMS = TB_TAYLOR>
 __device__ __forceinline__ void expm_step(const PhiS &P, double h, double v[9])
 {
     double y[9], nxt[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) y[j] = v[j];
-    for (int n = TB_TAYLOR; n >= 1; --n) {
+    for (int n = TERMS; n >= 1; --n) {
         if (TRANSPOSED) phiT_mul(P, y, nxt); else phi_mul(P, y, nxt);
         const double f = h / (double)n;
 #pragma unroll
@@ -215,7 +219,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         double v[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) v[j] = (j == ch) ? 1.0 : 0.0;
-        for (int n = 0; n < TB_GSTEPS; ++n) expm_step<true>(P, t / TB_GSTEPS, v);
+        // (rows of exp(Phi t): TB_GSTEPS equal steps.  Eight 14-term steps covered |h| ||Phi|| < 0.5 to rounding; two 24-term steps cover the
+        // same range of ||Phi|| t (< 4: 2^25 / 25! = 2e-18) with 48 products instead of 112, at exp(2) ~ 7 roundings of cancellation instead of 2)
+        for (int n = 0; n < TB_GSTEPS; ++n) expm_step<true, TB_GTERMS>(P, t / TB_GSTEPS, v);
 #pragma unroll
         for (int j = 0; j < 9; ++j) { st[TS_G + 9 * ch + j] = v[j]; v[j] = (j == 3 + ch) ? 1.0 : 0.0; }
         double s_prev = 0.0;
