@@ -87,12 +87,13 @@ if __name__ == "__main__":
         else:
             exits.append((int(i), g, zo))
     print(f"{len(jobs)} instances to retry near the oracle's solution, {len(exits)} exits to study", flush=True)
+    skip_study = os.environ.get("FRP_HARD_SKIP_EXIT_STUDY") == "1"  # (the trust-constr runs of the study take hours on a few cores)
     with Pool(workers) as pool:
-        a1 = pool.map_async(_exit_study, exits, chunksize=1)
+        # the retries first: the study's tasks are long and would hold every worker but one
         res = []
         for r in pool.imap_unordered(_retry, jobs, chunksize=1):
             res.append(r); print('retry', r['i'], r['ok'], round(r['secs']), flush=True)
-        study = a1.get()
+        study = [] if skip_study else pool.map(_exit_study, exits, chunksize=1)
     start = g["start"].astype("U12")
     for r in res:
         if r["ok"]:
@@ -103,6 +104,8 @@ if __name__ == "__main__":
     np.savez_compressed(PATH, **g)
     print("retry: solved", sum(r["ok"] for r in res), "of", len(res), "; still unsolved:", [r["i"] for r in res if not r["ok"]], flush=True)
     flat = [e for s in study for e in s]
+    if skip_study:
+        sys.exit(0)
     with open(os.path.join(ROOT, "profiles", "r05_hard_exits_study.json"), "w") as f:
         json.dump(dict(what="instances of tests/golden/solutions_hard.npz the interior-point iteration exits -7 on: SciPy SLSQP and trust-constr on the "
                             "reference NLP (reference callbacks) from four starts each", runs=flat,

@@ -50,7 +50,9 @@ while time.time() < t_end:
         po, yo, fo = R.references_one(path, K, off[p], z[p], N)
         stats["ref_max_abs"] = max(stats["ref_max_abs"], float(np.abs(rp[p] - po).max()), float(np.abs(ry[p] - yo).max()))
         Eo = T.tube_one(z[p, :N])
-        stats["tube_max_rel"] = max(stats["tube_max_rel"], float(np.max(np.abs(E[p] - Eo) / (1e-3 + np.abs(Eo)))))
+        tr = float(np.max(np.abs(E[p] - Eo) / (1e-3 + np.abs(Eo))))
+        if tr > stats["tube_max_rel"]:
+            stats["tube_max_rel"] = tr; stats["tube_max_rel_at"] = [seed, p]  # (world seed, planner: to re-run the worst case)
         idx, polys = C.corridor_one(rp[p], ry[p], E[p], cloud, bbox=consts['bbox'], seed_len=consts['seed_len'], inflation=consts['inflation'])
         stats["planners"] += 1; stats["decompositions"] += len(polys)
         if not np.array_equal(pi[p], idx):
