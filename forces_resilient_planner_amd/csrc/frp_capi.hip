@@ -70,6 +70,7 @@ bool fill_args(const frp_nmpc_batch *b, const frp_nmpc_options *opt_in, void *ws
     a->order_hint = b->order_hint;
     a->counter = nullptr; a->order = nullptr;
     a->self_reset = 0;
+    a->done_flag = nullptr; a->done_seq = 0;
     return true;
 }
 
@@ -83,12 +84,17 @@ bool fill_args(const frp_nmpc_batch *b, const frp_nmpc_options *opt_in, void *ws
 // reads and writes those blocks in place over PCIe -- no copy commands around the launch, and no reset launch in front of it
 // (KernelArgs::self_reset): one call = one kernel launch and one stream synchronisation.  More rows (the variants that re-read
 // the rows every iteration) or FRP_NMPC_DROPIN_ZEROCOPY=0: one host-to-device and one device-to-host copy through the same blocks.
-constexpr int DI_IN_DOUBLES = 9 + 340 + 2600 + 10, DI_OUT_DOUBLES = 340 + FRP_INFO_STRIDE + 1;
+//   out (doubles): plan(340) | info(FRP_INFO_STRIDE) | (exitflag, iterations) | (completion word, pad)
+// In-place calls do not synchronise the stream either: the kernel stores the call's sequence number into the completion word (system-scope
+// release, behind a fence and a barrier over all its outputs) and the caller spins on it -- the runtime's own completion path costs ~10 us
+// of a 130 us call.  FRP_NMPC_DROPIN_SPIN=0: hipStreamSynchronize as before.
+constexpr int DI_IN_DOUBLES = 9 + 340 + 2600 + 10, DI_OUT_DOUBLES = 340 + FRP_INFO_STRIDE + 2;
 struct DropInCtx {
     bool ready = false;
     hipStream_t stream = nullptr;
     double *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr, *d_ws = nullptr;
     double *m_in = nullptr, *m_out = nullptr; // device addresses of the pinned blocks (null: not mapped, copies only)
+    int seq = 0;                              // completion word of the last in-place call
     size_t ws_bytes = 0;
     frp_forces_extfunc probed[2] = {nullptr, nullptr}; // the callback last probed per model (a different pointer is probed again)
     bool probe_ok[2] = {false, false};
@@ -140,6 +146,7 @@ int ctx_init()
             (void)hipGetLastError();
         }
     }
+    std::memset(g_ctx.h_out, 0, DI_OUT_DOUBLES * sizeof(double)); g_ctx.seq = 0; // (the completion word starts at 0; sequence numbers at 1)
     g_ctx.ready = true;
     return FRP_OK;
 }
@@ -254,9 +261,26 @@ int forces_solve(int model, frp_forces_params *params, frp_forces_output *output
     opt.twist = env_twist;
     if (!fill_args(&b, &opt, g_ctx.d_ws, g_ctx.ws_bytes, &a)) return FRP_EXIT_PARAM_VALUE;
     a.self_reset = 1;
+    static const bool spin_on = [] { const char *e = getenv("FRP_NMPC_DROPIN_SPIN"); return !(e && e[0] == '0'); }();
+    const bool spin = zero_copy && spin_on;
+    int *h_done = reinterpret_cast<int *>(g_ctx.h_out + 340 + FRP_INFO_STRIDE + 1);
+    if (spin) {
+        g_ctx.seq = g_ctx.seq == 0x7fffffff ? 1 : g_ctx.seq + 1;
+        a.done_flag = reinterpret_cast<int *>(g_ctx.m_out + 340 + FRP_INFO_STRIDE + 1); a.done_seq = g_ctx.seq;
+    }
     if (frp::launch_ipm(a, st) != hipSuccess) return device_fault("launch");
-    if ((!zero_copy && hipMemcpyAsync(g_ctx.h_out, g_ctx.d_out, DI_OUT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) ||
-        hipStreamSynchronize(st) != hipSuccess)
+    bool seen = false;
+    if (spin) { // (a solve is ~0.1 ms; a word that has not arrived after 50 ms is left to the runtime's own wait and error reporting)
+        const auto t_spin = std::chrono::steady_clock::now();
+        for (unsigned n = 0;; n++) {
+            if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) == g_ctx.seq) { seen = true; break; }
+            if ((n & 1023u) == 1023u && std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(50)) break;
+            __builtin_ia32_pause();
+        }
+    }
+    if (!seen &&
+        ((!zero_copy && hipMemcpyAsync(g_ctx.h_out, g_ctx.d_out, DI_OUT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) ||
+         hipStreamSynchronize(st) != hipSuccess))
         return device_fault("copy out / synchronise");
     std::memcpy(output->x, g_ctx.h_out, 340 * sizeof(double));
     const double *inf = g_ctx.h_out + 340;

@@ -3172,6 +3172,11 @@ __global__ __launch_bounds__(QW ? 192 : 256) __attribute__((amdgpu_waves_per_eu(
     else {
         if constexpr (!QW) role_loop<NP, FL, FREG, 3, TW>(a, sh);
     }
+    if (a.done_flag) { // (single-problem launches of the drop-in context: the host is spinning on this word)
+        __threadfence_system(); // every wave's outputs (the plan: wave 1; flags and diagnostics: wave 0) before the word
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 template <int NP, int FL, bool FREG, int WPE, bool TW = false>

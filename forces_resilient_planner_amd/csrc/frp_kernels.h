@@ -62,6 +62,8 @@ struct KernelArgs {
     const int *order_hint; // per-problem expected work (last tick's iteration count), or null = order by the cost of the initial guess
     int self_reset;        // B == 1 only (the drop-in context): the queue head is zero on entry and the kernel leaves it zero --
                            // no reset launch in front of the solve; no role placement (one workgroup: nothing to place)
+    int *done_flag;        // B == 1 only, or null: a word in host-coherent memory that receives done_seq once every output of the solve is
+    int done_seq;          // visible to the host -- the drop-in call spins on it instead of paying a stream synchronisation (~10 us)
 };
 
 constexpr int CU_SLOT_ENTRIES = 2048; // (XCC, SE, SH, CU) of HW_ID
