@@ -542,7 +542,7 @@ def main():
                 lat.append(time.perf_counter() - t1)
             out["dropin_latency_ms"] = {"value": float(np.median(lat[5:])) * 1e3, "exitflag": int(flag), "iterations": int(info.it),
                                         "what": "BASELINE configs[0] through FORCESNLPsolver_normal_solve (params staged in pinned mapped memory, read and written in place by "
-                                                "the one-problem solve; one launch + one synchronisation), warm, median of 20"}
+                                                "the one-problem solve; one launch, the completion word the kernel stores behind its outputs spun on), warm, median of 20"}
             try:  # the same call with the latency option; the environment variable is read once per process: a child measures it
                 import subprocess, re
                 e = dict(os.environ); e["FRP_NMPC_TWIST"] = "-1"
