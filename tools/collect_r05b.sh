@@ -19,6 +19,8 @@ if [ -f forces_resilient_planner_amd/lib_crprof.so ]; then
   echo "# full_tick_bench.py 4096 3 20000 0.5 0 (last tick)" >> $R/corridor_phases.txt
   FRP_LIB=$PWD/forces_resilient_planner_amd/lib_crprof.so python tools/full_tick_bench.py 4096 3 20000 0.5 0 2>&1 | grep "^wave" | tail -2 >> $R/corridor_phases.txt
 fi
+python tools/graph_tick.py 1 200 5000 2>/dev/null | tail -1 > $R/graph_tick.jsonl; python tools/graph_tick.py 64 200 5000 2>/dev/null | tail -1 >> $R/graph_tick.jsonl
+python tools/twist_latency.py dropin 2>/dev/null | tail -1 > $R/dropin.txt; FRP_NMPC_DROPIN_SPIN=0 python tools/twist_latency.py dropin 2>/dev/null | tail -1 >> $R/dropin.txt; FRP_NMPC_TWIST=-1 python tools/twist_latency.py dropin 2>/dev/null | tail -1 >> $R/dropin.txt
 python bench.py --steps 20 --warmup 3 > $R/bench_default.json 2> $R/bench_default.err
 P=$PWD/gpurun_out/prof_tick; rm -rf $P; mkdir -p $P
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -o tick -- python $ROOT/tools/full_tick_bench.py 4096 10 20000 0.5 0 > $P/full_tick_under_rocprof.json 2> $P/stats.log)
