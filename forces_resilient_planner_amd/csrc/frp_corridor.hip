@@ -1052,7 +1052,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
     __shared__ int s_row[128];                         // stream_hull's run offsets
     __shared__ double s_seedCi[9];                     // C^-1 of the seed ellipsoid, to tell whether find_ellipsoid changed it
     __shared__ int s_same;
-    int nbox_prev = 0; // in-box points of the planner's previous decomposition (the next box is a little further along the path)
+    double rho_prev = 0.0, T1_prev = 0.0; // the planner's previous decomposition (the next box is a little further along the path): cloud points per unit of
+    int cnt_prev = -1;                    // volume around its seed, the bound of its first shell and the points that shell held (-1: no decomposition yet)
     const int b = blockIdx.x, lane = threadIdx.x;
 #ifdef FRP_CORRIDOR_PROFILE
     long long tp_a = 0, tp_b = 0, tp_tile = 0, tp_shrink = 0, tp_rest = 0, tp_begin = wall_clock64();
@@ -1123,22 +1124,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
         const double d[3] = {u.mid[0], u.mid[1], u.mid[2]};
         const BoxFrame bf = load_box(u, c);
         box_hull(bf, c, hlo, hhi);
-        { // FRP_CS_FILL eighths of a tile at the previous box's mean density -- the cloud's, for the planner's first box (any value is correct; this one avoids retries)
-            const double vol = 8.0 * c.bbox[1] * c.bbox[2] * (0.5 * u.len + c.bbox[0]);
-            const double expect = nbox_prev > 0 ? (double)nbox_prev
-                                                : (double)c.P / (c.grid_cell * c.grid_cell * c.grid_cell * c.grid_dims[0] * c.grid_dims[1] * c.grid_dims[2]) * vol;
-            if (expect > 0.9 * CW_CAP) {
-                const double per_unit = expect / vol * 4.1887902047863905 * u.ax[0] * u.ax[1] * u.ax[2]; // points per unit of d2^(3/2)
-                const double r = cbrt((double)(CW_CAP * FRP_CS_FILL / 8) / per_unit);
-                if (r * r > 1.0 && r * r < __builtin_huge_val()) T1 = r * r;
-            } else
-                T1 = __builtin_huge_val();
+        // FRP_CS_FILL eighths of a tile at the density the previous decomposition met -- the cloud's mean, for the planner's first box (any
+        // value is correct; this one avoids retries)
+        const double box_vol = 8.0 * c.bbox[1] * c.bbox[2] * (0.5 * u.len + c.bbox[0]), unit_seed = 4.1887902047863905 * u.ax[0] * u.ax[1] * u.ax[2];
+        {
+            const double target = (double)(CW_CAP * FRP_CS_FILL / 8);
+            if (cnt_prev >= 0 && T1_prev > 1.0 && T1_prev < __builtin_huge_val()) {
+                // the previous shell held cnt_prev points: scale its bound for the target as if the count grew with the shell's volume, by at
+                // most 1.6 either way (a density from the shell's own volume would be fooled by the free space around the path)
+                double f = cnt_prev > 0 ? cbrt(target / (double)cnt_prev) : 1.26;
+                f = f * f; f = f < 0.6 ? 0.6 : (f > 1.6 ? 1.6 : f);
+                T1 = T1_prev * f > 1.0 ? T1_prev * f : T1_prev;
+            } else {
+                const double rho = rho_prev > 0.0 ? rho_prev : (double)c.P / (c.grid_cell * c.grid_cell * c.grid_cell * c.grid_dims[0] * c.grid_dims[1] * c.grid_dims[2]);
+                if (rho * box_vol > 0.9 * CW_CAP) {
+                    const double r = cbrt(target / (rho * unit_seed)); // (rho unit_seed: points per unit of d2^(3/2))
+                    if (r * r > 1.0 && r * r < __builtin_huge_val()) T1 = r * r;
+                } else
+                    T1 = __builtin_huge_val();
+            }
+        }
+        // A bounded first shell is an ellipsoid around the seed, a fraction of the box: its axis-aligned bounds join the box faces in the row
+        // clipping (cut slots 0..5, free until the first cut is made), so this pass reads the cells under the SHELL, not under the box
+        // (the points inside the seed ellipsoid lie inside it too).  The in-box count is then the shell's neighbourhood's, and whether
+        // anything lies beyond is not known: the pass behind the shell always runs.
+        bool clipped = T1 > 1.0 && T1 < __builtin_huge_val();
+        if (clipped) {
+            if (lane == 0) {
+                const M3 R = ld3(u.Ri);
+                for (int k = 0; k < 3; ++k) {
+                    double e2 = 0.0;
+                    for (int j = 0; j < 3; ++j) e2 += (R.m[3 * k + j] * u.ax[j]) * (R.m[3 * k + j] * u.ax[j]);
+                    const double ext = sqrt(T1 * e2) * (1.0 + 1e-9) + 1e-9;
+                    for (int sgn = 0; sgn < 2; ++sgn) {
+                        double *pl = s_pl + 36 + 6 * (2 * k + sgn);
+                        for (int j = 0; j < 3; ++j) { pl[j] = u.mid[j] + (j == k ? (sgn ? -ext : ext) : 0.0); pl[3 + j] = j == k ? (sgn ? -1.0 : 1.0) : 0.0; }
+                    }
+                }
+            }
+            CW_SYNC();
         }
         for (;;) {
             Best best{1.7976931348623157e308, 0x7fffffff, 0.0, 0.0, 0.0};
             int n_in = 0;
             count = 0; nbox = 0; rest1 = 0;
-            stream_hull(c, hlo, hhi, s_row, s_pl, 6, [&](const HullBatch &B, int chunks) {
+            stream_hull(c, hlo, hhi, s_row, s_pl, clipped ? 12 : 6, [&](const HullBatch &B, int chunks) {
 #pragma unroll
                 for (int k = 0; k < CS_U; ++k) {
                     if (k >= chunks) break;
@@ -1164,12 +1194,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
                 }
                 return count <= CW_CAP;
             });
-            if (count > CW_CAP && T1 > 0.0) { T1 = -1.0; CW_SYNC(); continue; } // the bet's shell overflowed the tile: the inside points alone
+            if (count > CW_CAP && T1 > 0.0) { // the bet's shell overflowed the tile: the inside points alone, the whole box; the next box starts from half the bound
+                T1_prev = T1 < __builtin_huge_val() ? 0.5 * T1 : 0.0; cnt_prev = T1_prev > 1.0 ? (int)(CW_CAP * FRP_CS_FILL / 8) : -1;
+                T1 = -1.0; clipped = false; CW_SYNC();
+                continue;
+            }
+            if (T1 > 0.0) { T1_prev = T1; cnt_prev = count - n_in; }
+            // the density met (for a first shell in another metric, below): the shell's points over its volume, or the box's over the box's
+            rho_prev = clipped ? (double)(count > 0 ? count : 1) / (T1 * sqrt(T1) * unit_seed) : (double)nbox / box_vol;
+            if (clipped) rest1 = 1;
             if (n_in > 0) T1 = -1.0; // find_ellipsoid has work to do: the listed shell is not one of the final ellipsoid (its points stay out of m1)
             cp = wave_best(best);
             break;
         }
-        nbox_prev = nbox;
 #ifdef FRP_CORRIDOR_PROFILE
         CR_ACC(tp_a) ++np_dec; np_box += nbox;
 #endif
@@ -1256,9 +1293,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
                 CW_SYNC();
                 have_tile = s_same != 0;
             }
-            if (!have_tile && nbox > CW_CAP) { // first shell: the same fraction of a tile at the box's mean density
-                const double vol = 8.0 * c.bbox[1] * c.bbox[2] * (0.5 * u.len + c.bbox[0]);
-                const double per_unit = (double)nbox / vol * 4.1887902047863905 * u.ax[0] * u.ax[1] * u.ax[2]; // points per unit of d2^(3/2)
+            if (!have_tile && rho_prev * box_vol > 0.9 * CW_CAP) { // first shell: the same fraction of a tile at the density pass A met, in the FINAL ellipsoid's metric
+                const double per_unit = rho_prev * 4.1887902047863905 * u.ax[0] * u.ax[1] * u.ax[2]; // points per unit of d2^(3/2)
                 const double r = cbrt((double)(CW_CAP * FRP_CS_FILL / 8) / per_unit);
                 if (r * r > 1.0 && r * r < inf) T_hi = r * r;
             }
