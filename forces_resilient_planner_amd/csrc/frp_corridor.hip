@@ -766,8 +766,8 @@ __global__ __launch_bounds__(CR_THREADS) __attribute__((amdgpu_waves_per_eu(FRP_
 //     points with T_lo <= d2 < T_hi that are in front of every plane cut so far (the planes sit in LDS; the test is the scan's own
 //     expression, and a point is alive iff it is in front of ALL planes, whatever the order they are tried in); the tile runs the
 //     reference's loop on them until none is left, and since every point outside the shell is farther than every point inside, the
-//     closest alive point of the shell IS the closest alive point.  The first shell is sized from the box's point density for 5/8 of a
-//     tile; behind it nearly everything is already cut, so the next shell is tried unbounded and narrowed only if it overflows.
+//     closest alive point of the shell IS the closest alive point.  The first shell is sized for 3/8 of a tile (from the count the previous decomposition's shell
+//     held; the cloud's mean density for a planner's first box); behind it nearly everything is already cut, so the next shell is tried unbounded and narrowed only if it overflows.
 //   Same picks, same cuts, same rows (tests/test_gpu_parity.py::test_corridor_dense_clouds_boxes_beyond_the_register_tile).
 // -- and with the box out of the registers the tile can be SMALL: a wavefront's rounds are a dependent chain (one wave per SIMD instead
 // of two: the same 87 us per planner and tick), so what counts is wavefronts in flight.  Measured, every planner through this form
@@ -776,8 +776,10 @@ __global__ __launch_bounds__(CR_THREADS) __attribute__((amdgpu_waves_per_eu(FRP_
 // with 9 KB of LDS per planner (64 cuts kept, a one-row packing buffer) so that sixteen planners fit a CU 1.43 / 2.61 / 0.339, and with
 // the stream two words deep instead of eight (fewer registers in the passes) 1.23 / 2.16 / 0.293 (6 rows at 5 waves: 1.63 / 4.11 /
 // 0.395); the rows of the cuts made after the loop, lane = cut, instead of by lane 0 inside every round 1.20 / 2.11 / 0.284; 7 rows and
-// shells sized for 5/8 of a tile **1.18 / 2.08 / 0.280** (profiles/r05_corridor_knobs.txt).  That is the shipped configuration; the
-// round-4 form (whole box, 20 rows) is gone: 1.89 / 3.22 / 0.385 with it in front.
+// shells sized for 5/8 of a tile 1.18 / 2.08 / 0.280; pass A reading only the cells under its first shell (whose bound follows the previous
+// decomposition's count) 1.05 / 1.40 / 0.270, and with that a first shell of 3/8 of a tile **0.97 / 1.46 / 0.254**
+// (profiles/r05_corridor_knobs.txt).  That is the shipped configuration; the round-4 form (whole box, 20 rows) is gone: 1.89 / 3.22 /
+// 0.385 with it in front.
 // Needs the uniform grid and the local box (the production configuration).  What this kernel gives up on -- more than a tile of points
 // inside the seed ellipsoid, more than CS_PLANES cuts, a shell it cannot narrow -- it flags for the workgroup kernels.
 #ifndef FRP_CW_TILE
@@ -858,8 +860,8 @@ __device__ __forceinline__ Best scan_wave(TileW &t, int W, unsigned in, unsigned
     return wave_best(best);
 }
 
-#ifndef FRP_CS_FILL // eighths of a tile a shell is sized for
-#define FRP_CS_FILL 5
+#ifndef FRP_CS_FILL // eighths of a tile a shell is sized for (3: since pass A reads only the cells under its shell a smaller one pays -- profiles/r05_corridor_knobs.txt)
+#define FRP_CS_FILL 3
 #endif
 #ifndef FRP_CS_PLANES
 #define FRP_CS_PLANES 64
