@@ -1437,20 +1437,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
         }
         CW_SYNC();
         const int rows = u.rows < c.F ? u.rows : c.F;
-        // ---- which of the stages behind still fit this polytope (nmpc_solver.cpp:291-313)?  lane = stage, all of them at once
+        // ---- which of the stages behind still fit this polytope (nmpc_solver.cpp:291-313)?  All of them at once: lane = (row group, stage) --
+        // 64 / N lanes share a stage's rows (three at N = 20: a row costs a square root, thirty of them on twenty lanes were 6 us of every
+        // decomposition) and a ballot puts the groups' verdicts together
+        const int cgrp = 64 / c.N, cst = lane % c.N, csub = lane / c.N;
         bool viol = false;
-        if (lane > i && lane < c.N) {
-            const double *E = Eb + 9 * lane;
+        if (csub < cgrp && cst > i) {
+            const double *E = Eb + 9 * cst;
             const double E0 = E[0], E1 = E[1], E2 = E[2], E3 = E[3], E4 = E[4], E5 = E[5], E6 = E[6], E7 = E[7], E8 = E[8];
-            const double r0 = ref[3 * lane], r1 = ref[3 * lane + 1], r2 = ref[3 * lane + 2];
-            for (int r = 0; r < rows; ++r) {
+            const double r0 = ref[3 * cst], r1 = ref[3 * cst + 1], r2 = ref[3 * cst + 2];
+            for (int r = csub; r < rows; r += cgrp) {
                 const double a0 = s_A[3 * r], a1 = s_A[3 * r + 1], a2 = s_A[3 * r + 2];
                 const double e0 = E0 * a0 + E1 * a1 + E2 * a2, e1 = E3 * a0 + E4 * a1 + E5 * a2, e2 = E6 * a0 + E7 * a1 + E8 * a2;
                 const double add = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
                 viol = viol || (a0 * r0 + a1 * r1 + a2 * r2 - (s_b[r] - c.inflation * add)) > 0;
             }
         }
-        const uint64_t vm = __ballot(viol);
+        uint64_t vm = __ballot(viol);
+        for (int g = 1; g < cgrp; ++g) vm |= vm >> (g * c.N); // (bits 0 .. N-1: the stage's verdict over all its row groups; garbage above)
+        if (c.N < 64) vm &= (1ull << c.N) - 1ull;
         const int next = vm ? (int)__builtin_ctzll(vm) : c.N; // the first stage whose inflated tube ellipsoid leaves the polytope
         if (lane > i && lane < next) c.poly_index[(size_t)b * c.N + lane] = npoly;
         ++npoly;
