@@ -35,6 +35,9 @@ def run(B=4096, TICKS=10, P=20000, GRID=0.5, SPLIT=2, mu0=None):
         mu0 = float(os.environ["FRP_TICK_MU0"])
     if mu0 is not None:
         fleet.solver.opt.mu0 = float(mu0)
+    for k in ("hessian", "ftb"):  # (experiments: other frp_nmpc_options fields from the environment, FRP_TICK_HESSIAN / FRP_TICK_FTB)
+        if os.environ.get("FRP_TICK_" + k.upper()):
+            setattr(fleet.solver.opt, k, type(getattr(fleet.solver.opt, k))(float(os.environ["FRP_TICK_" + k.upper()])))
     fleet.mpc_output.copy_(fleet.to_device(plan))
     d_path, d_cloud = fleet.to_device(path), fleet.to_device(cloud)
     d_f = fleet.to_device(rng.normal(0, 0.5, (B, 3)))
