@@ -863,6 +863,9 @@ __device__ __forceinline__ Best scan_wave(TileW &t, int W, unsigned in, unsigned
 #ifndef FRP_CS_FILL // eighths of a tile a shell is sized for (3: since pass A reads only the cells under its shell a smaller one pays -- profiles/r05_corridor_knobs.txt)
 #define FRP_CS_FILL 3
 #endif
+#ifndef FRP_CS_FMAX // the most a first shell's bound grows from one decomposition to the next
+#define FRP_CS_FMAX 1.6
+#endif
 #ifndef FRP_CS_PLANES
 #define FRP_CS_PLANES 64
 #endif
@@ -1135,7 +1138,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FRP_CW_WPE, 
                 // the previous shell held cnt_prev points: scale its bound for the target as if the count grew with the shell's volume, by at
                 // most 1.6 either way (a density from the shell's own volume would be fooled by the free space around the path)
                 double f = cnt_prev > 0 ? cbrt(target / (double)cnt_prev) : 1.26;
-                f = f * f; f = f < 0.6 ? 0.6 : (f > 1.6 ? 1.6 : f);
+                f = f * f; f = f < 0.6 ? 0.6 : (f > FRP_CS_FMAX ? FRP_CS_FMAX : f);
                 T1 = T1_prev * f > 1.0 ? T1_prev * f : T1_prev;
             } else {
                 const double rho = rho_prev > 0.0 ? rho_prev : (double)c.P / (c.grid_cell * c.grid_cell * c.grid_cell * c.grid_dims[0] * c.grid_dims[1] * c.grid_dims[2]);
