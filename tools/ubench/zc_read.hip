@@ -90,6 +90,35 @@ int main()
                 printf("gather mode %d blocks %4d: %.3f ms = %.1f GB/s of live bytes\n", mode, blocks, best, rows * 34 * 8 / best * 1e-6);
             }
     }
+    { // the two parts of the gather at once: 11 MB contiguous (the plans) on one stream, the row segments on another
+        const size_t rows = 4096 * 20, pb = rows * 130 * 8, zb = rows * 17 * 8;
+        double *hp = (double *)aligned_alloc(4096, pb), *hz = (double *)aligned_alloc(4096, zb), *dg = nullptr, *dz = nullptr;
+        memset(hp, 1, pb); memset(hz, 1, zb);
+        hipHostRegister(hp, pb, hipHostRegisterMapped); hipHostRegister(hz, zb, hipHostRegisterMapped);
+        void *mp = nullptr, *mz = nullptr; hipHostGetDevicePointer(&mp, hp, 0); hipHostGetDevicePointer(&mz, hz, 0);
+        hipMalloc(&dg, rows * 34 * 8); hipMalloc(&dz, zb);
+        hipStream_t s1, s2; hipStreamCreate(&s1); hipStreamCreate(&s2);
+        hipEvent_t ea, eb; hipEventCreate(&ea); hipEventCreate(&eb);
+        for (int conc = 0; conc < 2; conc++) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 5; rep++) {
+                hipDeviceSynchronize();
+                hipEventRecord(e0, s1);
+                if (conc) {
+                    hipEventRecord(ea, s1); hipStreamWaitEvent(s2, ea, 0);
+                    hipLaunchKernelGGL(cp<double>, dim3(256), dim3(256), 0, s2, (const double *)mz, dz, zb / 8);
+                    hipLaunchKernelGGL(gather<0>, dim3(1024), dim3(256), 0, s1, (const double *)mp, dg, rows);
+                    hipEventRecord(eb, s2); hipStreamWaitEvent(s1, eb, 0);
+                } else {
+                    hipLaunchKernelGGL(cp<double>, dim3(256), dim3(256), 0, s1, (const double *)mz, dz, zb / 8);
+                    hipLaunchKernelGGL(gather<0>, dim3(1024), dim3(256), 0, s1, (const double *)mp, dg, rows);
+                }
+                hipEventRecord(e1, s1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
+            }
+            printf("plans (11 MB contiguous) + parameter rows (22 MB live), %s: %.3f ms\n", conc ? "on two streams" : "one after the other", best);
+        }
+    }
     // the copy engine for comparison
     for (int w = 0; w < 2; w++) {
         float best = 1e9f;
