@@ -952,8 +952,11 @@ __device__ __forceinline__ void stream_hull(const frp_nmpc_corridor &c, const in
                     xlo = inf;
             }
             if (xlo <= xhi) {
+                // the cells of [xlo, xhi] the way the grid bins a coordinate: clamped to the grid -- a bound outside the grid still meets the
+                // border cell, which holds the points out there (tests: test_corridor_grid_smaller_than_the_cloud) -- then to the hull
                 const double a = floor((xlo - c.grid_origin[0]) / c.grid_cell), bb = floor((xhi - c.grid_origin[0]) / c.grid_cell);
-                const int ia = a > (double)lo[0] ? (a > (double)hi[0] ? hi[0] + 1 : (int)a) : lo[0], ib = bb < (double)hi[0] ? (bb < (double)lo[0] ? lo[0] - 1 : (int)bb) : hi[0];
+                int ia = a < 0 ? 0 : (a > nx - 1 ? nx - 1 : (int)a), ib = bb < 0 ? 0 : (bb > nx - 1 ? nx - 1 : (int)bb);
+                ia = ia > lo[0] ? ia : lo[0]; ib = ib < hi[0] ? ib : hi[0];
                 if (ia <= ib) {
                     const size_t row = ((size_t)iz * c.grid_dims[1] + iy) * nx;
                     mbeg = c.grid_start[row + ia];

@@ -947,6 +947,34 @@ def test_corridor_dense_clouds_boxes_beyond_the_register_tile():
         assert all(np.array_equal(x, y) for x, y in zip(g, plain)), cell
 
 
+def test_corridor_grid_smaller_than_the_cloud():
+    """frp_nmpc_cloud_grid_build bins the points outside the grid into its border cells, so a border cell's points reach as far as the
+    cloud does -- the row clipping of the one-wavefront kernel must treat those cells as unbounded on their outer side.  A grid that covers
+    a fraction of the cloud in every direction (the path leaves it), 0.5 and 0.3 m cells: same polytopes as the plain-cloud launch."""
+    import torch
+    cloud, ref, yaw, E = _corridor_world(31, P=30000, B=3)
+    plain = solver.corridor_batch_host(cloud, ref, yaw, E)
+    dev = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0", dtype=dt)
+    B, N, F = ref.shape[0], ref.shape[1], solver.CORRIDOR_MAX_F
+    for cell, origin, dims in ((0.5, (0.5, -1.5, 0.2), (8, 6, 3)), (0.3, (-1.0, -0.9, 0.5), (20, 6, 4)), (0.5, (2.0, -3.0, -0.4), (3, 12, 7))):
+        d_cloud = dev(cloud)
+        grid = solver.CloudGrid(d_cloud, cell, origin=origin, dims=dims)
+        A = torch.zeros((B, N, F, 3), dtype=torch.float64, device="cuda:0"); b = torch.zeros((B, N, F), dtype=torch.float64, device="cuda:0")
+        nf = torch.zeros((B, N), dtype=torch.int32, device="cuda:0"); pi = torch.zeros((B, N), dtype=torch.int32, device="cuda:0")
+        cnt = torch.zeros((B,), dtype=torch.int32, device="cuda:0")
+        solver.corridor_batch_device(d_cloud, dev(ref), dev(yaw), dev(E), A, b, nf, pi, cnt, grid=grid)
+        torch.cuda.synchronize()
+        got = (pi.cpu().numpy(), A.cpu().numpy(), b.cpu().numpy(), nf.cpu().numpy(), cnt.cpu().numpy())
+        assert all(np.array_equal(x, y) for x, y in zip(got, plain)), (cell, origin, dims)
+    # fewer rows stored than a polytope has (F = 8 of ~25): the truncation, its flag (a negative polytope count) and the containment checks on
+    # the stored rows are the same in the one-wavefront kernel (rows made after the loop, lane = cut) as in the workgroup kernels
+    few = solver.corridor_batch_host(cloud, ref, yaw, E, F=8)
+    assert (few[4] < 0).all() and few[3].max() > 8
+    for cell in (0.5, 0.23):
+        g = solver.corridor_batch_host(cloud, ref, yaw, E, F=8, grid_cell=cell)
+        assert all(np.array_equal(x, y) for x, y in zip(g, few)), cell
+
+
 # ---- SURVEY 8f row f-4 (first half): stage references from the kinodynamic path ----
 def _reference_oracle():
     import sys
