@@ -953,7 +953,7 @@ __device__ __forceinline__ void stream_hull(const frp_nmpc_corridor &c, const in
             }
             if (xlo <= xhi) {
                 // the cells of [xlo, xhi] the way the grid bins a coordinate: clamped to the grid -- a bound outside the grid still meets the
-                // border cell, which holds the points out there (tests: test_corridor_grid_smaller_than_the_cloud) -- then to the hull
+                // border cell, which holds the points out there (tests: test_corridor_grid_smaller_than_the_cloud_and_other_edges) -- then to the hull
                 const double a = floor((xlo - c.grid_origin[0]) / c.grid_cell), bb = floor((xhi - c.grid_origin[0]) / c.grid_cell);
                 int ia = a < 0 ? 0 : (a > nx - 1 ? nx - 1 : (int)a), ib = bb < 0 ? 0 : (bb > nx - 1 ? nx - 1 : (int)bb);
                 ia = ia > lo[0] ? ia : lo[0]; ib = ib < hi[0] ? ib : hi[0];

@@ -947,7 +947,7 @@ def test_corridor_dense_clouds_boxes_beyond_the_register_tile():
         assert all(np.array_equal(x, y) for x, y in zip(g, plain)), cell
 
 
-def test_corridor_grid_smaller_than_the_cloud():
+def test_corridor_grid_smaller_than_the_cloud_and_other_edges():
     """frp_nmpc_cloud_grid_build bins the points outside the grid into its border cells, so a border cell's points reach as far as the
     cloud does -- the row clipping of the one-wavefront kernel must treat those cells as unbounded on their outer side.  A grid that covers
     a fraction of the cloud in every direction (the path leaves it), 0.5 and 0.3 m cells: same polytopes as the plain-cloud launch."""
@@ -968,6 +968,15 @@ def test_corridor_grid_smaller_than_the_cloud():
         assert all(np.array_equal(x, y) for x, y in zip(got, plain)), (cell, origin, dims)
     # fewer rows stored than a polytope has (F = 8 of ~25): the truncation, its flag (a negative polytope count) and the containment checks on
     # the stored rows are the same in the one-wavefront kernel (rows made after the loop, lane = cut) as in the workgroup kernels
+    # the longest horizon (one lane per stage in the containment check), a horizon that gives a stage two lanes, and an empty cloud behind a grid
+    for Nh in (64, 30):
+        c2, r2, y2, E2 = _corridor_world(32 + Nh, P=9000, B=2, N=Nh)
+        p2 = solver.corridor_batch_host(c2, r2, y2, E2)
+        g2 = solver.corridor_batch_host(c2, r2, y2, E2, grid_cell=0.5)
+        assert all(np.array_equal(x, y) for x, y in zip(g2, p2)), Nh
+    e0 = solver.corridor_batch_host(np.zeros((0, 3)), ref, yaw, E)
+    e1 = solver.corridor_batch_host(np.zeros((0, 3)), ref, yaw, E, grid_cell=0.5)
+    assert all(np.array_equal(x, y) for x, y in zip(e1, e0)) and np.all(e0[3][:, 0] == 6)
     few = solver.corridor_batch_host(cloud, ref, yaw, E, F=8)
     assert (few[4] < 0).all() and few[3].max() > 8
     for cell in (0.5, 0.23):
