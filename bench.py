@@ -143,17 +143,40 @@ def self_launch_command(n, argv, port=None):
             "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
-def auto_chunks(world, B, N, MF):
+XGMI_LINK_GBS = 153.0  # one xGMI link, one direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU, point to point)
+
+
+def device_cus(default=256):
+    """CUs of the current device from the runtime's device properties (hipDeviceProp_t::multiProcessorCount through torch), not a constant;
+    `default` only where no device is visible (--dry-run on a CPU box), and the plan says which it was."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count), "hipDeviceProp"
+    except Exception:  # noqa: BLE001
+        pass
+    return default, "assumed (no device visible)"
+
+
+def auto_chunks(world, B, N, MF, cus=None):
     """--chunks 0 of the strong-scaling step: pieces per shard and the reason (logged).  A piece below two rounds of resident workgroups
     costs more than its transfer can hide (profiles/r04_strong_chunks.txt: 4 pieces +46 % at configs[2] on one GPU), and on one rank
     nothing is transferred."""
     per_cu = 4 if (N <= 20 and MF <= 6) else (3 if N <= 20 else (2 if N <= 32 else 1))  # resident workgroups per CU of the variant the launch takes
-    slots = 256 * per_cu
+    if cus is None:
+        cus = device_cus()[0]
+    slots = cus * per_cu
     if world <= 1:
         return 1, "one rank: nothing to overlap"
     if B >= 2 * slots:
-        return 2, f"shard of {B} >= two rounds of the {slots} resident workgroups: transfers of piece c +- 1 under the solve of piece c"
-    return 1, f"shard of {B} < two rounds of the {slots} resident workgroups: a smaller piece costs more than its transfer hides"
+        return 2, f"shard of {B} >= two rounds of the {slots} resident workgroups ({cus} CUs x {per_cu}): transfers of piece c +- 1 under the solve of piece c"
+    return 1, f"shard of {B} < two rounds of the {slots} resident workgroups ({cus} CUs x {per_cu}): a smaller piece costs more than its transfer hides"
+
+
+def transfer_bytes_per_problem(N, M):
+    """What the strong-scaling step ships per problem: xinit (9) + x0 (17 N) + parameters ((10 + 4 M) N) doubles + face counts (N ints) to the
+    rank, the plan (17 N doubles) + exit flag + iteration count back (bench.py: full_in / full_out)."""
+    return (9 + 17 * N + (10 + 4 * M) * N) * 8 + 4 * N, 17 * N * 8 + 8
 
 
 def launch_plan(args):
@@ -173,12 +196,30 @@ def launch_plan(args):
         B = args.batch or (base_B if cfg == 2 else base_B // world)
         B_total = B * world
         shards = [(r * B, (r + 1) * B) for r in range(world)]
-    plan = {"world_size": world, "config": cfg, "scaling": args.scaling, "batch_total": B_total, "ranks": []}
+    cus, cus_src = device_cus()
+    M = {2: 30, 3: 15, 4: 30}[cfg]
+    b_in, b_out = transfer_bytes_per_problem(N, M)
+    plan = {"world_size": world, "config": cfg, "scaling": args.scaling, "batch_total": B_total, "cus_per_device": cus, "cus_source": cus_src, "ranks": []}
     for r, (lo, hi) in enumerate(shards):
-        ch, why = (auto_chunks(world, hi - lo, N, MF) if args.chunks <= 0 else (args.chunks, "--chunks given")) if (strong and cfg != 4) else (1, "weak scaling: no transfer in the step")
+        ch, why = (auto_chunks(world, hi - lo, N, MF, cus) if args.chunks <= 0 else (args.chunks, "--chunks given")) if (strong and cfg != 4) else (1, "weak scaling: no transfer in the step")
         cb = D.chunk_bounds(hi - lo, ch)  # (the same boundaries strong_step_overlapped walks)
         pieces = [[lo + int(a), lo + int(b)] for a, b in zip(cb[:-1], cb[1:])]
-        plan["ranks"].append({"rank": r, "problems": [lo, hi], "pieces": ch, "piece_ranges": pieces, "why": why})
+        rec = {"rank": r, "problems": [lo, hi], "pieces": ch, "piece_ranges": pieces, "why": why}
+        if strong and cfg != 4 and r != 0:
+            # what the first real 8-GPU line can be compared with: every peer's pieces travel over ITS OWN xGMI link to / from rank 0 (the
+            # scatter of a piece is one grouped P2P exchange: the root's seven links carry seven shards in parallel), so the time of a
+            # piece is its bytes over one link's rate, not over the sum of the links
+            rec["bytes_to_rank_per_piece"] = [int((b - a) * b_in) for a, b in pieces]
+            rec["bytes_from_rank_per_piece"] = [int((b - a) * b_out) for a, b in pieces]
+            rec["expected_scatter_ms_per_piece_at_153GBs"] = [round((b - a) * b_in / (XGMI_LINK_GBS * 1e9) * 1e3, 4) for a, b in pieces]
+            rec["expected_gather_ms_per_piece_at_153GBs"] = [round((b - a) * b_out / (XGMI_LINK_GBS * 1e9) * 1e3, 4) for a, b in pieces]
+        plan["ranks"].append(rec)
+    if strong and cfg != 4 and world > 1:
+        per = shards[1][1] - shards[1][0]
+        plan["transfer_model"] = {"bytes_in_per_problem": b_in, "bytes_out_per_problem": b_out, "link_GBs": XGMI_LINK_GBS,
+                                  "shard_scatter_ms": round(per * b_in / (XGMI_LINK_GBS * 1e9) * 1e3, 4), "shard_gather_ms": round(per * b_out / (XGMI_LINK_GBS * 1e9) * 1e3, 4),
+                                  "note": "per peer, one link each way; the pieces of a shard travel under the solves of its other pieces (strong_scaling_phases.exposed_transfer_ms of the "
+                                          "real line is what was NOT hidden); an exposed time well above shard_scatter_ms / pieces means the links are shared or the group is serialised"}
     plan["collectives"] = ("none on the data path (weak scaling: every rank solves its own problems); summary statistics by all_reduce / all_gather" if not strong
                            else "grouped P2P scatter of the inputs from rank 0 / gather of the plans to rank 0 per piece (RCCL), under the solves")
     return plan
@@ -431,6 +472,9 @@ def main():
         phase_ms = {"scatter_ms": acc[0] / 5 * 1e3, "solve_ms": acc[1] / 5 * 1e3, "gather_ms": acc[2] / 5 * 1e3, "chunks": args.chunks,
                     # what the overlapped step still pays for the transfers: its time minus the solve of the whole shard in one launch
                     "exposed_transfer_ms": elapsed / args.steps * 1e3 - acc[1] / 5 * 1e3,
+                    # the prediction `--dry-run` prints for this launch: one peer's shard over ONE xGMI link each way (world 1: nothing crosses a link)
+                    "predicted_shard_scatter_ms_at_153GBs": (0.0 if world <= 1 else (B_total + world - 1) // world * transfer_bytes_per_problem(int(N), int(M))[0] / (XGMI_LINK_GBS * 1e9) * 1e3),
+                    "predicted_shard_gather_ms_at_153GBs": (0.0 if world <= 1 else (B_total + world - 1) // world * transfer_bytes_per_problem(int(N), int(M))[1] / (XGMI_LINK_GBS * 1e9) * 1e3),
                     "note": "scatter / solve / gather timed one after the other, each between barriers (what the serial step would cost); the timed "
                             "step itself cuts every shard into `chunks` pieces and streams the transfers under the solves"}
 
@@ -509,41 +553,74 @@ def main():
             for _ in range(7):
                 t1 = time.perf_counter(); solver.solve_batch_host(wcomp, out=outc); e2c.append(time.perf_counter() - t1)
             # the same call with the caller's arrays registered once (frp_nmpc_host_register): nothing is staged, a gather kernel reads the
-            # live part of the inputs from the caller's memory, the solver writes the plans in place
-            wreg = {k: (np.ascontiguousarray(v, dtype=(np.int32 if k in ("nfaces", "models") else np.float64)) if isinstance(v, np.ndarray) else v) for k, v in wcpu.items()}
-            outr = tuple(np.zeros_like(a) for a in outs)
-            reg = [wreg[k] for k in ("xinit", "x0", "params", "nfaces") if isinstance(wreg.get(k), np.ndarray)] + list(outr)
-            e2r = []
-            try:
+            # live part of the inputs from the caller's memory, the solver writes the plans in place.  (Guarded like the other secondary
+            # legs: a hipHostRegister refusal -- a container's memlock limit at ~30 MB of pinned memory -- must not cost the bench line.)
+            as_c = lambda d: {k: (np.ascontiguousarray(v, dtype=(np.int32 if k in ("nfaces", "models") else np.float64)) if isinstance(v, np.ndarray) else v) for k, v in d.items()}
+
+            def registered_leg(wl, pipelined):
+                wr = as_c(wl)
+                outr = tuple(np.zeros_like(a) for a in outs)
+                reg = [wr[k] for k in ("xinit", "x0", "params", "nfaces") if isinstance(wr.get(k), np.ndarray)] + list(outr)
+                res = {}
                 solver.host_register(*reg)
-                solver.solve_batch_host(wreg, out=outr)
-                for _ in range(7):
-                    t1 = time.perf_counter(); solver.solve_batch_host(wreg, out=outr); e2r.append(time.perf_counter() - t1)
-            finally:
-                solver.host_unregister(*reg)
-            # ... and the 6-row layout in registered buffers: every input contiguous, the gather at the link's rate (tools/ubench/zc_read)
-            wcr = {k: (np.ascontiguousarray(v, dtype=(np.int32 if k in ("nfaces", "models") else np.float64)) if isinstance(v, np.ndarray) else v) for k, v in wcomp.items()}
-            outcr = tuple(np.zeros_like(a) for a in outs)
-            regc = [wcr[k] for k in ("xinit", "x0", "params", "nfaces") if isinstance(wcr.get(k), np.ndarray)] + list(outcr)
-            e2cr = []
+                try:
+                    solver.solve_batch_host(wr, out=outr)
+                    tt = []
+                    for _ in range(7):
+                        t1 = time.perf_counter(); solver.solve_batch_host(wr, out=outr); tt.append(time.perf_counter() - t1)
+                    res["s"] = float(np.median(tt)); res["out"] = outr
+                    if pipelined:
+                        # two batches in flight (frp_nmpc_solve_batch_host_begin / _wait): a second set of registered buffers with the same problems;
+                        # while one batch solves the other's inputs are gathered over the host link.  Steady state: time per batch over 16 batches.
+                        wr2 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in wr.items()}
+                        out2 = tuple(np.zeros_like(a) for a in outs)
+                        reg2 = [wr2[k] for k in ("xinit", "x0", "params", "nfaces") if isinstance(wr2.get(k), np.ndarray)] + list(out2)
+                        solver.host_register(*reg2)
+                        try:
+                            sets = [(wr, outr), (wr2, out2)]
+                            tk = [solver.solve_batch_host_begin(*sets[0]), solver.solve_batch_host_begin(*sets[1])]
+                            for q in (0, 1):
+                                solver.solve_batch_host_wait(tk[q]); tk[q] = solver.solve_batch_host_begin(*sets[q])
+                            nb = 16
+                            t1 = time.perf_counter()
+                            for i in range(nb):
+                                q = i & 1
+                                solver.solve_batch_host_wait(tk[q]); tk[q] = solver.solve_batch_host_begin(*sets[q])
+                            for q in (0, 1):
+                                solver.solve_batch_host_wait(tk[q])
+                            res["pipelined_s"] = (time.perf_counter() - t1) / (nb + 2)
+                            res["pipelined_same"] = bool(np.array_equal(out2[0], outs[0]) and np.array_equal(outr[0], outs[0]) and np.array_equal(out2[1], outs[1]))
+                        finally:
+                            solver.host_unregister(*reg2)
+                finally:
+                    solver.host_unregister(*reg)
+                return res
+
+            e2 = {"solves_per_s": B / float(np.median(e2e)), "ms_per_batch": float(np.median(e2e)) * 1e3,
+                  "buffers": "solves_per_s / ms_per_batch: the caller's PAGEABLE numpy arrays (persistent device buffers, pinned staging filled by a few copy threads, chunks "
+                             "of B/16, B/4 and the rest whose copies and solves overlap) -- the key rounds 1-4 reported; registered_*: the same arrays registered once "
+                             "(frp_nmpc_host_register): pinned in place, read by a gather kernel and written by the solver over PCIe, no staging (round 5 reported THIS "
+                             "under solves_per_s); pipelined_*: registered buffers, two batches in flight (frp_nmpc_solve_batch_host_begin / _wait)",
+                  "compact_layout_solves_per_s": B / float(np.median(e2c)), "compact_layout_ms_per_batch": float(np.median(e2c)) * 1e3,
+                  "same_plans": bool(np.array_equal(outs[0], outc[0]))}
             try:
-                solver.host_register(*regc)
-                solver.solve_batch_host(wcr, out=outcr)
-                for _ in range(7):
-                    t1 = time.perf_counter(); solver.solve_batch_host(wcr, out=outcr); e2cr.append(time.perf_counter() - t1)
-            finally:
-                solver.host_unregister(*regc)
-            out["end_to_end"] = {"solves_per_s": B / float(np.median(e2r)), "ms_per_batch": float(np.median(e2r)) * 1e3,
-                                 "buffers": "the caller's numpy arrays, registered once (frp_nmpc_host_register): pinned in place, read and written over PCIe by the kernels, no staging",
-                                 "pageable_solves_per_s": B / float(np.median(e2e)), "pageable_ms_per_batch": float(np.median(e2e)) * 1e3,
-                                 "registered_equals_pageable": bool(np.array_equal(outs[0], outr[0]) and np.array_equal(outs[1], outr[1])),
-                                 "compact_layout_solves_per_s": B / float(np.median(e2c)), "compact_layout_ms_per_batch": float(np.median(e2c)) * 1e3,
-                                 "compact_layout_registered_solves_per_s": B / float(np.median(e2cr)), "compact_layout_registered_ms_per_batch": float(np.median(e2cr)) * 1e3,
-                                 "same_plans": bool(np.array_equal(outs[0], outc[0]) and np.array_equal(outs[0], outcr[0])),
-                                 "what": "frp_nmpc_solve_batch_host, host buffers in and out (PCIe-inclusive, median of 7).  pageable_*: persistent device buffers, "
-                                         "pinned staging filled by a few copy threads, chunks of B/16, B/4 and the rest whose copies and solves overlap; dense = the reference's "
-                                         "30-row parameter layout in the caller's buffers (face counts given: the staging copy packs the 6 live rows, "
-                                         "8.9 of 26.4 KB per problem cross PCIe), compact = the same problems handed over with M = 6 rows (pageable, and in registered buffers: every input contiguous)"}
+                r = registered_leg(wcpu, True)
+                e2.update({"registered_solves_per_s": B / r["s"], "registered_ms_per_batch": r["s"] * 1e3,
+                           "registered_equals_pageable": bool(np.array_equal(outs[0], r["out"][0]) and np.array_equal(outs[1], r["out"][1])),
+                           "pipelined_solves_per_s": B / r["pipelined_s"], "pipelined_ms_per_batch": r["pipelined_s"] * 1e3, "pipelined_same_plans": r["pipelined_same"]})
+            except Exception as ex:  # noqa: BLE001
+                e2["registered_error"] = repr(ex)[:300]
+            try:  # ... and the 6-row layout in registered buffers: every input contiguous, the gather at the link's rate (tools/ubench/zc_read)
+                r = registered_leg(wcomp, True)
+                e2.update({"compact_layout_registered_solves_per_s": B / r["s"], "compact_layout_registered_ms_per_batch": r["s"] * 1e3,
+                           "compact_layout_pipelined_solves_per_s": B / r["pipelined_s"], "compact_layout_pipelined_ms_per_batch": r["pipelined_s"] * 1e3,
+                           "same_plans": bool(e2["same_plans"] and np.array_equal(outs[0], r["out"][0]) and r["pipelined_same"])})
+            except Exception as ex:  # noqa: BLE001
+                e2["compact_layout_registered_error"] = repr(ex)[:300]
+            e2["what"] = ("frp_nmpc_solve_batch_host, host buffers in and out (PCIe-inclusive, median of 7; pipelined: 18 batches back to back).  dense = the reference's "
+                          "30-row parameter layout in the caller's buffers (face counts given: the staging copy / the gather packs the 6 live rows, "
+                          "8.9 of 26.4 KB per problem cross PCIe), compact = the same problems handed over with M = 6 rows")
+            out["end_to_end"] = e2
             import ctypes
             w0 = workloads.config0()
             p = solver.ForcesParams(); o = solver.ForcesOutput(); info = solver.ForcesInfo()

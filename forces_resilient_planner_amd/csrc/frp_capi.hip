@@ -70,6 +70,8 @@ bool fill_args(const frp_nmpc_batch *b, const frp_nmpc_options *opt_in, void *ws
     a->order_hint = b->order_hint;
     a->counter = nullptr; a->order = nullptr;
     a->self_reset = 0;
+    a->variant_B = 0;
+    a->slot_reserve = 0;
     a->done_flag = nullptr; a->done_seq = 0;
     return true;
 }
@@ -270,12 +272,16 @@ int forces_solve(int model, frp_forces_params *params, frp_forces_output *output
     }
     if (frp::launch_ipm(a, st) != hipSuccess) return device_fault("launch");
     bool seen = false;
-    if (spin) { // (a solve is ~0.1 ms; a word that has not arrived after 50 ms is left to the runtime's own wait and error reporting)
+    if (spin) { // (a solve is ~0.1 ms; the caller's thread spins for at most 2 ms -- twenty ordinary solves -- then blocks in the runtime's own wait like the call it replaces: a MAXIT solve or a device fault does not burn a real-time thread for the whole tick)
         const auto t_spin = std::chrono::steady_clock::now();
         for (unsigned n = 0;; n++) {
             if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) == g_ctx.seq) { seen = true; break; }
-            if ((n & 1023u) == 1023u && std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(50)) break;
+            if ((n & 1023u) == 1023u && std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(2)) break;
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#elif defined(__aarch64__)
+            asm volatile("yield" ::: "memory");
+#endif
         }
     }
     if (!seen &&
@@ -445,9 +451,14 @@ HostPipe g_pipe;
 // caller's memory over PCIe into the chunk's device block (what the staging copy + hipMemcpyAsync did, without the host's memcpy, which
 // set the pace: 16 host threads against a 0.85 ms solve), and the solver writes plans, flags and diagnostics in place.
 struct HostRegistry {
-    struct Range { char *base; size_t bytes; char *dev; };
+    // refs: registrations of exactly this base (a second registration of the same pointer is counted, the pages are unpinned by the
+    // last unregistration).  A registration that lies INSIDE a range somebody else registered is kept as an alias of that range
+    // (nothing is pinned for it; it is unregistered by its own pointer like any other; the owner cannot leave while it has aliases).
+    struct Range { char *base; size_t bytes; char *dev; int refs; };
+    struct Alias { char *ptr; char *owner; };
     std::mutex mtx;
     std::vector<Range> ranges;
+    std::vector<Alias> aliases;
     template <typename T>
     T *device_ptr(const T *p, size_t bytes)
     {
@@ -456,8 +467,47 @@ struct HostRegistry {
             if (c >= r.base && c + bytes <= r.base + r.bytes) return reinterpret_cast<T *>(r.dev + (c - r.base));
         return nullptr;
     }
+    Range *containing(const char *c, size_t bytes)
+    {
+        for (Range &r : ranges)
+            if (c >= r.base && c + bytes <= r.base + r.bytes) return &r;
+        return nullptr;
+    }
 };
 HostRegistry g_reg;
+
+// ---- two batches in flight (frp_nmpc_solve_batch_host_begin / _wait; registered buffers only): while batch k solves, the gather kernel of
+// batch k + 1 reads its inputs over the host link.  The solver's workgroups are persistent and fill every CU's registers, so a gather block
+// that arrives later finds no room until a solver workgroup retires: the pipelined solves leave `reserve` resident slots free (KernelArgs::
+// slot_reserve) and the gather runs as a SMALL persistent grid of that many workgroups (64 suffice for the link: tools/ubench/zc_read).
+struct AsyncPipe {
+    std::mutex mtx;
+    bool ready = false;
+    int device = -1;
+    hipStream_t s_gather = nullptr, s_solve = nullptr;
+    static constexpr int NSLOT = 2;
+    struct Slot {
+        double *d_in = nullptr, *d_ws = nullptr;
+        size_t in_bytes = 0, ws_bytes = 0;
+        hipEvent_t e_in = nullptr, e_done = nullptr;
+        bool busy = false;
+    } slot[NSLOT];
+    void release()
+    {
+        for (auto &s : slot) {
+            if (s.busy && s.e_done) (void)hipEventSynchronize(s.e_done);
+            (void)hipFree(s.d_in); (void)hipFree(s.d_ws);
+            if (s.e_in) (void)hipEventDestroy(s.e_in);
+            if (s.e_done) (void)hipEventDestroy(s.e_done);
+            s = Slot();
+        }
+        if (s_gather) (void)hipStreamDestroy(s_gather);
+        if (s_solve) (void)hipStreamDestroy(s_solve);
+        s_gather = s_solve = nullptr; ready = false; device = -1;
+    }
+    ~AsyncPipe() { release(); }
+};
+AsyncPipe g_async;
 
 // one chunk's device block [xinit | x0 | params (Md live rows of the caller's M) | nfaces | models] from the caller's (mapped) arrays
 __global__ __launch_bounds__(256) void gather_inputs_kernel(size_t nb, size_t N, int M, int Md, const double *__restrict__ xinit, const double *__restrict__ x0,
@@ -591,24 +641,58 @@ int frp_nmpc_host_register(void *ptr, size_t bytes)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FRP_ERR_NO_DEVICE;
     std::lock_guard<std::mutex> lock(g_reg.mtx);
-    if (g_reg.device_ptr(reinterpret_cast<char *>(ptr), bytes)) return FRP_OK; // (already inside a registered range)
+    char *c = reinterpret_cast<char *>(ptr);
+    if (HostRegistry::Range *r = g_reg.containing(c, bytes)) {
+        if (r->base == c) r->refs++;                    // the same buffer once more: counted
+        else g_reg.aliases.push_back({c, r->base});     // inside somebody's range: an alias, unregistered by its own pointer
+        return FRP_OK;
+    }
+    // a range that OVERLAPS a registered one without lying inside it cannot be pinned a second time by the runtime: refuse it by name
+    for (const HostRegistry::Range &r : g_reg.ranges)
+        if (c < r.base + r.bytes && r.base < c + bytes) return FRP_ERR_ARG;
     if (hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); return FRP_ERR_HIP; }
     void *dev = nullptr;
     if (hipHostGetDevicePointer(&dev, ptr, 0) != hipSuccess || !dev) { (void)hipHostUnregister(ptr); (void)hipGetLastError(); return FRP_ERR_HIP; }
-    g_reg.ranges.push_back({reinterpret_cast<char *>(ptr), bytes, reinterpret_cast<char *>(dev)});
+    g_reg.ranges.push_back({c, bytes, reinterpret_cast<char *>(dev), 1});
     return FRP_OK;
 }
 
 int frp_nmpc_host_unregister(void *ptr)
 {
     std::lock_guard<std::mutex> lock(g_reg.mtx);
+    char *c = reinterpret_cast<char *>(ptr);
+    for (size_t i = 0; i < g_reg.aliases.size(); i++)
+        if (g_reg.aliases[i].ptr == c) { g_reg.aliases.erase(g_reg.aliases.begin() + (long)i); return FRP_OK; }
     for (size_t i = 0; i < g_reg.ranges.size(); i++)
-        if (g_reg.ranges[i].base == reinterpret_cast<char *>(ptr)) {
+        if (g_reg.ranges[i].base == c) {
+            if (g_reg.ranges[i].refs > 1) { g_reg.ranges[i].refs--; return FRP_OK; }
+            for (const HostRegistry::Alias &al : g_reg.aliases)
+                if (al.owner == c) return FRP_ERR_ARG; // (sub-ranges registered through it are still in use)
             const hipError_t rc = hipHostUnregister(ptr);
             g_reg.ranges.erase(g_reg.ranges.begin() + (long)i);
             return rc == hipSuccess ? FRP_OK : FRP_ERR_HIP;
         }
     return FRP_ERR_ARG;
+}
+
+int frp_nmpc_host_registered(const void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return 0;
+    std::lock_guard<std::mutex> lock(g_reg.mtx);
+    return g_reg.containing(reinterpret_cast<const char *>(ptr), bytes) ? 1 : 0;
+}
+
+int frp_nmpc_host_unregister_all(void)
+{
+    // (a caller that lost track -- e.g. arrays garbage-collected without frp_nmpc_host_unregister -- starts over: no stale range may
+    // survive to be taken for a new allocation at the same address)
+    std::lock_guard<std::mutex> pipe_lock(g_pipe.mtx); // no host batch is in flight on the ranges while they go
+    std::lock_guard<std::mutex> lock(g_reg.mtx);
+    int rc = FRP_OK;
+    for (const HostRegistry::Range &r : g_reg.ranges)
+        if (hipHostUnregister(r.base) != hipSuccess) { (void)hipGetLastError(); rc = FRP_ERR_HIP; }
+    g_reg.ranges.clear(); g_reg.aliases.clear();
+    return rc;
 }
 
 int frp_nmpc_set_q4_min_batch(int min_batch) { return frp::lds_q4_set_min_batch(min_batch); }
@@ -630,11 +714,8 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FRP_ERR_NO_DEVICE;
     std::lock_guard<std::mutex> lock(g_pipe.mtx);
     // every chunk of this call runs on the kernel variants ONE launch of the whole batch would run on (the four-per-CU variants are
-    // chosen by batch size and sum in another order): the plans do not depend on how the staging is cut
-    struct VariantOfWholeBatch {
-        explicit VariantOfWholeBatch(int B) { frp::lds_q4_pin_for_batch(B); }
-        ~VariantOfWholeBatch() { frp::lds_q4_pin_for_batch(0); }
-    } pin(h->B);
+    // chosen by batch size and sum in another order): the plans do not depend on how the staging is cut (KernelArgs::variant_B --
+    // an argument of the launch, not process state: concurrent frp_nmpc_solve_batch calls on other threads keep their own choice)
     // The pipeline (streams, events, device and pinned buffers) belongs to ONE device: the one current when it was built.  A call
     // made with another device current rebuilds it there (the per-call allocation it replaced worked on any device).
     int dev = 0;
@@ -646,6 +727,9 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
         g_pipe.release();
         FRP_HIP(hipSetDevice(dev));
     }
+    // (declared before the guard below: on an error path the kernels still writing the caller's registered memory are drained UNDER the
+    // registry lock, so nobody unregisters -- unpins -- those pages while they are being written)
+    std::lock_guard<std::mutex> reg_lock(g_reg.mtx);
     struct DirtyOnError { // every early return below leaves the slots in use: they are drained before the error is returned
         int rc = FRP_ERR_HIP;
         ~DirtyOnError() { if (rc != FRP_OK && g_pipe.ready) { g_pipe.drain_all(); } }
@@ -671,7 +755,6 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
     // the reference's 30-row layout with 6-face corridors -- and the device solves the same problems in the compact layout.
     const bool compact = h->nfaces && h->MF < h->M;
     // every array of the batch inside ranges the caller registered (frp_nmpc_host_register): no staging, see HostRegistry
-    std::lock_guard<std::mutex> reg_lock(g_reg.mtx);
     const size_t Bz = (size_t)h->B, Tz = Bz * (size_t)h->N;
     const double *m_xinit = g_reg.device_ptr(h->xinit, Bz * 9 * 8), *m_x0 = g_reg.device_ptr(h->x0, Tz * 17 * 8);
     const double *m_params = g_reg.device_ptr(h->params, Tz * FRP_NPAR(h->M) * 8);
@@ -781,8 +864,12 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
         d.exitflag = reinterpret_cast<int *>(s.d_out + nb * N * 17 + (h->info ? nb * FRP_INFO_STRIDE : 0)); d.iters = d.exitflag + nb;
         if (mapped) { d.z = m_z + b0 * N * 17; d.info = m_info ? m_info + b0 * FRP_INFO_STRIDE : nullptr; d.exitflag = m_flag + b0; d.iters = m_it + b0; }
         FRP_HIP(hipStreamWaitEvent(g_pipe.s_solve, s.e_in, 0));
-        const int rc = frp_nmpc_solve_batch(&d, opt, s.d_ws, s.ws_bytes, g_pipe.s_solve);
-        if (rc != FRP_OK) return rc;
+        {
+            frp::KernelArgs ka;
+            if (!fill_args(&d, opt, s.d_ws, s.ws_bytes, &ka)) return FRP_ERR_ARG;
+            ka.variant_B = h->B;
+            FRP_HIP(frp::launch_ipm(ka, g_pipe.s_solve));
+        }
         FRP_HIP(hipEventRecord(s.e_solve, g_pipe.s_solve));
         if (mapped) { FRP_HIP(hipEventRecord(s.e_out, g_pipe.s_solve)); continue; }
         FRP_HIP(hipStreamWaitEvent(g_pipe.s_out, s.e_solve, 0));
@@ -795,6 +882,91 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *h, const frp_nmpc_options *o
         if (rc != FRP_OK) return rc;
     }
     guard.rc = FRP_OK;
+    return FRP_OK;
+}
+
+int frp_nmpc_solve_batch_host_begin(const frp_nmpc_batch *h, const frp_nmpc_options *opt, int *ticket)
+{
+    if (!ticket) return FRP_ERR_ARG;
+    *ticket = -1;
+    if (!h || h->B <= 0 || h->N < 2 || h->N > 64 || h->M < 0 || h->MF < 0 || h->MF > h->M || h->MF > frp::FRP_MAX_FACES) return FRP_ERR_ARG;
+    if (!h->xinit || !h->x0 || !h->params || !h->z || !h->exitflag || !h->iters) return FRP_ERR_ARG;
+    if (h->model != FRP_MODEL_NORMAL && h->model != FRP_MODEL_FINAL) return FRP_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FRP_ERR_NO_DEVICE;
+    std::lock_guard<std::mutex> lock(g_async.mtx);
+    int dev = 0;
+    FRP_HIP(hipGetDevice(&dev));
+    if (g_async.ready && g_async.device != dev) { // (the pipeline belongs to the device it was built on; a call from another one rebuilds it there)
+        const int prev = g_async.device;
+        (void)hipSetDevice(prev);
+        g_async.release();
+        FRP_HIP(hipSetDevice(dev));
+    }
+    if (!g_async.ready) {
+        g_async.device = dev; g_async.ready = true;
+        bool ok = hipStreamCreateWithFlags(&g_async.s_gather, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&g_async.s_solve, hipStreamNonBlocking) == hipSuccess;
+        for (auto &s : g_async.slot)
+            ok = ok && hipEventCreateWithFlags(&s.e_in, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s.e_done, hipEventDisableTiming) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); g_async.release(); return FRP_ERR_HIP; }
+    }
+    int si = -1;
+    for (int i = 0; i < AsyncPipe::NSLOT; i++)
+        if (!g_async.slot[i].busy) { si = i; break; }
+    if (si < 0) return FRP_ERR_ARG; // (FRP_NMPC_HOST_INFLIGHT batches are out: wait for one)
+    AsyncPipe::Slot &s = g_async.slot[si];
+    std::lock_guard<std::mutex> reg_lock(g_reg.mtx);
+    const size_t Bz = (size_t)h->B, N = (size_t)h->N, Tz = Bz * N;
+    const double *m_xinit = g_reg.device_ptr(h->xinit, Bz * 9 * 8), *m_x0 = g_reg.device_ptr(h->x0, Tz * 17 * 8);
+    const double *m_params = g_reg.device_ptr(h->params, Tz * FRP_NPAR(h->M) * 8);
+    const int *m_nf = h->nfaces ? g_reg.device_ptr(h->nfaces, Tz * 4) : nullptr, *m_md = h->model_per_problem ? g_reg.device_ptr(h->model_per_problem, Bz * 4) : nullptr;
+    double *m_z = g_reg.device_ptr(h->z, Tz * 17 * 8), *m_info = h->info ? g_reg.device_ptr(h->info, Bz * FRP_INFO_STRIDE * 8) : nullptr;
+    int *m_flag = g_reg.device_ptr(h->exitflag, Bz * 4), *m_it = g_reg.device_ptr(h->iters, Bz * 4);
+    if (!(m_xinit && m_x0 && m_params && (!h->nfaces || m_nf) && (!h->model_per_problem || m_md) && m_z && (!h->info || m_info) && m_flag && m_it))
+        return FRP_ERR_ARG; // every array of a pipelined batch is registered (frp_nmpc_host_register): nothing is staged on this path
+    const bool compact = h->nfaces && h->MF < h->M;
+    const int Md = compact ? h->MF : h->M;
+    const size_t np = FRP_NPAR(Md), in_d = 9 + N * 17 + N * np, nf_d = h->nfaces ? (N + 1) / 2 : 0, md_d = h->model_per_problem ? 1 : 0;
+    const size_t in_bytes = Bz * (in_d + nf_d + md_d) * sizeof(double), ws_bytes = frp::ws_bytes(h->B, h->N, h->MF);
+    if (in_bytes > s.in_bytes) { (void)hipFree(s.d_in); s.d_in = nullptr; s.in_bytes = 0; FRP_HIP(hipMalloc(&s.d_in, in_bytes)); s.in_bytes = in_bytes; }
+    if (ws_bytes > s.ws_bytes) { (void)hipFree(s.d_ws); s.d_ws = nullptr; s.ws_bytes = 0; FRP_HIP(hipMalloc(&s.d_ws, ws_bytes)); s.ws_bytes = ws_bytes; }
+    static const int gather_wgs = [] { const char *e = getenv("FRP_HOST_GATHER_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 64; }(); // (tuning knob)
+    hipLaunchKernelGGL(gather_inputs_kernel, dim3((unsigned)gather_wgs), dim3(256), 0, g_async.s_gather, Bz, N, h->M, Md, m_xinit, m_x0, m_params, m_nf, m_md, s.d_in);
+    FRP_HIP(hipGetLastError());
+    FRP_HIP(hipEventRecord(s.e_in, g_async.s_gather));
+    frp_nmpc_batch d = *h;
+    d.M = Md;
+    d.xinit = s.d_in; d.x0 = s.d_in + Bz * 9; d.params = s.d_in + Bz * 9 + Tz * 17;
+    const double *d_tail = s.d_in + Bz * in_d;
+    d.nfaces = h->nfaces ? reinterpret_cast<const int *>(d_tail) : nullptr;
+    d.model_per_problem = h->model_per_problem ? reinterpret_cast<const int *>(d_tail + Bz * nf_d) : nullptr;
+    d.order_hint = nullptr;
+    d.z = m_z; d.info = m_info; d.exitflag = m_flag; d.iters = m_it; // (the solver writes the caller's arrays in place)
+    frp::KernelArgs ka;
+    if (!fill_args(&d, opt, s.d_ws, s.ws_bytes, &ka)) return FRP_ERR_ARG;
+    ka.slot_reserve = gather_wgs;
+    FRP_HIP(hipStreamWaitEvent(g_async.s_solve, s.e_in, 0));
+    FRP_HIP(frp::launch_ipm(ka, g_async.s_solve));
+    FRP_HIP(hipEventRecord(s.e_done, g_async.s_solve));
+    s.busy = true;
+    *ticket = si;
+    return FRP_OK;
+}
+
+int frp_nmpc_solve_batch_host_wait(int ticket)
+{
+    if (ticket < 0 || ticket >= AsyncPipe::NSLOT) return FRP_ERR_ARG;
+    hipEvent_t ev;
+    {
+        std::lock_guard<std::mutex> lock(g_async.mtx);
+        if (!g_async.ready || !g_async.slot[ticket].busy) return FRP_ERR_ARG;
+        ev = g_async.slot[ticket].e_done;
+    }
+    const hipError_t rc = hipEventSynchronize(ev); // (outside the lock: another thread may begin the next batch meanwhile)
+    std::lock_guard<std::mutex> lock(g_async.mtx);
+    g_async.slot[ticket].busy = false;
+    if (rc != hipSuccess) { fprintf(stderr, "[frp_nmpc] HIP error %s while waiting for a pipelined host batch\n", hipGetErrorString(rc)); return FRP_ERR_HIP; }
     return FRP_OK;
 }
 

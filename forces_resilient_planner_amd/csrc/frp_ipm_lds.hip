@@ -23,6 +23,7 @@
 #include <type_traits>
 #include <math.h>
 #include <cstdlib>
+#include <atomic>
 #include "frp_model.hpp"
 #include "../../include/frp_nmpc.h"
 #include "frp_kernels.h"
@@ -1704,6 +1705,12 @@ __device__ __forceinline__ void model_phase3(ldouble *recs, ldouble *xs, ModelSt
     const double *z = st.z;
     l_eq = 0.0;
     ldouble *rec = recs + (act ? k : 0) * RS;
+#ifdef FRP_PROFILE_W1 // (profile build) blocks of this phase: slots 18.. of the segment counters (park + step, d, linearisation + M'y)
+    long long m3t_ = clock64();
+#define M3_SEG(i) do { const long long tn_ = clock64(); if (lane == 0) atomicAdd((unsigned long long *)&g_prof_seg[18 + (i)], (unsigned long long)(tn_ - m3t_)); m3t_ = tn_; } while (0)
+#else
+#define M3_SEG(i)
+#endif
     if (act && sub == 0) {
 #pragma unroll
         for (int i = 0; i < NS; i++) rec[RT_Y + i] = st.y[i];
@@ -1751,6 +1758,7 @@ __device__ __forceinline__ void model_phase3(ldouble *recs, ldouble *xs, ModelSt
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    M3_SEG(0);
     // ---- block 2: d = prev(z_k) - s_{k+1}: the next stage's [w; x] comes from lane + 1 (same sub); stored by sub 0
     {
         double dmax = 0.0, dv[NS];
@@ -1767,6 +1775,7 @@ __device__ __forceinline__ void model_phase3(ldouble *recs, ldouble *xs, ModelSt
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    M3_SEG(1);
     // ---- block 3: column `sub` of the linearisation and the entries (sub, 4 + sub, 8 + sub, 11 + sub, 14 + sub) of
     // gm = M' y_{k+1} - [0; y_k] (3 and 7 on sub 0)
     if (act) {
@@ -1824,6 +1833,7 @@ __device__ __forceinline__ void model_phase3(ldouble *recs, ldouble *xs, ModelSt
 #pragma unroll
         for (int i = 0; i < NS; i++) st.y[i] = yk[i];
     }
+    M3_SEG(2);
     // ---- block 4 (twisted solve): the stages of the first half keep the INVERTED transition [u; x]_k = T~ [w+; x+] + t~ in place of the
     // linearisation (layout: ma_src).  A = [I Apv Ape; 0 Avv Ave; 0 0 I] inverts in closed form around the 3 x 3 block Avv; lane `sub`
     // forms row `sub` of every block:  A~vv = Avv^-1,  A~ve = -Avv^-1 Ave,  A~pv = -Apv Avv^-1,  A~pe = -Ape - A~pv Ave,
@@ -2507,8 +2517,19 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         // (Q4, corridor rows on the model wave: their state does not fit beside the model phase's temporaries -- ~25 scratch accesses, 14.9 k
         // cycles for the phase instead of ~10 k.  Measured and dropped: evaluating the rows first, parking their 15 doubles in the global
         // workspace across the model phase and fetching them back in one batch behind it -- the barrier waits for the loads: 18.7 k.)
-        constexpr bool PARK = false;
-        if constexpr (IS_M && !PARK) model_block();
+        // Q4, corridor rows on the model wave: which of the two runs first (FRP_Q4_FACES_FIRST: the rows' residuals only need z; with the
+        // rows ahead of the model their accumulators are dead before the model's temporaries come alive -- VERDICT r05 item 1a / DESIGN 9.5-5b)
+#ifndef FRP_Q4_FACES_FIRST
+#define FRP_Q4_FACES_FIRST 0
+#endif
+        constexpr bool FACES_FIRST = QW && IS_M && IS_F && FRP_Q4_FACES_FIRST;
+#ifdef FRP_PROFILE_W1 // (profile build) where the model + corridor wave spends its evaluation phase: slots 16.. of the segment counters
+        long long w1t_ = clock64();
+#define W1_SEG(i) do { if constexpr (IS_M) { const long long tn_ = clock64(); if (lane == 0) atomicAdd((unsigned long long *)&g_prof_seg[16 + (i)], (unsigned long long)(tn_ - w1t_)); w1t_ = tn_; } } while (0)
+#else
+#define W1_SEG(i)
+#endif
+        if constexpr (IS_M && !FACES_FIRST) { model_block(); W1_SEG(0); }
         if constexpr (IS_BO) {
             double l_in = 0.0, l_rc = 0.0, l_gap = 0.0;
             bounds_eval(l_in, l_rc, l_gap);
@@ -2549,7 +2570,9 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 rec[R_CC + 0] = fp0; rec[R_CC + 1] = fp1; rec[R_CC + 2] = fp2;
             }
             publish(xs, wave, lane, 0, wave_max(l_in)); publish(xs, wave, lane, 1, wave_max(l_rc)); publish(xs, wave, lane, 2, wave_sum_mx(l_gap));
+            W1_SEG(1);
         }
+        if constexpr (FACES_FIRST) { FRP_SB(); model_block(); W1_SEG(0); }
         BAR_P(0); // ------------------------------------------------------------- A
         // (workgroup-uniform scalars that live across phases go to scalar registers: the element-wise roles are at the
         // 168-VGPR cap of three workgroups per CU, and every spilled value is an L2 round trip on an in-order wavefront)
@@ -3257,12 +3280,11 @@ static int device_cus()
     }
     return cus[dev];
 }
-static int g_q4_min_b = [] { const char *e = getenv("FRP_Q4_MIN_B"); return e ? atoi(e) : -1; }(); // (frp_nmpc_set_q4_min_batch; -1: three workgroups per CU)
-static int g_q4_pin_b = 0; // (lds_q4_pin_for_batch)
+static std::atomic<int> g_q4_min_b{[] { const char *e = getenv("FRP_Q4_MIN_B"); return e ? atoi(e) : -1; }()}; // (frp_nmpc_set_q4_min_batch, a process-wide tuning hook; -1: three workgroups per CU)
 static bool q4_covers(const KernelArgs &k)
 {
-    const int B = g_q4_pin_b > 0 ? g_q4_pin_b : k.B;
-    return q4_enabled() && k.pws && k.N <= 20 && k.MF <= 6 && FRP_LR::twist_stages(k) == 0 && B > (g_q4_min_b >= 0 ? g_q4_min_b : 3 * device_cus());
+    const int B = k.variant_B > 0 ? k.variant_B : k.B; // (the chunks of a host batch: the whole batch's variant)
+    return q4_enabled() && k.pws && k.N <= 20 && k.MF <= 6 && FRP_LR::twist_stages(k) == 0 && B > (g_q4_min_b.load(std::memory_order_relaxed) >= 0 ? g_q4_min_b.load(std::memory_order_relaxed) : 3 * device_cus());
 }
 #endif
 
@@ -3273,10 +3295,8 @@ size_t lds_q4_pws_doubles_per_slot() { return (size_t)20 * FRP_LR::PG; }
 bool lds_q4_enabled() { return q4_enabled(); }
 #if (defined(FRP_QP) || defined(FRP_QW)) && !defined(FRP_LDS_Q4_TU)
 int lds_q4_set_min_batch(int) { return -1; }
-void lds_q4_pin_for_batch(int) {}
 #else
-void lds_q4_pin_for_batch(int B) { g_q4_pin_b = B > 0 ? B : 0; }
-int lds_q4_set_min_batch(int min_b) { const int old = g_q4_min_b; g_q4_min_b = min_b < 0 ? -1 : min_b; return old; }
+int lds_q4_set_min_batch(int min_b) { return g_q4_min_b.exchange(min_b < 0 ? -1 : min_b); }
 #endif
 
 bool lds_kernel_supports(int N, int MF) { return N >= 1 && N <= 64 && MF >= 0 && MF <= FRP_MAX_FACES; }

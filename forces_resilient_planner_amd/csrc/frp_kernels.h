@@ -62,6 +62,10 @@ struct KernelArgs {
     const int *order_hint; // per-problem expected work (last tick's iteration count), or null = order by the cost of the initial guess
     int self_reset;        // B == 1 only (the drop-in context): the queue head is zero on entry and the kernel leaves it zero --
                            // no reset launch in front of the solve; no role placement (one workgroup: nothing to place)
+    int variant_B;         // > 0: the kernel variant (three / four problems per CU) is chosen as for a launch of this many problems -- the chunks
+                           // of frp_nmpc_solve_batch_host all run the whole batch's variant (they sum in another order); 0 = by B
+    int slot_reserve;      // resident workgroups the launch leaves free (0 = none): the pipelined host path keeps room for the NEXT batch's
+                           // gather kernel beside the persistent solver workgroups (frp_nmpc_solve_batch_host_begin)
     int *done_flag;        // B == 1 only, or null: a word in host-coherent memory that receives done_seq once every output of the solve is
     int done_seq;          // visible to the host -- the drop-in call spins on it instead of paying a stream synchronisation (~10 us)
 };
@@ -77,7 +81,6 @@ int lds_workgroups_per_cu(const KernelArgs &k);
 size_t lds_q4_pws_doubles_per_slot();
 bool lds_q4_enabled();
 int lds_q4_set_min_batch(int min_b); // (frp_nmpc_set_q4_min_batch)
-void lds_q4_pin_for_batch(int B);    // B > 0: launches decide as a launch of B problems would, until the next call with 0 (frp_nmpc_solve_batch_host's chunks)
 bool lds_kernel_supports(int N, int MF);
 hipError_t launch_ipm_lds(const KernelArgs &k, int slots, hipStream_t stream);
 hipError_t launch_stage_eval(int B, int N, int M, int model, const double *z, const double *params, double *f,

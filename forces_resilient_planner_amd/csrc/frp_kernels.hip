@@ -443,7 +443,12 @@ hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
         const uintptr_t p = reinterpret_cast<uintptr_t>(q + QUEUE_RESERVED + (size_t)a.B + ((size_t)a.B + 1) / 2);
         k.pws = reinterpret_cast<double *>((p + 127) & ~(uintptr_t)127);
     }
-    const int slots = lds_resident_slots(a.B, k);
+    int slots = lds_resident_slots(a.B, k);
+    if (a.slot_reserve > 0) { // room for another kernel's workgroups beside the persistent ones (the pipelined host path's gather)
+        int lim = resident_cap(lds_workgroups_per_cu(k)) - a.slot_reserve;
+        if (lim < 64) lim = 64;
+        if (slots > lim) slots = lim;
+    }
     k.counter = reinterpret_cast<int *>(q);
     k.cu_slots = reinterpret_cast<int *>(q + 32);
     // Long solves get their CU to themselves (frp_ipm_lds.hip, Q4 variants): from iteration `iso_it` on the other workgroups of the CU

@@ -128,7 +128,8 @@ EXPORTS = ["frp_nmpc_default_options", "frp_nmpc_workspace_bytes", "frp_nmpc_sol
            "frp_nmpc_coldstart_batch", "frp_nmpc_cloud_grid_build",
            "frp_nmpc_mode_batch", "frp_nmpc_astar_batch", "frp_nmpc_astar_workspace_bytes",
            "frp_nmpc_kernel_timing_begin", "frp_nmpc_kernel_timing_end", "frp_nmpc_set_q4_min_batch",
-           "frp_nmpc_abi_version", "frp_nmpc_abi_check", "frp_nmpc_host_register", "frp_nmpc_host_unregister"]
+           "frp_nmpc_abi_version", "frp_nmpc_abi_check", "frp_nmpc_host_register", "frp_nmpc_host_unregister",
+           "frp_nmpc_host_registered", "frp_nmpc_host_unregister_all", "frp_nmpc_solve_batch_host_begin", "frp_nmpc_solve_batch_host_wait"]
 
 _lib = None
 
@@ -168,6 +169,9 @@ def lib():
         l.frp_nmpc_set_q4_min_batch.argtypes = [ctypes.c_int]
         l.frp_nmpc_host_register.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
         l.frp_nmpc_host_unregister.argtypes = [ctypes.c_void_p]
+        l.frp_nmpc_host_registered.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        l.frp_nmpc_solve_batch_host_begin.argtypes = [ctypes.POINTER(Batch), ctypes.POINTER(Options), ctypes.POINTER(ctypes.c_int)]
+        l.frp_nmpc_solve_batch_host_wait.argtypes = [ctypes.c_int]
         l.frp_nmpc_kernel_timing_begin.argtypes = [ctypes.c_int, ctypes.c_int]
         l.frp_nmpc_kernel_timing_end.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
         l.frp_nmpc_pack_batch.argtypes = [ctypes.POINTER(Pack), ctypes.c_void_p]
@@ -227,19 +231,62 @@ def solve_batch_host(w, opt: Options | None = None, MF: int | None = None, x0=No
     return z, flag, iters, info
 
 
+def solve_batch_host_begin(w, out, opt: Options | None = None, MF: int | None = None):
+    """frp_nmpc_solve_batch_host_begin: every array of `w` (C-contiguous float64 / int32) and of `out` = (z, flag, iters, info) registered with
+    host_register; returns the ticket.  The outputs are valid after solve_batch_host_wait(ticket)."""
+    B, N, M = int(w["xinit"].shape[0]), int(w["N"]), int(w["M"])
+    nf = w.get("nfaces")
+    if MF is None:
+        MF = int(nf.max()) if nf is not None and nf.size else M
+    z, flag, iters, info = out
+    models = w.get("models")
+    for a in (w["xinit"], w["x0"], w["params"], z, info):
+        assert a.flags["C_CONTIGUOUS"] and a.dtype == np.float64
+    for a in (nf, models, flag, iters):
+        assert a is None or (a.flags["C_CONTIGUOUS"] and a.dtype == np.int32)
+    b = Batch(B, N, M, MF, int(w["model"]), w["xinit"].ctypes.data, w["x0"].ctypes.data, w["params"].ctypes.data,
+              nf.ctypes.data if nf is not None else None, z.ctypes.data, flag.ctypes.data, iters.ctypes.data,
+              info.ctypes.data, models.ctypes.data if models is not None else None)
+    t = ctypes.c_int(-1)
+    _check(lib().frp_nmpc_solve_batch_host_begin(ctypes.byref(b), ctypes.byref(opt) if opt is not None else None, ctypes.byref(t)),
+           "frp_nmpc_solve_batch_host_begin")
+    return int(t.value)
+
+
+def solve_batch_host_wait(ticket):
+    _check(lib().frp_nmpc_solve_batch_host_wait(int(ticket)), "frp_nmpc_solve_batch_host_wait")
+
+
+_registered = {}  # ptr -> [array, count]: a strong reference for as long as the library holds the pages pinned under that address
+
+
 def host_register(*arrays):
     """frp_nmpc_host_register for numpy arrays a caller reuses from call to call (inputs and the `out` arrays of solve_batch_host):
-    with every array of a call registered, frp_nmpc_solve_batch_host stages nothing.  Keep the arrays alive until host_unregister."""
+    with every array of a call registered, frp_nmpc_solve_batch_host stages nothing.  The wrapper keeps a reference to every
+    registered array until host_unregister: an array that were garbage-collected while registered would leave its address range
+    in the library's registry, and a later array placed at the same address would be taken for the old mapping."""
     for a in arrays:
         if a is not None:
             assert a.flags["C_CONTIGUOUS"]
             _check(lib().frp_nmpc_host_register(a.ctypes.data, a.nbytes), "frp_nmpc_host_register")
+            ent = _registered.setdefault(a.ctypes.data, [a, 0])
+            ent[1] += 1
 
 
 def host_unregister(*arrays):
     for a in arrays:
         if a is not None:
-            lib().frp_nmpc_host_unregister(a.ctypes.data)
+            _check(lib().frp_nmpc_host_unregister(a.ctypes.data), "frp_nmpc_host_unregister")
+            ent = _registered.get(a.ctypes.data)
+            if ent is not None:
+                ent[1] -= 1
+                if ent[1] <= 0:
+                    del _registered[a.ctypes.data]
+
+
+def host_unregister_all():
+    _check(lib().frp_nmpc_host_unregister_all(), "frp_nmpc_host_unregister_all")
+    _registered.clear()
 
 
 def stage_eval_host(z, params, M, model, want=("f", "gf", "c", "Jc", "h")):

@@ -158,9 +158,29 @@ int frp_nmpc_solve_batch_host(const frp_nmpc_batch *batch_host, const frp_nmpc_o
  * frp_nmpc_solve_batch_host call lies inside registered ranges the call stages nothing: a gather kernel reads the live part of the
  * inputs straight from the caller's memory and the solver writes plans, flags and diagnostics in place (same plans, bit for bit).
  * The caller keeps the buffer alive and unchanged in size until frp_nmpc_host_unregister(ptr) (same `ptr`); registering costs
- * milliseconds -- do it once for buffers that are reused from tick to tick, not per call. */
+ * milliseconds -- do it once for buffers that are reused from tick to tick, not per call.
+ * Registrations are counted: the same (ptr) registered twice is unpinned by its second unregistration; a range that lies INSIDE a
+ * registered range is accepted as an alias of it (nothing is pinned twice) and is unregistered by its own pointer -- the enclosing
+ * range cannot be unregistered before its aliases (FRP_ERR_ARG); a range that partly overlaps a registered one is refused.  An array
+ * that is freed without being unregistered leaves its pages pinned AND its address range in the registry: a later allocation at the same
+ * address would be taken for the old mapping.  frp_nmpc_host_registered() answers whether [ptr, ptr + bytes) is covered;
+ * frp_nmpc_host_unregister_all() drops every registration (it waits for a host batch in flight). */
 int frp_nmpc_host_register(void *ptr, size_t bytes);
 int frp_nmpc_host_unregister(void *ptr);
+int frp_nmpc_host_registered(const void *ptr, size_t bytes);
+int frp_nmpc_host_unregister_all(void);
+
+/* Two host batches in flight (registered buffers only; FRP_ERR_ARG if any array of the batch is not registered): _begin enqueues the
+ * gather of the batch's inputs and its solve and returns a ticket, _wait blocks until that batch's plans, flags and diagnostics are in
+ * the caller's arrays (written in place by the solver).  While batch k solves, the gather kernel of batch k + 1 reads its inputs over
+ * the host link (the pipelined solves leave a few resident workgroup slots free for it), so a caller that alternates two sets of
+ * registered buffers -- begin(A); begin(B); loop { wait(A); use A; refill A; begin(A); wait(B); ... } -- sees max(gather, solve) per
+ * batch instead of their sum.  Same plans as frp_nmpc_solve_batch_host, bit for bit.  At most FRP_NMPC_HOST_INFLIGHT tickets may be
+ * outstanding (a further _begin returns FRP_ERR_ARG); the arrays of a batch must stay registered and untouched between its _begin and
+ * _wait.  (A caller that keeps its planner state on the device needs none of this: frp_nmpc_solve_batch.) */
+#define FRP_NMPC_HOST_INFLIGHT 2
+int frp_nmpc_solve_batch_host_begin(const frp_nmpc_batch *batch_host, const frp_nmpc_options *opt, int *ticket);
+int frp_nmpc_solve_batch_host_wait(int ticket);
 
 /* Batched model callback = the reference's extfunc (FORCESNLPsolver_normal.h:321,
  * FORCESNLPsolver_normal_casadi2forces.c:42-245) for B*N stage points at once.

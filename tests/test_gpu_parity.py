@@ -720,8 +720,79 @@ def test_host_path_with_registered_buffers_stages_nothing_and_changes_no_plan():
         for a, b in zip(ref, out2):
             assert np.array_equal(a, b)
     finally:
-        solver.host_unregister(*reg)
+        solver.host_unregister(*[a for a in reg if a is not w["x0"]])
     assert solver.lib().frp_nmpc_host_unregister(w["xinit"].ctypes.data) != 0  # (already gone: an argument error, nothing else)
+    assert not solver._registered  # the wrapper's references went with the registrations
+
+
+def test_two_host_batches_in_flight_give_the_plans_of_the_blocking_call():
+    """frp_nmpc_solve_batch_host_begin / _wait: two sets of registered buffers alternate, the gather of one batch runs
+    under the solve of the other (the pipelined solves leave resident slots free for it) -- plans, flags, counts and diagnostics are those
+    of the blocking call bit for bit, for DIFFERENT problems in the two sets; a third begin while two are out is refused, as is a batch with
+    an unregistered array, and a ticket can be waited for once."""
+    B = 3000
+    ws = [workloads.config2(B, seed=31), workloads.config2(B, seed=32)]
+    ws = [{k: (np.ascontiguousarray(v, dtype=(np.int32 if k == "nfaces" else np.float64)) if isinstance(v, np.ndarray) else v) for k, v in w.items()} for w in ws]
+    refs = [solver.solve_batch_host(w) for w in ws]
+    outs = [tuple(np.full_like(a, -7) for a in refs[0]) for _ in ws]
+    regs = [[w["xinit"], w["x0"], w["params"], w["nfaces"]] + list(o) for w, o in zip(ws, outs)]
+    L_ = solver.lib()
+    # not registered: refused, nothing enqueued
+    t = ctypes.c_int(5)
+    with pytest.raises(RuntimeError):
+        solver.solve_batch_host_begin(ws[0], outs[0])
+    for r in regs:
+        solver.host_register(*r)
+    try:
+        for rnd in range(3):
+            tk = [solver.solve_batch_host_begin(ws[q], outs[q]) for q in (0, 1)]
+            assert sorted(tk) == [0, 1]
+            with pytest.raises(RuntimeError):
+                solver.solve_batch_host_begin(ws[0], outs[0])  # FRP_NMPC_HOST_INFLIGHT batches are out
+            for q in (1, 0):
+                solver.solve_batch_host_wait(tk[q])
+            assert L_.frp_nmpc_solve_batch_host_wait(tk[0]) != 0  # (waited for already)
+            for q in (0, 1):
+                for a, b in zip(refs[q], outs[q]):
+                    assert np.array_equal(a, b), (rnd, q)
+                for o in outs[q]:
+                    o[...] = -7
+    finally:
+        for r in regs:
+            solver.host_unregister(*r)
+
+
+def test_host_registrations_are_counted_and_sub_ranges_are_aliases():
+    """frp_nmpc_host_register: the same buffer registered twice is unpinned by its second unregistration; a sub-range of a
+    registered buffer is an alias that is unregistered by its own pointer and keeps the enclosing range alive; a range that partly overlaps
+    a registered one is refused; frp_nmpc_host_unregister_all drops everything; the Python wrapper holds a reference to every registered
+    array, so a registered array cannot be garbage-collected under the registry."""
+    import gc, weakref
+    L_ = solver.lib()
+    a = np.zeros(1 << 16)
+    p, nb = a.ctypes.data, a.nbytes
+    assert L_.frp_nmpc_host_registered(p, nb) == 0
+    solver.host_register(a); solver.host_register(a)
+    assert L_.frp_nmpc_host_registered(p, nb) == 1
+    solver.host_unregister(a)
+    assert L_.frp_nmpc_host_registered(p, nb) == 1          # one registration left
+    sub = a[1024:2048]
+    solver.host_register(sub)                               # alias: nothing pinned twice
+    assert L_.frp_nmpc_host_unregister(p) != 0              # the enclosing range has an alias: refused
+    assert L_.frp_nmpc_host_registered(p, nb) == 1
+    solver.host_unregister(sub)
+    solver.host_unregister(a)
+    assert L_.frp_nmpc_host_registered(p, nb) == 0 and L_.frp_nmpc_host_unregister(p) != 0
+    # partial overlap: refused by name
+    solver.host_register(a[:4096])
+    assert L_.frp_nmpc_host_register(a[2048:].ctypes.data, a[2048:].nbytes) != 0
+    solver.host_unregister(a[:4096])
+    # the wrapper keeps registered arrays alive
+    b = np.zeros(1 << 14); wr = weakref.ref(b); pb, nbb = b.ctypes.data, b.nbytes
+    solver.host_register(b); del b; gc.collect()
+    assert wr() is not None and L_.frp_nmpc_host_registered(pb, nbb) == 1
+    solver.host_unregister_all(); gc.collect()
+    assert wr() is None and L_.frp_nmpc_host_registered(pb, nbb) == 0 and not solver._registered
 
 
 def test_queue_order_hint_changes_the_order_and_nothing_else():

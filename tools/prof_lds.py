@@ -27,6 +27,9 @@ for wv, role in enumerate(["riccati", "model+f", "bounds"] if q4 else ["riccati"
 print("  factor sweep segments (cycles per iteration): " + "  ".join(f"{n} {sg[i] / its:6.0f}" for i, n in enumerate(["mfma X/G", "gather", "pivot", "tail mfma", "P update+stores", "loop"])))
 print("  whole sweeps (cycles per iteration; forward and forward+y are cumulative with the sweep before them): " + "  ".join(f"{n} {sg[8 + i] / its:6.0f}" for i, n in enumerate(["factor", "+forward", "backvec", "+forward y"])))
 print("  model phase segments (cycles per iteration): " + "  ".join(f"{n} {sg[16 + i] / its:6.0f}" for i, n in enumerate(["park y, dx0", "trig1+accel1+J1", "trig2+accel2", "J2 J1 products", "d + shifts", "gm"])))
+if q4 and sg[16:21].sum() > 0:  # -DFRP_PROFILE_W1
+    print("  model + corridor wave, evaluation phase (cycles per iteration, lane 0's clock; timer reads drain the LDS queue): " +
+          "  ".join(f"{n} {sg[16 + i] / its:6.0f}" for i, n in enumerate(["model phase", "corridor rows + sums", "model: park y + trig + step", "model: d", "model: linearisation + M'y"])))
 if q4:
     print("  Riccati wave on SIMD 0..3 / role = wave index (workgroups of both launches): " + " ".join(str(int(v)) for v in sg[24:29]))
 if twist:
