@@ -410,8 +410,14 @@ __device__ __forceinline__ double stationarity_norm(cldouble *recs, int N)
 
 struct Ctl { // workgroup-shared control words
     int next, fail, bad, mtot, fail1, fail2; // twisted solve: fail1 = the first half's factorisation, fail2 = the system where the halves meet
+    // FRP_EARLY_FACTOR: the termination decision of an iteration, taken by the helper waves while the Riccati wave is already factoring
+    // (dec_tag = (problem << 8 | iteration) once dec_stop / dec_flag are valid; reset at kernel start: LDS keeps a previous launch's words)
+    unsigned dec_tag;
+    int dec_stop, dec_flag;
+    int head_first; // (Q4) >= 0: this workgroup was first on its CU and took a head-start problem (KernelArgs::head_start): its first solve holds the CU's mark
 };
 
+typedef __attribute__((address_space(3))) Ctl lctl_t;
 // ================================================================== wave 0: Riccati sweeps
 // ---- stage-0 solve (both passes): dx_0 = xinit - x_0, dw_0 = -Pww^-1 (Pwx dx_0 + p_w); leaves ds_0 in X_DS0.
 // pw_here: p_w[g] in the lanes (g, 13).
@@ -523,10 +529,25 @@ __device__ __forceinline__ void gst(const double *base, unsigned boff, double v)
 #endif
 // twist (second half of a twisted solve: `recs` is the record of the meeting stage, N the stages from there to the end): the stage-0
 // tail is replaced by publishing p of the meeting stage (column 13 of the tile) in its R_PV slots.
-template <bool twist>
-__device__ FRP_FACTOR_LINKAGE int sweep_factor(ldouble *recs, ldouble *xs, int N, double theta FRP_GP_PARAM)
+// POLL (FRP_EARLY_FACTOR): the sweep starts before the iteration's termination test is known; between its passes it looks for the helper
+// waves' decision (Ctl::dec_tag == want) and leaves at once when that says "stop".  Return value: bit 0 = a pivot block failed, bit 1 =
+// stopped by the decision, bit 2 = the decision has been seen (and said "go on").
+template <bool twist, bool POLL = false>
+__device__ FRP_FACTOR_LINKAGE int sweep_factor(ldouble *recs, ldouble *xs, int N, double theta FRP_GP_PARAM, lctl_t *ctl = nullptr, unsigned want = 0)
 {
     N = uni(N); theta = uni(theta);
+    want = (unsigned)uni((int)want); // (the problem index comes out of an LDS load: uniform, but not to the compiler -- a loop exit on it would make every value of the loop "divergent")
+    bool decided = false;
+    auto poll = [&]() -> bool { // true: stop
+        if constexpr (POLL) {
+            // (an LDS-address-space pointer: through a generic one the load is a FLAT instruction, whose wait drains the S_xx stores too -- measured +6 %)
+            if (!decided && uni((int)*(volatile __attribute__((address_space(3))) unsigned *)&ctl->dec_tag) == (int)want) {
+                decided = true;
+                return uni(*(volatile __attribute__((address_space(3))) int *)&ctl->dec_stop) != 0;
+            }
+        }
+        return false;
+    };
 #ifdef FRP_QP
     const double *gpk = uni(gp) + (size_t)(N - 1) * PG; // block of the stage the pointers sit on
 #endif
@@ -677,6 +698,7 @@ __device__ FRP_FACTOR_LINKAGE int sweep_factor(ldouble *recs, ldouble *xs, int N
     using std::integral_constant;
     int kk = N - 1;
     for (; kk >= 4; kk -= 4) {
+        if (poll()) return 2;
         move(4); // pointers on stage kk - 4
         stage(integral_constant<int, 4 * RS>{}, std::false_type{});
         stage(integral_constant<int, 3 * RS>{}, std::false_type{});
@@ -694,6 +716,7 @@ __device__ FRP_FACTOR_LINKAGE int sweep_factor(ldouble *recs, ldouble *xs, int N
             stage(integral_constant<int, RS>{}, std::false_type{});
         }
     }
+    if (poll()) return 2;
     stage(integral_constant<int, 0>{}, std::true_type{}); // stage 0
     SEG_FLUSH();
     int fail = ok ? 0 : 1;
@@ -718,7 +741,7 @@ __device__ FRP_FACTOR_LINKAGE int sweep_factor(ldouble *recs, ldouble *xs, int N
         }
     }
     WSYNC();
-    return fail;
+    return fail | (decided ? 4 : 0);
 }
 
 // ---- the two vector sweeps.  One wavefront issues in order and its MFMAs do not overlap its own VALU / LDS instructions
@@ -2045,6 +2068,8 @@ struct Shared {
     ldouble *recs, *xs, *tw;
     Ctl *ctl;
     int cukey; // this workgroup's CU in the per-CU words of the workspace (KernelArgs::cu_slots), or -1
+    int late;  // (Q4, head start) 1: another workgroup was on this CU first -- it may be about to mark the CU: the first claim waits a moment
+    int rsimd; // (Q4) the SIMD this workgroup's Riccati wave claimed (0..3: distinct for the four workgroups of a CU), or -1
 };
 
 // The next problem of this workgroup: queue position from the device counter, mapped through the launch order (longest
@@ -2058,7 +2083,14 @@ __device__ __forceinline__ int claim_next(const KernelArgs &a, int cukey = -1)
         while (__hip_atomic_load(a.cu_slots + cukey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 256) __builtin_amdgcn_s_sleep(64);
     }
     const int p = atomicAdd(a.counter, 1);
-    if (p >= a.B) return a.B;
+    if (p >= a.B) {
+        // (head-start problems nobody took -- fewer first arrivals than KernelArgs::head_start -- are ordinary problems for whoever comes here)
+        if (QW && a.head_start > 0) {
+            const int h = atomicAdd(a.counter + 2, 1);
+            if (h < a.head_start) return a.order ? a.order[h] : h;
+        }
+        return a.B;
+    }
     return a.order ? a.order[p] : p;
 }
 
@@ -2411,7 +2443,10 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     BAR();
     const int mtot = sh.ctl->mtot;
     if (sh.ctl->bad) { // a stage has more live corridor rows than the caller sized the problem for (MF)
-        if (wave == 0 && lane == 0) { sh.ctl->next = claim_next(a, sh.cukey); a.exitflag[b] = FRP_EXIT_PARAM_VALUE; a.iters[b] = 0; }
+        if (wave == 0 && lane == 0) {
+            if (QW && sh.ctl->head_first >= 0) { sh.ctl->head_first = -1; atomicSub(a.cu_slots + sh.cukey, 256); atomicSub(a.counter + 1, 1); } // (a head-start solve gives its CU back)
+            sh.ctl->next = claim_next(a, sh.cukey); a.exitflag[b] = FRP_EXIT_PARAM_VALUE; a.iters[b] = 0;
+        }
         if (wave == 1 && own0) {
             double *zo = a.z + ((size_t)b * N + k) * NZ;
 #pragma unroll
@@ -2440,6 +2475,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     const double inv_kmtot = 1.0 / (KAPPA_LAM * (double)mtot);
     int flag = FRP_EXIT_MAXIT, it = 0, nfallback = 0;
     bool iso_mine = false; // (Riccati wave) this solve holds a mark on its CU
+    if constexpr (QW && wave == 0) iso_mine = uni(sh.ctl->head_first) >= 0; // (a head-start solve: marked by the kernel prologue)
     // Twisted variants: the iterations are solved the twisted way only until the residuals of an iteration fall below TW_EXACT_BELOW,
     // the ones after that (one-way switch, decided one iteration ahead) by the plain recursion
     // (the twisted solve is an inexact Newton method -- penalty on x_0 --: the end game, and with it the accuracy of the returned point,
@@ -2574,20 +2610,40 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         }
         if constexpr (FACES_FIRST) { FRP_SB(); model_block(); W1_SEG(0); }
         BAR_P(0); // ------------------------------------------------------------- A
-        // (workgroup-uniform scalars that live across phases go to scalar registers: the element-wise roles are at the
-        // 168-VGPR cap of three workgroups per CU, and every spilled value is an L2 round trip on an in-order wavefront)
-        nm.eq = uni(red(xs, WEQ, 0));
-        nm.in = uni(rmax(0));
-        nm.rc = uni(rmax(1));
-        nm.gap = uni(rsum(2));
-        nm.rs = uni(stationarity_norm<NP>(recs, N));
-        mu = uni(nm.gap * (KAPPA_LAM * inv_kmtot));
-        const bool tw_next = TW && fmax(fmax(nm.eq, nm.in), fmax(nm.rs, nm.rc)) > TW_EXACT_BELOW; // (for the NEXT iteration)
-        if (!gn_retry) {
-            if (!(nm.eq == nm.eq) || !(nm.rs == nm.rs) || !(nm.gap == nm.gap)) { flag = FRP_EXIT_BADFUNCEVAL; break; }
-            if (nm.eq <= a.tol_eq && nm.in <= a.tol_ineq && nm.rs <= a.tol_stat && nm.rc <= a.tol_comp) { flag = FRP_EXIT_OPTIMAL; break; }
-            if (it >= a.maxit) { flag = FRP_EXIT_MAXIT; break; }
-            if (mu > a.diverge_mu * fmax(1.0, a.mu0) || nm.rs > DIVERGE_RS) { flag = FRP_EXIT_NOPROGRESS; break; }
+        // FRP_EARLY_FACTOR: the Riccati wave does not take part in the termination test -- ~2 k cycles of LDS reads and reductions in front of
+        // its 46 k-cycle predictor, on the chain of every iteration -- but starts the factorisation at once; the helper waves, idle until
+        // barrier C anyway, take the decision and leave it in Ctl::dec_*; the factorisation sweep looks for it between its passes and the
+        // wave leaves the iteration like the others when it says "stop" (once per solve: a few stages of a sweep nobody needs).  What the
+        // wave needs of the norms later (mu, for the centring parameter) it reads from the partial results after its sweeps; the values
+        // it reports at exit it computes there.
+#ifndef FRP_EARLY_FACTOR
+#define FRP_EARLY_FACTOR 0
+#endif
+        constexpr bool EARLY = FRP_EARLY_FACTOR && !TW && FWD_P == 0;
+        constexpr bool EARLY_R = EARLY && wave == 0;
+        const unsigned dec_want = ((unsigned)b << 8) | (unsigned)(it & 255);
+        bool tw_next = false;
+        if constexpr (!EARLY_R) {
+            // (workgroup-uniform scalars that live across phases go to scalar registers: the element-wise roles are at the
+            // 168-VGPR cap of three workgroups per CU, and every spilled value is an L2 round trip on an in-order wavefront)
+            nm.eq = uni(red(xs, WEQ, 0));
+            nm.in = uni(rmax(0));
+            nm.rc = uni(rmax(1));
+            nm.gap = uni(rsum(2));
+            nm.rs = uni(stationarity_norm<NP>(recs, N));
+            mu = uni(nm.gap * (KAPPA_LAM * inv_kmtot));
+            tw_next = TW && fmax(fmax(nm.eq, nm.in), fmax(nm.rs, nm.rc)) > TW_EXACT_BELOW; // (for the NEXT iteration)
+            int stop = 0, stop_flag = flag;
+            if (!gn_retry) {
+                if (!(nm.eq == nm.eq) || !(nm.rs == nm.rs) || !(nm.gap == nm.gap)) { stop_flag = FRP_EXIT_BADFUNCEVAL; stop = 1; }
+                else if (nm.eq <= a.tol_eq && nm.in <= a.tol_ineq && nm.rs <= a.tol_stat && nm.rc <= a.tol_comp) { stop_flag = FRP_EXIT_OPTIMAL; stop = 1; }
+                else if (it >= a.maxit) { stop_flag = FRP_EXIT_MAXIT; stop = 1; }
+                else if (mu > a.diverge_mu * fmax(1.0, a.mu0) || nm.rs > DIVERGE_RS) { stop_flag = FRP_EXIT_NOPROGRESS; stop = 1; }
+            }
+            if constexpr (EARLY && wave == 2) {
+                if (lane == 0) { sh.ctl->dec_flag = stop_flag; sh.ctl->dec_stop = stop; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); *(volatile unsigned *)&sh.ctl->dec_tag = dec_want; }
+            }
+            if (stop) { flag = stop_flag; break; }
         }
         if constexpr (QW && wave == 0) { // a long solve: it takes the CU for itself (see claim_next)
             if (it == a.iso_it && a.iso_it > 0 && sh.cukey >= 0 && !iso_mine) {
@@ -2643,12 +2699,27 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             }
         } else if constexpr (wave == 0) {
             SWEEP_T0();
-            const int fr = sweep_factor<false>(recs, xs, N, gn_retry ? 0.0 : theta_h FRP_GP_ARG(pws));
+            lctl_t *lctl = (lctl_t *)sh.ctl;
+            int fr = sweep_factor<false, EARLY>(recs, xs, N, gn_retry ? 0.0 : theta_h FRP_GP_ARG(pws), lctl, dec_want);
+            if constexpr (EARLY) {
+                bool stopped = (fr & 2) != 0;
+                if (!stopped && !(fr & 4)) { // the sweep is through and the helpers' decision is not in yet (never observed to take that long)
+                    while (uni((int)*(volatile __attribute__((address_space(3))) unsigned *)&lctl->dec_tag) != (int)dec_want) __builtin_amdgcn_s_sleep(1);
+                    stopped = uni(*(volatile __attribute__((address_space(3))) int *)&lctl->dec_stop) != 0;
+                }
+                if (stopped) {
+                    flag = uni(*(volatile __attribute__((address_space(3))) int *)&lctl->dec_flag);
+                    if constexpr (QP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    break;
+                }
+                fr &= 1;
+            }
             SWEEP_T1(0);
             if (FWD_P == 0 && !fr) sweep_forward(recs, xs, N);
             SWEEP_T1(1);
             if (lane == 0) sh.ctl->fail = fr;
             if constexpr (QP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the P stores of the factorisation sweep (long retired by now)
+            if constexpr (EARLY) { nm.gap = uni(rsum(2)); mu = uni(nm.gap * (KAPPA_LAM * inv_kmtot)); } // (for the centring parameter behind barrier D)
         }
         if constexpr (FWD_P != 0 && !TW) { // the forward sweep works from the records alone: it runs on the wave whose SIMD has room
             BAR();
@@ -3024,12 +3095,19 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     }
 
     // ---------------------------------------------------------------- outputs
+#if FRP_EARLY_FACTOR
+    if constexpr (wave == 0 && !TW) { // (the Riccati wave skipped the termination tests: what it reports it computes here, from the same partial results)
+        nm.eq = uni(red(xs, WEQ, 0)); nm.in = uni(rmax(0)); nm.rc = uni(rmax(1)); nm.gap = uni(rsum(2));
+        nm.rs = uni(stationarity_norm<NP>(recs, N));
+        mu = uni(nm.gap * (KAPPA_LAM * inv_kmtot));
+    }
+#endif
     PROF_FLUSH(wave, it);
     __builtin_amdgcn_s_setprio(0);
     // the next problem is claimed only now (its latency hides behind the write-out): a slot that claimed it while it still
     // had a solve ahead of it would keep it from the slots that go idle at the end of the launch
     if constexpr (QW && wave == 0) { // (a long solve gives its CU back first)
-        if (iso_mine && lane == 0) { atomicSub(a.cu_slots + sh.cukey, 256); atomicSub(a.counter + 1, 1); }
+        if (iso_mine && lane == 0) { atomicSub(a.cu_slots + sh.cukey, 256); atomicSub(a.counter + 1, 1); sh.ctl->head_first = -1; }
     }
     if (wave == 0 && lane == 0) sh.ctl->next = claim_next(a, sh.cukey); // (two dependent global round trips, under the model wave's write-out)
     if constexpr (wave == 1) {
@@ -3071,7 +3149,21 @@ template <int NP, int FL, bool FREG, int ROLE, bool TW>
 __device__ __forceinline__ void role_loop(const KernelArgs &a, const Shared &sh)
 {
     // (solve_one claims the next problem when it leaves its iteration)
-    if (ROLE == 0 && (threadIdx.x & 63) == 0) sh.ctl->next = claim_next(a, sh.cukey);
+#ifndef FRP_STAGGER // experiment knob: the k-th workgroup of a CU starts its first solve k * FRP_STAGGER * 8 k cycles late (the four workgroups of a
+#define FRP_STAGGER 0 // CU otherwise run the first round of a launch in lockstep -- 46 us per iteration against 41 later: profiles/r05_timeline.txt)
+#endif
+    if (QW && FRP_STAGGER > 0 && ROLE == 0 && sh.rsimd > 0)
+        for (int q = 0; q < sh.rsimd * FRP_STAGGER; q++) __builtin_amdgcn_s_sleep(127);
+    if (ROLE == 0 && (threadIdx.x & 63) == 0) {
+        const int hf = QW ? sh.ctl->head_first : -1;
+        if (hf >= 0) sh.ctl->next = a.order ? a.order[hf] : hf; // a head-start problem: this workgroup was first on its CU and has marked it
+        else {
+            // (a workgroup that arrived behind the CU's first one gives that one the ~2 us its two atomics need to mark the CU -- losing the race
+            // costs nothing but the head start: the long solve then shares its CU with this workgroup's first solve)
+            if (QW && a.head_start > 0 && sh.late) __builtin_amdgcn_s_sleep(100); // (~6 k cycles)
+            sh.ctl->next = claim_next(a, sh.cukey);
+        }
+    }
     for (;;) {
         BAR();
         const int b = sh.ctl->next;
@@ -3092,9 +3184,9 @@ __global__ __launch_bounds__(QW ? 192 : 256) __attribute__((amdgpu_waves_per_eu(
     __shared__ int s_place[5];
     static_assert(!TW || NP == 20, "the twisted solve is built on the three-lanes-per-stage model phase");
     Shared sh;
-    sh.recs = (ldouble *)s_recs; sh.xs = (ldouble *)s_xs; sh.tw = (ldouble *)s_tw; sh.ctl = &s_ctl; sh.cukey = -1;
+    sh.recs = (ldouble *)s_recs; sh.xs = (ldouble *)s_xs; sh.tw = (ldouble *)s_tw; sh.ctl = &s_ctl; sh.cukey = -1; sh.late = 0; sh.rsimd = -1;
     if (TW && threadIdx.x == 0) { s_tw[TW_DUMP] = 0.0; s_tw[TW_ZERO] = 0.0; s_ctl.fail1 = 0; s_ctl.fail2 = 0; }
-    if (threadIdx.x == 0) { s_xs[X_C0] = 0.0; s_xs[X_C1] = 1.0; }
+    if (threadIdx.x == 0) { s_xs[X_C0] = 0.0; s_xs[X_C1] = 1.0; s_ctl.dec_tag = 0xffffffffu; s_ctl.dec_stop = 0; s_ctl.head_first = -1; if constexpr (QW) s_place[3] = 1; }
     // ---- which wave plays which role.  A wavefront stays on the SIMD it was launched on, and one wavefront of every
     // resident workgroup sits on each SIMD of the CU.  The Riccati role keeps its SIMD busy for ~70 % of an iteration, the
     // three helper roles for 13-18 % each, so the iteration rate of a CU is set by the SIMD with the most work on it.  With
@@ -3125,18 +3217,30 @@ __global__ __launch_bounds__(QW ? 192 : 256) __attribute__((amdgpu_waves_per_eu(
             __syncthreads();
             const int s0 = s_place[0], s1 = s_place[1], s2 = s_place[2];
             if (threadIdx.x == 0) {
-                int rs = -1;
+                int rs = -1, first = 0;
                 if (s0 != s1 && s0 != s2 && s1 != s2) {
                     const int cand[3] = {s0, s1, s2};
                     for (int q = 0; q < 3 && rs < 0; q++) {
                         const int old = atomicOr(a.cu_slots + key, 1 << cand[q]);
                         if (!(old & (1 << cand[q]))) rs = cand[q];
+                        if (q == 0 && (old & 15) == 0) first = 1; // no workgroup had claimed a SIMD of this CU before this one
                     }
                 }
                 s_place[4] = rs;
+                // head start: the first workgroup on a CU takes one of the longest expected solves and marks the CU at once (see claim_next:
+                // the workgroups that arrive behind it find the mark and wait for the solve to end)
+                int hf = -1;
+                if (first && a.head_start > 0 && a.iso_it > 0) {
+                    const int h = atomicAdd(a.counter + 2, 1);
+                    if (h < a.head_start) { hf = h; atomicAdd(a.cu_slots + key, 256); atomicAdd(a.counter + 1, 1); }
+                }
+                s_ctl.head_first = hf;
+                s_place[3] = first;
             }
             __syncthreads();
             const int rs = s_place[4];
+            sh.late = s_place[3] ? 0 : 1;
+            sh.rsimd = rs;
             if (rs >= 0) {
                 // the other two waves, ordered by (simd - rs) mod 4
                 const int da = (simd - rs) & 3;

@@ -55,6 +55,8 @@ struct KernelArgs {
     double *ws;       // queue workspace (ws_bytes): counter, per-CU counters, keys, order, packed-P blocks of the Q4 variants
     double *pws;      // packed P_k of the resident workgroups (Q4 variants: 20 x 92 doubles each; set by the launcher, null = not available)
     int *counter;     // work-queue head (set by the launcher); counter[1]: CUs a long solve has to itself right now
+    int head_start;   // (set by the launcher; Q4 variants) the first `head_start` problems of the launch order -- the longest expected solves -- are taken by the
+                      // first workgroup to arrive on a CU, which keeps that CU to itself from the start (counter[2] deals them out; 0 = none)
     int iso_it, iso_cap; // (set by the launcher) a solve that reaches iteration iso_it claims its CU (0 = never); at most iso_cap CUs at a time
     int *cu_slots;    // per-CU arrival counters of the resident workgroups, zeroed by the launcher (frp_ipm_lds.hip: role placement)
     const int *order; // launch order of the problems, or null = index order (set by the launcher)

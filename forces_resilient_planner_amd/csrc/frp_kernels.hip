@@ -16,6 +16,7 @@
 #include "frp_kernels.h"
 #include "frp_device.hpp"
 #include <cstdlib>
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 
@@ -119,14 +120,14 @@ __global__ __launch_bounds__(256) void order_hint_kernel(int B, const int *__res
 // order = the problems sorted by decreasing key, to bucket resolution (also zeroes the work-queue head): one workgroup, a 1024-bin counting sort on the
 // (monotone) bit pattern of the non-negative keys -- i.e. on a log scale -- with the bins spread over the key range of
 // this batch.  The order inside a bin is arbitrary (atomics); order[] is a permutation for any input.
-__global__ __launch_bounds__(1024) void order_bucket_kernel(int B, const double *__restrict__ keys, int *__restrict__ order, int *__restrict__ counter, int *__restrict__ cu_slots)
+__global__ __launch_bounds__(1024) void order_bucket_kernel(int B, const double *__restrict__ keys, int *__restrict__ order, int *__restrict__ counter, int *__restrict__ cu_slots, int head)
 {
     // (the kernel is all latency: the keys of a batch of up to 4096 are read once and stay in registers, the extrema
     // go through one shuffle reduction per wavefront, and the prefix sum is a shuffle scan plus sixteen wave totals)
     __shared__ unsigned long long w_lo[16], w_hi[16];
     __shared__ int hist[1024], wtot[16];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    if (t == 0) { counter[0] = 0; counter[1] = 0; } // queue head of the solve that follows on this stream; CUs its long solves have to themselves
+    if (t == 0) { counter[0] = head; counter[1] = 0; counter[2] = 0; } // queue head of the solve that follows on this stream (behind the `head` problems dealt out by counter[2]: KernelArgs::head_start); CUs its long solves have to themselves
     for (int i = t; i < CU_SLOT_ENTRIES; i += 1024) cu_slots[i] = 0;
     hist[t] = 0;
     constexpr int KR = 4; // keys per thread held in registers
@@ -358,7 +359,7 @@ size_t ws_bytes(int B, int N, int MF)
 
 __global__ void reset_counter_kernel(int *counter, int *cu_slots)
 {
-    if (threadIdx.x == 0) { counter[0] = 0; counter[1] = 0; }
+    if (threadIdx.x == 0) { counter[0] = 0; counter[1] = 0; counter[2] = 0; }
     for (int i = threadIdx.x; i < CU_SLOT_ENTRIES; i += blockDim.x) cu_slots[i] = 0;
 }
 
@@ -458,6 +459,7 @@ hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
     k.iso_it = a.B > 1 ? iso_env : 0;
     k.iso_cap = resident_cap(1) / 16;
     k.order = nullptr;
+    k.head_start = 0;
     if (a.B > slots) { // more problems than resident workgroups: order the queue, longest expected solve first
         k.self_reset = 0;
         double *keys = q + QUEUE_RESERVED;
@@ -468,7 +470,12 @@ hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
         else
             hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)((a.B + 4 * (64 / a.N) - 1) / (4 * (64 / a.N)))), dim3(256), 0, stream, a.B, a.N, a.M, a.model,
                                a.models, a.xinit, a.x0, a.params, a.nfaces, order_weight(0), order_weight(1), keys);
-        hipLaunchKernelGGL(order_bucket_kernel, dim3(1), dim3(1024), 0, stream, a.B, keys, order, k.counter, k.cu_slots);
+        // The longest expected solves get a CU each FROM THE START (Q4 variants; FRP_HEAD_START=0 switches it off): the launch ends with its
+        // longest solve -- configs[2]: one 25-iteration problem of 4096, 8th in this order --, a problem alone on a CU iterates a sixth faster
+        // (76.6 k against 90.9 k cycles), and the isolation by iteration count (iso_it) only sees it at iteration 12.
+        static const int head_env = [] { const char *e = getenv("FRP_HEAD_START"); return e ? atoi(e) : 0; }(); // (default off: measured 0.852 -> 0.861 / 0.868 ms at 8 / 16 -- the launch does not end with its longest solve, profiles/r06_head_start.txt)
+        if (lds_workgroups_per_cu(k) == 4 && k.iso_it > 0 && head_env > 0) k.head_start = std::min(std::min(head_env, k.iso_cap), slots / 8);
+        hipLaunchKernelGGL(order_bucket_kernel, dim3(1), dim3(1024), 0, stream, a.B, keys, order, k.counter, k.cu_slots, k.head_start);
     } else if (a.self_reset && a.B == 1) {
         k.cu_slots = nullptr; // (the caller zeroed the queue head once; the kernel puts it back)
     } else {

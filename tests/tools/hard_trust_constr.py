@@ -191,7 +191,11 @@ if __name__ == "__main__":
         for name, z0 in starts.items():
             if (int(i), name) not in done:
                 jobs.append((int(i), name, z0, zo, int(fl), maxiter))
-    jobs.sort(key=lambda j: (j[4] == 1, j[1] == "cold"))  # the exits first, the long cold starts of the stalled instances last
+    # the stalled instances from near the solver's point first (minutes each), then the exits (their equality Jacobian goes singular along the way and
+    # scipy falls back to dense SVD projections: an hour each at FRP_TC_MAXITER_EXITS iterations), the cold starts of the stalled instances last
+    mx_exits = int(os.environ.get("FRP_TC_MAXITER_EXITS", "400"))
+    jobs = [(j[0], j[1], j[2], j[3], j[4], (mx_exits if j[4] != 1 else j[5])) for j in jobs]
+    jobs.sort(key=lambda j: (0 if (j[4] == 1 and j[1] != "cold") else (1 if j[4] != 1 else 2)))
     print(f"{len(jobs)} runs", flush=True)
     with Pool(workers) as pool:
         for r in pool.imap_unordered(run, jobs, chunksize=1):

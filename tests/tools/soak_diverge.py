@@ -55,7 +55,11 @@ for spec in (sys.argv[1:] or DEFAULT):
     print(f"\n== launch kind {kind} B {B} seed {seed} (N {w['N']}, M {w['M']}, {len(w['xinit'])} problems), problem {b}: flags gpu/oracle {full['fl']}, iterations {full['it']}", flush=True)
     hi = max(1, min(full["it"]))
     if both(w, b, hi)["dz"] <= 1e-9:
-        print(f"   iterates agree to 1e-9 through iteration {hi}: the flags part on the termination test of the last iteration"); continue
+        print(f"   the plans z agree to 1e-9 through iteration {hi}: the flags part on the termination test -- what each side reports around it (m = maxit):")
+        for m in range(max(1, hi - 4), hi + 6):
+            r = both(w, b, m)
+            print(f"   m {m:3d} |dz| {r['dz']:.1e} flags {r['fl']} its {r['it']}\n      gpu    {fmt(r['gpu'])}\n      oracle {fmt(r['orc'])}")
+        continue
     lo = 0  # iterates after `lo` iterations agree, after `hi` they do not
     while hi - lo > 1:
         mid = (lo + hi) // 2

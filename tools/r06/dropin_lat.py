@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""GPU box: latency of the drop-in call (BASELINE configs[0] through FORCESNLPsolver_normal_solve), median of 200 warm calls, for the library
+FRP_LIB selects; with FRP_NMPC_TWIST in the environment the latency option.   python tools/r06/dropin_lat.py"""
+import ctypes, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from forces_resilient_planner_amd import solver, workloads
+w0 = workloads.config0()
+p = solver.ForcesParams(); o = solver.ForcesOutput(); info = solver.ForcesInfo()
+p.xinit[:] = w0["xinit"][0]; p.x0[:] = w0["x0"][0].ravel(); p.all_parameters[:] = w0["params"][0].ravel(); p.num_of_threads = 1
+lat = []
+for i in range(230):
+    t1 = time.perf_counter()
+    flag = solver.lib().FORCESNLPsolver_normal_solve(ctypes.byref(p), ctypes.byref(o), ctypes.byref(info), None, None)
+    lat.append(time.perf_counter() - t1)
+print("drop-in call: median %.4f ms  p10 %.4f  p90 %.4f  flag %d its %d pobj %.10f" % (np.median(lat[30:]) * 1e3, np.percentile(lat[30:], 10) * 1e3, np.percentile(lat[30:], 90) * 1e3, flag, info.it, info.pobj))
