@@ -573,7 +573,7 @@ int frp_nmpc_abi_check(int abi_version, size_t options_bytes, size_t batch_bytes
     return FRP_ERR_ARG;
 }
 
-const char *frp_nmpc_version(void) { return "frp_nmpc_amd 0.5 (gfx950, FP64 interior point: three / four wavefronts per problem, stage records in LDS)"; }
+const char *frp_nmpc_version(void) { return "frp_nmpc_amd 0.6 (gfx950, FP64 interior point: three / four wavefronts per problem, stage records in LDS)"; }
 
 int frp_nmpc_device_count(void)
 {
