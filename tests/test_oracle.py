@@ -136,7 +136,12 @@ def hard_family_check(g, z, fl, pobj, zt, flt):
     (a non-convex NLP has several; which one a method lands on is not a parity question), certified with the reference's callbacks only."""
     N, M = int(g["N"]), int(g["M"])
     good = np.where(g["status"] == 0)[0]
-    assert len(good) >= 100
+    # (ADVICE r05) the fixture's 'near-retry' entries -- SLSQP started 0.02 / 0.002 from the solver's OWN 1e-8 solution (tests/tools/extend_hard_golden.py) --
+    # confirm that point as a local solution of the reference NLP but are near-guaranteed to agree with the solver under test: they are held to
+    # the same bounds below, and they do NOT count towards the independent agreement the family is asked for
+    retry = np.array([str(s_).startswith("near-retry") for s_ in g["start"]])
+    independent = good[~retry[good]]
+    assert len(independent) >= 100, len(independent)
     assert np.all(fl[good] == 1), ("not converged", good[fl[good] != 1], fl[good][fl[good] != 1])
     assert np.all(flt[good] == 1)
     exceptions = []
@@ -150,7 +155,8 @@ def hard_family_check(g, z, fl, pobj, zt, flt):
         k = OL.reference_kkt(zt[i], g["xinit"][i], g["params"][i], g["nfaces"][i], N, M, int(g["model"][i]))
         assert k["stat"] < 1e-6 and k["eq"] < 1e-8 and k["ineq"] < 1e-8 and k["bound"] < 1e-8, (i, k)
         exceptions.append((int(i), float(dz), float(pobj[i]), float(g["f"][i])))
-    print("hard family: %d SLSQP-solved instances, all converged; other (better) KKT point on:" % len(good), exceptions)
+    print("hard family: %d SLSQP-solved instances (%d from a start independent of the solver under test, %d 'near-retry' confirmations), all converged; "
+          "other (better) KKT point on:" % (len(good), len(independent), len(good) - len(independent)), exceptions)
     assert len(exceptions) <= 0.03 * len(good)
     #  EVERY instance the solver converges on -- also the ones SciPy did not solve, which used to be counted as wins
     # on status alone -- is a KKT point of the reference NLP by the reference's own functions (the 1e-8 solve: stationarity <= 1e-6,
