@@ -30,8 +30,10 @@
 #include "frp_device.hpp"
 
 // (the Q4 translation unit instantiates the same templates on another record layout: a namespace of its own)
-#ifdef FRP_LDS_Q4_TU
+#if defined(FRP_LDS_Q4_TU)
 #define FRP_LR lrq
+#elif defined(FRP_LDS_Q30_TU)
+#define FRP_LR lrs
 #else
 #define FRP_LR lr
 #endif
@@ -51,6 +53,20 @@ namespace FRP_LR {
 #define FRP_QP 1
 #define FRP_QL 1
 #define FRP_QW 1
+#endif
+// The "Q30" translation unit (frp_ipm_lds_q30.hip, round 6): N <= 30 at THREE problems per CU.  P in global memory and the overlay record as in Q4, on four-wave
+// workgroups with the lane == stage model phase, and a record of 215 doubles (FRP_QS): no trig hand-over slots, P d aliased onto the p slots, no hole between the
+// B and C twins, the external force read from the parameters instead of the workgroup scratch: 30 x 215 x 8 + 1.4 KB = 53 032 B per workgroup.
+#ifdef FRP_LDS_Q30_TU
+#define FRP_QP 1
+#define FRP_QL 1
+#define FRP_QS 1
+#define FRP_NO_YPARK 1
+#endif
+#ifdef FRP_QS
+constexpr bool QS = true;
+#else
+constexpr bool QS = false;
 #endif
 #ifdef FRP_QP
 constexpr bool QP = true;
@@ -95,20 +111,37 @@ constexpr int R_PHI = 135;   // predictor rhs gradient phi_aff without its corri
 constexpr int R_T = 64;      // T' (64), over HD / PHID / the head of PHIPOS
 constexpr int R_PV = 128;    // p_k of the corrector solve (13), over PHIPOS / PHI
 constexpr int R_P = 0;       // (P_k lives in global memory: packed index 0..90 of the stage's block, 91 = dump)
+#ifndef FRP_QS
 constexpr int R_PD = 152;    // P_{k+1} d_k (13): written by the factorisation sweep, read by the corrector's backward sweep;
                              //   from there to the next factorisation: the model wave's parked y (RT_Y)
 constexpr int R_PHIB = 165;  // corrector rhs phi_cc = PHIB + (sigma mu) PHIC (17 + 17), bound rows and cost;
+#else
+// QS: P_{k+1} d_k lives in the p slots of stage k.  The factorisation step of stage k+1 stores it into stage k's record AFTER it has gathered stage k's
+// tiles (the slots lie in the overlay over PHIPOS / PHI: the timing argument of T'), the vector backward sweep reads it one step before its own step at
+// stage k overwrites the slot with p_k, and nothing reads p before that sweep.
+constexpr int R_PD = R_PV;
+constexpr int R_PHIB = 152;
+#endif
 constexpr int R_PHIW = R_PV + 13; // Phi_w of the stage (4) behind p, left by the factorisation step (the y+ rows of w are formed from T' and this)
-static_assert(R_PHIW + 4 <= R_PD, "Phi_w stash");
+static_assert(QS || R_PHIW + 4 <= R_PD, "Phi_w stash");
 #endif
 constexpr int R_CB = R_PHIB + 17; //   corridor part (pos entries) of PHIB; evaluation phase: A' lam (stationarity residual)
+#ifndef FRP_QS
 constexpr int R_BC = 21;     // distance from every "B" slot (PHIB, CB) to its "C" twin (PHIC, CC): one ds_read2 fetches both
+#else
+constexpr int R_BC = 20;     // (no hole between CB and PHIC: the spare is the twisted solve's)
+#endif
 constexpr int R_PHIC = R_PHIB + R_BC; // evaluation phase: PHIB = cost gradient + bound multipliers, PHIC = M'y part (stationarity residual)
 constexpr int R_CC = R_CB + R_BC;     // corridor part of PHIC; evaluation phase: corridor part of phi_aff
+#ifndef FRP_QS
 constexpr int R_HC = R_PHIB + 41;    // (u_i, w_i) cost coupling -2 w_rate of this stage
 constexpr int R_ZERO = R_HC + 1, R_ONE = R_HC + 2, R_DT = R_HC + 3; // constants the gathers pick up
 constexpr int R_DUMP = R_HC + 4;  // target of masked-out writes (never read)
 constexpr int R_DZ = R_HC + 5;    // Newton step [du(4); ds(13)]
+#else
+// [0 | Newton step 17 | hc | 1 | 0' | dt | dump]: the two zeros R_BC apart around the step
+constexpr int R_ZERO = R_CC + 3, R_DZ = R_ZERO + 1, R_HC = R_DZ + 17, R_ONE = R_HC + 1, R_DT = R_ONE + 2, R_DUMP = R_DT + 1;
+#endif
 constexpr int R_ZERO2 = R_ZERO + R_BC; // second zero, R_BC behind the first: masked (B, C) pair reads
 // Twisted solve: a stage of the FIRST half keeps the inverted transition [u; x]_k = T~ [w+; x+] + t~ where a stage of
 // the second half keeps the linearisation: A~ = A^-1 has A's block pattern (A~pv, A~pe, A~vv, A~ve in the slots of Apv, Ape, Avv, Ave),
@@ -120,14 +153,24 @@ constexpr int R_ZERO2 = R_ZERO + R_BC; // second zero, R_BC behind the first: ma
 constexpr int RS = 309;      // odd stride: lane == stage accesses are conflict-free
 static_assert(R_HD + REC_HD_SIZE <= R_PV && R_PV + 13 <= R_PD, "overlay region");
 static_assert(R_PHIB == 245 && R_HC == 286 && R_DZ == 291 && R_ZERO2 == 308, "the plain record");
-#else
+#elif !defined(FRP_QS)
 constexpr int RQ_MTRIG = R_ZERO2 + 1; // the model wave's trig hand-over (12): slots of its own (nothing else is free in the evaluation phase)
 constexpr int RS = RQ_MTRIG + 12;     // 241, odd
 static_assert(RS == 241 && (RS & 1), "the Q4 record");
 static_assert(R_HD + REC_HD_SIZE == R_PHID && R_PHID + 17 == R_PHIPOS && R_PHIPOS + 9 == R_PHI && R_PHI + 17 == R_PD, "overlay region");
 static_assert(R_T + 64 <= R_PV && R_PV + 13 <= R_PD && R_PD + 13 == R_PHIB, "overlay region after the factorisation");
+#else
+constexpr int RQ_MTRIG = R_DUMP;      // (the lane == stage model phase has no trig hand-over)
+constexpr int RS = R_DUMP + 1;        // 215, odd
+static_assert(RS == 215 && (RS & 1) && R_ZERO2 == R_ONE + 1 && R_ZERO2 == R_DT - 1, "the Q30 record");
+static_assert(R_HD + REC_HD_SIZE == R_PHID && R_PHID + 17 == R_PHIPOS && R_PHIPOS + 9 == R_PHI && R_PHI + 17 == R_PHIB, "overlay region");
+static_assert(R_T + 64 <= R_PV && R_PHIW + 4 <= R_PHIB, "overlay region after the factorisation");
 #endif
+#ifndef FRP_QS
 static_assert(R_PHIC + 17 <= R_CC && R_CC + 3 <= R_HC && R_DZ + 17 <= R_ZERO2 && R_ZERO2 < RS, "record tail");
+#else
+static_assert(R_PHIC + 17 == R_CC && R_CC + 3 == R_ZERO && R_DZ + 17 == R_HC && R_DUMP < RS, "record tail");
+#endif
 #ifndef FRP_TW_RHO
 #define FRP_TW_RHO 1e12
 #endif
@@ -377,7 +420,8 @@ template <int NP>
 __device__ __forceinline__ double xsub_sum(double v) // sum over the H lanes that share a stage (valid in every lane of the group for H = 2, 4; in sub == 0 for H = 3)
 {
     constexpr int H = 64 / NP;
-    if (H == 2) return v + __shfl_xor(v, 32);
+    if (H == 2 && NP == 32) return v + __shfl_xor(v, 32);
+    if (H == 2) { const int lane = threadIdx.x & 63; return v + __shfl(v, lane < NP ? (lane + NP < 64 ? lane + NP : lane) : lane - NP); } // (lanes k and NP + k; the lanes beyond 2 NP are inactive)
     if (H == 4) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
     if (H == 3) {
         const int lane = threadIdx.x & 63;
@@ -1435,7 +1479,9 @@ constexpr int RX_MTRIG = R_PV, RX_HTRIG = R_PD; // trig hand-over of the model w
 // to the T' slots the y+ lanes do not read -- R (columns 0..3) and the zero columns 14, 15 of the rows 0..2.  The y+ lanes' own scratch
 // (block hand-over RT_YV, 9; y+ rows 4..9 for the Hessian lanes RT_HYP, 6) takes Kbar_x slots AFTER their last read of T' (same wave).
 constexpr int RT_HU = R_T + 0, RT_HVE = R_T + 14, RT_HY = R_T + 30, RT_YV = R_T + 4, RT_HYP = R_T + 20;
+#ifndef FRP_QS
 constexpr int RT_J1 = R_T; // (the lane == stage model phase: not built with QP)
+#endif
 #ifndef FRP_QL
 constexpr int RT_Y = R_T + 36; // (bisection builds: T' is a region of its own, dead in the evaluation phase)
 constexpr int RX_MTRIG = R_PV, RX_HTRIG = R_PD;
@@ -1444,10 +1490,18 @@ constexpr int RX_MTRIG = R_PV, RX_HTRIG = R_PD;
 // phase has slots outside the overlay (y in the P d slots, dead from the corrector's backward sweep to the next factorisation; the trig
 // hand-over at the record's end); what the Riccati wave reads at the start of the evaluation (RT_H*) and its trig hand-over sit inside HD,
 // which only that wave writes in the phase (the hand-over overlaps RT_HYP / RT_HY: written after they were read, by the same wave)
-constexpr int RT_Y = R_PD;
+constexpr int RT_Y = R_PD; // (QS: unused -- y stays in the model wave's registers, FRP_NO_YPARK)
 constexpr int RX_HTRIG = R_T + 20, RX_MTRIG = RQ_MTRIG;
 static_assert(RX_HTRIG + 12 <= R_HD + REC_HD_SIZE && RT_HY + 6 <= R_HD + REC_HD_SIZE, "the Riccati wave's scratch inside HD");
 #endif
+#endif
+// where the lane == stage model phase parks J1 = [F_vv (9) | F_ve (9) | g_T (3)] of the first RK2 point while J2 is formed.  QS: T' shares the Hessian's slots, which
+// the other waves fill during this phase -- the scratch is what THIS wave writes last: the M'y slots (PHIC, written at the end of the phase) and the d slots (written
+// behind the J2 J1 products; they carried y+ until this wave's commit)
+#ifndef FRP_QS
+constexpr int RT_J1V = RT_J1, RT_J1E = RT_J1 + 9, RT_J1T = RT_J1 + 18;
+#else
+constexpr int RT_J1V = R_PHIC, RT_J1E = R_D, RT_J1T = R_D + 9;
 #endif
 template <int NP>
 __device__ __forceinline__ void model_phase(ldouble *recs, ldouble *xs, ModelState &st, int N, double &l_eq)
@@ -1486,14 +1540,14 @@ __device__ __forceinline__ void model_phase(ldouble *recs, ldouble *xs, ModelSta
             accel_t<true>(zk + 11, tg1, zk[3], st.fext, a1, &J1);
 #pragma unroll
             for (int i = 0; i < 9; i++) {
-                rec[RT_J1 + i] = J1.Fvv[i];
-                rec[RT_J1 + 9 + i] = J1.Fve[i];
+                rec[RT_J1V + i] = J1.Fvv[i];
+                rec[RT_J1E + i] = J1.Fve[i];
                 rec[R_LIN + i] = (i % 4 == 0 ? DT : 0.0) + 0.5 * DT * DT * J1.Fvv[i]; // Apv (i % 4 == 0: the diagonal of a row-major 3 x 3)
                 rec[R_LIN + 9 + i] = 0.5 * DT * DT * J1.Fve[i];                       // Ape
             }
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                rec[RT_J1 + 18 + i] = J1.gT[i];
+                rec[RT_J1T + i] = J1.gT[i];
                 rec[R_LIN + 36 + i] = 0.5 * DT * DT * J1.gT[i];                        // BpT
             }
         }
@@ -1521,8 +1575,8 @@ __device__ __forceinline__ void model_phase(ldouble *recs, ldouble *xs, ModelSta
         // products J2 J1, one column j of J1 at a time (read back from the record)
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            const double f0 = rec[RT_J1 + 0 + j], f1 = rec[RT_J1 + 3 + j], f2 = rec[RT_J1 + 6 + j];   // J1.Fvv[:, j]
-            const double e0 = rec[RT_J1 + 9 + j], e1 = rec[RT_J1 + 12 + j], e2 = rec[RT_J1 + 15 + j]; // J1.Fve[:, j]
+            const double f0 = rec[RT_J1V + 0 + j], f1 = rec[RT_J1V + 3 + j], f2 = rec[RT_J1V + 6 + j];   // J1.Fvv[:, j]
+            const double e0 = rec[RT_J1E + 0 + j], e1 = rec[RT_J1E + 3 + j], e2 = rec[RT_J1E + 6 + j]; // J1.Fve[:, j]
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 const double sv = J2.Fvv[i * 3 + j] + DT * (J2.Fvv[i * 3 + 0] * f0 + J2.Fvv[i * 3 + 1] * f1 + J2.Fvv[i * 3 + 2] * f2);
@@ -1534,7 +1588,7 @@ __device__ __forceinline__ void model_phase(ldouble *recs, ldouble *xs, ModelSta
             }
         }
         {
-            const double g0 = rec[RT_J1 + 18], g1 = rec[RT_J1 + 19], g2 = rec[RT_J1 + 20]; // J1.gT
+            const double g0 = rec[RT_J1T], g1 = rec[RT_J1T + 1], g2 = rec[RT_J1T + 2]; // J1.gT
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 const double sT = J2.gT[i] + DT * (J2.Fvv[i * 3 + 0] * g0 + J2.Fvv[i * 3 + 1] * g1 + J2.Fvv[i * 3 + 2] * g2);
@@ -2126,7 +2180,8 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     auto contrib = [](int w) constexpr { return QW ? (w == 2 || w == FRP_Q4_FWAVE || (w == 1 && FRP_Q4_RM > 0)) : (w == 2 || w == 3); };
     constexpr bool IS_B = contrib(wave);
     constexpr bool IS_BO = IS_B && !IS_F;                                      // ... bound rounds only
-    static_assert(!QP || (NP == 20 && !TW), "P in global memory: the y+ rows are dealt over the three lanes of a stage");
+    static_assert(!QP || ((NP == 20 || QS) && !TW), "P in global memory: the y+ rows are dealt over the three lanes of a stage (Q4) or formed by the lane of the stage (Q30)");
+    static_assert(!QS || (!QW && H == 2 && !TW), "Q30: four-wave workgroups, two lanes per stage in the element-wise phases, the lane == stage model phase");
     static_assert(!QW || (NP == 20 && !TW && FREG && wave < 3), "Q4: the three-lanes-per-stage model phase, plain solve, rows in registers");
     const int lane = threadIdx.x & 63;
     const int N = a.N, M = a.M, MF = a.MF, np = NPRE + 4 * M;
@@ -2285,7 +2340,11 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 #define FRP_RSPLIT_ADJ 0
 #endif
     constexpr int RSPLIT0 = R - (FL <= 2 ? R / 3 : (FL <= 5 ? R / 6 : 0));
-    constexpr int RSPLIT = RSPLIT0 + FRP_RSPLIT_ADJ <= R ? RSPLIT0 + FRP_RSPLIT_ADJ : R;
+#ifndef FRP_RSPLIT_ADJ32 // (same, for the N <= 32 variants only)
+#define FRP_RSPLIT_ADJ32 0
+#endif
+    constexpr int RSPLIT_ADJ_ = FRP_RSPLIT_ADJ + (NP == 32 ? FRP_RSPLIT_ADJ32 : 0);
+    constexpr int RSPLIT = RSPLIT0 + RSPLIT_ADJ_ <= R ? RSPLIT0 + RSPLIT_ADJ_ : R;
     constexpr int RQ = R - FRP_Q4_RM;
     constexpr int RB0 = QW ? (wave == 1 ? RQ : 0) : (IS_F ? RSPLIT : 0), RB1 = QW ? (wave == 1 ? R : RQ) : (IS_F ? R : RSPLIT);
     // evaluation: residuals, barrier Hessian / predictor rhs of this wave's bound rows -> record; norms
@@ -2390,7 +2449,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             for (int i = 0; i < NZ; i++) ms.z[i] = z0[i];
             ms.fext[0] = pk[3]; ms.fext[1] = pk[4]; ms.fext[2] = pk[5];
             if (half == 0) {
-                xs[X_FEXT + k] = ms.fext[0]; xs[X_FEXT + NP + k] = ms.fext[1]; xs[X_FEXT + 2 * NP + k] = ms.fext[2];
+                if constexpr (!QS) { xs[X_FEXT + k] = ms.fext[0]; xs[X_FEXT + NP + k] = ms.fext[1]; xs[X_FEXT + 2 * NP + k] = ms.fext[2]; }
                 ldouble *rec = recs + k * RS;
                 rec[R_HC] = -2.0 * pk[8]; // (u_i, w_i) cost coupling of this stage (constant)
                 rec[R_ZERO] = 0.0; rec[R_ZERO2] = 0.0; rec[R_ONE] = 1.0; rec[R_DT] = (TW && k < tw_m) ? -DT : DT; rec[R_DUMP] = 0.0;
@@ -2531,7 +2590,8 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                     const double yp = QP ? ((k < N - 1) ? rec[RS + RT_HYP + i] : 0.0) : hyp[i]; // (QP: left in the record by the y+ lanes)
                     hs.y6[i] = yo + hap * (yp - yo);
                 }
-                hs.fext[0] = xs[X_FEXT + k]; hs.fext[1] = xs[X_FEXT + NP + k]; hs.fext[2] = xs[X_FEXT + 2 * NP + k];
+                if constexpr (QS) { hs.fext[0] = pk[3]; hs.fext[1] = pk[4]; hs.fext[2] = pk[5]; } // (no room for [3][NP] in the workgroup scratch: from the parameters, L2-resident)
+                else { hs.fext[0] = xs[X_FEXT + k]; hs.fext[1] = xs[X_FEXT + NP + k]; hs.fext[2] = xs[X_FEXT + 2 * NP + k]; }
                 WSYNC(); // (the neighbour lane's reads of this stage's RT_HY slots come before the scratch use of the record below)
                 if constexpr (H3) hessian_phase3(recs + k * RS, hs, half, k < N - 1, hess);
                 else hessian_phase(recs + k * RS, hs, k < N - 1, hess);
@@ -2899,7 +2959,54 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         //     y_w = Phi_w dw + hc (du + kbar) + p_w        (the w rows of P are [Phi_w - hc^2 R | -hc Kbar_x] and du = -(hc R dw + Kbar_x dx + kbar))
         //     y_x = S_xx dx - hc Kbar_x' dw + p_x          (lane a of a stage: rows 3a .. 3a+2; S_aa and S_{a,a+1} are its own, the
         //                                                   contribution S_{a,a+1}' dx_a goes to the lane that owns the rows a+1)
-        if constexpr (wave == WY && QP) {
+        if constexpr (wave == WY && QP && QS) {
+            // Q30: the lane of a stage forms all thirteen rows itself -- its three blocks of S_xx (block b: S_bb lower triangle, then S_{b,b+1} row-major, b + 1 cyclic:
+            // every unique entry of the symmetric 9 x 9 once) in one trip to the L2, T', p, Phi_w, hc from its record; no hand-over between lanes
+            static_assert(WY == 0, "Q30: y+ on the Riccati wave");
+            __builtin_amdgcn_s_setprio(FRP_H_PRIO);
+            if (hact) {
+                typedef double gd2 __attribute__((ext_vector_type(2)));
+                ldouble *rec = recs + k * RS;
+                const gd2 *src = (const gd2 *)((const char *)pws + (unsigned)opq(k) * (PG * 8));
+                double sb[PG];
+#pragma unroll
+                for (int q = 0; q < PG / 2; q++) { const gd2 v = src[q]; sb[2 * q] = v.x; sb[2 * q + 1] = v.y; }
+                const double hcq = rec[R_HC];
+                double dx[9], dw[4], yx[9], yw[4];
+#pragma unroll
+                for (int i = 0; i < 9; i++) { dx[i] = rec[R_DZ + 8 + i]; yx[i] = 0.0; }
+#pragma unroll
+                for (int g = 0; g < 4; g++) dw[g] = rec[R_DZ + 4 + g];
+#pragma unroll
+                for (int bq = 0; bq < 3; bq++) {
+                    const int ia = 3 * bq, ib = bq == 2 ? 0 : ia + 3;
+                    const double *S = sb + 16 * bq, *da = dx + ia, *db = dx + ib;
+                    yx[ia + 0] += S[0] * da[0] + S[1] * da[1] + S[3] * da[2];
+                    yx[ia + 1] += S[1] * da[0] + S[2] * da[1] + S[4] * da[2];
+                    yx[ia + 2] += S[3] * da[0] + S[4] * da[1] + S[5] * da[2];
+#pragma unroll
+                    for (int t = 0; t < 3; t++) yx[ia + t] += S[6 + 3 * t] * db[0] + S[7 + 3 * t] * db[1] + S[8 + 3 * t] * db[2];
+#pragma unroll
+                    for (int q = 0; q < 3; q++) yx[ib + q] += S[6 + q] * da[0] + S[9 + q] * da[1] + S[12 + q] * da[2];
+                }
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    const double kd = rec[R_T + 4 + i] * dw[0] + rec[R_T + 20 + i] * dw[1] + rec[R_T + 36 + i] * dw[2] + rec[R_T + 52 + i] * dw[3];
+                    yx[i] = __builtin_fma(-hcq, kd, yx[i]) + rec[R_PV + 4 + i];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    yw[g] = __builtin_fma(rec[R_PHIW + g], dw[g], __builtin_fma(hcq, rec[R_DZ + g] + rec[R_T + 16 * g + 13], rec[R_PV + g]));
+                // (every read of T' by this lane is behind it: RT_HYP is a Kbar_x slot of its own record)
+#pragma unroll
+                for (int i = 0; i < 9; i++) rec[R_D + 4 + i] = yx[i];
+#pragma unroll
+                for (int i = 0; i < 6; i++) rec[RT_HYP + i] = yx[i]; // rows 4..9 once more, for the Hessian lane of stage k - 1 in the next evaluation
+#pragma unroll
+                for (int g = 0; g < 4; g++) rec[R_D + g] = yw[g];
+            }
+            __builtin_amdgcn_s_setprio(FRP_R_PRIO);
+        } else if constexpr (wave == WY && QP) {
             if constexpr (WY == 0) { __builtin_amdgcn_s_setprio(FRP_H_PRIO); fetch_sx(); } // (one trip to the L2 on the path: 8 x 16 bytes per lane)
             ldouble *rec = recs + k * RS;
             const int aq = opq(half) < 3 ? opq(half) : 2, ia = 3 * aq, ib = aq == 2 ? 0 : ia + 3;
@@ -3173,15 +3280,28 @@ __device__ __forceinline__ void role_loop(const KernelArgs &a, const Shared &sh)
     }
 }
 
+#ifdef FRP_NUM_VGPR // experiment knob: a hard register cap for every kernel of the translation unit (the waves-per-EU attribute is relaxed by the compiler when the LDS size limits the occupancy anyway)
+#define FRP_VGPR_ATTR __attribute__((amdgpu_num_vgpr(FRP_NUM_VGPR)))
+#else
+#define FRP_VGPR_ATTR
+#endif
 template <int NP, int FL, bool FREG, int WPE, bool TW>
-__global__ __launch_bounds__(QW ? 192 : 256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void nmpc_ipm_lds_kernel(KernelArgs a)
+__global__ __launch_bounds__(QW ? 192 : 256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) FRP_VGPR_ATTR void nmpc_ipm_lds_kernel(KernelArgs a)
 {
     static_assert(!(QW && QL) || (size_t)(NP * RS + X_TOTAL + 3 * NP + 1) * 8 + sizeof(Ctl) + 5 * sizeof(int) <= 40960, "Q4: four workgroups per CU in 160 KB of LDS");
+    static_assert(!QS || (size_t)(NP * RS + X_TOTAL + 1) * 8 + sizeof(Ctl) + 5 * sizeof(int) <= 53248, "Q30: three workgroups per CU in 160 KB of LDS");
+#ifdef FRP_DYN_LDS // experiment knob (round 6): LDS sized at launch -- the compiler then cannot tell that the LDS limits the occupancy below WPE and keeps the register cap of WPE waves per SIMD
+    extern __shared__ double s_dyn_[];
+    double *s_recs = s_dyn_, *s_xs = s_recs + NP * RS, *s_tw = s_xs + X_TOTAL + (QS ? 0 : 3 * NP);
+    Ctl &s_ctl = *reinterpret_cast<Ctl *>(s_tw + (TW ? TW_TOTAL : 1));
+    int *s_place = reinterpret_cast<int *>(&s_ctl + 1);
+#else
     __shared__ double s_recs[NP * RS];
-    __shared__ double s_xs[X_TOTAL + 3 * NP];
+    __shared__ double s_xs[X_TOTAL + (QS ? 0 : 3 * NP)];
     __shared__ double s_tw[TW ? TW_TOTAL : 1];
     __shared__ Ctl s_ctl;
     __shared__ int s_place[5];
+#endif
     static_assert(!TW || NP == 20, "the twisted solve is built on the three-lanes-per-stage model phase");
     Shared sh;
     sh.recs = (ldouble *)s_recs; sh.xs = (ldouble *)s_xs; sh.tw = (ldouble *)s_tw; sh.ctl = &s_ctl; sh.cukey = -1; sh.late = 0; sh.rsimd = -1;
@@ -3309,7 +3429,14 @@ __global__ __launch_bounds__(QW ? 192 : 256) __attribute__((amdgpu_waves_per_eu(
 template <int NP, int FL, bool FREG, int WPE, bool TW = false>
 static hipError_t launch_variant(const KernelArgs &k, int slots, hipStream_t stream)
 {
+#ifdef FRP_DYN_LDS
+    const size_t lds = (size_t)(NP * RS + X_TOTAL + (QS ? 0 : 3 * NP) + (TW ? TW_TOTAL : 1)) * 8 + sizeof(Ctl) + 5 * sizeof(int) + 16;
+    static bool once = [&] { return hipFuncSetAttribute(reinterpret_cast<const void *>(&nmpc_ipm_lds_kernel<NP, FL, FREG, WPE, TW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess; }();
+    (void)once;
+    hipLaunchKernelGGL((nmpc_ipm_lds_kernel<NP, FL, FREG, WPE, TW>), dim3(slots), dim3(QW ? 192 : 256), lds, stream, k);
+#else
     hipLaunchKernelGGL((nmpc_ipm_lds_kernel<NP, FL, FREG, WPE, TW>), dim3(slots), dim3(QW ? 192 : 256), 0, stream, k);
+#endif
     return hipGetLastError();
 }
 // the twisted variants: frp_nmpc_options.twist = m (stages eliminated forward), -1 = 9 N / 20 (3 N / 10 beyond 1024 problems); anything the twisted solve does not cover
@@ -3333,6 +3460,15 @@ static inline int twist_stages(const KernelArgs &k)
 hipError_t launch_ipm_lds_q4(const KernelArgs &k, int slots, hipStream_t stream)
 {
     return FRP_LR::launch_variant<20, 2, true, 3>(k, slots, stream);
+}
+#elif defined(FRP_LDS_Q30_TU)
+// frp_ipm_lds_q30.hip: N <= 30, <= 16 corridor rows, three problems per CU (215-double records, P in global memory); contributes launch_ipm_lds_q30 only
+#ifndef FRP_Q30_FREG
+#define FRP_Q30_FREG 1
+#endif
+hipError_t launch_ipm_lds_q30(const KernelArgs &k, int slots, hipStream_t stream)
+{
+    return FRP_LR::launch_variant<30, 8, (FRP_Q30_FREG != 0), 3>(k, slots, stream);
 }
 #elif defined(FRP_LDS_MEM_TU)
 hipError_t launch_ipm_lds_mem(const KernelArgs &k, int slots, hipStream_t stream)
@@ -3358,14 +3494,22 @@ void debug_read_prof_lds(long long *out)
 // FRP_Q4=0 in the environment keeps the three-per-CU variants (A/B runs).
 #ifdef FRP_LDS_SPLIT_TU
 hipError_t launch_ipm_lds_q4(const KernelArgs &k, int slots, hipStream_t stream); // frp_ipm_lds_q4.hip
+hipError_t launch_ipm_lds_q30(const KernelArgs &k, int slots, hipStream_t stream); // frp_ipm_lds_q30.hip
 static bool q4_enabled()
 {
     static const bool on = [] { const char *e = getenv("FRP_Q4"); return !(e && e[0] == '0'); }();
     return on;
 }
+static bool q30_enabled() // FRP_Q30=0 keeps the two-per-CU variants (A/B runs)
+{
+    static const bool on = [] { const char *e = getenv("FRP_Q30"); return !(e && e[0] == '0'); }();
+    return on;
+}
 #else
 static hipError_t launch_ipm_lds_q4(const KernelArgs &, int, hipStream_t) { return hipErrorInvalidValue; }
+static hipError_t launch_ipm_lds_q30(const KernelArgs &, int, hipStream_t) { return hipErrorInvalidValue; }
 static bool q4_enabled() { return false; } // (a single-translation-unit build has one record layout)
+static bool q30_enabled() { return false; }
 #endif
 #if (defined(FRP_QP) || defined(FRP_QW)) && !defined(FRP_LDS_Q4_TU)
 static bool q4_covers(const KernelArgs &) { return false; } // (bisection builds: the launch stays on this translation unit)
@@ -3392,8 +3536,22 @@ static bool q4_covers(const KernelArgs &k)
 }
 #endif
 
-// workgroups resident per CU: LDS-bound (4 x 40 KB on the Q4 variants; 3 x 51 KB, 2 x 79 KB, 1 x 157 KB)
-int lds_workgroups_per_cu(const KernelArgs &k) { return k.N <= 20 ? (q4_covers(k) ? 4 : 3) : (k.N <= 32 ? 2 : 1); }
+// The Q30 variant (frp_ipm_lds_q30.hip): 20 < N <= 30, at most 16 corridor rows per stage, plain solve, and more problems than the two-per-CU variants hold at once
+// (below that a problem gains nothing from the third slot and the 168-register build is 6 % slower per iteration than the 243-register one)
+#if (defined(FRP_QP) || defined(FRP_QW)) && !defined(FRP_LDS_Q4_TU)
+static bool q30_covers(const KernelArgs &) { return false; }
+#else
+static bool q30_covers(const KernelArgs &k)
+{
+    const int B = k.variant_B > 0 ? k.variant_B : k.B;
+    static const int min_b = [] { const char *e = getenv("FRP_Q30_MIN_B"); return e ? atoi(e) : -1; }(); // (tests: 0 sends every covered launch here)
+    return q30_enabled() && k.pws && k.N > 20 && k.N <= 30 && k.MF <= 16 && FRP_LR::twist_stages(k) == 0 && B > (min_b >= 0 ? min_b : 2 * device_cus());
+}
+#endif
+// workgroups resident per CU: LDS-bound (4 x 40 KB on the Q4 variants; 3 x 51 KB, 3 x 52 KB on the Q30 variant, 2 x 79 KB, 1 x 157 KB)
+int lds_workgroups_per_cu(const KernelArgs &k) { return k.N <= 20 ? (q4_covers(k) ? 4 : 3) : (k.N <= 32 ? (q30_covers(k) ? 3 : 2) : 1); }
+bool lds_q30_enabled() { return q30_enabled(); }
+size_t lds_q30_pws_doubles_per_slot() { return (size_t)30 * FRP_LR::PG; }
 // doubles of packed-P workspace a resident workgroup of the Q4 variants needs (KernelArgs::pws)
 size_t lds_q4_pws_doubles_per_slot() { return (size_t)20 * FRP_LR::PG; }
 bool lds_q4_enabled() { return q4_enabled(); }
@@ -3427,6 +3585,7 @@ hipError_t launch_ipm_lds(const KernelArgs &k0, int slots, hipStream_t stream)
     k.twist = FRP_LR::twist_stages(k0);
     const int MF = k.MF;
     if (q4_covers(k0)) return launch_ipm_lds_q4(k, slots, stream);
+    if (q30_covers(k0)) return launch_ipm_lds_q30(k, slots, stream);
 #if (defined(FRP_QP) || defined(FRP_QW)) && !defined(FRP_LDS_Q4_TU) // bisection builds (parts of Q4 on the main translation unit): one variant
     return (k.N <= 20 && MF <= 6 && !k.twist && k.pws) ? FRP_LR::launch_variant<20, 2, true, FRP_WPE20>(k, slots, stream) : hipErrorInvalidValue;
 #else
@@ -3438,7 +3597,13 @@ hipError_t launch_ipm_lds(const KernelArgs &k0, int slots, hipStream_t stream)
         if (MF <= 15) return FRP_LR::launch_variant<20, 5, true, FRP_WPE20>(k, slots, stream);
     } else if (k.N <= 32) {
         if (MF <= 6) return FRP_LR::launch_variant<32, 3, true, 2>(k, slots, stream);
-        if (MF <= 16) return FRP_LR::launch_variant<32, 8, true, 2>(k, slots, stream);
+#ifndef FRP_N32_WPE // experiment knobs (round 6): register budget / rows in registers of the N <= 32, <= 16-row variant -- the proxy for three problems per CU
+#define FRP_N32_WPE 2
+#endif
+#ifndef FRP_N32_FREG
+#define FRP_N32_FREG 1
+#endif
+        if (MF <= 16) return FRP_LR::launch_variant<32, 8, (FRP_N32_FREG != 0), FRP_N32_WPE>(k, slots, stream);
     } else if (MF <= 8) return FRP_LR::launch_variant<64, 8, true, 1>(k, slots, stream);
     return launch_ipm_lds_mem(k, slots, stream);
 #endif

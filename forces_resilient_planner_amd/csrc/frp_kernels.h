@@ -82,6 +82,8 @@ hipError_t kernel_timing_end(float *avg_ms, int *launches);
 int lds_workgroups_per_cu(const KernelArgs &k);
 size_t lds_q4_pws_doubles_per_slot();
 bool lds_q4_enabled();
+bool lds_q30_enabled();                // (frp_ipm_lds_q30.hip: 20 < N <= 30 at three problems per CU)
+size_t lds_q30_pws_doubles_per_slot();
 int lds_q4_set_min_batch(int min_b); // (frp_nmpc_set_q4_min_batch)
 bool lds_kernel_supports(int N, int MF);
 hipError_t launch_ipm_lds(const KernelArgs &k, int slots, hipStream_t stream);

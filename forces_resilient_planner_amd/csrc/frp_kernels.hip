@@ -346,8 +346,10 @@ static int resident_cap(int per_cu)
     return cap;
 }
 static bool q4_shape(int N, int MF) { return lds_q4_enabled() && N <= 20 && MF <= 6; } // (frp_ipm_lds.hip: q4_covers also looks at the options)
+static bool q30_shape(int N, int MF) { return lds_q30_enabled() && N > 20 && N <= 30 && MF <= 16; }
 static size_t pws_doubles(int B, int N, int MF)
 {
+    if (q30_shape(N, MF)) { const int cap = resident_cap(3); return (size_t)(B <= cap ? B : cap) * lds_q30_pws_doubles_per_slot() + 16; }
     if (!q4_shape(N, MF)) return 0;
     const int cap = resident_cap(4);
     return (size_t)(B <= cap ? B : cap) * lds_q4_pws_doubles_per_slot() + 16; // (+ 128 bytes: the blocks start on a cache line)
@@ -440,7 +442,7 @@ hipError_t launch_ipm(const KernelArgs &a, hipStream_t stream)
     KernelArgs k = a;
     double *q = a.ws;
     k.pws = nullptr;
-    if (q4_shape(a.N, a.MF)) {
+    if (q4_shape(a.N, a.MF) || q30_shape(a.N, a.MF)) {
         const uintptr_t p = reinterpret_cast<uintptr_t>(q + QUEUE_RESERVED + (size_t)a.B + ((size_t)a.B + 1) / 2);
         k.pws = reinterpret_cast<double *>((p + 127) & ~(uintptr_t)127);
     }
