@@ -2343,7 +2343,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 #ifndef FRP_RSPLIT_ADJ32 // (same, for the N <= 32 variants only)
 #define FRP_RSPLIT_ADJ32 0
 #endif
-    constexpr int RSPLIT_ADJ_ = FRP_RSPLIT_ADJ + (NP == 32 ? FRP_RSPLIT_ADJ32 : 0);
+    constexpr int RSPLIT_ADJ_ = FRP_RSPLIT_ADJ + ((NP == 32 || NP == 30) ? FRP_RSPLIT_ADJ32 : 0);
     constexpr int RSPLIT = RSPLIT0 + RSPLIT_ADJ_ <= R ? RSPLIT0 + RSPLIT_ADJ_ : R;
     constexpr int RQ = R - FRP_Q4_RM;
     constexpr int RB0 = QW ? (wave == 1 ? RQ : 0) : (IS_F ? RSPLIT : 0), RB1 = QW ? (wave == 1 ? R : RQ) : (IS_F ? R : RSPLIT);
@@ -3536,16 +3536,19 @@ static bool q4_covers(const KernelArgs &k)
 }
 #endif
 
-// The Q30 variant (frp_ipm_lds_q30.hip): 20 < N <= 30, at most 16 corridor rows per stage, plain solve, and more problems than the two-per-CU variants hold at once
-// (below that a problem gains nothing from the third slot and the 168-register build is 6 % slower per iteration than the 243-register one)
+// The Q30 variant (frp_ipm_lds_q30.hip): 20 < N <= 30, at most 16 corridor rows per stage, plain solve, and a launch of at least ~2.3 rounds of its resident
+// workgroups (7 x CUs problems): the 168-register build is 6 % slower per iteration than the 243-register one, and measured on configs[3] the third slot per CU
+// pays from B = 2048 on (B = 512 / 1024 / 2048 / 4096 / 16384: 1.72 / 2.18 / 2.56 / 3.48 / 11.09 ms against 1.63 / 2.06 / 2.58 / 4.05 / 13.90 at two per CU)
 #if (defined(FRP_QP) || defined(FRP_QW)) && !defined(FRP_LDS_Q4_TU)
 static bool q30_covers(const KernelArgs &) { return false; }
 #else
 static bool q30_covers(const KernelArgs &k)
 {
     const int B = k.variant_B > 0 ? k.variant_B : k.B;
-    static const int min_b = [] { const char *e = getenv("FRP_Q30_MIN_B"); return e ? atoi(e) : -1; }(); // (tests: 0 sends every covered launch here)
-    return q30_enabled() && k.pws && k.N > 20 && k.N <= 30 && k.MF <= 16 && FRP_LR::twist_stages(k) == 0 && B > (min_b >= 0 ? min_b : 2 * device_cus());
+    static const int env_b = [] { const char *e = getenv("FRP_Q30_MIN_B"); return e ? atoi(e) : -1; }();
+    const int set_b = g_q4_min_b.load(std::memory_order_relaxed); // (frp_nmpc_set_q4_min_batch moves the threshold of BOTH high-residency variant sets: the tests send every covered launch here)
+    const int min_b = set_b >= 0 ? set_b : env_b;
+    return q30_enabled() && k.pws && k.N > 20 && k.N <= 30 && k.MF <= 16 && FRP_LR::twist_stages(k) == 0 && B > (min_b >= 0 ? min_b : 7 * device_cus());
 }
 #endif
 // workgroups resident per CU: LDS-bound (4 x 40 KB on the Q4 variants; 3 x 51 KB, 3 x 52 KB on the Q30 variant, 2 x 79 KB, 1 x 157 KB)
@@ -3612,12 +3615,22 @@ hipError_t launch_ipm_lds(const KernelArgs &k0, int slots, hipStream_t stream)
 
 } // namespace frp
 
-#if defined(FRP_PROFILE) && !defined(FRP_LDS_MEM_TU) && !defined(FRP_LDS_Q4_TU)
+#if defined(FRP_PROFILE) && !defined(FRP_LDS_MEM_TU) && !defined(FRP_LDS_Q4_TU) && !defined(FRP_LDS_Q30_TU)
 extern "C" void frp_debug_read_prof_lds(long long *out) { frp::debug_read_prof_lds(out); }
 #endif
 #if defined(FRP_PROFILE) && defined(FRP_LDS_Q4_TU)
 // (the Q4 variants too; slots 24..28 of the segment counters: workgroups whose Riccati wave claimed SIMD 0..3 / fell back to role = wave index)
 extern "C" void frp_debug_read_prof_lds_q4(long long *out)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(frp::FRP_LR::g_prof_lds), sizeof(long long) * 64);
+    (void)hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(frp::FRP_LR::g_prof_seg), sizeof(long long) * 32);
+    long long z[64] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(frp::FRP_LR::g_prof_lds), z, sizeof z);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(frp::FRP_LR::g_prof_seg), z, sizeof(long long) * 32);
+}
+#endif
+#if defined(FRP_PROFILE) && defined(FRP_LDS_Q30_TU)
+extern "C" void frp_debug_read_prof_lds_q30(long long *out)
 {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(frp::FRP_LR::g_prof_lds), sizeof(long long) * 64);
     (void)hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(frp::FRP_LR::g_prof_seg), sizeof(long long) * 32);

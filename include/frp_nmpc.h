@@ -210,7 +210,9 @@ int frp_nmpc_kernel_timing_end(float *avg_ms, int *launches);
  * four-problems-per-CU kernel variants (three-wavefront workgroups) when they hold MORE than `min_batch` problems;
  * below that a problem has a CU nearly to itself and the four-wavefront variants iterate faster.  Default (and `min_batch` < 0):
  * three workgroups per CU of the current device.  0 puts every covered launch on the four-per-CU variants (the parity tests
- * do that at their small batch sizes).  Returns the previous value.  Process-global. */
+ * do that at their small batch sizes).  Returns the previous value.  Process-global.
+ * Round 6: the same threshold moves the second high-residency variant -- horizons 20 < N <= 30 with at most 16 corridor rows per
+ * stage at THREE problems per CU (DESIGN 4 "Round 6"; its own default: more than two workgroups per CU worth of problems). */
 int frp_nmpc_set_q4_min_batch(int min_batch);
 
 /* ---- (3) SURVEY 8f row f-1: the adapter's packing / result bookkeeping on the device (all pointers DEVICE) ---- */

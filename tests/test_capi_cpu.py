@@ -129,17 +129,22 @@ def test_workspace_size_formula():
     """The solver keeps its per-iteration state in LDS and registers: the device workspace is the work queue (counter 256 B,
     per-CU counters 8 KB, one key and one order entry per problem = 12 B per problem), whatever the horizon and the face
     count -- plus, for the launches the four-per-CU variants take (N <= 20, at most 6 corridor rows), the packed Riccati
-    blocks S_xx of the RESIDENT workgroups (20 x 48 doubles each, at most four per CU; 128 bytes of alignment slack): bounded by the
-    chip, not by B."""
+    blocks S_xx of the RESIDENT workgroups (20 x 48 doubles each, at most four per CU; 128 bytes of alignment slack) and, for the launches
+    the three-per-CU variant of round 6 takes (20 < N <= 30, at most 16 rows), 30 x 48 doubles for at most three workgroups per CU: bounded by
+    the chip, not by B."""
     lib = solver.lib()
     ws = lib.frp_nmpc_workspace_bytes
     queue = lambda B: 8 * (32 + 1024 + B + (B + 1) // 2)
     slot = 8 * 20 * 48  # S_xx of 20 stages: 48 doubles each
     cap = (ws(10 ** 6, 20, 6) - queue(10 ** 6) - 128) // slot
     assert cap % 4 == 0 and 4 <= cap <= 4 * 1024  # four workgroups per CU (256 CUs assumed without a device)
+    slot30 = 8 * 30 * 48
+    cap30 = (ws(10 ** 6, 30, 15) - queue(10 ** 6) - 128) // slot30
+    assert cap30 % 3 == 0 and cap30 * 4 == cap * 3
     for B in (1, 7, 4096, 10 ** 6):
-        assert ws(B, 64, 30) == ws(B, 20, 7) == ws(B, 21, 6) == queue(B)
+        assert ws(B, 64, 30) == ws(B, 20, 7) == ws(B, 31, 6) == ws(B, 30, 17) == queue(B)
         assert ws(B, 20, 6) == queue(B) + 128 + min(B, cap) * slot
+        assert ws(B, 21, 6) == ws(B, 30, 16) == queue(B) + 128 + min(B, cap30) * slot30
 
 
 @pytest.mark.skipif(_has_gpu(), reason="checks the no-device behaviour")

@@ -11,8 +11,9 @@ twist = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 opt = solver.default_options(twist=twist)
 buf = (ctypes.c_longlong * 96)()
 # (the Q4 variants are a translation unit of their own with their own counters: FRP_Q4=0 in the environment keeps the launch on the three-per-CU variants)
-q4 = os.environ.get("FRP_Q4", "1") != "0" and cfg in ("1", "2") and not twist
-reader = solver.lib().frp_debug_read_prof_lds_q4 if q4 else solver.lib().frp_debug_read_prof_lds
+q4 = os.environ.get("FRP_Q4", "1") != "0" and cfg in ("1", "2") and not twist and B > 768
+q30 = os.environ.get("FRP_Q30", "1") != "0" and cfg == "3" and not twist and (B > 1792 or os.environ.get("FRP_Q30_MIN_B") == "0")  # the three-per-CU variant of round 6 (its own counters)
+reader = solver.lib().frp_debug_read_prof_lds_q4 if q4 else (solver.lib().frp_debug_read_prof_lds_q30 if q30 else solver.lib().frp_debug_read_prof_lds)
 solver.solve_batch_host(w, opt)
 reader(buf)
 z, fl, it, info = solver.solve_batch_host(w, opt)
