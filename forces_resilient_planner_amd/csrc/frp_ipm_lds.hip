@@ -2182,7 +2182,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     constexpr bool IS_BO = IS_B && !IS_F;                                      // ... bound rounds only
     static_assert(!QP || ((NP == 20 || QS) && !TW), "P in global memory: the y+ rows are dealt over the three lanes of a stage (Q4) or formed by the lane of the stage (Q30)");
     static_assert(!QS || (!QW && H == 2 && !TW), "Q30: four-wave workgroups, two lanes per stage in the element-wise phases, the lane == stage model phase");
-    static_assert(!QW || (NP == 20 && !TW && FREG && wave < 3), "Q4: the three-lanes-per-stage model phase, plain solve, rows in registers");
+    static_assert(!QW || (NP == 20 && !TW && wave < 3), "Q4: the three-lanes-per-stage model phase, plain solve");
     const int lane = threadIdx.x & 63;
     const int N = a.N, M = a.M, MF = a.MF, np = NPRE + 4 * M;
     ldouble *recs = sh.recs, *xs = sh.xs;
@@ -3459,6 +3459,10 @@ static inline int twist_stages(const KernelArgs &k)
 // frp_ipm_lds_q4.hip: the four-problems-per-CU variants (three-wave workgroups, P in global memory); contributes launch_ipm_lds_q4 only
 hipError_t launch_ipm_lds_q4(const KernelArgs &k, int slots, hipStream_t stream)
 {
+#ifdef FRP_Q4_MORE_ROWS // experiment (round 6): the four-per-CU form for up to 15 rows in registers / up to 30 rows re-read (the tick's 30-row stages)
+    if (k.MF > 15) return FRP_LR::launch_variant<20, 10, false, 3>(k, slots, stream);
+    if (k.MF > 6) return FRP_LR::launch_variant<20, 5, true, 3>(k, slots, stream);
+#endif
     return FRP_LR::launch_variant<20, 2, true, 3>(k, slots, stream);
 }
 #elif defined(FRP_LDS_Q30_TU)
@@ -3513,6 +3517,7 @@ static bool q30_enabled() { return false; }
 #endif
 #if (defined(FRP_QP) || defined(FRP_QW)) && !defined(FRP_LDS_Q4_TU)
 static bool q4_covers(const KernelArgs &) { return false; } // (bisection builds: the launch stays on this translation unit)
+int lds_q4_max_rows() { return 6; }
 #else
 // ... and only launches with more problems than the three-per-CU variants hold at once: a problem that has a CU (nearly) to itself
 // iterates faster on four wavefronts (69 k cycles per iteration against 80 k: profiles/r05_wave_phases.txt)
@@ -3529,10 +3534,11 @@ static int device_cus()
     return cus[dev];
 }
 static std::atomic<int> g_q4_min_b{[] { const char *e = getenv("FRP_Q4_MIN_B"); return e ? atoi(e) : -1; }()}; // (frp_nmpc_set_q4_min_batch, a process-wide tuning hook; -1: three workgroups per CU)
+int lds_q4_max_rows() { static const int m = [] { const char *e = getenv("FRP_Q4_MAXF"); return e ? atoi(e) : 6; }(); return m; } // (experiment knob: needs a -DFRP_Q4_MORE_ROWS build of the Q4 unit)
 static bool q4_covers(const KernelArgs &k)
 {
     const int B = k.variant_B > 0 ? k.variant_B : k.B; // (the chunks of a host batch: the whole batch's variant)
-    return q4_enabled() && k.pws && k.N <= 20 && k.MF <= 6 && FRP_LR::twist_stages(k) == 0 && B > (g_q4_min_b.load(std::memory_order_relaxed) >= 0 ? g_q4_min_b.load(std::memory_order_relaxed) : 3 * device_cus());
+    return q4_enabled() && k.pws && k.N <= 20 && k.MF <= lds_q4_max_rows() && FRP_LR::twist_stages(k) == 0 && B > (g_q4_min_b.load(std::memory_order_relaxed) >= 0 ? g_q4_min_b.load(std::memory_order_relaxed) : 3 * device_cus());
 }
 #endif
 

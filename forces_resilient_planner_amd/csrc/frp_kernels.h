@@ -82,6 +82,7 @@ hipError_t kernel_timing_end(float *avg_ms, int *launches);
 int lds_workgroups_per_cu(const KernelArgs &k);
 size_t lds_q4_pws_doubles_per_slot();
 bool lds_q4_enabled();
+int lds_q4_max_rows();                 // corridor rows per stage the four-per-CU variants take (6; experiment knob FRP_Q4_MAXF)
 bool lds_q30_enabled();                // (frp_ipm_lds_q30.hip: 20 < N <= 30 at three problems per CU)
 size_t lds_q30_pws_doubles_per_slot();
 int lds_q4_set_min_batch(int min_b); // (frp_nmpc_set_q4_min_batch)

@@ -345,7 +345,7 @@ static int resident_cap(int per_cu)
     }
     return cap;
 }
-static bool q4_shape(int N, int MF) { return lds_q4_enabled() && N <= 20 && MF <= 6; } // (frp_ipm_lds.hip: q4_covers also looks at the options)
+static bool q4_shape(int N, int MF) { return lds_q4_enabled() && N <= 20 && MF <= lds_q4_max_rows(); } // (frp_ipm_lds.hip: q4_covers also looks at the options)
 static bool q30_shape(int N, int MF) { return lds_q30_enabled() && N > 20 && N <= 30 && MF <= 16; }
 static size_t pws_doubles(int B, int N, int MF)
 {
