@@ -162,9 +162,10 @@ def auto_chunks(world, B, N, MF, cus=None):
     """--chunks 0 of the strong-scaling step: pieces per shard and the reason (logged).  A piece below two rounds of resident workgroups
     costs more than its transfer can hide (profiles/r04_strong_chunks.txt: 4 pieces +46 % at configs[2] on one GPU), and on one rank
     nothing is transferred."""
-    per_cu = 4 if (N <= 20 and MF <= 6) else (3 if N <= 20 else (2 if N <= 32 else 1))  # resident workgroups per CU of the variant the launch takes
     if cus is None:
         cus = device_cus()[0]
+    # resident workgroups per CU of the variant the launch takes (round 6: horizons 20 < N <= 30 with <= 16 rows run three per CU from 7 x CUs problems on)
+    per_cu = 4 if (N <= 20 and MF <= 6) else (3 if N <= 20 else ((3 if (N <= 30 and MF <= 16 and B > 7 * cus) else 2) if N <= 32 else 1))
     slots = cus * per_cu
     if world <= 1:
         return 1, "one rank: nothing to overlap"

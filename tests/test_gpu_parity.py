@@ -736,6 +736,44 @@ def test_host_path_with_registered_buffers_stages_nothing_and_changes_no_plan():
     assert not solver._registered  # the wrapper's references went with the registrations
 
 
+def test_three_per_cu_variant_for_horizons_up_to_30_against_the_oracle_and_the_two_per_cu_variant():
+    """Round 6 (csrc/frp_ipm_lds_q30.hip): launches of the plain solve with 20 < N <= 30 and <= 16 corridor rows that hold more than 7 x CUs problems run on
+    the three-problems-per-CU variant (215-double records: P d aliased onto the p slots, S_xx in the L2 workspace, y+ formed by the lane of the stage).  At the
+    DEFAULT threshold a batch of 2304 problems of configs[3] takes it; with the threshold out of reach the same batch runs two per CU: identical flags, the
+    oracle's iteration counts on >= 99 % of the problems on both, iterates within 1e-6 of the oracle's and of each other where the counts agree
+    (same iteration, other summation order); shorter horizons (N = 21, 25) and the final model likewise on a small batch with the threshold at zero."""
+    lib = solver.lib()
+    w = workloads.config3(2304, seed=21)
+    zo, flo, io = OL.solve_batch(w, nthreads=16)
+    ito = np.array([i.it for i in io])
+    res = {}
+    for name, thr in (("three_per_cu", -1), ("two_per_cu", 10 ** 9)):
+        old = lib.frp_nmpc_set_q4_min_batch(thr)
+        try:
+            res[name] = solver.solve_batch_host(w)
+        finally:
+            lib.frp_nmpc_set_q4_min_batch(old)
+        z, fl, it, info = res[name]
+        assert np.array_equal(fl, flo), name
+        same = (fl == 1) & (it == ito)
+        assert (it == ito).mean() > 0.99 and np.max(np.abs(z[same] - zo[same])) < 1e-6, (name, (it == ito).mean())
+    a, b = res["three_per_cu"], res["two_per_cu"]
+    both = (a[1] == 1) & (a[2] == b[2])
+    assert both.mean() > 0.85 and np.max(np.abs(a[0][both] - b[0][both])) < 1e-6 and not np.array_equal(a[0], b[0])  # (close, and NOT the same kernel)
+    old = lib.frp_nmpc_set_q4_min_batch(0)
+    try:
+        for N, model in ((21, L.MODEL_NORMAL), (25, L.MODEL_FINAL), (30, L.MODEL_FINAL)):
+            ws = workloads.config3(96, N=N, seed=22 + N, model=model)
+            z, fl, it, _ = solver.solve_batch_host(ws)
+            zo2, flo2, io2 = OL.solve_batch(ws)
+            ito2 = np.array([i.it for i in io2])
+            assert np.array_equal(fl, flo2) and (it == ito2).mean() > 0.97, (N, model)
+            same = (fl == 1) & (it == ito2)
+            assert np.max(np.abs(z[same] - zo2[same])) < 1e-6, (N, model)
+    finally:
+        lib.frp_nmpc_set_q4_min_batch(old)
+
+
 def test_two_host_batches_in_flight_give_the_plans_of_the_blocking_call():
     """frp_nmpc_solve_batch_host_begin / _wait: two sets of registered buffers alternate, the gather of one batch runs
     under the solve of the other (the pipelined solves leave resident slots free for it) -- plans, flags, counts and diagnostics are those
