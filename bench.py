@@ -395,6 +395,10 @@ def main():
             A1, b1 = _bbox_faces(r1, np.full((1, N), yaw))
             refs.append(torch.from_numpy(r1).to(dev)); As.append(torch.from_numpy(A1).to(dev)); bs.append(torch.from_numpy(b1).to(dev))
         tick = [0]
+        # every tick of a receding horizon has its own iteration counts (5.0 on the first ticks, 3.0 forty ticks on): the rate and the
+        # kernel time are averages over the timed ticks, so the iteration count they are priced with is too -- summed on the device,
+        # one small reduction per tick inside the timed step (~10 us of a ~10 ms tick)
+        it_acc = torch.zeros(2, dtype=torch.int64, device=dev)
 
         def step():
             t = tick[0]; tick[0] += 1
@@ -402,6 +406,7 @@ def main():
             if t > 0:
                 fleet.coldstart(thrust=7.3)
             fleet.tick(f_ext, refs[t].expand(max(B, 1), N, 3).contiguous(), ref_yaw)
+            it_acc[0] += ds.iters[:max(B, 1)].sum(); it_acc[1] += 1
     torch.cuda.synchronize(dev)
 
     def barrier():
@@ -426,7 +431,10 @@ def main():
     nrep = max(1, args.repeats)
     ev_stride = 4 if nrep * args.steps >= 16 and not strong else 1   # (strong scaling: a step is several piece launches, all of them timed)
     solver.kernel_timing_begin((nrep * args.steps + 8) * (max(1, args.chunks) if strong else 1), ev_stride)
+    if cfg == 4:
+        it_acc.zero_()
     reps = [timed(step, args.steps) for _ in range(nrep)]
+    timed_ticks_it = [int(x) for x in it_acc.cpu()] if cfg == 4 else None  # [sum of iterations over the timed ticks, ticks]
     kernel_ms, kernel_launches = solver.kernel_timing_end()
     if strong and kernel_launches:  # per step: the sum over the pieces of this rank's shard
         kernel_ms = kernel_ms * kernel_launches / (nrep * args.steps)
@@ -482,9 +490,12 @@ def main():
     fl = ds.exitflag[:max(B, 1)].cpu().numpy(); it = ds.iters[:max(B, 1)].cpu().numpy()
     if B == 0:
         fl = fl[:0]; it = it[:0]
-    stats = torch.tensor([float((fl == 1).sum()), float(it.sum()), float(len(fl)), float(it.max() if len(it) else 0)], **f64)
+    redo = ds.info[:max(B, 1), 7].cpu().numpy() if B > 0 else np.zeros(0)  # iterations redone with the Gauss-Newton Hessian (uncounted in `iters`)
+    stats = torch.tensor([float((fl == 1).sum()), float(it.sum()), float(len(fl)), float(it.max() if len(it) else 0), float(redo.sum())], **f64)
+    if cfg == 4 and B > 0 and timed_ticks_it[1] > 0:
+        stats[1] = timed_ticks_it[0] / timed_ticks_it[1]  # mean over the timed ticks (the other statistics: the last tick)
     if dist is not None:
-        mx = stats[3:].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        mx = stats[3:4].clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)  # summary statistics, not on the data path
         stats[3] = mx[0]
     conv_frac = float(stats[0] / stats[2]); mean_it = float(stats[1] / stats[2])
@@ -519,7 +530,7 @@ def main():
                        "per_rank_ms_per_step": [x / args.steps * 1e3 for x in per_rank_s],
                        "per_rank_solves_per_s": ([B_total / max(1, ranks_seen) * args.steps / x for x in per_rank_s] if not strong else None), "collectives": ("RCCL (torch.distributed nccl backend)" if dist is not None else "none (single process)"),
                        "batch_per_gpu": B, "batch_total": B_total, "horizon": int(N), "converged_frac": conv_frac,
-                       "mean_ipm_iterations": mean_it, "max_ipm_iterations": int(stats[3]), "p95_ipm_iterations": float(np.percentile(it, 95)) if len(it) else 0.0,
+                       "mean_ipm_iterations": mean_it, **({"mean_ipm_iterations_note": "mean over the timed ticks (what the rate and the kernel time average over); p95 / max / redos: the last tick"} if cfg == 4 else {}), "mean_gauss_newton_redos": float(stats[4] / stats[2]), "max_ipm_iterations": int(stats[3]), "p95_ipm_iterations": float(np.percentile(it, 95)) if len(it) else 0.0,
                        "timing": f"median of {len(reps)} repeats of the {args.steps}-step region, strictly serial launches on one stream; max over ranks per repeat",
                        "repeat_ms_per_step": [r / args.steps * 1e3 for r in reps],
                        "pipelined_solves_per_s": pipelined,
