@@ -199,6 +199,7 @@ constexpr int X_DS0 = 68;             // ds_0 = [dw_0; dx_0] (16)
 constexpr int X_XINIT = 84;           // xinit (9)
 constexpr int X_DX0 = 96;             // xinit - x_0 (9)
 constexpr int X_C0 = 93, X_C1 = 94;   // constants 0, 1
+constexpr int X_IKM = 95;             // 1 / (KAPPA_LAM mtot) of the problem, for the wave that has no register for it (PARK)
 constexpr int X_RED = 106;            // per-wave partial results: [4][16] (evaluation 0..2, affine 3..7, step 8..12: no slot is reused inside an iteration)
 constexpr int X_FEXT = 170;           // external-force acceleration of every stage: [3][NP]
 constexpr int X_TOTAL = 170;          // (+ 3 NP)
@@ -316,7 +317,6 @@ constexpr LaneTables make_tables()
 static __device__ const LaneTables g_tab = make_tables();
 
 __device__ __forceinline__ int tab(int row, int lane) { return (int)g_tab.v[row][lane]; }
-
 #define BAR() __syncthreads()
 #define FRP_SB() __builtin_amdgcn_sched_barrier(0)
 // between the rounds / rows of the element-wise loops (unrolled): keeps the scheduler from interleaving them, i.e. from multiplying
@@ -1491,7 +1491,14 @@ constexpr int RX_MTRIG = R_PV, RX_HTRIG = R_PD;
 // hand-over at the record's end); what the Riccati wave reads at the start of the evaluation (RT_H*) and its trig hand-over sit inside HD,
 // which only that wave writes in the phase (the hand-over overlaps RT_HYP / RT_HY: written after they were read, by the same wave)
 constexpr int RT_Y = R_PD; // (QS: unused -- y stays in the model wave's registers, FRP_NO_YPARK)
+#ifndef FRP_Q4_PARK // 1: the 12 slots at the record's end are the corridor lanes' parking (see PARK in solve_one); the model wave's trig hand-over uses the d slots instead --
+#define FRP_Q4_PARK 1 // dead from that wave's commit (they carried y+) to its own store of d, a few hundred instructions behind the hand-over
+#endif
+#if !defined(FRP_QS) && FRP_Q4_PARK
+constexpr int RX_HTRIG = R_T + 20, RX_MTRIG = R_D;
+#else
 constexpr int RX_HTRIG = R_T + 20, RX_MTRIG = RQ_MTRIG;
+#endif
 static_assert(RX_HTRIG + 12 <= R_HD + REC_HD_SIZE && RT_HY + 6 <= R_HD + REC_HD_SIZE, "the Riccati wave's scratch inside HD");
 #endif
 #endif
@@ -2266,6 +2273,20 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     // in scratch on this wave is two row constants, the second-order terms between the barriers D and F and three integers)
     constexpr bool FPZ = IS_M && IS_F;
     double *const fpq = FPZ ? ms.z + 8 : fpos;
+    // Three-wave workgroups, rows in registers: the merged model + corridor wave is a few registers short in its model phase, and what the allocator sent to
+    // scratch for it -- one constant of every row all iteration long, the rows' second-order terms from barrier D to the commit -- came back one dependent
+    // round trip to memory at a time: six in the evaluation phase, two in the affine phase, four each in the step phase and the commit (the disassembly:
+    // scratch_load, s_waitcnt vmcnt(0), use, next scratch_load), on the wave that is the long pole of every one of them.  Those values live in LDS instead:
+    // four slots per lane at the record's end (lane (k, half): slots 4 half .. 4 half + 3 of stage k -- b of its two rows, then their second-order terms),
+    // written and read by their own lane only.
+#if defined(FRP_QL) && !defined(FRP_QS) && FRP_Q4_PARK
+    constexpr bool PARK = QW && FREG && IS_F && FL <= 2;
+    constexpr int R_PRK = RQ_MTRIG;
+#else
+    constexpr bool PARK = false;
+    constexpr int R_PRK = 0;
+#endif
+    ldouble *const prk = recs + (k < NP ? k : 0) * RS + R_PRK + 4 * (half < 3 ? half : 0);
 
     // face t of this lane is row j = t * H + half of its stage; its constants come from registers or from the parameters
     // (re-reading variants: two per-lane base pointers -- row `half` of A and of b -- made opaque once per phase by face_bases(),
@@ -2282,7 +2303,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         }
     };
     auto face_consts = [&](int t, double &a0, double &a1, double &a2, double &bb) {
-        if (FREG) { a0 = fa0[t]; a1 = fa1[t]; a2 = fa2[t]; bb = fbb[t]; }
+        if (FREG) { a0 = fa0[t]; a1 = fa1[t]; a2 = fa2[t]; bb = PARK ? prk[t] : fbb[t]; }
         else { a0 = pkA[3 * H * t]; a1 = pkA[3 * H * t + 1]; a2 = pkA[3 * H * t + 2]; bb = pkB[H * t] + HU; }
     };
     // body(t, a0, a1, a2, bb) for the live rows of this lane.  Re-reading variants: a load inside `if (row is live)` cannot be hoisted
@@ -2484,7 +2505,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 if (j < nf) {
                     const double a0 = pk[NPRE + 3 * j], a1 = pk[NPRE + 3 * j + 1], a2 = pk[NPRE + 3 * j + 2];
                     const double bb = pk[NPRE + 3 * M + j] + HU;
-                    if (FREG) { fa0[t] = a0; fa1[t] = a1; fa2[t] = a2; fbb[t] = bb; }
+                    if (FREG) { fa0[t] = a0; fa1[t] = a1; fa2[t] = a2; if (PARK) prk[t] = bb; else fbb[t] = bb; }
                     fs[t] = -(a0 * fpq[0] + a1 * fpq[1] + a2 * fpq[2] - bb);
                     smin = fmin(smin, fs[t]);
                 }
@@ -2531,7 +2552,11 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         }
     }
 
-    const double inv_kmtot = 1.0 / (KAPPA_LAM * (double)mtot);
+    const double inv_kmtot_r = 1.0 / (KAPPA_LAM * (double)mtot);
+    if constexpr (PARK) { // (this wave keeps it in the workgroup scratch: in a register it is spilled, and the commit waited for the reload; first read: barriers later)
+        if (lane == 0) xs[X_IKM] = inv_kmtot_r;
+    }
+#define inv_kmtot (PARK ? (double)xs[X_IKM] : inv_kmtot_r)
     int flag = FRP_EXIT_MAXIT, it = 0, nfallback = 0;
     bool iso_mine = false; // (Riccati wave) this solve holds a mark on its CU
     if constexpr (QW && wave == 0) iso_mine = uni(sh.ctl->head_first) >= 0; // (a head-start solve: marked by the kernel prologue)
@@ -2845,7 +2870,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                     s_sdl += s * dl; s_lds += l * ds;
                     const double cr = ds * dl;
                     s_dsdl += cr;
-                    fcr[t] = cr;
+                    if (PARK) prk[FL + t] = cr; else fcr[t] = cr;
                     const double t1 = (l * rin - cr) * sinv;
                     b0 += a0 * t1; b1 += a1 * t1; b2 += a2 * t1;
                     c0 += a0 * sinv; c1 += a1 * sinv; c2 += a2 * sinv;
@@ -2889,6 +2914,14 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
         // (FRP_QP_YWAVE = 2; the default is the Riccati wave, which fetches at the start of the step phase: the bounds wave has no
         // room for 32 more registers between the barriers D and F -- 310 spilled VGPRs instead of 126)
         if constexpr (wave == WY && WY != 0 && QP) fetch_sx();
+#ifndef FRP_QP_TOUCH // experiment knob: the bounds wave -- idle from here to barrier E -- reads one word of every 128-byte line of this workgroup's S_xx blocks, so
+#define FRP_QP_TOUCH 0 // that the Riccati wave's fetch at the head of the step phase finds them in the CU's vector cache (one register, waited for before barrier E)
+#endif
+        unsigned touch_ = 0;
+        if constexpr (FRP_QP_TOUCH != 0 && QP && !QS && WY == 0 && IS_BO) {
+            const char *tp_ = (const char *)pws + (unsigned)(lane < 3 * N ? lane : 0) * 128u;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(touch_) : "v"(tp_) : "memory");
+        }
         if constexpr (W0H) __builtin_amdgcn_s_setprio(FRP_R_PRIO);
 
         // ============================================================ corrector: vector backward sweep + forward sweep with y+
@@ -2928,6 +2961,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             BAR();
             if constexpr (wave == FWD_C) sweep_forward(recs, xs, N);
         }
+        if constexpr (FRP_QP_TOUCH != 0 && QP && !QS && WY == 0 && IS_BO) asm volatile("s_waitcnt vmcnt(0)" : "+v"(touch_) : : "memory");
         BAR_P(3); // ------------------------------------------------------------- E
 
         // ============================================================ step: pass A (ratios), pass B (commit)
@@ -3130,7 +3164,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 face_bases();
                 for_faces([&](int t, double a0, double a1, double a2, double bb) __attribute__((always_inline)) {
                     double ds, dl;
-                    cstep(fs[t], fl_[t], fcr[t], a0 * dzf[0] + a1 * dzf[1] + a2 * dzf[2],
+                    cstep(fs[t], fl_[t], PARK ? prk[FL + t] : fcr[t], a0 * dzf[0] + a1 * dzf[1] + a2 * dzf[2],
                           a0 * fpq[0] + a1 * fpq[1] + a2 * fpq[2] - bb, ds, dl);
                 });
             }
@@ -3182,7 +3216,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
                 }
                 face_bases();
                 for_faces([&](int t, double a0, double a1, double a2, double bb) __attribute__((always_inline)) {
-                    commit(fs[t], fl_[t], fcr[t], a0 * dzf[0] + a1 * dzf[1] + a2 * dzf[2], a0 * fpq[0] + a1 * fpq[1] + a2 * fpq[2] - bb);
+                    commit(fs[t], fl_[t], PARK ? prk[FL + t] : fcr[t], a0 * dzf[0] + a1 * dzf[1] + a2 * dzf[2], a0 * fpq[0] + a1 * fpq[1] + a2 * fpq[2] - bb);
                 });
                 if constexpr (!FPZ) { fpos[0] += ap * dzf[0]; fpos[1] += ap * dzf[1]; fpos[2] += ap * dzf[2]; }
             }
@@ -3252,6 +3286,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
 
 // Persistent workgroups: grid = min(B, resident workgroups); each pulls the next problem index from a device counter
 // (zeroed by the launcher) until the batch is exhausted.
+#undef inv_kmtot
 template <int NP, int FL, bool FREG, int ROLE, bool TW>
 __device__ __forceinline__ void role_loop(const KernelArgs &a, const Shared &sh)
 {

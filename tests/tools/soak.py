@@ -1,5 +1,5 @@
 """Soak test (GPU box): many launches with random batch sizes / configs / horizons (and the hard family of workloads.config_hard),
-exit flags, iteration counts AND iterates against the oracle on every launch.   python tests/tools/soak.py [seconds=90]
+exit flags, iteration counts AND iterates against the oracle on every launch.   python tests/tools/soak.py [seconds=90] [seed=2026]
 Bound on the iterates (round 4): two converged solves with equal iteration counts agree to DZ_TOL = 1e-3; a pair beyond it must be a
 documented bifurcation -- both points KKT points within the tolerances with different objectives -- and is PRINTED as an exception,
 at most MAX_EXCEPTIONS of them per run; anything else fails the run."""
@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from forces_resilient_planner_amd import solver, workloads
 import tests.oracle_lib as OL
 T = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
-rng = np.random.default_rng(2026)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)  # (soak_diverge.py replays the default sequence)
 t0 = time.time(); n = 0; solved = 0; worst = 0.0; worst_at = None
 DZ_TOL, MAX_EXCEPTIONS = 1e-3, 3
 exceptions = []; flag_mismatches = 0; mismatch_list = []
@@ -59,7 +59,8 @@ while time.time() - t0 < T:
     conv = fl == 1
     assert np.all(info[conv, 0] <= 1e-4) and np.all(info[conv, 1] <= 1e-4) and np.all(info[conv, 2] <= 1e-4) and np.all(info[conv, 3] <= 1e-4)
     assert np.all(np.isfinite(z[fl == 1]))
-    assert (it[ok] == ito[ok]).mean() > 0.97 if ok.any() else True
+    # (at most 3 % of a launch -- one problem on a small launch -- may end on different iteration counts: a rounding-decided last iteration)
+    assert int((it[ok] != ito[ok]).sum()) <= max(1, int(0.03 * ok.sum())), ("iteration counts differ on more than 3 % of the launch", kind, B, seed, int(w["N"]), int(w["M"]), int(ok.sum()), np.where(ok & (it != ito))[0][:10].tolist(), it[ok & (it != ito)][:10].tolist(), ito[ok & (it != ito)][:10].tolist())
     n += 1; solved += len(fl)
 print(f"soak: {n} launches, {solved} problems, {time.time() - t0:.0f} s, {flag_mismatches} exit-flag mismatches ({flag_mismatches / max(1, solved):.2e} of the problems), "
       f"worst |dz| at equal iteration counts {worst:.2e}; pairs beyond {DZ_TOL:g}: {len(exceptions)} (allowed: {MAX_EXCEPTIONS}, each a certified bifurcation)")
