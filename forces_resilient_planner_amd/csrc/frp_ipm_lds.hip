@@ -465,6 +465,9 @@ typedef __attribute__((address_space(3))) Ctl lctl_t;
 // ================================================================== wave 0: Riccati sweeps
 // ---- stage-0 solve (both passes): dx_0 = xinit - x_0, dw_0 = -Pww^-1 (Pwx dx_0 + p_w); leaves ds_0 in X_DS0.
 // pw_here: p_w[g] in the lanes (g, 13).
+#ifndef FRP_S0_OPQ // 1: the lane opaque at the call in the factorisation sweep -- inlined into the kernel, the stage-0 solve's lane-dependent LDS addresses are loop
+#define FRP_S0_OPQ 1 // invariants of the interior-point loop: hoisted, spilled, and fetched from scratch one round trip at a time at the tail of the factorisation
+#endif
 __device__ __forceinline__ void stage0_solve(ldouble *xs, int lane, double pw_here)
 {
     const int g = lane >> 4, c = lane & 15;
@@ -781,7 +784,7 @@ __device__ FRP_FACTOR_LINKAGE int sweep_factor(ldouble *recs, ldouble *xs, int N
 #pragma unroll
             for (int i = 0; i < 16; i++) xs[X_RW + i] = Rw[i];
             if (c >= 4 && c <= 12) xs[X_PWX + g * 9 + c - 4] = P[0];
-            stage0_solve(xs, lane, P[0]); // (p_w sits in column 13 of the w rows)
+            stage0_solve(xs, FRP_S0_OPQ ? opq(lane) : lane, P[0]); // (p_w sits in column 13 of the w rows)
         }
     }
     WSYNC();
