@@ -154,7 +154,7 @@ constexpr int RS = 309;      // odd stride: lane == stage accesses are conflict-
 static_assert(R_HD + REC_HD_SIZE <= R_PV && R_PV + 13 <= R_PD, "overlay region");
 static_assert(R_PHIB == 245 && R_HC == 286 && R_DZ == 291 && R_ZERO2 == 308, "the plain record");
 #elif !defined(FRP_QS)
-constexpr int RQ_MTRIG = R_ZERO2 + 1; // the model wave's trig hand-over (12): slots of its own (nothing else is free in the evaluation phase)
+constexpr int RQ_MTRIG = R_ZERO2 + 1; // 12 slots of the model + corridor wave's own: four parking slots per lane of the stage (FRP_Q4_PARK; without it: that wave's trig hand-over)
 constexpr int RS = RQ_MTRIG + 12;     // 241, odd
 static_assert(RS == 241 && (RS & 1), "the Q4 record");
 static_assert(R_HD + REC_HD_SIZE == R_PHID && R_PHID + 17 == R_PHIPOS && R_PHIPOS + 9 == R_PHI && R_PHI + 17 == R_PD, "overlay region");
