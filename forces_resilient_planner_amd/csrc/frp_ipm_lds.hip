@@ -2298,10 +2298,17 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     // (the row group clamped to the last one: the lanes 3 NP .. 63 of the three-lanes-per-stage mapping are inactive, but the chunked
     // fetch below is unconditional -- with the unclamped group their last row would lie one row behind the stage's block)
     const int halfc = half < H ? half : H - 1;
-    const double *pkA = pk + NPRE + 3 * halfc, *pkB = pk + NPRE + 3 * M + halfc;
+    // (pointers into GLOBAL memory by type: behind the opaque asm of face_bases() a generic pointer's loads are FLAT instructions, which count on the LDS counter as well --
+    // every wait for a row constant then drains the wave's LDS reads, and the other way round)
+#ifdef FRP_ROWS_FLAT // (experiment knob: the generic pointers of rounds 2-5)
+    typedef const double gcdouble;
+#else
+    typedef const __attribute__((address_space(1))) double gcdouble;
+#endif
+    gcdouble *pkA = (gcdouble *)(pk + NPRE + 3 * halfc), *pkB = (gcdouble *)(pk + NPRE + 3 * M + halfc);
     auto face_bases = [&]() {
         if constexpr (!FREG) {
-            pkA = pk + NPRE + 3 * halfc; pkB = pk + NPRE + 3 * M + halfc;
+            pkA = (gcdouble *)(pk + NPRE + 3 * halfc); pkB = (gcdouble *)(pk + NPRE + 3 * M + halfc);
             asm volatile("" : "+v"(pkA), "+v"(pkB));
         }
     };
