@@ -2258,7 +2258,8 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
     auto fetch_sx = [&]() {
         typedef double gd2 __attribute__((ext_vector_type(2)));
         const int aq = opq(half) < 3 ? opq(half) : 2;
-        const gd2 *src = (const gd2 *)((const char *)pws + ((unsigned)opq(k) * (PG * 8) + (unsigned)aq * 128u));
+        // (a GLOBAL pointer by type: through the generic one these were FLAT loads -- the one trip to memory on the path of the step phase took the flat route and counted on the LDS counter too)
+        const __attribute__((address_space(1))) gd2 *src = (const __attribute__((address_space(1))) gd2 *)((const char *)pws + ((unsigned)opq(k) * (PG * 8) + (unsigned)aq * 128u));
 #pragma unroll
         for (int q = 0; q < 8; q++) { const gd2 v = src[q]; sx[2 * q] = v.x; sx[2 * q + 1] = v.y; }
     };
@@ -3011,7 +3012,7 @@ __device__ __forceinline__ void solve_one(const KernelArgs &a, const int b, cons
             if (hact) {
                 typedef double gd2 __attribute__((ext_vector_type(2)));
                 ldouble *rec = recs + k * RS;
-                const gd2 *src = (const gd2 *)((const char *)pws + (unsigned)opq(k) * (PG * 8));
+                const __attribute__((address_space(1))) gd2 *src = (const __attribute__((address_space(1))) gd2 *)((const char *)pws + (unsigned)opq(k) * (PG * 8));
                 double sb[PG];
 #pragma unroll
                 for (int q = 0; q < PG / 2; q++) { const gd2 v = src[q]; sb[2 * q] = v.x; sb[2 * q + 1] = v.y; }
