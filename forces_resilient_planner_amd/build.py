@@ -7,7 +7,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libfrp_nmpc_amd.so")
-SOURCES = ["frp_kernels.hip", "frp_ipm_lds.hip", "frp_ipm_lds_mem.hip", "frp_ipm_lds_q4.hip", "frp_ipm_lds_q30.hip", "frp_capi.hip", "frp_pack.hip", "frp_tube.hip", "frp_corridor.hip", "frp_reference.hip", "frp_astar.hip"]
+SOURCES = ["frp_kernels.hip", "frp_ipm_lds.hip", "frp_ipm_lds_mem.hip", "frp_ipm_lds_q4.hip", "frp_ipm_lds_q30.hip", "frp_ipm_lds_s2.hip", "frp_capi.hip", "frp_pack.hip", "frp_tube.hip", "frp_corridor.hip", "frp_reference.hip", "frp_astar.hip"]
 HEADERS = ["frp_kernels.h", "frp_device.hpp", "frp_model.hpp", "frp_adapter.hpp", os.path.join(ROOT, "include", "frp_nmpc.h")]
 
 
@@ -106,6 +106,7 @@ PER_SOURCE_FLAGS = {"frp_ipm_lds.hip": CODEGEN_FLAGS + ["-DFRP_LDS_SPLIT_TU"],
                     # vector sweeps as well loses that again, profiles/r05_q4_flags.txt)
                     "frp_ipm_lds_q4.hip": CODEGEN_FLAGS + ["-DFRP_INLINE_FACTOR"],
                     "frp_ipm_lds_q30.hip": CODEGEN_FLAGS,
+                    "frp_ipm_lds_s2.hip": CODEGEN_FLAGS,
                     "frp_corridor.hip": NO_HOIST,
                     # the A* agrees with its oracle to the bit (node order depends on comparisons of nearly equal costs): no a * b + c contraction
                     "frp_astar.hip": ["-ffp-contract=off"]}

@@ -34,6 +34,8 @@
 #define FRP_LR lrq
 #elif defined(FRP_LDS_Q30_TU)
 #define FRP_LR lrs
+#elif defined(FRP_LDS_S2_TU)
+#define FRP_LR lr2
 #else
 #define FRP_LR lr
 #endif
@@ -3520,6 +3522,15 @@ hipError_t launch_ipm_lds_q30(const KernelArgs &k, int slots, hipStream_t stream
 {
     return FRP_LR::launch_variant<30, 8, (FRP_Q30_FREG != 0), 3>(k, slots, stream);
 }
+#elif defined(FRP_LDS_S2_TU)
+// frp_ipm_lds_s2.hip: the small-launch variants (N <= 20, rows in registers, at most two problems per CU): the kernels of the main translation unit compiled for
+// TWO wavefronts per SIMD -- in a translation unit of their own so that the sweeps, functions behind calls, get the 256-register budget too (a function takes the
+// tightest budget among its callers); contributes launch_ipm_lds_s2 only
+hipError_t launch_ipm_lds_s2(const KernelArgs &k, int slots, hipStream_t stream)
+{
+    if (k.twist) return k.MF <= 6 ? FRP_LR::launch_variant<20, 2, true, 2, true>(k, slots, stream) : FRP_LR::launch_variant<20, 5, true, 2, true>(k, slots, stream); // (k.twist: resolved by launch_ipm_lds)
+    return k.MF <= 6 ? FRP_LR::launch_variant<20, 2, true, 2>(k, slots, stream) : FRP_LR::launch_variant<20, 5, true, 2>(k, slots, stream);
+}
 #elif defined(FRP_LDS_MEM_TU)
 hipError_t launch_ipm_lds_mem(const KernelArgs &k, int slots, hipStream_t stream)
 {
@@ -3545,6 +3556,7 @@ void debug_read_prof_lds(long long *out)
 #ifdef FRP_LDS_SPLIT_TU
 hipError_t launch_ipm_lds_q4(const KernelArgs &k, int slots, hipStream_t stream); // frp_ipm_lds_q4.hip
 hipError_t launch_ipm_lds_q30(const KernelArgs &k, int slots, hipStream_t stream); // frp_ipm_lds_q30.hip
+hipError_t launch_ipm_lds_s2(const KernelArgs &k, int slots, hipStream_t stream);  // frp_ipm_lds_s2.hip
 static bool q4_enabled()
 {
     static const bool on = [] { const char *e = getenv("FRP_Q4"); return !(e && e[0] == '0'); }();
@@ -3603,8 +3615,20 @@ static bool q30_covers(const KernelArgs &k)
     return q30_enabled() && k.pws && k.N > 20 && k.N <= 30 && k.MF <= 16 && FRP_LR::twist_stages(k) == 0 && B > (min_b >= 0 ? min_b : 7 * device_cus());
 }
 #endif
-// workgroups resident per CU: LDS-bound (4 x 40 KB on the Q4 variants; 3 x 51 KB, 3 x 52 KB on the Q30 variant, 2 x 79 KB, 1 x 157 KB)
-int lds_workgroups_per_cu(const KernelArgs &k) { return k.N <= 20 ? (q4_covers(k) ? 4 : 3) : (k.N <= 32 ? (q30_covers(k) ? 3 : 2) : 1); }
+// Small launches (N <= 20, rows in registers, at most two problems per CU -- the drop-in call is the case of ONE): the same kernels compiled for two wavefronts per
+// SIMD, i.e. 256 registers instead of 168 -- no spills, nothing to fetch back on the chain: 0.1260 -> 0.1226 ms per drop-in call, 0.1142 -> 0.1095 with the twisted
+// solve (FRP_SMALL2=0 switches it off).  The choice goes by the size of the whole batch (variant_B), like that of the high-residency variants.
+static bool small2_covers(const KernelArgs &k)
+{
+#ifndef FRP_LDS_SPLIT_TU
+    return false; // (a build without the other translation units has no such variants)
+#endif
+    static const int env = [] { const char *e = getenv("FRP_SMALL2"); return e ? atoi(e) : 1; }();
+    const int B = k.variant_B > 0 ? k.variant_B : k.B;
+    return env != 0 && k.N <= 20 && k.MF <= 15 && B <= 2 * device_cus() && !q4_covers(k);
+}
+// workgroups resident per CU: LDS-bound (4 x 40 KB on the Q4 variants; 3 x 51 KB, 3 x 52 KB on the Q30 variant, 2 x 79 KB, 1 x 157 KB), two by registers on the small-launch variants
+int lds_workgroups_per_cu(const KernelArgs &k) { return k.N <= 20 ? (q4_covers(k) ? 4 : (small2_covers(k) ? 2 : 3)) : (k.N <= 32 ? (q30_covers(k) ? 3 : 2) : 1); }
 bool lds_q30_enabled() { return q30_enabled(); }
 size_t lds_q30_pws_doubles_per_slot() { return (size_t)30 * FRP_LR::PG; }
 // doubles of packed-P workspace a resident workgroup of the Q4 variants needs (KernelArgs::pws)
@@ -3644,6 +3668,9 @@ hipError_t launch_ipm_lds(const KernelArgs &k0, int slots, hipStream_t stream)
 #if (defined(FRP_QP) || defined(FRP_QW)) && !defined(FRP_LDS_Q4_TU) // bisection builds (parts of Q4 on the main translation unit): one variant
     return (k.N <= 20 && MF <= 6 && !k.twist && k.pws) ? FRP_LR::launch_variant<20, 2, true, FRP_WPE20>(k, slots, stream) : hipErrorInvalidValue;
 #else
+#ifdef FRP_LDS_SPLIT_TU
+    if (small2_covers(k0)) return launch_ipm_lds_s2(k, slots, stream);
+#endif
     if (k.N <= 20 && k.twist) {
         if (MF <= 6) return FRP_LR::launch_variant<20, 2, true, FRP_WPE20, true>(k, slots, stream);
         if (MF <= 15) return FRP_LR::launch_variant<20, 5, true, FRP_WPE20, true>(k, slots, stream);
@@ -3667,7 +3694,7 @@ hipError_t launch_ipm_lds(const KernelArgs &k0, int slots, hipStream_t stream)
 
 } // namespace frp
 
-#if defined(FRP_PROFILE) && !defined(FRP_LDS_MEM_TU) && !defined(FRP_LDS_Q4_TU) && !defined(FRP_LDS_Q30_TU)
+#if defined(FRP_PROFILE) && !defined(FRP_LDS_MEM_TU) && !defined(FRP_LDS_Q4_TU) && !defined(FRP_LDS_Q30_TU) && !defined(FRP_LDS_S2_TU)
 extern "C" void frp_debug_read_prof_lds(long long *out) { frp::debug_read_prof_lds(out); }
 #endif
 #if defined(FRP_PROFILE) && defined(FRP_LDS_Q4_TU)
