@@ -106,7 +106,7 @@ PER_SOURCE_FLAGS = {"frp_ipm_lds.hip": CODEGEN_FLAGS + ["-DFRP_LDS_SPLIT_TU"],
                     # vector sweeps as well loses that again, profiles/r05_q4_flags.txt)
                     "frp_ipm_lds_q4.hip": CODEGEN_FLAGS + ["-DFRP_INLINE_FACTOR"],
                     "frp_ipm_lds_q30.hip": CODEGEN_FLAGS,
-                    "frp_ipm_lds_s2.hip": CODEGEN_FLAGS,
+                    "frp_ipm_lds_s2.hip": CODEGEN_FLAGS + ["-DFRP_INLINE_FACTOR", "-DFRP_INLINE_SWEEPS"],
                     "frp_corridor.hip": NO_HOIST,
                     # the A* agrees with its oracle to the bit (node order depends on comparisons of nearly equal costs): no a * b + c contraction
                     "frp_astar.hip": ["-ffp-contract=off"]}
