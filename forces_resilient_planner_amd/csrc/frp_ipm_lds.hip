@@ -3528,8 +3528,10 @@ hipError_t launch_ipm_lds_q30(const KernelArgs &k, int slots, hipStream_t stream
 // tightest budget among its callers); contributes launch_ipm_lds_s2 only
 hipError_t launch_ipm_lds_s2(const KernelArgs &k, int slots, hipStream_t stream)
 {
-    if (k.twist) return k.MF <= 6 ? FRP_LR::launch_variant<20, 2, true, 2, true>(k, slots, stream) : FRP_LR::launch_variant<20, 5, true, 2, true>(k, slots, stream); // (k.twist: resolved by launch_ipm_lds)
-    return k.MF <= 6 ? FRP_LR::launch_variant<20, 2, true, 2>(k, slots, stream) : FRP_LR::launch_variant<20, 5, true, 2>(k, slots, stream);
+    // (more than 15 rows: ten per lane IN REGISTERS -- at 256 registers the corridor wave holds the constants of its rows, 140 registers of state, where the
+    // three-per-CU build re-reads them from the parameters in every phase; 55 spilled.  Built for ONE wavefront per SIMD the kernel takes 316 registers, i.e. AGPR copies: slower, 0.156 ms)
+    if (k.twist) return k.MF <= 6 ? FRP_LR::launch_variant<20, 2, true, 2, true>(k, slots, stream) : (k.MF <= 15 ? FRP_LR::launch_variant<20, 5, true, 2, true>(k, slots, stream) : FRP_LR::launch_variant<20, 10, true, 2, true>(k, slots, stream)); // (k.twist: resolved by launch_ipm_lds)
+    return k.MF <= 6 ? FRP_LR::launch_variant<20, 2, true, 2>(k, slots, stream) : (k.MF <= 15 ? FRP_LR::launch_variant<20, 5, true, 2>(k, slots, stream) : FRP_LR::launch_variant<20, 10, true, 2>(k, slots, stream));
 }
 #elif defined(FRP_LDS_MEM_TU)
 hipError_t launch_ipm_lds_mem(const KernelArgs &k, int slots, hipStream_t stream)
@@ -3625,7 +3627,7 @@ static bool small2_covers(const KernelArgs &k)
 #endif
     static const int env = [] { const char *e = getenv("FRP_SMALL2"); return e ? atoi(e) : 1; }();
     const int B = k.variant_B > 0 ? k.variant_B : k.B;
-    return env != 0 && k.N <= 20 && k.MF <= 15 && B <= 2 * device_cus() && !q4_covers(k);
+    return env != 0 && k.N <= 20 && k.MF <= 30 && B <= 2 * device_cus() && !q4_covers(k);
 }
 // workgroups resident per CU: LDS-bound (4 x 40 KB on the Q4 variants; 3 x 51 KB, 3 x 52 KB on the Q30 variant, 2 x 79 KB, 1 x 157 KB), two by registers on the small-launch variants
 int lds_workgroups_per_cu(const KernelArgs &k) { return k.N <= 20 ? (q4_covers(k) ? 4 : (small2_covers(k) ? 2 : 3)) : (k.N <= 32 ? (q30_covers(k) ? 3 : 2) : 1); }

@@ -679,14 +679,33 @@ def test_launch_order_without_face_counts_and_at_other_horizons():
             w = workloads.config3(B, N=N, seed=5) if N != 20 else workloads.config2(B, seed=6)
             z, fl, it, _ = solver.solve_batch_host(dict(w, nfaces=None), MF=w["M"])
             zs, fls, its = [], [], []
-            for lo in range(0, B, 200):  # 200 <= resident workgroups of every variant: index order
-                sub = {k: (v[lo:lo + 200] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in w.items()}
+            # pieces no larger than the resident workgroups of the variant (index order); at N = 20 larger than two problems per CU, so that they stay on the
+            # variant of the big batch (smaller launches run builds of their own -- csrc/frp_ipm_lds_s2.hip -- that agree with it to rounding, not to the bit)
+            P = 600 if N == 20 else 200
+            for lo in range(0, B, P):
+                sub = {k: (v[lo:lo + P] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in w.items()}
                 a, b_, c, _ = solver.solve_batch_host(dict(sub, nfaces=None), MF=w["M"])
                 zs.append(a); fls.append(b_); its.append(c)
             assert np.array_equal(fl, np.concatenate(fls)) and np.array_equal(it, np.concatenate(its))
             assert np.max(np.abs(z - np.concatenate(zs))) == 0.0
     finally:
         solver.lib().frp_nmpc_set_q4_min_batch(old)
+
+
+def test_small_launches_with_many_rows_agree_with_the_batch_variants_and_the_oracle():
+    """Launches of at most two problems per CU run builds of their own (csrc/frp_ipm_lds_s2.hip: two wavefronts per SIMD, rows in registers up to 30 per stage).
+    The same problems inside a larger batch -- the three-per-CU variants, which re-read more than 15 rows per stage from the parameters -- give the same flags and
+    iteration counts and plans within 1e-10; both match the oracle."""
+    B = 700
+    w = workloads.config2(B, seed=29)
+    full = dict(w, nfaces=None)
+    z, fl, it, _ = solver.solve_batch_host(full, MF=w["M"])            # 700 > two per CU: three-per-CU, rows re-read
+    sub = {k: (v[:150] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in w.items()}
+    zs, fls, its, _ = solver.solve_batch_host(dict(sub, nfaces=None), MF=w["M"])   # 150 problems: the small-launch build, 30 rows in registers
+    assert np.array_equal(fls, fl[:150]) and np.array_equal(its, it[:150])
+    assert np.max(np.abs(zs - z[:150])) < 1e-10
+    zo, flo, _ = OL.solve_batch(sub)  # (the oracle takes the row counts: the trailing rows of the blocks are zero)
+    assert np.array_equal(fls, flo) and np.max(np.abs(zs[fls == 1] - zo[fls == 1])) < 1e-6
 
 
 def test_host_path_packs_live_rows_and_chunks_without_changing_a_plan():
