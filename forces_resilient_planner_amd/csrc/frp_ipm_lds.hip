@@ -3627,7 +3627,8 @@ static bool small2_covers(const KernelArgs &k)
 #endif
     static const int env = [] { const char *e = getenv("FRP_SMALL2"); return e ? atoi(e) : 1; }();
     const int B = k.variant_B > 0 ? k.variant_B : k.B;
-    return env != 0 && k.N <= 20 && k.MF <= 30 && B <= 2 * device_cus() && !q4_covers(k);
+    static const int max_b = [] { const char *e = getenv("FRP_SMALL2_MAXB"); return e ? atoi(e) : 0; }(); // (experiments: the two-per-CU builds for larger batches too)
+    return env != 0 && k.N <= 20 && k.MF <= 30 && B <= (max_b > 0 ? max_b : 2 * device_cus()) && !q4_covers(k);
 }
 // workgroups resident per CU: LDS-bound (4 x 40 KB on the Q4 variants; 3 x 51 KB, 3 x 52 KB on the Q30 variant, 2 x 79 KB, 1 x 157 KB), two by registers on the small-launch variants
 int lds_workgroups_per_cu(const KernelArgs &k) { return k.N <= 20 ? (q4_covers(k) ? 4 : (small2_covers(k) ? 2 : 3)) : (k.N <= 32 ? (q30_covers(k) ? 3 : 2) : 1); }
