@@ -32,7 +32,9 @@ __global__ __launch_bounds__(256) void pack_kernel(frp_nmpc_pack p)
     for (int e = tid; e < p.N * PK_NZ; e += 256) p.x0[(size_t)b * p.N * PK_NZ + e] = mo[PK_NZ + e];
     if (tid < 9) p.xinit[(size_t)b * 9 + tid] = mo[PK_NZ + 8 + tid];
     // per stage: its polytope (poly_constraints[poly_indices(i)], forces_normal.cpp:112) and live face count
-    __shared__ int s_pi[64], s_nf[64];
+    // s_lim: rows of the stage this call has to write -- all M, or (frp_nmpc_pack.padded_rows_are_zero) the live rows and those the PREVIOUS call on these buffers left
+    // live: everything beyond is zero already.  A Monte-Carlo fleet with six-face corridors writes 34 of the 130 slots of a stage instead of all of them.
+    __shared__ int s_pi[64], s_nf[64], s_lim[64];
     if (tid < p.N) {
         int pi = p.poly_index ? p.poly_index[(size_t)b * p.N + tid] : tid;
         pi = pi < 0 ? 0 : (pi < p.NPOLY ? pi : p.NPOLY - 1); // a corrupt index must not read outside the polytope arrays
@@ -40,10 +42,18 @@ __global__ __launch_bounds__(256) void pack_kernel(frp_nmpc_pack p)
         nf = nf < p.M ? nf : p.M;              // faces beyond num_const are dropped (:114)
         nf = nf < p.F ? nf : p.F;
         nf = nf > 0 ? nf : 0;
-        s_pi[tid] = pi; s_nf[tid] = nf;
+        int lim = p.M;
+        if (p.padded_rows_are_zero) {
+            int old = p.nfaces[(size_t)b * p.N + tid]; // (what the previous call stored; clamped: a caller that set the flag on fresh buffers must not make this kernel skip a row it owes)
+            old = old < 0 ? p.M : (old > p.M ? p.M : old);
+            lim = nf > old ? nf : old;
+        }
+        s_pi[tid] = pi; s_nf[tid] = nf; s_lim[tid] = lim;
         p.nfaces[(size_t)b * p.N + tid] = nf;
     }
     __syncthreads();
+    int lmax = 0;
+    for (int i = 0; i < p.N; i++) lmax = s_lim[i] > lmax ? s_lim[i] : lmax;
     const bool fin = p.mode && p.mode[b] == FRP_MODEL_FINAL; // this planner runs the final solver: setParasFinal's weights
     const double w_wp = fin ? p.wf_stage_wp : p.w_stage_wp, w_in = fin ? p.wf_stage_input : p.w_stage_input, w_rate = fin ? p.wf_input_rate : p.w_input_rate;
     const double wt_wp = fin ? p.wf_terminal_wp : p.w_terminal_wp, wt_in = fin ? p.wf_terminal_input : p.w_terminal_input;
@@ -65,22 +75,24 @@ __global__ __launch_bounds__(256) void pack_kernel(frp_nmpc_pack p)
         out[(size_t)i * np + c] = v;
     }
     // (2) A row-major, rows beyond the live count zero (:116-123)
-    const int m3 = 3 * p.M;
-    if (m3 > 0) {
-        const float inv_m3 = 1.0f / (float)m3;
-        for (int e = tid; e < p.N * m3; e += 256) {
-            int i = (int)(((float)e + 0.5f) * inv_m3); // stage (exact: e < 2^16)
-            i = i * m3 > e ? i - 1 : ((i + 1) * m3 <= e ? i + 1 : i);
-            const int c = e - i * m3;
+    const int m3 = 3 * p.M, l3 = 3 * lmax; // (the loops run over the first lmax rows of every stage: lmax = M unless the flag above is set)
+    if (l3 > 0) {
+        const float inv_l3 = 1.0f / (float)l3;
+        for (int e = tid; e < p.N * l3; e += 256) {
+            int i = (int)(((float)e + 0.5f) * inv_l3); // stage (exact: e < 2^16)
+            i = i * l3 > e ? i - 1 : ((i + 1) * l3 <= e ? i + 1 : i);
+            const int c = e - i * l3;
+            if (c / 3 >= s_lim[i]) continue;
             const size_t pbase = (size_t)b * p.NPOLY + s_pi[i];
             out[(size_t)i * np + PK_NPRE + c] = (c / 3 < s_nf[i]) ? p.poly_A[pbase * p.F * 3 + c] : 0.0;
         }
         // (3) b_j - ||E a_j||_2 (:124-125)
-        const float inv_m = 1.0f / (float)p.M;
-        for (int e = tid; e < p.N * p.M; e += 256) {
+        const float inv_m = 1.0f / (float)lmax;
+        for (int e = tid; e < p.N * lmax; e += 256) {
             int i = (int)(((float)e + 0.5f) * inv_m);
-            i = i * p.M > e ? i - 1 : ((i + 1) * p.M <= e ? i + 1 : i);
-            const int j = e - i * p.M;
+            i = i * lmax > e ? i - 1 : ((i + 1) * lmax <= e ? i + 1 : i);
+            const int j = e - i * lmax;
+            if (j >= s_lim[i]) continue;
             double v = 0.0;
             if (j < s_nf[i]) {
                 const size_t pbase = (size_t)b * p.NPOLY + s_pi[i];

@@ -15,7 +15,7 @@ from . import layout as L
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRP_LIB") or os.path.join(_PKG, "libfrp_nmpc_amd.so")  # FRP_LIB: an experiment build (tools/build_variant.sh)
 INFO_STRIDE = 12
-ABI_VERSION = 5  # FRP_NMPC_ABI_VERSION of include/frp_nmpc.h
+ABI_VERSION = 6  # FRP_NMPC_ABI_VERSION of include/frp_nmpc.h
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int_p = ctypes.POINTER(ctypes.c_int)
@@ -45,7 +45,8 @@ class Pack(ctypes.Structure):  # frp_nmpc_pack (include/frp_nmpc.h)
                 ("w_terminal_wp", ctypes.c_double), ("w_terminal_input", ctypes.c_double),
                 ("xinit", ctypes.c_void_p), ("x0", ctypes.c_void_p), ("params", ctypes.c_void_p), ("nfaces", ctypes.c_void_p),
                 ("mode", ctypes.c_void_p), ("wf_stage_wp", ctypes.c_double), ("wf_stage_input", ctypes.c_double),
-                ("wf_input_rate", ctypes.c_double), ("wf_terminal_wp", ctypes.c_double), ("wf_terminal_input", ctypes.c_double)]
+                ("wf_input_rate", ctypes.c_double), ("wf_terminal_wp", ctypes.c_double), ("wf_terminal_input", ctypes.c_double),
+                ("padded_rows_are_zero", ctypes.c_int)]
 
 
 class Tube(ctypes.Structure):  # frp_nmpc_tube (include/frp_nmpc.h)
@@ -329,6 +330,7 @@ class DeviceSolver:
 
     def upload(self, w):
         t = self.torch
+        self._packed_by = None  # (a fleet's pack may no longer assume what it left in params / nfaces)
         self.xinit.copy_(t.from_numpy(np.ascontiguousarray(w["xinit"])))
         self.x0.copy_(t.from_numpy(np.ascontiguousarray(w["x0"])))
         self.params.copy_(t.from_numpy(np.ascontiguousarray(w["params"])))
@@ -657,8 +659,11 @@ class DeviceFleet:
                   self.poly_b.data_ptr(), self.poly_nfaces.data_ptr(),
                   self.poly_index.data_ptr() if self.poly_index is not None else None, *self.weights,
                   ds.xinit.data_ptr(), ds.x0.data_ptr(), ds.params.data_ptr(), ds.nfaces.data_ptr(),
-                  self.mode.data_ptr() if self.mode is not None else None, *(self.weights_final or (0.0,) * 5))
+                  self.mode.data_ptr() if self.mode is not None else None, *(self.weights_final or (0.0,) * 5),
+                  # (from the second pack on: this fleet's solver buffers are as its own previous pack left them -- DeviceSolver.upload takes the promise back)
+                  1 if getattr(ds, "_packed_by", None) is self else 0)
         _check(lib().frp_nmpc_pack_batch(ctypes.byref(pk), ctypes.c_void_p(s.cuda_stream)), "frp_nmpc_pack_batch")
+        ds._packed_by = self
 
     def update(self, stream=None, keep_failed=True):
         s = stream if stream is not None else self.torch.cuda.current_stream(self.solver.device)

@@ -74,7 +74,7 @@ extern "C" {
  * struct of this header gains, loses or moves a field or FRP_INFO_STRIDE changes: a caller built against another header would
  * hand over short structs / a short info array.  Call FRP_NMPC_ABI_CHECK() once after loading the library (the C++ adapter and the
  * Python loader do) and refuse to continue unless it returns FRP_OK. */
-#define FRP_NMPC_ABI_VERSION 5
+#define FRP_NMPC_ABI_VERSION 6
 int frp_nmpc_abi_version(void);
 /* FRP_OK when the caller's header agrees with the library on the version, on the size of frp_nmpc_options and frp_nmpc_batch and
  * on the info stride; FRP_ERR_ARG otherwise (with one line on stderr saying what differs). */
@@ -242,6 +242,11 @@ typedef struct frp_nmpc_pack {
     /* optional: planners in final mode (switch_to_final) get setParasFinal's weights (forces_final.cpp:36-52)  */
     const int *mode; /* [B] FRP_MODEL_NORMAL / FRP_MODEL_FINAL per planner, or NULL: the weights above for everyone */
     double wf_stage_wp, wf_stage_input, wf_input_rate, wf_terminal_wp, wf_terminal_input;
+    /* != 0: the caller guarantees that `params` and `nfaces` are as the PREVIOUS frp_nmpc_pack_batch call with the same
+       B, N, M left them (a receding-horizon loop that owns its buffers): the rows of a stage beyond nfaces[stage] are
+       zero already, the call writes the live rows and zeroes only those that were live before -- a fleet with six-face
+       corridors writes 34 of the 130 slots of a stage.  0 (the first call on fresh buffers, or when in doubt): every slot. */
+    int padded_rows_are_zero;
 } frp_nmpc_pack;
 
 /* forces_normal.cpp:36-136 for B planners: weights, xinit / shifted x0, per-stage parameters with the robust

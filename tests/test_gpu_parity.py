@@ -579,6 +579,42 @@ def test_device_packing_matches_the_adapter():
     assert np.all(np.abs(yaw) <= np.pi + 1e-12)
 
 
+def test_repeated_packs_write_only_what_changed_and_leave_the_full_image():
+    """frp_nmpc_pack.padded_rows_are_zero (a fleet's second and later packs): the call writes the live rows of a stage and zeroes only those the previous call left live.
+    With face counts that grow, shrink and drop to zero from call to call -- and other polytopes each time -- the parameter image equals that of a full pack into
+    fresh buffers, bit for bit; DeviceSolver.upload takes the promise back."""
+    import torch
+    rng = np.random.default_rng(3)
+    w = workloads.config3(48)
+    B, N, M = w["B"], w["N"], w["M"]
+    F = w["poly_A"].shape[2]
+    wts = workloads._weights(w["model"])
+    fleet = solver.DeviceFleet(B, N, M, F, w["model"], wts)
+    fleet.mpc_output.copy_(fleet.to_device(w["mpc_output"])); fleet.ellipsoid.copy_(fleet.to_device(w["E"]))
+    args = (fleet.to_device(w["f_ext"]), fleet.to_device(w["ref_pos"]), fleet.to_device(w["ref_yaw"]))
+    for rep in range(6):
+        nf = w["nfaces"].copy()
+        if rep == 1: nf = np.maximum(nf - 3, 0)
+        if rep == 2: nf = np.minimum(nf + 2, F)
+        if rep == 3: nf[:, ::2] = 0
+        if rep >= 4: nf = rng.integers(0, F + 1, size=nf.shape)
+        A = w["poly_A"] * (1.0 + 0.01 * rep); b = w["poly_b"] + 0.1 * rep
+        fleet.poly_A.copy_(fleet.to_device(A)); fleet.poly_b.copy_(fleet.to_device(b))
+        fleet.poly_nfaces.copy_(fleet.to_device(nf, dtype=torch.int32))
+        if rep == 5:  # somebody else writes the solver's buffers: the next pack must be a full one again
+            fleet.solver.upload(dict(xinit=w["xinit"], x0=w["x0"], params=rng.normal(size=w["params"].shape), nfaces=w["nfaces"]))
+        fleet.pack(*args)
+        fresh = solver.DeviceFleet(B, N, M, F, w["model"], wts)
+        fresh.solver.params.fill_(float("nan"))
+        fresh.mpc_output.copy_(fleet.mpc_output); fresh.ellipsoid.copy_(fleet.ellipsoid)
+        fresh.poly_A.copy_(fleet.poly_A); fresh.poly_b.copy_(fleet.poly_b); fresh.poly_nfaces.copy_(fleet.poly_nfaces)
+        fresh.pack(*args)
+        torch.cuda.synchronize()
+        assert np.array_equal(fleet.solver.nfaces.cpu().numpy(), fresh.solver.nfaces.cpu().numpy())
+        assert np.array_equal(fleet.solver.params.cpu().numpy(), fresh.solver.params.cpu().numpy()), rep
+        assert np.all(np.isfinite(fresh.solver.params.cpu().numpy()))
+
+
 @pytest.mark.parametrize("M", [0, 1, 7])
 def test_device_packing_without_live_rows_and_small_layouts(M):
     """The packing kernel's three regions (header, A block, b block) at the edges: no corridor rows in the layout at all (M = 0: the
